@@ -1,0 +1,445 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the r9y9/gantts G+D training step.
+
+This module is the *checker* for the HIP engine in ``gantts_amd/``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+product path never does (and fails loudly when the HIP library is missing).
+
+What it restates (reference file:line, relative to the upstream tree):
+
+* ``MLP``                       gantts/models.py:121-141
+* ``In2OutHighwayNet``          gantts/models.py:21-69
+* ``sequence_mask`` / masked MSE gantts/seqloss.py:9-43
+* stream index arithmetic       gantts/multistream.py:33-123
+* ``apply_generator``           train.py:336-355
+* ``update_discriminator``      train.py:245-279
+* ``update_generator``          train.py:282-320
+* ``clip_grad_norm_`` + ``torch.optim.Adagrad/Adam`` as used at train.py:275-276,
+  317-318, 796-799 (restated from the published update rules, checked against
+  ``torch.optim`` in tests/test_oracle.py)
+* ``unit_variance_mlpg_matrix`` / ``unit_variance_mlpg`` -- third-party nnmnkwii
+  (>= 0.0.14, reference setup.py:58-68, NOT vendored under /root/reference).
+  Restated from its published definition: W = vstack of per-window band matrices with
+  zero edges, R = (W^T W)^-1 W^T in float64, cast to float32; apply = window-major
+  reshape then R @ means.  The reference tests pin only shapes and stream slicing at
+  this boundary (tests/test_gantts.py:132-163) => numeric values of R are
+  **parity unpinned**; self-consistency (R W = I) is checked in tests/test_oracle.py.
+
+Pinning: ``tests/golden/make_golden.py`` (run in the build container, where the
+reference tree can be imported through ``oracle/ref_loader.py``) executes the REAL
+reference ``train.update_*`` on seeded inputs and stores the results under
+``tests/golden/``; ``tests/test_oracle.py`` checks this restatement against those
+fixtures, and (container only) live against the reference.
+
+The numeric backend is torch-CPU float32 because that *is* the reference's backend
+(ATen/MKL); gradients come from autograd exactly as in the reference, including the
+un-detached D-loss -> G gradient leak (train.py:265,274,316-318).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LEAKY_SLOPE = 0.01  # nn.LeakyReLU() default, gantts/models.py:132
+
+
+# ----------------------------------------------------------------------------
+# MLPG (nnmnkwii restatement)
+# ----------------------------------------------------------------------------
+def _window_matrix(left, right, coef, T):
+    """(W c)[t] = sum_k coef[k + left] * c[t + k], zero outside [0, T)."""
+    W = np.zeros((T, T), dtype=np.float64)
+    for k in range(-left, right + 1):
+        c = float(coef[k + left])
+        if c == 0.0:
+            continue
+        idx = np.arange(max(0, -k), min(T, T - k))
+        W[idx, idx + k] = c
+    return W
+
+
+def unit_variance_mlpg_matrix(windows, T):
+    """R = (W^T W)^-1 W^T, shape (T, num_windows*T), float32 (window-major columns)."""
+    T = int(T)
+    W = np.vstack([_window_matrix(l, u, c, T) for (l, u, c) in windows])
+    R = np.linalg.solve(W.T @ W, W.T)
+    return R.astype(np.float32)
+
+
+def unit_variance_mlpg(R, means):
+    """means (B,T,nW*d) with per-frame layout [static(d)|delta(d)|delta2(d)] -> (B,T,d)."""
+    squeeze = means.dim() == 2
+    if squeeze:
+        means = means.unsqueeze(0)
+    B, T, D = means.shape
+    nW = R.shape[1] // R.shape[0]
+    d = D // nW
+    m = means.contiguous().view(B, T, nW, d).transpose(1, 2).contiguous().view(B, nW * T, d)
+    out = torch.matmul(R, m)
+    return out.squeeze(0) if squeeze else out
+
+
+# ----------------------------------------------------------------------------
+# stream index arithmetic (gantts/multistream.py)
+# ----------------------------------------------------------------------------
+def get_static_stream_sizes(stream_sizes, has_dynamic_features, num_windows):
+    # multistream.py:46-53 -- integer array; dynamic streams divided by num_windows
+    out = []
+    for s, dyn in zip(stream_sizes, has_dynamic_features):
+        out.append(int(s // num_windows) if dyn else int(s))
+    return np.array(out, dtype=np.int64)
+
+
+def select_streams(inputs, stream_sizes, streams):
+    # multistream.py:33-43
+    cols, start = [], 0
+    for size, enabled in zip(stream_sizes, streams):
+        if enabled:
+            cols.append(inputs[:, :, start:start + int(size)])
+        start += int(size)
+    return torch.cat(cols, dim=-1)
+
+
+def get_static_features(inputs, num_windows, stream_sizes, has_dynamic_features, streams=None):
+    # multistream.py:56-79
+    D = inputs.shape[-1]
+    if stream_sizes is None or (len(stream_sizes) == 1 and has_dynamic_features[0]):
+        return inputs[:, :, :D // num_windows]
+    if len(stream_sizes) == 1 and not has_dynamic_features[0]:
+        return inputs
+    if streams is None:
+        streams = [True] * len(stream_sizes)
+    cols, start = [], 0
+    for size, dyn, enabled in zip(stream_sizes, has_dynamic_features, streams):
+        if enabled:
+            w = size // num_windows if dyn else size
+            cols.append(inputs[:, :, start:start + w])
+        start += size
+    return torch.cat(cols, dim=-1)
+
+
+def multi_stream_mlpg(inputs, R, stream_sizes, has_dynamic_features, streams=None):
+    # multistream.py:82-123
+    if inputs.shape[-1] != sum(stream_sizes):
+        raise RuntimeError("You probably have specified wrong dimention params.")
+    if streams is None:
+        streams = [True] * len(stream_sizes)
+    cols, start = [], 0
+    for size, dyn, enabled in zip(stream_sizes, has_dynamic_features, streams):
+        if enabled:
+            x = inputs[:, :, start:start + size]
+            cols.append(unit_variance_mlpg(R, x) if dyn else x)
+        start += size
+    return torch.cat(cols, dim=-1)
+
+
+def adversarial_columns(stream_sizes, has_dynamic_features, num_windows,
+                        adversarial_streams, mask_nth_mgc):
+    """Column indices (into the static layout) fed to D: train.py:232-242."""
+    ss = get_static_stream_sizes(stream_sizes, has_dynamic_features, num_windows)
+    if adversarial_streams is None:
+        return list(range(int(ss.sum())))
+    cols, start = [], 0
+    for size, enabled in zip(ss, adversarial_streams):
+        if enabled:
+            cols.extend(range(start, start + int(size)))
+        start += int(size)
+    return cols[int(mask_nth_mgc):] if mask_nth_mgc > 0 else cols
+
+
+# ----------------------------------------------------------------------------
+# loss pieces (gantts/seqloss.py)
+# ----------------------------------------------------------------------------
+def sequence_mask(lengths, max_len=None):
+    lengths = torch.as_tensor(lengths).long()
+    if max_len is None:
+        max_len = int(lengths.max())
+    ar = torch.arange(0, max_len).long().unsqueeze(0)
+    return (ar < lengths.unsqueeze(1)).float()
+
+
+def masked_mse(inp, target, mask):
+    """sum((inp*m - target*m)^2) / sum(m)  -- divides by valid FRAMES (seqloss.py:42-43)."""
+    m = mask.expand_as(inp)
+    return F.mse_loss(inp * m, target * m, reduction="sum") / mask.sum()
+
+
+# ----------------------------------------------------------------------------
+# models
+# ----------------------------------------------------------------------------
+def linear_init(out_dim, in_dim, gen):
+    """nn.Linear default init: U(+-1/sqrt(in)) for weight and bias."""
+    k = 1.0 / math.sqrt(in_dim)
+    W = (torch.rand(out_dim, in_dim, generator=gen) * 2 - 1) * k
+    b = (torch.rand(out_dim, generator=gen) * 2 - 1) * k
+    return W, b
+
+
+class _DropoutSource(object):
+    """Hands out dropout masks: injected (list), or fresh Bernoulli(1-p) draws."""
+
+    def __init__(self, masks=None, generator=None):
+        self.masks = list(masks) if masks is not None else None
+        self.generator = generator
+        self.drawn = []
+
+    def next(self, like, p):
+        if self.masks is not None:
+            m = self.masks.pop(0)
+            assert m.shape == like.shape, (m.shape, like.shape)
+        else:
+            m = torch.bernoulli(torch.full_like(like, 1.0 - p), generator=self.generator)
+        self.drawn.append(m)
+        return m
+
+
+class OracleMLP(object):
+    """gantts/models.py:121-141.  state-dict keys: layers.{i}.weight/bias, last_linear.*"""
+
+    def __init__(self, in_dim=118, out_dim=1, num_hidden=2, hidden_dim=256,
+                 dropout=0.5, last_sigmoid=True, bidirectional=None, seed=0):
+        gen = torch.Generator().manual_seed(seed)
+        ins = [in_dim] + [hidden_dim] * (num_hidden - 1)
+        self.names, self.params = [], []
+        for i, n_in in enumerate(ins):
+            W, b = linear_init(hidden_dim, n_in, gen)
+            self.names += ["layers.%d.weight" % i, "layers.%d.bias" % i]
+            self.params += [W, b]
+        W, b = linear_init(out_dim, hidden_dim, gen)
+        self.names += ["last_linear.weight", "last_linear.bias"]
+        self.params += [W, b]
+        for p in self.params:
+            p.requires_grad_(True)
+        self.num_hidden, self.p, self.last_sigmoid = num_hidden, float(dropout), last_sigmoid
+        self.training = True
+
+    def include_parameter_generation(self):
+        return False
+
+    def state_dict(self):
+        return {n: p.detach().clone() for n, p in zip(self.names, self.params)}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for n, p in zip(self.names, self.params):
+                p.copy_(torch.as_tensor(sd[n]))
+
+    def forward(self, x, lengths=None, drop=None):
+        drop = drop or _DropoutSource()
+        for i in range(self.num_hidden):
+            W, b = self.params[2 * i], self.params[2 * i + 1]
+            x = F.leaky_relu(F.linear(x, W, b), LEAKY_SLOPE)
+            if self.training and self.p > 0:
+                x = x * drop.next(x, self.p) / (1.0 - self.p)
+        x = F.linear(x, self.params[-2], self.params[-1])
+        return torch.sigmoid(x) if self.last_sigmoid else x
+
+    __call__ = forward
+
+
+class OracleIn2OutHighwayNet(object):
+    """gantts/models.py:21-69.  keys: T.*, H.{i}.*, last_linear.*"""
+
+    def __init__(self, in_dim=118, out_dim=118, static_dim=59, num_hidden=3,
+                 hidden_dim=512, dropout=0.5, seed=0):
+        gen = torch.Generator().manual_seed(seed)
+        self.static_dim = static_dim
+        self.names, self.params = ["T.weight", "T.bias"], list(linear_init(static_dim, static_dim, gen))
+        ins = [in_dim] + [hidden_dim] * (num_hidden - 1)
+        for i, n_in in enumerate(ins):
+            W, b = linear_init(hidden_dim, n_in, gen)
+            self.names += ["H.%d.weight" % i, "H.%d.bias" % i]
+            self.params += [W, b]
+        W, b = linear_init(out_dim, hidden_dim, gen)
+        self.names += ["last_linear.weight", "last_linear.bias"]
+        self.params += [W, b]
+        for p in self.params:
+            p.requires_grad_(True)
+        self.num_hidden, self.p = num_hidden, float(dropout)
+        self.training = True
+
+    def include_parameter_generation(self):
+        return True
+
+    state_dict = OracleMLP.state_dict
+    load_state_dict = OracleMLP.load_state_dict
+
+    def forward(self, x, R, lengths=None, drop=None):
+        drop = drop or _DropoutSource()
+        x_static = x[:, :, :self.static_dim]
+        Tx = torch.sigmoid(F.linear(x_static, self.params[0], self.params[1]))
+        h = x
+        for i in range(self.num_hidden):
+            W, b = self.params[2 + 2 * i], self.params[3 + 2 * i]
+            h = F.leaky_relu(F.linear(h, W, b), LEAKY_SLOPE)
+            if self.training and self.p > 0:
+                h = h * drop.next(h, self.p) / (1.0 - self.p)
+        h = F.linear(h, self.params[-2], self.params[-1])
+        Gx = unit_variance_mlpg(R, h)
+        return h, x_static + Tx * Gx
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------
+# optimizers (torch.optim.Adagrad / Adam update rules, single param group)
+# ----------------------------------------------------------------------------
+def clip_grad_norm_(params, max_norm=1.0):
+    """torch.nn.utils.clip_grad_norm_ (L2): coef = clamp(max_norm/(||g||+1e-6), max=1)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    total = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+class OracleAdagrad(object):
+    def __init__(self, params, lr=0.01, lr_decay=0.0, weight_decay=0.0, eps=1e-10):
+        self.params = list(params)
+        self.lr, self.lr_decay, self.wd, self.eps = lr, lr_decay, weight_decay, eps
+        self.sum = [torch.zeros_like(p) for p in self.params]
+        self.step_count = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        self.step_count += 1
+        clr = self.lr / (1.0 + (self.step_count - 1) * self.lr_decay)
+        with torch.no_grad():
+            for p, s in zip(self.params, self.sum):
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if self.wd != 0:
+                    g = g + self.wd * p
+                s.addcmul_(g, g, value=1.0)
+                p.addcdiv_(g, s.sqrt() + self.eps, value=-clr)
+
+
+class OracleAdam(object):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = list(params)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.step_count = 0
+
+    zero_grad = OracleAdagrad.zero_grad
+
+    def step(self):
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        with torch.no_grad():
+            for p, m, v in zip(self.params, self.m, self.v):
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if self.wd != 0:
+                    g = g + self.wd * p
+                m.mul_(b1).add_(g, alpha=1.0 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                denom = (v.sqrt() / math.sqrt(bc2)) + self.eps
+                p.addcdiv_(m, denom, value=-self.lr / bc1)
+
+
+def make_optimizer(kind, params, **kw):
+    return {"Adagrad": OracleAdagrad, "Adam": OracleAdam}[kind](params, **kw)
+
+
+# ----------------------------------------------------------------------------
+# step functions (train.py)
+# ----------------------------------------------------------------------------
+class StreamConfig(object):
+    """The hp.* fields the step functions read (train.py:61,233-241,248,254,299,304,352)."""
+
+    def __init__(self, stream_sizes, has_dynamic_features, num_windows,
+                 adversarial_streams=None, mask_nth_mgc_for_adv_loss=0,
+                 discriminator_linguistic_condition=False):
+        self.stream_sizes = list(stream_sizes)
+        self.has_dynamic_features = list(has_dynamic_features)
+        self.num_windows = int(num_windows)
+        self.adversarial_streams = None if adversarial_streams is None else list(adversarial_streams)
+        self.mask_nth_mgc_for_adv_loss = int(mask_nth_mgc_for_adv_loss)
+        self.discriminator_linguistic_condition = bool(discriminator_linguistic_condition)
+
+    def adv_cols(self):
+        return adversarial_columns(self.stream_sizes, self.has_dynamic_features, self.num_windows,
+                                   self.adversarial_streams, self.mask_nth_mgc_for_adv_loss)
+
+
+def apply_generator(cfg, model_g, x, R, lengths, drop=None):
+    """train.py:336-355"""
+    if model_g.include_parameter_generation():
+        return model_g(x, R, lengths=lengths, drop=drop)
+    y_hat = model_g(x, lengths=lengths, drop=drop)
+    y_hat_static = multi_stream_mlpg(y_hat, R, cfg.stream_sizes, cfg.has_dynamic_features) \
+        if R is not None else y_hat
+    return y_hat, y_hat_static
+
+
+def _adv_input(cfg, x, feats):
+    sel = feats[:, :, cfg.adv_cols()] if cfg.adversarial_streams is not None else feats
+    return torch.cat((x, sel), -1) if cfg.discriminator_linguistic_condition else sel
+
+
+def update_discriminator(cfg, model_d, optimizer_d, x, y_static, y_hat_static, lengths,
+                         mask, phase, eps=1e-20, drop=None):
+    """train.py:245-279.  y_hat_static is NOT detached: loss_d.backward also fills G grads."""
+    real_in = _adv_input(cfg, x, y_static)
+    fake_in = _adv_input(cfg, x, y_hat_static)
+    Tv = mask.sum().item()
+    D_real = model_d(real_in, lengths=lengths, drop=drop)
+    real_correct = ((D_real > 0.5).float() * mask).sum().item()
+    D_fake = model_d(fake_in, lengths=lengths, drop=drop)
+    fake_correct = ((D_fake < 0.5).float() * mask).sum().item()
+    loss_real = -(torch.log(D_real + eps) * mask).sum() / Tv
+    loss_fake = -(torch.log(1 - D_fake + eps) * mask).sum() / Tv
+    loss_d = loss_real + loss_fake
+    if phase == "train":
+        loss_d.backward(retain_graph=True)
+        clip_grad_norm_(model_d.params, 1.0)
+        optimizer_d.step()
+    return loss_d.item(), loss_fake.item(), loss_real.item(), real_correct, fake_correct
+
+
+def update_generator(cfg, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
+                     adv_w, lengths, mask, phase, mse_w=None, mge_w=None, eps=1e-20, drop=None):
+    """train.py:282-320.  D forward here uses the ALREADY UPDATED D weights."""
+    Tv = mask.sum().item()
+    loss_mge = masked_mse(y_hat_static, y_static, mask)
+    loss_mse = masked_mse(y_hat, y, mask)
+    if adv_w > 0:
+        fake_in = _adv_input(cfg, x, y_hat_static)
+        loss_adv = -(torch.log(model_d(fake_in, lengths=lengths, drop=drop) + eps) * mask).sum() / Tv
+    else:
+        loss_adv = torch.zeros(1)
+    loss_g = (mse_w * loss_mse + mge_w * loss_mge) + adv_w * loss_adv
+    if phase == "train":
+        loss_g.backward()
+        clip_grad_norm_(model_g.params, 1.0)
+        optimizer_g.step()
+    return loss_mse.item(), loss_mge.item(), loss_adv.item(), loss_g.item()
+
+
+def train_step(cfg, model_g, model_d, opt_g, opt_d, x, y, R, lengths, mask,
+               adv_w=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=True,
+               phase="train", drop_g=None, drop_d=None):
+    """One batch of train.py:train_loop (:528-585) without data loading / metrics."""
+    y_static = get_static_features(y, cfg.num_windows, cfg.stream_sizes, cfg.has_dynamic_features)
+    opt_g.zero_grad()
+    opt_d.zero_grad()
+    y_hat, y_hat_static = apply_generator(cfg, model_g, x, R, lengths, drop=drop_g)
+    out = {"y_hat": y_hat.detach(), "y_hat_static": y_hat_static.detach()}
+    if update_d:
+        out["d"] = update_discriminator(cfg, model_d, opt_d, x, y_static, y_hat_static,
+                                        lengths, mask, phase, drop=drop_d)
+    if update_g:
+        out["g"] = update_generator(cfg, model_g, model_d, opt_g, x, y, y_hat, y_static,
+                                    y_hat_static, adv_w, lengths, mask, phase,
+                                    mse_w=mse_w, mge_w=mge_w, drop=drop_d)
+    return out

@@ -1,0 +1,193 @@
+"""Seeded, toolchain-independent definitions of the golden cases.
+
+Shared by ``make_golden.py`` (drives the REAL reference in the build container),
+``tests/test_oracle.py`` (pins the CPU restatement) and the ``-m gpu`` parity tests
+(HIP engine vs oracle vs fixtures).  Everything random comes from
+``numpy.random.RandomState`` so inputs/weights/masks are bit-identical everywhere.
+"""
+import math
+
+import numpy as np
+
+WINDOWS = [
+    (0, 0, np.array([1.0])),
+    (1, 1, np.array([-0.5, 0.0, 0.5])),
+    (1, 1, np.array([1.0, -2.0, 1.0])),
+]
+
+# name -> case description.  "hp" mirrors the hp.* fields read on the step path.
+CASES = {
+    # cfg2 (headline) shape family at reduced size: TTS acoustic MLP G/D, conditioned D.
+    "acoustic_mlp": dict(
+        hp="tts_acoustic", B=4, T=40, din=425, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=64,
+               dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=32,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # same, with dropout masks injected and a non-zero MSE weight
+    "acoustic_mlp_dropout": dict(
+        hp="tts_acoustic", B=3, T=33, din=425, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=64,
+               dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=32,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=0.7, mse_w=0.25, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
+    # multi-stream adversarial selection (mgc + bap), unconditioned D, Adam
+    "acoustic_multistream_adam": dict(
+        hp="tts_acoustic", B=3, T=24, din=40, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, True], mask_nth_mgc=0, cond=False,
+        g=dict(kind="MLP", in_dim=40, out_dim=187, num_hidden=2, hidden_dim=48,
+               dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=61, out_dim=1, num_hidden=2, hidden_dim=24,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # cfg1: VC In2OutHighwayNet (order 25) + MLP D, CPU plumbing config at reduced size
+    "vc_in2out": dict(
+        hp="vc", B=3, T=48, din=75, dout=75,
+        stream_sizes=[75], has_dynamic_features=[True],
+        adversarial_streams=[True], mask_nth_mgc=0, cond=False,
+        g=dict(kind="In2OutHighwayNet", in_dim=75, out_dim=75, static_dim=25,
+               num_hidden=3, hidden_dim=64, dropout=0.5),
+        d=dict(kind="MLP", in_dim=25, out_dim=1, num_hidden=2, hidden_dim=32,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=0)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
+        windows=3, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # duration model: no dynamic features (R=None), Adam, conditioned D
+    "duration_mlp": dict(
+        hp="tts_duration", B=5, T=17, din=60, dout=5,
+        stream_sizes=[5], has_dynamic_features=[False],
+        adversarial_streams=[True], mask_nth_mgc=0, cond=True,
+        g=dict(kind="MLP", in_dim=60, out_dim=5, num_hidden=2, hidden_dim=32,
+               dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=65, out_dim=1, num_hidden=3, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=1, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # curriculum stages (train_gan.sh): D warm-up only / G only with w_d=0
+    "acoustic_d_warmup": dict(
+        hp="tts_acoustic", B=3, T=20, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32,
+               dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=False),
+    "acoustic_g_only": dict(
+        hp="tts_acoustic", B=3, T=20, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32,
+               dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=0.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=False, update_g=True),
+}
+
+
+def param_shapes(spec):
+    """(name, shape) in state_dict / parameters() order for a model spec."""
+    kind = spec["kind"]
+    out = []
+    if kind == "MLP":
+        ins = [spec["in_dim"]] + [spec["hidden_dim"]] * (spec["num_hidden"] - 1)
+        for i, n_in in enumerate(ins):
+            out += [("layers.%d.weight" % i, (spec["hidden_dim"], n_in)),
+                    ("layers.%d.bias" % i, (spec["hidden_dim"],))]
+        out += [("last_linear.weight", (spec["out_dim"], spec["hidden_dim"])),
+                ("last_linear.bias", (spec["out_dim"],))]
+    elif kind == "In2OutHighwayNet":
+        sd = spec["static_dim"]
+        out += [("T.weight", (sd, sd)), ("T.bias", (sd,))]
+        ins = [spec["in_dim"]] + [spec["hidden_dim"]] * (spec["num_hidden"] - 1)
+        for i, n_in in enumerate(ins):
+            out += [("H.%d.weight" % i, (spec["hidden_dim"], n_in)),
+                    ("H.%d.bias" % i, (spec["hidden_dim"],))]
+        out += [("last_linear.weight", (spec["out_dim"], spec["hidden_dim"])),
+                ("last_linear.bias", (spec["out_dim"],))]
+    else:
+        raise ValueError(kind)
+    return out
+
+
+def make_weights(spec, seed):
+    """U(+-1/sqrt(fan_in)) like nn.Linear's default init, from numpy RandomState."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    shapes = param_shapes(spec)
+    fan_in = None
+    for name, shape in shapes:
+        if name.endswith("weight"):
+            fan_in = shape[1]
+        k = 1.0 / math.sqrt(fan_in)
+        sd[name] = ((rs.rand(*shape) * 2 - 1) * k).astype(np.float32)
+    return sd
+
+
+def make_lengths(B, T, seed):
+    rs = np.random.RandomState(seed)
+    lens = np.sort(rs.randint(max(1, T // 2), T + 1, size=B))[::-1].copy()
+    lens[0] = T
+    return lens.astype(np.int64)
+
+
+def make_batch(case, seed=1234):
+    """x in [0.01,0.99] (min-max scaled linguistic features), y ~ N(0,1) with a
+    standardised binary vuv column; zero beyond each length (train.py:139-142)."""
+    B, T, din, dout = case["B"], case["T"], case["din"], case["dout"]
+    rs = np.random.RandomState(seed)
+    x = (0.01 + 0.98 * rs.rand(B, T, din)).astype(np.float32)
+    y = rs.randn(B, T, dout).astype(np.float32)
+    if case["stream_sizes"] == [180, 3, 1, 3]:
+        v = (rs.rand(B, T) > 0.5).astype(np.float32)
+        y[:, :, 183] = (v - 0.5) / 0.5
+    lengths = make_lengths(B, T, seed + 1)
+    for b, n in enumerate(lengths):
+        x[b, n:] = 0
+        y[b, n:] = 0
+    return x, y, lengths
+
+
+def hidden_sites(spec):
+    return [spec["hidden_dim"]] * spec["num_hidden"]
+
+
+def make_dropout_masks(case, step, seed=99):
+    """Per step: masks for G forward (1 pass), D real, D fake (D step), D fake (G step).
+    Returned in the order the reference consumes nn.Dropout calls."""
+    rs = np.random.RandomState(seed + 1000 * step)
+    B, T = case["B"], case["T"]
+
+    def draw(spec):
+        if spec["dropout"] <= 0:
+            return []
+        return [(rs.rand(B, T, h) >= spec["dropout"]).astype(np.float32) for h in hidden_sites(spec)]
+
+    g = draw(case["g"])
+    d = draw(case["d"]) + draw(case["d"]) + draw(case["d"])
+    return g, d

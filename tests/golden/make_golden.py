@@ -1,0 +1,147 @@
+"""Generate golden vectors by running the REAL reference (r9y9/gantts @ /root/reference).
+
+Build-container only (the reference tree does not exist on the GPU box).  Usage:
+
+    python tests/golden/make_golden.py            # writes tests/golden/<case>.npz
+
+For every case in ``cases.py`` this executes the reference's own
+``train.apply_generator`` / ``train.update_discriminator`` / ``train.update_generator``
+(train.py:336-355, 245-279, 282-320) with ``gantts.models`` modules and
+``torch.optim`` optimizers, on seeded numpy inputs/weights, in the order
+``train_loop`` uses them (train.py:528-585), and records outputs, the 9 step scalars,
+the G gradient norm right after the D update (the D->G leak), and the final
+parameters / optimizer state.  Dropout parity uses injected masks: ``nn.Dropout.forward``
+is patched to multiply by a supplied mask and 1/(1-p) (what torch's dropout computes).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+
+import cases as C  # noqa: E402
+import ref_loader  # noqa: E402
+
+
+def run_case(name, case):
+    train, hparams, gantts = ref_loader.load_reference()
+    from gantts.multistream import get_static_features
+    from gantts.seqloss import sequence_mask
+    from nnmnkwii.paramgen import unit_variance_mlpg_matrix
+
+    hp = getattr(hparams, case["hp"])
+    saved = dict(hp.__dict__)
+    try:
+        windows = C.WINDOWS[:case["windows"]]
+        hp.__dict__.update(
+            stream_sizes=case["stream_sizes"], has_dynamic_features=case["has_dynamic_features"],
+            windows=windows, adversarial_streams=case["adversarial_streams"],
+            mask_nth_mgc_for_adv_loss=case["mask_nth_mgc"],
+            discriminator_linguistic_condition=case["cond"])
+        train.hp = hp
+
+        def build(spec, seed):
+            kw = {k: v for k, v in spec.items() if k != "kind"}
+            m = getattr(gantts.models, spec["kind"])(**kw)
+            sd = {k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed).items()}
+            m.load_state_dict(sd)
+            return m
+
+        model_g, model_d = build(case["g"], 11), build(case["d"], 22)
+        og = getattr(torch.optim, case["opt_g"][0])(model_g.parameters(), **case["opt_g"][1])
+        od = getattr(torch.optim, case["opt_d"][0])(model_d.parameters(), **case["opt_d"][1])
+
+        queue = []
+        orig_dropout = torch.nn.Dropout.forward
+
+        def patched(self, inp):
+            if not self.training or self.p == 0:
+                return inp
+            m = queue.pop(0)
+            assert m.shape == inp.shape, (m.shape, inp.shape)
+            return inp * m / (1.0 - self.p)
+
+        torch.nn.Dropout.forward = patched
+        if case["dropout_on"]:
+            model_g.train(), model_d.train()
+        else:
+            model_g.eval(), model_d.eval()
+
+        x_np, y_np, lengths = C.make_batch(case)
+        x, y = torch.from_numpy(x_np), torch.from_numpy(y_np)
+        T = case["T"]
+        has_dyn = bool(np.any(case["has_dynamic_features"]))
+        R = torch.from_numpy(unit_variance_mlpg_matrix(windows, T)) if has_dyn else None
+        sl = torch.from_numpy(lengths)
+        cpu_lengths = list(sl)
+        out = {}
+        try:
+            for step in range(case["steps"]):
+                if case["dropout_on"]:
+                    gm, dm = C.make_dropout_masks(case, step)
+                    queue[:] = [torch.from_numpy(m) for m in gm + dm]
+                y_static = get_static_features(y, len(windows), hp.stream_sizes, hp.has_dynamic_features)
+                mask = sequence_mask(sl).unsqueeze(-1)
+                og.zero_grad()
+                od.zero_grad()
+                y_hat, y_hat_static = train.apply_generator(model_g, x, R, cpu_lengths)
+                if step == 0:
+                    out["y_hat"] = y_hat.detach().numpy().copy()
+                    out["y_hat_static"] = y_hat_static.detach().numpy().copy()
+                if case["update_d"]:
+                    res = train.update_discriminator(model_d, od, x, y_static, y_hat_static,
+                                                     cpu_lengths, mask, "train")
+                    out["d_scalars_%d" % step] = np.array(res, dtype=np.float64)
+                    gn = [p.grad for p in model_g.parameters() if p.grad is not None]
+                    out["g_leak_norm_%d" % step] = np.array(
+                        float(torch.sqrt(sum((g ** 2).sum() for g in gn))) if gn else 0.0)
+                if case["update_g"]:
+                    res = train.update_generator(model_g, model_d, og, x, y, y_hat, y_static,
+                                                 y_hat_static, case["adv_w"], cpu_lengths, mask, "train",
+                                                 mse_w=case["mse_w"], mge_w=case["mge_w"])
+                    out["g_scalars_%d" % step] = np.array(res, dtype=np.float64)
+                if case["dropout_on"] and not case["update_g"]:
+                    queue[:] = []
+                assert not queue, "unused dropout masks: %d" % len(queue)
+        finally:
+            torch.nn.Dropout.forward = orig_dropout
+
+        for k, v in model_g.state_dict().items():
+            out["G." + k] = v.numpy().copy()
+        for k, v in model_d.state_dict().items():
+            out["D." + k] = v.numpy().copy()
+        for tag, opt, model in (("G", og, model_g), ("D", od, model_d)):
+            names = list(model.state_dict().keys())
+            for i, p in enumerate(opt.param_groups[0]["params"]):
+                st = opt.state.get(p, {})
+                for key in ("sum", "exp_avg", "exp_avg_sq"):
+                    if key in st:
+                        out["%s.opt.%s.%s" % (tag, key, names[i])] = st[key].numpy().copy()
+        return out
+    finally:
+        hp.__dict__.clear()
+        hp.__dict__.update(saved)
+
+
+def main():
+    only = sys.argv[1:]
+    for name, case in C.CASES.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        out = run_case(name, case)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-28s -> %s (%.1f KB)" % (name, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+        for k in sorted(out):
+            if "scalars" in k or "leak" in k:
+                print("    %-18s %s" % (k, np.array2string(np.atleast_1d(out[k]), precision=6)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/gantts_oracle.py): against the golden fixtures generated
+from the REAL reference (tests/golden/*.npz), against torch.optim, against the
+self-consistency properties of MLPG, and -- when the reference tree is present (build
+container only) -- live against the reference's own functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import gantts_oracle as O
+from oracle_runner import run_oracle_case
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(C.CASES))
+def test_oracle_matches_reference_golden(name):
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_oracle_case(C.CASES[name])
+    assert set(gold.files) == set(got.keys())
+    for k in gold.files:
+        g, o = gold[k], np.asarray(got[k])
+        if "scalars" in k:
+            np.testing.assert_allclose(o, g, rtol=2e-6, atol=1e-7, err_msg=k)
+            if k.startswith("d_scalars"):
+                assert o[3] == g[3] and o[4] == g[4], k  # counts exact
+        else:
+            np.testing.assert_allclose(o, g, rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+def test_mlpg_matrix_is_left_inverse_of_window_stack():
+    for T in (5, 17, 64):
+        W = np.vstack([O._window_matrix(l, u, c, T) for (l, u, c) in C.WINDOWS])
+        R = O.unit_variance_mlpg_matrix(C.WINDOWS, T).astype(np.float64)
+        np.testing.assert_allclose(R @ W, np.eye(T), atol=1e-5)
+
+
+def test_mlpg_recovers_static_from_consistent_deltas():
+    T, d = 50, 4
+    rs = np.random.RandomState(0)
+    c = rs.randn(T, d)
+    feats = np.concatenate([O._window_matrix(l, u, w, T) @ c for (l, u, w) in C.WINDOWS], axis=1)
+    R = torch.from_numpy(O.unit_variance_mlpg_matrix(C.WINDOWS, T))
+    out = O.unit_variance_mlpg(R, torch.from_numpy(feats.astype(np.float32)))
+    np.testing.assert_allclose(out.numpy(), c, atol=1e-4)
+
+
+def test_mlpg_matrix_is_numerically_banded():
+    R = O.unit_variance_mlpg_matrix(C.WINDOWS, 256)
+    T = 256
+    t = np.arange(T)
+    for w in range(3):
+        blk = np.abs(R[:, w * T:(w + 1) * T])
+        far = np.abs(t[:, None] - t[None, :]) > 24
+        assert blk[far].max() < 1e-10
+
+
+def test_stream_index_arithmetic_reference_cases():
+    # mirrors reference tests/test_gantts.py:60-129 (exact equality of selected columns)
+    ss = [60, 1, 1, 1]
+    x = torch.arange(0, 63).expand(2, 5, 63)
+    assert O.select_streams(x, ss, [True, True, True, True]).shape == (2, 5, 63)
+    assert O.select_streams(x, ss, [True, False, False, True]).shape == (2, 5, 61)
+    assert (O.select_streams(x, ss, [False, False, False, True]).squeeze(-1) == x[:, :, -1]).all()
+    assert (O.select_streams(x, ss, [False, True, False, False]).squeeze(-1) == x[:, :, -3]).all()
+    assert list(O.get_static_stream_sizes([180, 3, 1, 3], [True, True, False, True], 3)) == [60, 1, 1, 1]
+    y = torch.rand(2, 5, 187)
+    s = O.get_static_features(y, 3, [180, 3, 1, 3], [True, True, False, True])
+    assert s.shape == (2, 5, 63)
+    assert torch.equal(s[:, :, :60], y[:, :, :60]) and torch.equal(s[:, :, 61], y[:, :, 183])
+    assert O.adversarial_columns([180, 3, 1, 3], [True, True, False, True], 3,
+                                 [True, False, False, False], 2) == list(range(2, 60))
+    assert O.adversarial_columns([180, 3, 1, 3], [True, True, False, True], 3,
+                                 [True, False, False, True], 0) == list(range(60)) + [62]
+
+
+def test_multi_stream_mlpg_matches_per_stream_and_vuv_passthrough():
+    # reference tests/test_gantts.py:132-163
+    T = 30
+    R = torch.from_numpy(O.unit_variance_mlpg_matrix(C.WINDOWS, T))
+    x = torch.rand(4, T, 187)
+    y = O.multi_stream_mlpg(x, R, [180, 3, 1, 3], [True, True, False, True])
+    assert y.shape == (4, T, 63)
+    assert torch.equal(O.unit_variance_mlpg(R, x[:, :, :180]), y[:, :, :60])
+    assert torch.equal(O.unit_variance_mlpg(R, x[:, :, 180:183]).squeeze(-1), y[:, :, 60])
+    assert torch.equal(x[:, :, 183], y[:, :, 61])
+    assert torch.equal(O.unit_variance_mlpg(R, x[:, :, 184:187]).squeeze(-1), y[:, :, 62])
+    with pytest.raises(RuntimeError):
+        O.multi_stream_mlpg(x[:, :, :100], R, [180, 3, 1, 3], [True, True, False, True])
+
+
+@pytest.mark.parametrize("kind,kw", [("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+                                     ("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0))])
+def test_optimizer_restatement_matches_torch_optim(kind, kw):
+    torch.manual_seed(0)
+    p0 = [torch.randn(7, 5), torch.randn(5)]
+    a = [p.clone().requires_grad_(True) for p in p0]
+    b = [p.clone().requires_grad_(True) for p in p0]
+    oa = O.make_optimizer(kind, a, **kw)
+    ob = getattr(torch.optim, kind)(b, **kw)
+    for _ in range(4):
+        gs = [torch.randn_like(p) * 3 for p in p0]
+        for p, q, g in zip(a, b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        O.clip_grad_norm_(a, 1.0)
+        torch.nn.utils.clip_grad_norm_(b, 1.0)
+        oa.step(), ob.step()
+    for p, q in zip(a, b):
+        np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_masked_mse_divides_by_valid_frames():
+    m = O.sequence_mask([3, 1], 4).unsqueeze(-1)
+    a, b = torch.ones(2, 4, 5), torch.zeros(2, 4, 5)
+    assert float(O.masked_mse(a, b, m)) == pytest.approx(5.0)  # 4 valid frames * 5 dims / 4
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/train.py"), reason="reference tree absent")
+def test_oracle_live_against_reference_models():
+    import ref_loader
+    train, hparams, gantts = ref_loader.load_reference()
+    spec = dict(kind="MLP", in_dim=20, out_dim=7, num_hidden=2, hidden_dim=16, dropout=0.5, last_sigmoid=True)
+    ref = gantts.models.MLP(**{k: v for k, v in spec.items() if k != "kind"}).eval()
+    sd = C.make_weights(spec, 3)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    mine = O.OracleMLP(**{k: v for k, v in spec.items() if k != "kind"})
+    mine.load_state_dict(sd)
+    mine.training = False
+    x = torch.rand(2, 9, 20)
+    assert torch.allclose(ref(x), mine(x), atol=1e-7)
+    assert list(ref.state_dict().keys()) == mine.names
