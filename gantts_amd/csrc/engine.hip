@@ -1,0 +1,1056 @@
+// libgantts_hip.so -- host orchestration + C ABI (include/gantts_hip.h) of the MI355X GAN step.
+//
+// The engine keeps the reference's step semantics (train.py:245-320) while restructuring the
+// work for the hardware:
+//   * D(real) and D(fake) of the D step run as ONE 2N-row pass (same weights), so the frame x
+//     weight GEMMs see 32768 rows at the headline config;
+//   * G is back-propagated ONCE per step: dloss_d/dy_hat_static (old D weights, the reference's
+//     un-detached "leak", train.py:265,274) is stashed and summed with dloss_g/dy_hat_static at
+//     y_hat_static before MLPG^T and the G backward (backward is linear in the upstream gradient);
+//   * the G-step D pass computes no weight gradients (the reference's are discarded by the next
+//     zero_grad, train.py:538-539);
+//   * every reduction is two-stage with a fixed order => run-to-run bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/gantts_hip.h"
+#include "frame_kernels.hip.h"
+#include "gemm_f32.hip.h"
+
+using namespace gt;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(GT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != GT_OK) return _r; \
+  } while (0)
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+extern "C" const char* gt_last_error(void) { return g_err; }
+extern "C" const char* gt_version(void) { return "gantts_hip 0.1 (gfx950, f32 MFMA)"; }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------
+// GEMM dispatch
+// ------------------------------------------------------------------------------------------
+template <int KIND, int BM, int BN>
+static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = gemm_lds_bytes<BM, BN>();
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, BM, BN>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  g.n_tiles_m = cdiv(g.M, BM);
+  g.n_tiles_n = cdiv(g.N, BN);
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  if (grid <= 0) return GT_OK;
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
+
+static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
+  const int bn = pick_bn(g.N);
+  switch (kind) {
+    case GEMM_NT: return bn == 64 ? launch_gemm_t<GEMM_NT, 128, 64>(g, 1, s) : launch_gemm_t<GEMM_NT, 128, 128>(g, 1, s);
+    case GEMM_NN: return bn == 64 ? launch_gemm_t<GEMM_NN, 128, 64>(g, 1, s) : launch_gemm_t<GEMM_NN, 128, 128>(g, 1, s);
+    default: return bn == 64 ? launch_gemm_t<GEMM_TN, 128, 64>(g, nslab, s) : launch_gemm_t<GEMM_TN, 128, 128>(g, nslab, s);
+  }
+}
+
+static DropoutSpec no_drop() {
+  DropoutSpec d;
+  memset(&d, 0, sizeof(d));
+  d.mode = DROP_NONE;
+  d.scale = 1.f;
+  return d;
+}
+
+// Y = act(X W^T + b)
+static int linear_forward(const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int ldy,
+                          long rows, int in, int out, int act, const DropoutSpec& drop, hipStream_t s) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+  g.M = (int)rows; g.N = out; g.K = in; g.bias = b; g.act = act; g.drop = drop;
+  return launch_gemm(GEMM_NT, g, 1, s);
+}
+// dX = (dZ W[:, col0:col0+ncols]) (.) f'(H)
+static int linear_backward_data(const float* dZ, int lddz, const float* W, int ldw, int col0, float* dX, int lddx,
+                                long rows, int out, int ncols, int act_prev, const float* H, int ldh,
+                                const DropoutSpec& drop, hipStream_t s) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dZ; g.lda = lddz; g.B = W + col0; g.ldb = ldw; g.C = dX; g.ldc = lddx;
+  g.M = (int)rows; g.N = ncols; g.K = out; g.act = act_prev; g.H = H; g.ldh = ldh; g.drop = drop;
+  return launch_gemm(GEMM_NN, g, 1, s);
+}
+
+struct Scratch {  // growable device buffer
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return GT_OK;
+    if (p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(p)); p = nullptr; bytes = 0; }
+    const size_t cap = need + need / 8;
+    HIPCHK(hipMalloc(&p, cap));
+    bytes = cap;
+    return GT_OK;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+// dW (+)= dZ^T X ; db (+)= colsum(dZ)   -- split over the frame dimension, fixed-order combine
+static int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
+                                  float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s) {
+  if (dW) {
+    const int bn = pick_bn(in);
+    const int tiles = cdiv(out, 128) * cdiv(in, bn);
+    int nslab = cdiv(768, tiles);
+    const int max_slab = (int)((rows + 255) / 256);
+    if (nslab > max_slab) nslab = max_slab;
+    if (nslab < 1) nslab = 1;
+    int k_chunk = cdiv(cdiv(rows, nslab), GEMM_BK) * GEMM_BK;
+    nslab = cdiv(rows, k_chunk);
+    const long slab_stride = (long)out * in;
+    CHK(slabs.ensure((size_t)nslab * slab_stride * sizeof(float)));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dZ; g.lda = lddz; g.B = X; g.ldb = ldx; g.C = slabs.as<float>(); g.ldc = in;
+    g.M = out; g.N = in; g.K = (int)rows; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+    g.drop = no_drop();
+    CHK(launch_gemm(GEMM_TN, g, nslab, s));
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slabs.as<float>(),
+                       slab_stride, nslab, slab_stride, dW, accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  if (db) {
+    const int rows_per_blk = 256;
+    const int nblk = cdiv(rows, rows_per_blk);
+    CHK(colp.ensure((size_t)nblk * out * sizeof(float)));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, s, dZ, lddz, rows, out, rows_per_blk, colp.as<float>());
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, colp.as<float>(), nblk, out, db,
+                       accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// engine state
+// ------------------------------------------------------------------------------------------
+struct Lin { float *W, *b, *dW, *db; int in, out; };
+
+struct Net {
+  bool bound = false;
+  gt_model_desc d;
+  std::vector<Lin> hidden;
+  Lin last, gate;
+  bool training = true;
+  bool grads_dirty = false;      // false after zero_grad: next backward overwrites instead of accumulating
+  bool has_opt = false;
+  gt_optim_desc od;
+  long step = 0;
+  // injected dropout masks [pass][layer]
+  const float* inj[3][16];
+  Net() { memset(inj, 0, sizeof(inj)); }
+};
+
+struct MlpgCache {
+  const float* R = nullptr;
+  int T = 0, kb = 0;
+  Scratch band;
+};
+
+struct gt_engine {
+  gt_stream_config cfg;
+  Net net[2];
+  uint64_t seed = 0x5DEECE66DULL;
+  uint64_t step_counter = 0;
+  float tv_override = -1.f;
+  // derived stream maps (device)
+  int Dout_cfg = 0, Ds = 0, Da = 0;
+  std::vector<int> h_scol, h_sstride, h_adv_cols, h_adv_inv;
+  int *d_scol = nullptr, *d_sstride = nullptr, *d_adv_cols = nullptr, *d_adv_inv = nullptr;
+  // In2Out uses a single dynamic stream of width out_dim
+  int *d_scol_i2o = nullptr, *d_sstride_i2o = nullptr; int i2o_ds = 0;
+  MlpgCache mlpg;
+  // workspace
+  std::vector<Scratch> g_act, d_act;       // hidden activations
+  Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, dmask, tx, gx, dgx, dtz, dout;
+  Scratch scal;                            // StepScalars + StepResults
+  StepResults* h_res = nullptr;            // pinned
+  // per-step state
+  int B = 0, T = 0; long N = 0;
+  const float* last_x = nullptr; const float* last_yhat = nullptr; const float* last_yhs = nullptr;
+  bool g_pass_valid = false, leak_pending = false, fake_cat_valid = false;
+  const float* fake_cat_x = nullptr; const float* fake_cat_yhs = nullptr;
+  bool d_begin_done = false, g_begin_done = false, g_has_adv = false, g_used_mlpg = false;
+  std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
+  StepScalars* sc() { return scal.as<StepScalars>(); }
+  StepResults* res() { return (StepResults*)((char*)scal.p + 256); }
+};
+
+static int upload_ints(const std::vector<int>& v, int** dptr) {
+  if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+  if (v.empty()) return GT_OK;
+  HIPCHK(hipMalloc((void**)dptr, v.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(*dptr, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return GT_OK;
+}
+
+extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
+  if (!cfg || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (cfg->n_streams < 1 || cfg->n_streams > GT_MAX_STREAMS) return fail(GT_ERR_INVALID, "n_streams out of range");
+  if (cfg->num_windows < 1) return fail(GT_ERR_INVALID, "num_windows must be >= 1");
+  gt_engine* e = new gt_engine();
+  e->cfg = *cfg;
+  // static layout: get_static_stream_sizes (multistream.py:46-53) + per-column source map
+  int col = 0, scol_out = 0;
+  std::vector<int> static_start, static_size;
+  for (int s = 0; s < cfg->n_streams; ++s) {
+    const int sz = cfg->stream_sizes[s];
+    const bool dyn = cfg->has_dynamic_features[s] != 0;
+    const int ss = dyn ? sz / cfg->num_windows : sz;
+    static_start.push_back(scol_out);
+    static_size.push_back(ss);
+    for (int c = 0; c < ss; ++c) {
+      e->h_scol.push_back(col + c);
+      e->h_sstride.push_back(dyn ? ss : 0);
+    }
+    col += sz;
+    scol_out += ss;
+  }
+  e->Dout_cfg = col;
+  e->Ds = scol_out;
+  // adversarial columns: select_streams on the static layout, then drop the first n (train.py:232-242)
+  if (cfg->adversarial_streams[0] < 0) {
+    for (int c = 0; c < e->Ds; ++c) e->h_adv_cols.push_back(c);
+  } else {
+    for (int s = 0; s < cfg->n_streams; ++s)
+      if (cfg->adversarial_streams[s])
+        for (int c = 0; c < static_size[s]; ++c) e->h_adv_cols.push_back(static_start[s] + c);
+    if (cfg->mask_nth_mgc_for_adv_loss > 0) {
+      if ((size_t)cfg->mask_nth_mgc_for_adv_loss >= e->h_adv_cols.size()) { delete e; return fail(GT_ERR_INVALID, "mask_nth_mgc_for_adv_loss too large"); }
+      e->h_adv_cols.erase(e->h_adv_cols.begin(), e->h_adv_cols.begin() + cfg->mask_nth_mgc_for_adv_loss);
+    }
+  }
+  e->Da = (int)e->h_adv_cols.size();
+  e->h_adv_inv.assign(e->Ds, -1);
+  for (int j = 0; j < e->Da; ++j) e->h_adv_inv[e->h_adv_cols[j]] = j;
+  int r;
+  if ((r = upload_ints(e->h_scol, &e->d_scol)) || (r = upload_ints(e->h_sstride, &e->d_sstride)) ||
+      (r = upload_ints(e->h_adv_cols, &e->d_adv_cols)) || (r = upload_ints(e->h_adv_inv, &e->d_adv_inv))) { delete e; return r; }
+  if ((r = e->scal.ensure(1024))) { delete e; return r; }
+  if (hipMemset(e->scal.p, 0, 1024) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMemset failed"); }
+  if (hipHostMalloc((void**)&e->h_res, sizeof(StepResults)) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  *out = e;
+  return GT_OK;
+}
+
+extern "C" void gt_engine_destroy(gt_engine* e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  for (auto& s : e->g_act) s.release();
+  for (auto& s : e->d_act) s.release();
+  Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
+                    &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.band};
+  for (auto* s : all) s->release();
+  int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
+  for (int* p : ints) if (p) (void)hipFree(p);
+  if (e->h_res) (void)hipHostFree(e->h_res);
+  delete e;
+}
+
+static long expected_params(const gt_model_desc& d) {
+  long n = 0;
+  if (d.arch == GT_ARCH_IN2OUT) n += (long)d.static_dim * d.static_dim + d.static_dim;
+  int in = d.in_dim;
+  for (int l = 0; l < d.num_hidden; ++l) { n += (long)d.hidden_dim * in + d.hidden_dim; in = d.hidden_dim; }
+  n += (long)d.out_dim * in + d.out_dim;
+  return n;
+}
+
+extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) {
+  if (!e || !desc || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
+  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT) return fail(GT_ERR_INVALID, "unsupported arch %d", desc->arch);
+  if (desc->num_hidden < 1 || desc->num_hidden > 16) return fail(GT_ERR_INVALID, "num_hidden must be in [1,16]");
+  if (desc->dropout < 0.f || desc->dropout >= 1.f) return fail(GT_ERR_INVALID, "dropout must be in [0,1)");
+  if (!desc->params) return fail(GT_ERR_INVALID, "params is null");
+  if (desc->n_params != expected_params(*desc))
+    return fail(GT_ERR_INVALID, "n_params %ld does not match the architecture (%ld)", (long)desc->n_params, expected_params(*desc));
+  if (role == GT_ROLE_D && (desc->arch != GT_ARCH_MLP || desc->out_dim != 1 || !desc->last_sigmoid))
+    return fail(GT_ERR_INVALID, "discriminator must be MLP(out_dim=1, last_sigmoid=True) (hparams.py:56-64,230-239)");
+  Net& n = e->net[role];
+  n.d = *desc;
+  n.hidden.clear();
+  float* p = desc->params;
+  float* g = desc->grads;
+  auto take = [&](int out, int in) {
+    Lin l;
+    l.in = in; l.out = out;
+    l.W = p; l.dW = g; p += (long)out * in; if (g) g += (long)out * in;
+    l.b = p; l.db = g; p += out; if (g) g += out;
+    return l;
+  };
+  if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
+  int in = desc->in_dim;
+  for (int l = 0; l < desc->num_hidden; ++l) { n.hidden.push_back(take(desc->hidden_dim, in)); in = desc->hidden_dim; }
+  n.last = take(desc->out_dim, in);
+  n.bound = true;
+  n.grads_dirty = false;
+  auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
+  acts.resize(desc->num_hidden);
+  if (role == GT_ROLE_G && desc->arch == GT_ARCH_IN2OUT) {
+    // single dynamic stream of width out_dim (models.py:66)
+    const int sd = desc->out_dim / e->cfg.num_windows;
+    std::vector<int> sc(sd), ss(sd, sd);
+    for (int c = 0; c < sd; ++c) sc[c] = c;
+    e->i2o_ds = sd;
+    CHK(upload_ints(sc, &e->d_scol_i2o));
+    CHK(upload_ints(ss, &e->d_sstride_i2o));
+    if (sd != desc->static_dim) return fail(GT_ERR_DIM, "In2OutHighwayNet: out_dim/num_windows (%d) != static_dim (%d)", sd, desc->static_dim);
+  }
+  e->g_pass_valid = false;
+  return GT_OK;
+}
+
+extern "C" int gt_bind_optimizer(gt_engine* e, int role, const gt_optim_desc* od) {
+  if (!e || !od || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
+  Net& n = e->net[role];
+  if (!n.bound) return fail(GT_ERR_STATE, "bind the model before its optimizer");
+  if (!n.d.grads) return fail(GT_ERR_INVALID, "model was bound without a grads buffer");
+  if (od->kind != GT_OPT_ADAGRAD && od->kind != GT_OPT_ADAM) return fail(GT_ERR_INVALID, "unknown optimizer kind");
+  if (!od->state0 || (od->kind == GT_OPT_ADAM && !od->state1)) return fail(GT_ERR_INVALID, "optimizer state buffer is null");
+  n.od = *od;
+  n.step = od->step;
+  n.has_opt = true;
+  return GT_OK;
+}
+extern "C" int gt_set_training(gt_engine* e, int role, int training) {
+  if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
+  e->net[role].training = training != 0;
+  return GT_OK;
+}
+extern "C" int gt_set_lr(gt_engine* e, int role, float lr) {
+  if (!e || role < 0 || role > 1 || !e->net[role].has_opt) return fail(GT_ERR_INVALID, "no optimizer bound");
+  e->net[role].od.lr = lr;
+  return GT_OK;
+}
+extern "C" int gt_get_optimizer_step(gt_engine* e, int role, int64_t* step) {
+  if (!e || role < 0 || role > 1 || !step) return fail(GT_ERR_INVALID, "bad argument");
+  *step = e->net[role].step;
+  return GT_OK;
+}
+extern "C" int gt_set_seed(gt_engine* e, uint64_t seed) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->seed = seed;
+  e->step_counter = 0;
+  return GT_OK;
+}
+extern "C" int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, const float* mask) {
+  if (!e || role < 0 || role > 1 || pass < 0 || pass > 2 || layer < 0 || layer > 15) return fail(GT_ERR_INVALID, "bad argument");
+  e->net[role].inj[pass][layer] = mask;
+  return GT_OK;
+}
+extern "C" int gt_set_loss_normalizer(gt_engine* e, float tv) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->tv_override = tv;
+  return GT_OK;
+}
+extern "C" int gt_zero_grad(gt_engine* e, int role) {
+  if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
+  e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
+  if (role == GT_ROLE_G) e->leak_pending = false;
+  return GT_OK;
+}
+extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {
+  if (!e || !dev_ptr || !n) return fail(GT_ERR_INVALID, "bad argument");
+  *dev_ptr = &e->sc()->s_real;
+  *n = 7;   // s_real, s_fake, s_adv, n_real_ok, n_fake_ok, s_mge, s_mse
+  return GT_OK;
+}
+
+// dropout spec of (role, pass, layer).  rows_off: first row of `pass` inside the stacked mask buffer.
+static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const float* stacked_mask, int ld) {
+  Net& n = e->net[role];
+  DropoutSpec d = no_drop();
+  if (!n.training || n.d.dropout <= 0.f) return d;
+  d.p = n.d.dropout;
+  d.scale = 1.f / (1.f - n.d.dropout);
+  if (stacked_mask) {
+    d.mode = DROP_BUFFER; d.mask = stacked_mask; d.ld_mask = ld;
+  } else {
+    d.mode = DROP_PHILOX;
+    double th = (double)n.d.dropout * 4294967296.0;
+    d.thresh = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+    const uint64_t site = e->step_counter * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
+    d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
+    d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;
+  }
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------
+// MLPG band cache
+// ------------------------------------------------------------------------------------------
+static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
+  MlpgCache& m = e->mlpg;
+  if (m.R == R && m.T == T && m.band.p) return GT_OK;
+  const int nW = e->cfg.num_windows;
+  // per-offset maxima -> host, pick the smallest half-width whose outside is negligible
+  Scratch tmp;
+  CHK(tmp.ensure((size_t)(2 * T - 1) * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_offset_max_kernel, dim3(2 * T - 1), dim3(256), 0, s, R, T, nW, tmp.as<float>());
+  LAUNCH_CHECK();
+  std::vector<float> off(2 * T - 1);
+  HIPCHK(hipMemcpyAsync(off.data(), tmp.p, off.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  tmp.release();
+  float peak = 0.f;
+  for (float v : off) peak = fmaxf(peak, v);
+  if (!(peak > 0.f) || !isfinite(peak)) return fail(GT_ERR_INVALID, "MLPG matrix R is empty or not finite");
+  int kb = 0;
+  for (int o = -(T - 1); o <= T - 1; ++o)
+    if (off[o + T - 1] > 1e-9f * peak) kb = std::max(kb, abs(o));
+  if (kb > 64 && kb > T / 4)
+    return fail(GT_ERR_INVALID, "MLPG matrix R is not banded (half-width %d of T=%d): only window sets whose "
+                "R = (W^T W)^-1 W^T decays (hparams.py:22-26) are supported", kb, T);
+  const int nb = 2 * kb + 1;
+  CHK(m.band.ensure((size_t)T * nW * nb * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_extract_band_kernel, dim3(cdiv((long)T * nW * nb, 256)), dim3(256), 0, s, R, T, nW, kb, m.band.as<float>());
+  LAUNCH_CHECK();
+  m.R = R; m.T = T; m.kb = kb;
+  return GT_OK;
+}
+
+static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
+                        float* ys, int ldys, int B, int T, hipStream_t s) {
+  const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
+  const size_t lds = (size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)mlpg_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
+  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(256), lds, s, y, ldy, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+                     ys, ldys, B, T);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, const int* sstride, int Ds,
+                         float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
+                         const float* mask, hipStream_t s) {
+  const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
+  const size_t lds = (size_t)(MLPG_TT + 2 * kb) * MLPG_CC * sizeof(float);
+  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
+  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(256), lds, s, gs, ldgs, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+                     gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc());
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// network passes
+// ------------------------------------------------------------------------------------------
+// stacked injected-mask buffer for one layer of a D pass group (real rows then fake rows)
+static int stage_injected(gt_engine* e, int role, int layer, const int* passes, int npass, long rows_each, int width,
+                          const float** out, hipStream_t s) {
+  Net& n = e->net[role];
+  *out = nullptr;
+  if (!n.training || n.d.dropout <= 0.f) return GT_OK;
+  bool any = false, all = true;
+  for (int i = 0; i < npass; ++i) { any |= n.inj[passes[i]][layer] != nullptr; all &= n.inj[passes[i]][layer] != nullptr; }
+  if (!any) return GT_OK;
+  if (!all) return fail(GT_ERR_INVALID, "injected dropout masks must be given for every pass of a step or for none");
+  if (npass == 1) { *out = n.inj[passes[0]][layer]; return GT_OK; }
+  const size_t per_layer = (size_t)npass * rows_each * width * sizeof(float);
+  CHK(e->dmask.ensure(per_layer * n.d.num_hidden));
+  float* base = (float*)((char*)e->dmask.p + per_layer * layer);
+  for (int i = 0; i < npass; ++i)
+    HIPCHK(hipMemcpyAsync(base + (size_t)i * rows_each * width, n.inj[passes[i]][layer], (size_t)rows_each * width * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+  *out = base;
+  return GT_OK;
+}
+
+// hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
+static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
+                         const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s) {
+  Net& n = e->net[role];
+  specs.resize(n.hidden.size());
+  const float* cur = in;
+  int ld = ld_in;
+  for (size_t l = 0; l < n.hidden.size(); ++l) {
+    const Lin& L = n.hidden[l];
+    CHK(acts[l].ensure((size_t)rows * L.out * sizeof(float)));
+    const float* inj = nullptr;
+    CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out);
+    CHK(linear_forward(cur, ld, L.W, L.in, L.b, acts[l].as<float>(), L.out, rows, L.in, L.out, ACT_LEAKY_DROPOUT, specs[l], s));
+    cur = acts[l].as<float>();
+    ld = L.out;
+  }
+  return GT_OK;
+}
+
+// hidden stack backward.  dz_top: gradient w.r.t. the pre-activation of the TOP hidden layer
+// (already multiplied by f'), in buffer `cur` (rows x hidden).  Produces dW/db (if want_w) and,
+// optionally, dX[:, col0:col0+ncols] of the stack input for rows [row0, row0+nrows).
+static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
+                          const std::vector<DropoutSpec>& specs, float* cur, float* other, bool want_w,
+                          float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s) {
+  Net& n = e->net[role];
+  for (int l = (int)n.hidden.size() - 1; l >= 0; --l) {
+    const Lin& L = n.hidden[l];
+    const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
+    const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
+    if (want_w) CHK(linear_backward_weight(cur, L.out, Xin, ldx, rows, L.out, L.in, L.dW, L.db, n.grads_dirty, e->slabs, e->colp, s));
+    if (l > 0) {
+      CHK(linear_backward_data(cur, L.out, L.W, L.in, 0, other, L.in, rows, L.out, L.in, ACT_LEAKY_DROPOUT,
+                               acts[l - 1].as<float>(), L.in, specs[l - 1], s));
+      std::swap(cur, other);
+    } else if (dX) {
+      CHK(linear_backward_data(cur + row0 * L.out, L.out, L.W, L.in, col0, dX, lddx, nrows, L.out, ncols, ACT_NONE, nullptr, 0,
+                               no_drop(), s));
+    }
+  }
+  return GT_OK;
+}
+
+static int check_common(gt_engine* e, int B, int T) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  if (B < 1 || T < 1) return fail(GT_ERR_INVALID, "B and T must be positive");
+  if ((long)B * T > 0x3fffffffL) return fail(GT_ERR_INVALID, "B*T too large");
+  return GT_OK;
+}
+
+static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
+                             bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = (long)B * T;
+  const int pass0[1] = {0};
+  CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+  const Lin& Lh = G.hidden.back();
+  CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                     G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+  if (G.d.arch == GT_ARCH_IN2OUT) {
+    if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
+    const int sd = G.d.static_dim;
+    CHK(ensure_band(e, R, T, s));
+    CHK(e->tx.ensure((size_t)N * sd * sizeof(float)));
+    CHK(e->gx.ensure((size_t)N * sd * sizeof(float)));
+    // T(x) = sigmoid(T x_static), x_static = x[:, :, :static_dim]   (models.py:57-60)
+    CHK(linear_forward(x, G.d.in_dim, G.gate.W, sd, G.gate.b, e->tx.as<float>(), sd, N, sd, sd, ACT_SIGMOID, no_drop(), s));
+    CHK(mlpg_forward(e, y_hat, G.d.out_dim, e->d_scol_i2o, e->d_sstride_i2o, sd, e->gx.as<float>(), sd, B, T, s));
+    if (stash) e->g_used_mlpg = true;
+    hipLaunchKernelGGL(highway_forward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, x, G.d.in_dim, e->tx.as<float>(), sd,
+                       e->gx.as<float>(), sd, y_hat_static, sd, N, sd);
+    LAUNCH_CHECK();
+  } else {
+    if (G.d.out_dim != e->Dout_cfg)
+      return fail(GT_ERR_DIM, "You probably have specified wrong dimention params.");  // multistream.py:93-94
+    if (R) {
+      CHK(ensure_band(e, R, T, s));
+      CHK(mlpg_forward(e, y_hat, G.d.out_dim, e->d_scol, e->d_sstride, e->Ds, y_hat_static, e->Ds, B, T, s));
+      if (stash) e->g_used_mlpg = true;
+    } else {
+      if (e->Ds != G.d.out_dim) return fail(GT_ERR_INVALID, "R is None but the stream config has dynamic features");
+      if (stash) e->g_used_mlpg = false;
+      // R is None: num_windows = 1, every stream passes through (multistream.py:88-89,119-120)
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * G.d.out_dim, 256)), dim3(256), 0, s, y_hat, G.d.out_dim, 0,
+                         (const int*)nullptr, y_hat_static, G.d.out_dim, 0, (int)N, G.d.out_dim);
+      LAUNCH_CHECK();
+    }
+  }
+  return GT_OK;
+}
+
+extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat,
+                                  float* y_hat_static, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& G = e->net[GT_ROLE_G];
+  if (!G.bound) return fail(GT_ERR_STATE, "generator not bound");
+  if (!x || !y_hat || !y_hat_static) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  e->step_counter++;
+  e->B = B; e->T = T; e->N = (long)B * T;
+  e->g_pass_valid = false;
+  e->fake_cat_valid = false;
+  CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
+  e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
+  e->g_pass_valid = true;
+  return GT_OK;
+}
+
+// width of the conditioning input x fed to D (train.py:254-256); derived from the bound D when not configured
+static int cond_dim(gt_engine* e) {
+  if (!e->cfg.discriminator_linguistic_condition) return 0;
+  if (e->cfg.cond_dim > 0) return e->cfg.cond_dim;
+  return e->net[GT_ROLE_D].bound ? e->net[GT_ROLE_D].d.in_dim - e->Da : 0;
+}
+static int d_in_dim(gt_engine* e) { return e->Da + cond_dim(e); }
+
+// rows [row0, row0+N) of dcat <- [x | feats[:, adv_cols]]
+static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_feats, long row0, long N, int ldc, hipStream_t s) {
+  float* dst = e->dcat.as<float>() + row0 * ldc;
+  int off = 0;
+  if (e->cfg.discriminator_linguistic_condition) {
+    if (!x) return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+    const int cd = cond_dim(e);
+    if (cd <= 0) return fail(GT_ERR_DIM, "discriminator in_dim too small for linguistic conditioning");
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * cd, 256)), dim3(256), 0, s, x, cd, 0, (const int*)nullptr, dst, ldc, 0,
+                       (int)N, cd);
+    LAUNCH_CHECK();
+    off = cd;
+  }
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * e->Da, 256)), dim3(256), 0, s, feats, ld_feats, 0, e->d_adv_cols, dst, ldc,
+                     off, (int)N, e->Da);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
+                    float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s) {
+  Net& D = e->net[GT_ROLE_D];
+  const int nblk = (int)std::min<long>(1024, (n_rows + 3) / 4);
+  CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
+  CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
+  CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
+  const size_t lds = (size_t)4 * K * sizeof(float);
+  hipLaunchKernelGGL(d_head_kernel, dim3(nblk), dim3(256), lds, s, H, K, K, D.last.W, D.last.b, mask, (int)n_mask, (int)n_real,
+                     (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(),
+                     e->headp.as<HeadPartials>(), e->headw.as<float>());
+  LAUNCH_CHECK();
+  const bool w = want_grad && want_w;
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t s) {
+  Net& n = e->net[role];
+  if (!n.has_opt) return fail(GT_ERR_STATE, "phase == \"train\" but no optimizer is bound for role %d", role);
+  const long np = n.d.n_params;
+  const int nblk = (int)std::min<long>(512, cdiv(np, RED_THREADS * 4));
+  CHK(e->partial.ensure(4096 * sizeof(double)));
+  double* part = e->partial.as<double>() + 2048;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, n.d.grads, np, part);
+  LAUNCH_CHECK();
+  n.step += 1;
+  OptimSpec o;
+  o.kind = n.od.kind; o.lr = n.od.lr; o.weight_decay = n.od.weight_decay; o.eps = n.od.eps; o.lr_decay = n.od.lr_decay;
+  o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step; o.max_norm = n.od.max_grad_norm;
+  const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
+  hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
+                     part, nblk, norm2_out, o);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+static int fetch_results(gt_engine* e, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// update_discriminator
+// ------------------------------------------------------------------------------------------
+extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                                             const float* mask, int B, int T, int train, float eps, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& D = e->net[GT_ROLE_D];
+  if (!D.bound) return fail(GT_ERR_STATE, "discriminator not bound");
+  if (!y_static || !y_hat_static || !mask) return fail(GT_ERR_INVALID, "null tensor");
+  if (D.d.in_dim != d_in_dim(e))
+    return fail(GT_ERR_DIM, "discriminator in_dim %d != adversarial input width %d (train.py:760-768)", D.d.in_dim, d_in_dim(e));
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
+  LAUNCH_CHECK();
+  CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+  CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
+  CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
+  e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+  const int passes[2] = {0, 1};
+  CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  const int H = D.d.hidden_dim;
+  const bool tr = train != 0;
+  if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
+  CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
+  CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
+  CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
+               e->d_specs.back(), true, s));
+  if (tr) {
+    // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
+    // (the autograd graph in the reference, train.py:265) and a generator with grads exists
+    Net& G = e->net[GT_ROLE_G];
+    const bool want_leak = G.bound && G.d.grads && e->g_pass_valid && y_hat_static == e->last_yhs && e->N == N;
+    if (want_leak && e->leak_pending)
+      return fail(GT_ERR_STATE, "update_discriminator called twice without optimizer_g.zero_grad() (train.py:538)");
+    float* leak = nullptr;
+    if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
+    const int col0 = cond_dim(e);
+    CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
+                       e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
+    D.grads_dirty = true;
+    if (want_leak) e->leak_pending = true;
+  }
+  e->d_begin_done = true;
+  return GT_OK;
+}
+
+extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->d_begin_done) return fail(GT_ERR_STATE, "gt_update_discriminator_end without _begin");
+  hipStream_t s = (hipStream_t)stream;
+  e->d_begin_done = false;
+  HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
+  if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+  hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
+  LAUNCH_CHECK();
+  CHK(fetch_results(e, s));
+  out->loss_d = e->h_res->loss_d; out->loss_fake_d = e->h_res->loss_fake_d; out->loss_real_d = e->h_res->loss_real_d;
+  out->real_correct_count = e->h_res->real_correct; out->fake_correct_count = e->h_res->fake_correct;
+  out->grad_norm = e->h_res->gnorm_d;
+  return GT_OK;
+}
+
+extern "C" int gt_update_discriminator(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                                       const float* mask, int B, int T, int train, float eps, gt_d_result* out, void* stream) {
+  CHK(gt_update_discriminator_begin(e, x, y_static, y_hat_static, mask, B, T, train, eps, stream));
+  return gt_update_discriminator_end(e, train, out, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// update_generator
+// ------------------------------------------------------------------------------------------
+static int sum_sqerr(gt_engine* e, const float* a, int lda, const float* b, int ldb, const float* mask, long rows, int D,
+                     double* out, float* g, int ldg, float gscale, hipStream_t s) {
+  const int nblk = (int)std::min<long>(1024, cdiv(rows * D, RED_THREADS * 4));
+  CHK(e->partial.ensure(4096 * sizeof(double)));
+  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, a, lda, b, ldb, mask, rows, D, e->partial.as<double>(),
+                     g, ldg, gscale, e->sc());
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, e->partial.as<double>(), nblk, out);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// backward of G from the gradient at y_hat_static (gs) [+ masked-MSE term at y_hat]
+static int generator_backward(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* mask,
+                              float mse_w, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = e->N;
+  const int B = e->B, T = e->T, Do = G.d.out_dim;
+  CHK(e->gy.ensure((size_t)N * Do * sizeof(float)));
+  float* gy = e->gy.as<float>();
+  const float* gs = e->gs.as<float>();
+  if (G.d.arch == GT_ARCH_IN2OUT) {
+    const int sd = G.d.static_dim;
+    CHK(e->dgx.ensure((size_t)N * sd * sizeof(float)));
+    CHK(e->dtz.ensure((size_t)N * sd * sizeof(float)));
+    hipLaunchKernelGGL(highway_backward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, gs, sd, e->tx.as<float>(), sd,
+                       e->gx.as<float>(), sd, e->dgx.as<float>(), sd, e->dtz.as<float>(), sd, N, sd);
+    LAUNCH_CHECK();
+    CHK(linear_backward_weight(e->dtz.as<float>(), sd, x, G.d.in_dim, N, sd, sd, G.gate.dW, G.gate.db, G.grads_dirty, e->slabs,
+                               e->colp, s));
+    CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
+  } else if (e->g_used_mlpg) {
+    CHK(mlpg_backward(e, gs, e->Ds, e->d_scol, e->d_sstride, e->Ds, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
+  } else {
+    // no parameter generation: y_hat_static == y_hat, the gradient passes straight through,
+    // plus the masked-MSE gradient (which also yields loss_mse's sum)
+    if (mse_w != 0.f) CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, gy, Do, mse_w, s));
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
+  const Lin& Lt = G.hidden.back();
+  CHK(linear_backward_weight(gy, Do, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
+                             e->slabs, e->colp, s));
+  const int H = G.d.hidden_dim;
+  CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
+  CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
+  CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
+                           e->g_act.back().as<float>(), H, e->g_specs.back(), s));
+  CHK(stack_backward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
+                     nullptr, 0, 0, 0, 0, 0, s));
+  G.grads_dirty = true;
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* y_static,
+                                         const float* y_hat_static, float adv_w, const float* mask, int B, int T, int train,
+                                         float mse_w, float mge_w, float eps, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& G = e->net[GT_ROLE_G];
+  Net& D = e->net[GT_ROLE_D];
+  if (!G.bound) return fail(GT_ERR_STATE, "generator not bound");
+  if (!y || !y_hat || !y_static || !y_hat_static || !mask) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  const bool tr = train != 0;
+  if (tr) {
+    if (!e->g_pass_valid || y_hat != e->last_yhat || y_hat_static != e->last_yhs || N != e->N)
+      return fail(GT_ERR_STATE, "update_generator(phase=\"train\") needs the y_hat / y_hat_static returned by the last apply_generator");
+    if (!G.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the generator was bound without grads");
+    if (G.d.last_sigmoid) return fail(GT_ERR_INVALID, "training a generator with last_sigmoid=True is not supported");
+  }
+  const int Do = G.d.out_dim;
+  const int Ds = G.d.arch == GT_ARCH_IN2OUT ? G.d.static_dim : e->Ds;
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
+  LAUNCH_CHECK();
+  // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
+  const bool direct = G.d.arch != GT_ARCH_IN2OUT && !e->g_used_mlpg;
+  if (!(tr && direct && mse_w != 0.f))
+    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s));
+  // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
+  e->g_has_adv = adv_w > 0.f;
+  float* gadv = nullptr;
+  if (adv_w > 0.f) {
+    if (!D.bound) return fail(GT_ERR_STATE, "adv_w > 0 but no discriminator bound");
+    if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
+    const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
+    CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+    if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
+      CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
+      e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+    }
+    const float* cat = e->dcat.as<float>() + N * ldc;
+    const int passes[1] = {2};
+    CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    const int H = D.d.hidden_dim;
+    CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
+    CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
+    CHK(run_head(e, HEAD_G_ADV, e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr, e->dzA.as<float>(), e->d_specs.back(),
+                 false, s));
+    if (tr) {
+      CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
+      gadv = e->gadv.as<float>();
+      const int col0 = cond_dim(e);
+      CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
+                         e->Da, col0, e->Da, 0, N, s));
+    }
+  }
+  // MGE loss + gradient assembly at y_hat_static
+  {
+    const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
+    CHK(e->partial.ensure(4096 * sizeof(double)));
+    float* gs = nullptr;
+    if (tr) { CHK(e->gs.ensure((size_t)N * Ds * sizeof(float))); gs = e->gs.as<float>(); }
+    const float* leak = (tr && e->leak_pending) ? e->leak.as<float>() : nullptr;
+    hipLaunchKernelGGL(static_grad_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
+                       e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, e->partial.as<double>(), e->sc());
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
+    LAUNCH_CHECK();
+  }
+  if (tr) {
+    CHK(generator_backward(e, e->last_x, y, y_hat, mask, mse_w, s));  // G's own input (cat(x, z), train.py:542)
+    e->leak_pending = false;
+  }
+  e->g_begin_done = true;
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, float mse_w, float mge_w, gt_g_result* out,
+                                       void* stream) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->g_begin_done) return fail(GT_ERR_STATE, "gt_update_generator_end without _begin");
+  hipStream_t s = (hipStream_t)stream;
+  e->g_begin_done = false;
+  HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
+  if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+  hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
+  LAUNCH_CHECK();
+  CHK(fetch_results(e, s));
+  out->loss_mse = e->h_res->loss_mse; out->loss_mge = e->h_res->loss_mge; out->loss_adv = e->h_res->loss_adv;
+  out->loss_g = e->h_res->loss_g; out->grad_norm = e->h_res->gnorm_g;
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* y_static,
+                                   const float* y_hat_static, float adv_w, const float* mask, int B, int T, int train,
+                                   float mse_w, float mge_w, float eps, gt_g_result* out, void* stream) {
+  CHK(gt_update_generator_begin(e, x, y, y_hat, y_static, y_hat_static, adv_w, mask, B, T, train, mse_w, mge_w, eps, stream));
+  return gt_update_generator_end(e, train, adv_w, mse_w, mge_w, out, stream);
+}
+
+extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  Net& G = e->net[GT_ROLE_G];
+  if (!G.bound || !G.d.grads || !e->g_pass_valid) return fail(GT_ERR_STATE, "no generator pass to back-propagate");
+  hipStream_t s = (hipStream_t)stream;
+  const long N = e->N;
+  const int Ds = G.d.arch == GT_ARCH_IN2OUT ? G.d.static_dim : e->Ds;
+  CHK(e->gs.ensure((size_t)N * Ds * sizeof(float)));
+  HIPCHK(hipMemsetAsync(e->gs.p, 0, (size_t)N * Ds * sizeof(float), s));
+  if (e->leak_pending) {
+    // scatter leak[:, j] -> gs[:, adv_cols[j]]  (gather with swapped roles: one column at a time is fine here)
+    std::vector<int>& cols = e->h_adv_cols;
+    for (int j = 0; j < e->Da; ++j) {
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, e->leak.as<float>(), e->Da, j, (const int*)nullptr,
+                         e->gs.as<float>(), Ds, cols[j], (int)N, 1);
+    }
+    LAUNCH_CHECK();
+  }
+  CHK(generator_backward(e, e->last_x, e->last_yhat, e->last_yhat, (const float*)nullptr, 0.f, s));
+  e->leak_pending = false;
+  HIPCHK(hipStreamSynchronize(s));
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// plain forward
+// ------------------------------------------------------------------------------------------
+extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const float* R, int B, int T, float* out, float* out2,
+                                void* stream) {
+  CHK(check_common(e, B, T));
+  if (role < 0 || role > 1 || !e->net[role].bound) return fail(GT_ERR_STATE, "model not bound");
+  if (!x || !out) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  Net& n = e->net[role];
+  const long N = (long)B * T;
+  e->step_counter++;
+  std::vector<DropoutSpec> specs;
+  if (role == GT_ROLE_G && n.d.arch == GT_ARCH_IN2OUT) {
+    if (!out2) return fail(GT_ERR_INVALID, "In2OutHighwayNet forward returns two tensors");
+    e->g_pass_valid = false;
+    return generator_forward(e, x, R, B, T, out, out2, false, s, specs);
+  }
+  const int pass0[1] = {0};
+  auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
+  if (role == GT_ROLE_G) e->g_pass_valid = false;
+  CHK(stack_forward(e, role, x, n.d.in_dim, N, acts, pass0, 1, N, specs, s));
+  return linear_forward(acts.back().as<float>(), n.hidden.back().out, n.last.W, n.last.in, n.last.b, out, n.d.out_dim, N, n.last.in,
+                        n.last.out, n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------
+extern "C" int gt_op_sequence_mask(const int64_t* lengths, int B, int T, float* mask, void* stream) {
+  if (!lengths || !mask || B < 1 || T < 1) return fail(GT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(sequence_mask_kernel, dim3(cdiv((long)B * T, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)lengths, B, T, mask);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+extern "C" int gt_op_masked_mse(const float* input, const float* target, const float* mask, int B, int T, int D, float* loss_out,
+                                float* grad_input, void* stream) {
+  if (!input || !target) return fail(GT_ERR_INVALID, "null tensor");
+  if (!mask) return fail(GT_ERR_INVALID, "Should provide either lengths or mask");  // seqloss.py:33-34
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  void* ws = nullptr;
+  HIPCHK(hipMalloc(&ws, 1024 + 1024 * sizeof(double)));
+  StepScalars* sc = (StepScalars*)ws;
+  double* part = (double*)((char*)ws + 1024);
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, -1.f, sc);
+  const int nblk = (int)std::min<long>(1000, cdiv(N * D, RED_THREADS * 4));
+  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, input, D, target, D, mask, N, D, part, grad_input, D,
+                     1.f, sc);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, part, nblk, &sc->s_mse);
+  StepScalars h;
+  hipError_t err = hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  if (err != hipSuccess) return fail(GT_ERR_HIP, "masked_mse: %s", hipGetErrorString(err));
+  if (loss_out) *loss_out = (float)h.s_mse / h.tv;
+  return GT_OK;
+}
+
+extern "C" int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,
+                                 int out_col_offset, int64_t rows, void* stream) {
+  if (!in || !out || n_idx < 0 || rows < 0) return fail(GT_ERR_INVALID, "bad argument");
+  if (rows == 0 || n_idx == 0) return GT_OK;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(rows * n_idx, 256)), dim3(256), 0, (hipStream_t)stream, in, ld_in, 0, idx, out,
+                     ld_out, out_col_offset, (int)rows, n_idx);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+extern "C" int gt_op_mlpg_forward(gt_engine* e, const float* y, const float* R, int B, int T, float* y_static, void* stream) {
+  CHK(check_common(e, B, T));
+  if (!y || !R || !y_static) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  CHK(ensure_band(e, R, T, s));
+  return mlpg_forward(e, y, e->Dout_cfg, e->d_scol, e->d_sstride, e->Ds, y_static, e->Ds, B, T, s);
+}
+extern "C" int gt_op_mlpg_backward(gt_engine* e, const float* g_static, const float* R, int B, int T, float* g_y, void* stream) {
+  CHK(check_common(e, B, T));
+  if (!g_static || !R || !g_y) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  CHK(ensure_band(e, R, T, s));
+  return mlpg_backward(e, g_static, e->Ds, e->d_scol, e->d_sstride, e->Ds, g_y, e->Dout_cfg, B, T, 0.f, nullptr, nullptr, 0, nullptr, s);
+}
+
+static DropoutSpec buffer_spec(const float* keep_mask, float p, int ld) {
+  DropoutSpec d = no_drop();
+  if (keep_mask && p > 0.f) { d.mode = DROP_BUFFER; d.mask = keep_mask; d.ld_mask = ld; d.p = p; d.scale = 1.f / (1.f - p); }
+  return d;
+}
+
+extern "C" int gt_op_linear_forward(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int64_t rows,
+                                    int in_dim, int out_dim, int act, const float* keep_mask, float p, void* stream) {
+  if (!X || !W || !Y || rows < 1 || in_dim < 1 || out_dim < 1) return fail(GT_ERR_INVALID, "bad argument");
+  if (act < 0 || act > 2) return fail(GT_ERR_INVALID, "unknown activation");
+  return linear_forward(X, ldx, W, in_dim, bias, Y, ldy, rows, in_dim, out_dim, act, buffer_spec(keep_mask, p, out_dim), (hipStream_t)stream);
+}
+
+extern "C" int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, const float* W, int64_t rows, int in_dim,
+                                     int out_dim, float* dX, int lddx, const float* H_prev, int act_prev,
+                                     const float* keep_mask_prev, float p_prev, float* dW, float* db, void* stream) {
+  if (!dY || rows < 1 || in_dim < 1 || out_dim < 1) return fail(GT_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (dX) {
+    if (!W) return fail(GT_ERR_INVALID, "dX requested without W");
+    if (act_prev != ACT_NONE && !H_prev) return fail(GT_ERR_INVALID, "activation derivative requested without H_prev");
+    CHK(linear_backward_data(dY, lddy, W, in_dim, 0, dX, lddx, rows, out_dim, in_dim, act_prev, H_prev, in_dim,
+                             buffer_spec(keep_mask_prev, p_prev, in_dim), s));
+  }
+  if (dW || db) {
+    if (dW && !X) return fail(GT_ERR_INVALID, "dW requested without X");
+    Scratch slabs, colp;
+    int r = linear_backward_weight(dY, lddy, X, ldx, rows, out_dim, in_dim, dW, db, false, slabs, colp, s);
+    hipError_t err = hipStreamSynchronize(s);
+    slabs.release(); colp.release();
+    if (r) return r;
+    if (err != hipSuccess) return fail(GT_ERR_HIP, "linear_backward: %s", hipGetErrorString(err));
+  }
+  return GT_OK;
+}

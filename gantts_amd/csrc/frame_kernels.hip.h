@@ -1,0 +1,561 @@
+// HBM-bound per-frame kernels of the G+D step (gfx950): stream gathers, banded MLPG,
+// masked losses, the discriminator's sigmoid/BCE head, gradient assembly, fused
+// clip-norm + Adagrad/Adam.  All reductions are two-stage and deterministic (no float atomics).
+//
+// Layout everywhere: frames are rows, features are the fastest dimension ((B,T,D) contiguous,
+// reference train.py:145-159), so lane <-> feature gives coalesced rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_f32.hip.h"
+
+namespace gt {
+
+constexpr int RED_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block-wide sum (256 threads), result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+  return r;
+}
+
+__device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int col) {
+  if (d.mode == DROP_PHILOX) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(row >> 2), (uint32_t)col, d.key0, d.key1, r);
+    return r[row & 3] >= d.thresh;
+  }
+  if (d.mode == DROP_BUFFER) return d.mask[(long)row * d.ld_mask + col] != 0.f;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// device scalars of one step (engine workspace).  Sums are kept in double so the 9 reported
+// scalars do not depend on the reduction tree.
+// ---------------------------------------------------------------------------------------
+struct StepScalars {
+  float tv;          // sum(mask)  (valid frames, reference train.py:258,286)
+  float inv_tv;
+  double s_real, s_fake, s_adv;   // sum(log(..)*mask)
+  double n_real_ok, n_fake_ok;    // correct counts
+  double s_mge, s_mse;            // sum of squared masked differences
+  double gnorm2_d, gnorm2_g;      // squared grad norms (pre-clip)
+};
+
+// tv = sum(mask[0..n)) ; single workgroup (n = B*T is small)
+__global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, StepScalars* sc) {
+  __shared__ double sh[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)mask[i];
+  const double tot = block_sum_d(v, sh);
+  if (threadIdx.x == 0) {
+    const float tv = tv_override > 0.f ? tv_override : (float)tot;
+    sc->tv = tv;
+    sc->inv_tv = 1.0f / tv;
+  }
+}
+
+// mask[b][t] = t < len[b]   (reference gantts/seqloss.py:9-20)
+__global__ void sequence_mask_kernel(const long* __restrict__ lengths, int B, int T, float* __restrict__ mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int b = i / T, t = i - b * T;
+  mask[i] = (long)t < lengths[b] ? 1.f : 0.f;
+}
+
+// out[r*ldo + ooff + j] = in[r*ldi + (idx ? idx[j] : ioff + j)]   -- bit-exact column gather
+// (reference gantts/multistream.py:33-79, train.py:232-242,254-256)
+__global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int ioff, const int* __restrict__ idx,
+                                   float* __restrict__ out, int ldo, int ooff, int rows, int nj) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)rows * nj) return;
+  const int r = (int)(e / nj), j = (int)(e - (long)r * nj);
+  const int c = idx ? idx[j] : ioff + j;
+  out[(long)r * ldo + ooff + j] = in[(long)r * ldi + c];
+}
+
+// ---------------------------------------------------------------------------------------
+// MLPG.  The reference multiplies by a dense (T x nW*T) matrix R (nnmnkwii
+// unit_variance_mlpg, call sites gantts/multistream.py:120, models.py:66).  R is numerically
+// banded; the engine extracts band[t][w][j] = R[t][w*T + t + j - kb] from the caller's dense R
+// and verifies that everything outside the band is negligible before using the O(T*kb) form.
+// ---------------------------------------------------------------------------------------
+// per-offset max |R[t][w*T + t + o]| , o in [-(T-1), T-1]  ->  offmax[o + T - 1]
+__global__ void mlpg_offset_max_kernel(const float* __restrict__ R, int T, int nW, float* __restrict__ offmax) {
+  const int o = blockIdx.x - (T - 1);
+  __shared__ float sh[16];
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < T * nW; i += blockDim.x) {
+    const int w = i / T, t = i - w * T;
+    const int tt = t + o;
+    if (tt >= 0 && tt < T) mx = fmaxf(mx, fabsf(R[(long)t * nW * T + (long)w * T + tt]));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sh[wv] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, sh[i]);
+    offmax[blockIdx.x] = mx;
+  }
+}
+
+__global__ void mlpg_extract_band_kernel(const float* __restrict__ R, int T, int nW, int kb, float* __restrict__ band) {
+  const int nb = 2 * kb + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * nW * nb) return;
+  const int j = i % nb, w = (i / nb) % nW, t = i / (nb * nW);
+  const int tt = t + j - kb;
+  band[i] = (tt >= 0 && tt < T) ? R[(long)t * nW * T + (long)w * T + tt] : 0.f;
+}
+
+// static-column map: for static column c, scol[c] = column of its static component in the full
+// (static+delta) layout, sstride[c] = stream's static width (distance between window blocks),
+// 0 for a stream without dynamic features (pass-through copy, bit-exact).
+constexpr int MLPG_TT = 32;      // output frames per workgroup
+constexpr int MLPG_CC = 64;      // static columns per workgroup
+
+// y_static[b][t][c] = sum_w sum_j band[t][w][j] * y[b][t+j-kb][scol[c] + w*sstride[c]]
+__global__ __launch_bounds__(256) void mlpg_forward_kernel(
+    const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
+    const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
+    float* __restrict__ ys, int ldys, int B, int T) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [(TT+2kb)][nW][CC]
+  const int nb = 2 * kb + 1;
+  const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
+  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
+  const int c0 = blockIdx.y * MLPG_CC;
+  const int nc = min(MLPG_CC, Ds - c0);
+  const int rows = MLPG_TT + 2 * kb;
+  const float* yb = y + (long)b * T * ldy;
+  // stage: frames t0-kb .. t0+TT+kb-1, for each window the nc needed columns (coalesced in c)
+  for (int e = threadIdx.x; e < rows * nW * MLPG_CC; e += blockDim.x) {
+    const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
+    const int t = t0 - kb + r;
+    float v = 0.f;
+    if (c < nc && t >= 0 && t < T) {
+      const int st = sstride[c0 + c];
+      if (st > 0 || w == 0) v = yb[(long)t * ldy + scol[c0 + c] + w * st];
+    }
+    sm[e] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < MLPG_TT * MLPG_CC; e += blockDim.x) {
+    const int c = e % MLPG_CC, tl = e / MLPG_CC;
+    const int t = t0 + tl;
+    if (c >= nc || t >= T) continue;
+    float out;
+    if (sstride[c0 + c] == 0) {
+      out = sm[((tl + kb) * nW + 0) * MLPG_CC + c];
+    } else {
+      float acc = 0.f;
+      const float* bt = band + (long)t * nW * nb;
+      for (int w = 0; w < nW; ++w)
+        for (int j = 0; j < nb; ++j) acc = fmaf(bt[w * nb + j], sm[((tl + j) * nW + w) * MLPG_CC + c], acc);
+      out = acc;
+    }
+    ys[((long)b * T + t) * ldys + c0 + c] = out;
+  }
+}
+
+// transpose of the above:  gy[b][t'][scol[c]+w*st] = sum_t band[t][w][t'-t+kb] * gs[b][t][c]
+// plus the masked-MSE gradient in the static+delta domain when mse_scale != 0:
+//   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
+__global__ __launch_bounds__(256) void mlpg_backward_kernel(
+    const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
+    const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
+    float* __restrict__ gy, int ldgy, int B, int T,
+    float mse_w, const float* __restrict__ yhat, const float* __restrict__ ytgt, int ldt,
+    const float* __restrict__ mask, const StepScalars* __restrict__ sc) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [(TT+2kb)][CC]
+  const int nb = 2 * kb + 1;
+  const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
+  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
+  const int c0 = blockIdx.y * MLPG_CC;
+  const int nc = min(MLPG_CC, Ds - c0);
+  const int rows = MLPG_TT + 2 * kb;
+  const float* gb = gs + (long)b * T * ldgs;
+  for (int e = threadIdx.x; e < rows * MLPG_CC; e += blockDim.x) {
+    const int c = e % MLPG_CC, r = e / MLPG_CC;
+    const int t = t0 - kb + r;
+    sm[e] = (c < nc && t >= 0 && t < T) ? gb[(long)t * ldgs + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const float msk_scale = mse_w != 0.f ? 2.f * mse_w * sc->inv_tv : 0.f;
+  for (int e = threadIdx.x; e < MLPG_TT * nW * MLPG_CC; e += blockDim.x) {
+    const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, tl = e / (MLPG_CC * nW);
+    const int tp = t0 + tl;
+    if (c >= nc || tp >= T) continue;
+    const int st = sstride[c0 + c];
+    if (st == 0 && w > 0) continue;
+    float out;
+    if (st == 0) {
+      out = sm[(tl + kb) * MLPG_CC + c];
+    } else {
+      float acc = 0.f;
+      // t = tp + o, o in [-kb, kb]; coefficient band[t][w][kb - o]; staged row of t is tl + kb + o
+      for (int o = -kb; o <= kb; ++o) {
+        const int t = tp + o;
+        if (t < 0 || t >= T) continue;
+        acc = fmaf(band[((long)t * nW + w) * nb + (kb - o)], sm[(tl + kb + o) * MLPG_CC + c], acc);
+      }
+      out = acc;
+    }
+    const int col = scol[c0 + c] + w * st;
+    const long row = (long)b * T + tp;
+    if (msk_scale != 0.f) {
+      const float m = mask[row];
+      out += msk_scale * (yhat[row * ldt + col] * m - ytgt[row * ldt + col] * m) * m;
+    }
+    gy[row * ldgy + col] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// masked squared error: partial[blk] = sum_{rows of blk} sum_d (a*m - b*m)^2   (double)
+// optional gradient out: g[r][d] = gscale * 2 * (a*m - b*m) * m * inv_tv
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
+    const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+    const float* __restrict__ mask, long rows, int D, double* __restrict__ partial,
+    float* __restrict__ g, int ldg, float gscale, const StepScalars* __restrict__ sc) {
+  __shared__ double sh[16];
+  double acc = 0.0;
+  const long total = rows * D;
+  const float gs = g ? 2.f * gscale * sc->inv_tv : 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / D;
+    const int d = (int)(e - r * D);
+    const float m = mask[r];
+    const float diff = a[r * lda + d] * m - b[r * ldb + d] * m;
+    acc += (double)diff * (double)diff;
+    if (g) g[r * ldg + d] = gs * diff * m;
+  }
+  const double tot = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------
+// Discriminator head: last_linear (out_dim 1) + sigmoid + BCE terms + backward seed, fused.
+// rows [0, n_real) are "natural" frames, rows [n_real, n_rows) are generated frames
+// (reference train.py:261-271 for the D step; :307-308 for the adversarial term of the G step
+//  where every row is a generated frame scored against the "natural" label).
+// One wave per row, lane <-> hidden unit (coalesced), 4 rows per workgroup iteration.
+//   z = b + <h, w>;  D = sigmoid(z)
+//   real:  loss -= log(D + eps) * m / Tv          dD = -m / Tv / (D + eps)
+//   fake:  loss -= log(1 - D + eps) * m / Tv      dD = +m / Tv / ((1 - D) + eps)
+//   dz = dD * D * (1 - D);  dH[r][k] = dz * w[k] * f'(h[r][k]);  dw[k] += dz * h[r][k];  db += dz
+// ---------------------------------------------------------------------------------------
+enum HeadMode { HEAD_D_STEP = 0, HEAD_G_ADV = 1 };
+
+struct HeadPartials {   // one per workgroup; summed in fixed order afterwards
+  double s_real, s_fake, n_real_ok, n_fake_ok, db;
+};
+
+__global__ __launch_bounds__(256) void d_head_kernel(
+    const float* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ mask, int n_mask, int n_real, int n_rows, int mode, float eps,
+    float* __restrict__ Dout, float* __restrict__ dH, int lddh, int want_grad, DropoutSpec drop,
+    int has_act, const StepScalars* __restrict__ sc,
+    HeadPartials* __restrict__ hp, float* __restrict__ dw_partial /* [grid][K] */) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];   // [4][K] dw staging
+  __shared__ double shd[5][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float inv_tv = sc->inv_tv;
+  const float b0 = bias[0];
+  double s_real = 0, s_fake = 0, n_rok = 0, n_fok = 0, dbs = 0;
+  const int kper = (K + 63) / 64;   // hidden units per lane (strided by 64)
+  // per-lane dw accumulators live in LDS rows (K can exceed register budget in general)
+  float* dwrow = smf + wv * K;
+  for (int k = lane; k < K; k += 64) dwrow[k] = 0.f;
+  for (int r = blockIdx.x * 4 + wv; r < n_rows; r += gridDim.x * 4) {
+    const float* h = H + (long)r * ldh;
+    float part = 0.f;
+    for (int k = lane; k < K; k += 64) part = fmaf(h[k], w[k], part);
+    const float z = wave_sum(part) + b0;
+    const float D = 1.f / (1.f + expf(-z));
+    const float m = mask[r % n_mask];
+    const bool is_real = (mode == HEAD_G_ADV) || (r < n_real);
+    float dD;
+    if (is_real) {
+      const float l = logf(D + eps) * m;
+      if (mode == HEAD_G_ADV || r < n_real) { if (lane == 0) s_real += (double)l; }
+      if (lane == 0 && mode == HEAD_D_STEP) n_rok += (D > 0.5f ? 1.0 : 0.0) * (double)m;
+      dD = -m * inv_tv / (D + eps);
+    } else {
+      const float om = (1.f - D) + eps;
+      const float l = logf(om) * m;
+      if (lane == 0) { s_fake += (double)l; n_fok += (D < 0.5f ? 1.0 : 0.0) * (double)m; }
+      dD = m * inv_tv / om;
+    }
+    if (lane == 0 && Dout) Dout[r] = D;
+    if (want_grad) {
+      const float dz = dD * ((1.f - D) * D);
+      if (lane == 0) dbs += (double)dz;
+      for (int k = lane; k < K; k += 64) {
+        const float hv = h[k];
+        dwrow[k] = fmaf(dz, hv, dwrow[k]);
+        float f = 1.f;
+        if (has_act) f = leaky_drop_grad(hv, dropout_keep(drop, r, k), drop.mode == DROP_NONE ? 1.f : drop.scale);
+        dH[(long)r * lddh + k] = dz * w[k] * f;
+      }
+    }
+  }
+  (void)kper;
+  // reduce the scalar partials over the 4 waves
+  if (lane == 0) { shd[0][wv] = s_real; shd[1][wv] = s_fake; shd[2][wv] = n_rok; shd[3][wv] = n_fok; shd[4][wv] = dbs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    HeadPartials p;
+    p.s_real = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
+    p.s_fake = shd[1][0] + shd[1][1] + shd[1][2] + shd[1][3];
+    p.n_real_ok = shd[2][0] + shd[2][1] + shd[2][2] + shd[2][3];
+    p.n_fake_ok = shd[3][0] + shd[3][1] + shd[3][2] + shd[3][3];
+    p.db = shd[4][0] + shd[4][1] + shd[4][2] + shd[4][3];
+    hp[blockIdx.x] = p;
+  }
+  if (want_grad && dw_partial) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x)
+      dw_partial[(long)blockIdx.x * K + k] = (smf[k] + smf[K + k]) + (smf[2 * K + k] + smf[3 * K + k]);
+  }
+}
+
+// finalize head: sums HeadPartials in fixed order into StepScalars, writes dw/db of last_linear
+__global__ void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
+                                       int nblk, int K, int mode, StepScalars* sc,
+                                       float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dw && k < K) {
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += dw_partial[(long)i * K + k];
+    dw[k] = accumulate ? dw[k] + s : s;
+  }
+  if (k == 0) {
+    double a = 0, b = 0, c = 0, d = 0, e = 0;
+    for (int i = 0; i < nblk; ++i) { a += hp[i].s_real; b += hp[i].s_fake; c += hp[i].n_real_ok; d += hp[i].n_fake_ok; e += hp[i].db; }
+    if (mode == HEAD_D_STEP) { sc->s_real = a; sc->s_fake = b; sc->n_real_ok = c; sc->n_fake_ok = d; }
+    else sc->s_adv = a;
+    if (db) db[0] = accumulate ? db[0] + (float)e : (float)e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// generator-side gradient assembly at y_hat_static (the "linearity trick"):
+//   gs[n][c] = mge_w * 2 * (yhs*m - ys*m) * m / Tv                         (train.py:291,314)
+//            + leak[n][j]          (dloss_d/dy_hat_static, OLD D weights;   train.py:265,274)
+//            + adv_w * gadv[n][j]  (dloss_adv/dy_hat_static, NEW D weights; train.py:307-308,314)
+// for c = adv_cols[j]; also produces the MGE loss partials.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
+    const float* __restrict__ yhs, int ld1, const float* __restrict__ ys, int ld2,
+    const float* __restrict__ mask, long rows, int Ds, float mge_w,
+    const int* __restrict__ adv_inv /* [Ds] -> j or -1 */, const float* __restrict__ leak, int ldl,
+    const float* __restrict__ gadv, int lda, float adv_w,
+    float* __restrict__ gs, int ldg, double* __restrict__ partial, const StepScalars* __restrict__ sc) {
+  __shared__ double sh[16];
+  double acc = 0.0;
+  const long total = rows * Ds;
+  const float sc2 = 2.f * mge_w * sc->inv_tv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / Ds;
+    const int c = (int)(e - r * Ds);
+    const float m = mask[r];
+    const float diff = yhs[r * ld1 + c] * m - ys[r * ld2 + c] * m;
+    acc += (double)diff * (double)diff;
+    if (gs) {
+      float v = sc2 * diff * m;
+      const int j = adv_inv ? adv_inv[c] : -1;
+      if (j >= 0) {
+        if (leak) v += leak[r * ldl + j];
+        if (gadv) v += adv_w * gadv[r * lda + j];
+      }
+      gs[r * ldg + c] = v;
+    }
+  }
+  const double tot = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *out = s;
+  }
+}
+
+// column sums of a frame matrix (bias gradients): partial[blk][c] then a fixed-order finalize
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, long rows, int cols,
+                                                             int rows_per_blk, float* __restrict__ partial) {
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  const long r1 = min(rows, r0 + rows_per_blk);
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
+    partial[(long)blockIdx.x * cols + c] = s;
+  }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int cols, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < nblk; ++i) s += partial[(long)i * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// dW = (accumulate ? dW : 0) + sum_s slab[s]   (deterministic split-K combine of the TN GEMM)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n,
+                                   float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slabs[(long)k * slab_stride + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------
+// clip_grad_norm_(params, 1.0) + optimizer step, fused over the flat parameter buffer
+// (reference train.py:275-276, 317-318; torch.optim.Adagrad / Adam update rules)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void sqnorm_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+  __shared__ double sh[16];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double v = (double)g[i];
+    acc += v * v;
+  }
+  const double tot = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+struct OptimSpec {
+  int kind;            // 0 Adagrad, 1 Adam
+  float lr, weight_decay, eps;
+  float lr_decay;      // Adagrad
+  float beta1, beta2;  // Adam
+  long step;           // 1-based step count of THIS update
+  float max_norm;      // clip threshold (1.0 in the reference); <= 0 disables clipping
+};
+
+__global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
+    const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o) {
+  __shared__ float coef_sh;
+  if (threadIdx.x == 0) {
+    double tot = 0;
+    for (int i = 0; i < n_partial; ++i) tot += norm_partial[i];
+    if (blockIdx.x == 0 && norm2_out) *norm2_out = tot;
+    float coef = 1.f;
+    if (o.max_norm > 0.f) {
+      const float total_norm = (float)sqrt(tot);
+      coef = fminf(o.max_norm / (total_norm + 1e-6f), 1.f);
+    }
+    coef_sh = coef;
+  }
+  __syncthreads();
+  const float coef = coef_sh;
+  float clr = o.lr, bc2_sqrt = 1.f, step_size = o.lr;
+  if (o.kind == 0) {
+    clr = o.lr / (1.f + (float)(o.step - 1) * o.lr_decay);
+  } else {
+    const double bc1 = 1.0 - pow((double)o.beta1, (double)o.step);
+    const double bc2 = 1.0 - pow((double)o.beta2, (double)o.step);
+    step_size = (float)((double)o.lr / bc1);
+    bc2_sqrt = (float)sqrt(bc2);
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    g[i] = gi;                                  // clip_grad_norm_ scales .grad in place
+    float pi = p[i];
+    if (o.weight_decay != 0.f) gi = fmaf(o.weight_decay, pi, gi);
+    if (o.kind == 0) {
+      const float s = fmaf(gi, gi, s0[i]);
+      s0[i] = s;
+      p[i] = pi - clr * (gi / (sqrtf(s) + o.eps));
+    } else {
+      const float m = o.beta1 * s0[i] + (1.f - o.beta1) * gi;
+      const float v = o.beta2 * s1[i] + (1.f - o.beta2) * gi * gi;
+      s0[i] = m; s1[i] = v;
+      const float denom = sqrtf(v) / bc2_sqrt + o.eps;
+      p[i] = pi - step_size * (m / denom);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// In2OutHighwayNet combine (reference gantts/models.py:57-69):
+//   y_hat_static = x_static + Tx * Gx      ;  backward: dGx = g*Tx, dTz = g*Gx*Tx*(1-Tx)
+// ---------------------------------------------------------------------------------------
+__global__ void highway_forward_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Tx, int ldt,
+                                       const float* __restrict__ Gx, int ldg, float* __restrict__ out, int ldo,
+                                       long rows, int sd) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * sd) return;
+  const long r = e / sd; const int c = (int)(e - r * sd);
+  out[r * ldo + c] = x[r * ldx + c] + Tx[r * ldt + c] * Gx[r * ldg + c];
+}
+__global__ void highway_backward_kernel(const float* __restrict__ g, int ldgr, const float* __restrict__ Tx, int ldt,
+                                        const float* __restrict__ Gx, int ldg, float* __restrict__ dGx, int ld1,
+                                        float* __restrict__ dTz, int ld2, long rows, int sd) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * sd) return;
+  const long r = e / sd; const int c = (int)(e - r * sd);
+  const float gv = g[r * ldgr + c], t = Tx[r * ldt + c];
+  dGx[r * ld1 + c] = gv * t;
+  dTz[r * ld2 + c] = gv * Gx[r * ldg + c] * ((1.f - t) * t);
+}
+
+// ---------------------------------------------------------------------------------------
+// results of one update_* call, written by a single thread and copied D2H once
+// ---------------------------------------------------------------------------------------
+struct StepResults {
+  float loss_d, loss_fake_d, loss_real_d, real_correct, fake_correct;   // train.py:278-279 order
+  float loss_mse, loss_mge, loss_adv, loss_g;                           // train.py:320 order
+  float gnorm_d, gnorm_g, tv;
+};
+__global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const float T = sc->tv;
+  const float lr = -((float)sc->s_real) / T, lf = -((float)sc->s_fake) / T;
+  out->loss_real_d = lr; out->loss_fake_d = lf; out->loss_d = lr + lf;
+  out->real_correct = (float)sc->n_real_ok; out->fake_correct = (float)sc->n_fake_ok;
+  out->gnorm_d = (float)sqrt(sc->gnorm2_d); out->tv = T;
+}
+__global__ void finalize_g_kernel(const StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv) {
+  if (threadIdx.x || blockIdx.x) return;
+  const float T = sc->tv;
+  const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
+  const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;
+  out->loss_mse = mse; out->loss_mge = mge; out->loss_adv = adv;
+  out->loss_g = (mse_w * mse + mge_w * mge) + adv_w * adv;
+  out->gnorm_g = (float)sqrt(sc->gnorm2_g); out->tv = T;
+}
+
+}  // namespace gt

@@ -1,0 +1,263 @@
+"""Python handle on one ``gt_engine`` (libgantts_hip.so): binds networks / optimizers by raw
+device pointer and forwards the step functions.  PyTorch is used for device memory and the
+current HIP stream only."""
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr
+
+
+def stream_config_from_hp(hp):
+    """gt_stream_config from the hp.* fields read on the step path (reference train.py:61,
+    233-241, 248, 254, 299, 304, 352-353)."""
+    cfg = L.StreamConfig()
+    ss = list(hp.stream_sizes)
+    hd = list(hp.has_dynamic_features) if hp.has_dynamic_features is not None else [False] * len(ss)
+    if len(ss) > L.MAX_STREAMS:
+        raise ValueError("at most %d streams are supported" % L.MAX_STREAMS)
+    cfg.n_streams = len(ss)
+    for i, (s, d) in enumerate(zip(ss, hd)):
+        cfg.stream_sizes[i] = int(s)
+        cfg.has_dynamic_features[i] = int(bool(d))
+    cfg.num_windows = len(hp.windows)
+    adv = getattr(hp, "adversarial_streams", None)
+    if adv is None:
+        cfg.adversarial_streams[0] = -1
+    else:
+        for i, a in enumerate(adv):
+            cfg.adversarial_streams[i] = int(bool(a))
+    cfg.mask_nth_mgc_for_adv_loss = int(getattr(hp, "mask_nth_mgc_for_adv_loss", 0))
+    cfg.discriminator_linguistic_condition = int(bool(getattr(hp, "discriminator_linguistic_condition", False)))
+    cfg.cond_dim = 0   # derived from the bound discriminator's in_dim
+    return cfg
+
+
+def _hp_signature(hp):
+    adv = getattr(hp, "adversarial_streams", None)
+    return (tuple(hp.stream_sizes), tuple(bool(b) for b in hp.has_dynamic_features), len(hp.windows),
+            None if adv is None else tuple(bool(a) for a in adv),
+            int(getattr(hp, "mask_nth_mgc_for_adv_loss", 0)),
+            bool(getattr(hp, "discriminator_linguistic_condition", False)))
+
+
+def _check_frames(t, name, last_dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: gantts_amd runs on the GPU only (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % name)
+    if last_dim is not None and t.size(-1) != last_dim:
+        raise RuntimeError("%s: expected last dimension %d, got %d" % (name, last_dim, t.size(-1)))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _SingleStreamHP(object):
+    """hp stand-in for forward-only engines: one stream, no dynamic features."""
+
+    def __init__(self, width, num_windows=1, dynamic=False):
+        self.stream_sizes = [width]
+        self.has_dynamic_features = [dynamic]
+        self.windows = [None] * num_windows
+        self.adversarial_streams = None
+        self.mask_nth_mgc_for_adv_loss = 0
+        self.discriminator_linguistic_condition = False
+
+
+class StepEngine(object):
+    def __init__(self, hp):
+        self.signature = _hp_signature(hp)
+        cfg = stream_config_from_hp(hp)
+        h = C.c_void_p()
+        check(lib.gt_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._finalizer = weakref.finalize(self, lib.gt_engine_destroy, h)
+        self._bound = {L.ROLE_G: (None, -1, False), L.ROLE_D: (None, -1, False)}   # (model ref, version, with_grads)
+        self._bound_opt = {L.ROLE_G: (None, -1), L.ROLE_D: (None, -1)}
+        self._keep = {}
+        nW = len(hp.windows)
+        ss = [s // nW if d else s for s, d in zip(hp.stream_sizes, hp.has_dynamic_features)]
+        self.static_dim = int(sum(ss))
+        self.num_windows = nW
+
+    @classmethod
+    def for_forward_only(cls, model):
+        if model.include_parameter_generation():
+            return cls(_SingleStreamHP(model.out_dim, model.out_dim // model.static_dim, True))
+        return cls(_SingleStreamHP(model.out_dim))
+
+    # ---- binding --------------------------------------------------------------------------
+    def bind_model(self, role, model, with_grads=True):
+        ref, ver, wg = self._bound[role]
+        if ref is not None and ref() is model and ver == model._version and (wg or not with_grads):
+            check(lib.gt_set_training(self._h, role, int(model.training)))
+            return
+        desc = model._desc(with_grads)
+        check(lib.gt_bind_model(self._h, role, C.byref(desc)))
+        for (pass_idx, layer), m in model._masks.items():
+            check(lib.gt_set_dropout_mask(self._h, role, pass_idx, layer, ptr(m)))
+        check(lib.gt_set_training(self._h, role, int(model.training)))
+        self._bound[role] = (weakref.ref(model), model._version, with_grads)
+        self._bound_opt[role] = (None, -1)
+        model._bound_engines[id(self)] = (weakref.ref(self), role)
+
+    def bind_optimizer(self, role, optimizer):
+        ref, ver = self._bound_opt[role]
+        if ref is not None and ref() is optimizer and ver == optimizer._version:
+            check(lib.gt_set_lr(self._h, role, float(optimizer.param_groups[0]["lr"])))
+            return
+        desc = optimizer._desc()
+        check(lib.gt_bind_optimizer(self._h, role, C.byref(desc)))
+        self._bound_opt[role] = (weakref.ref(optimizer), optimizer._version)
+        optimizer._engines[id(self)] = (weakref.ref(self), role)
+
+    def optimizer_step_count(self, role):
+        n = C.c_int64()
+        check(lib.gt_get_optimizer_step(self._h, role, C.byref(n)))
+        return n.value
+
+    def zero_grad(self, role):
+        check(lib.gt_zero_grad(self._h, role))
+
+    def set_seed(self, seed):
+        check(lib.gt_set_seed(self._h, C.c_uint64(int(seed))))
+
+    def set_loss_normalizer(self, tv):
+        check(lib.gt_set_loss_normalizer(self._h, float(tv)))
+
+    # ---- step functions -------------------------------------------------------------------
+    def apply_generator(self, model_g, x, R):
+        x = _check_frames(x, "x", model_g.in_dim)
+        B, T, _ = x.shape
+        self.bind_model(L.ROLE_G, model_g, with_grads=True)
+        static_w = model_g.static_dim if model_g.include_parameter_generation() else self.static_dim
+        y_hat = torch.empty(B, T, model_g.out_dim, device=x.device, dtype=torch.float32)
+        y_hat_static = torch.empty(B, T, static_w, device=x.device, dtype=torch.float32)
+        if R is not None:
+            R = _check_frames(R, "R")
+            if R.dim() != 2 or R.size(0) != T or R.size(1) != self.num_windows * T:
+                raise RuntimeError("R must be (T, num_windows*T) = (%d, %d), got %s" % (T, self.num_windows * T, tuple(R.shape)))
+        check(lib.gt_apply_generator(self._h, ptr(x), ptr(R), B, T, ptr(y_hat), ptr(y_hat_static), L.current_stream()))
+        self._keep["g"] = (x, R, y_hat, y_hat_static)
+        y_hat._gt_engine = y_hat_static._gt_engine = self
+        return y_hat, y_hat_static
+
+    def _mask2d(self, mask, B, T):
+        mask = _check_frames(mask, "mask")
+        if mask.numel() != B * T:
+            raise RuntimeError("mask must have B*T = %d elements, got %s" % (B * T, tuple(mask.shape)))
+        return mask
+
+    def update_discriminator(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
+        y_static = _check_frames(y_static, "y_static")
+        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        B, T, _ = y_static.shape
+        mask = self._mask2d(mask, B, T)
+        train = phase == "train"
+        self.bind_model(L.ROLE_D, model_d, with_grads=True)
+        if train:
+            self.bind_optimizer(L.ROLE_D, optimizer_d)
+        if self.signature[5]:
+            x = _check_frames(x, "x", model_d.in_dim - self._adv_width())
+        else:
+            x = None
+        res = L.DResult()
+        check(lib.gt_update_discriminator(self._h, ptr(x), ptr(y_static), ptr(y_hat_static_c), ptr(mask), B, T,
+                                          int(train), float(eps), C.byref(res), L.current_stream()))
+        if train:
+            optimizer_d._note_step(self, L.ROLE_D)
+        return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
+
+    def update_generator(self, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
+                         adv_w, mask, phase, mse_w, mge_w, eps=1e-20):
+        y = _check_frames(y, "y", model_g.out_dim)
+        y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
+        y_static = _check_frames(y_static, "y_static")
+        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        B, T, _ = y.shape
+        mask = self._mask2d(mask, B, T)
+        train = phase == "train"
+        self.bind_model(L.ROLE_G, model_g, with_grads=True)
+        if train:
+            self.bind_optimizer(L.ROLE_G, optimizer_g)
+        if adv_w > 0:
+            self.bind_model(L.ROLE_D, model_d, with_grads=False)
+            x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+        else:
+            x = None
+        res = L.GResult()
+        check(lib.gt_update_generator(self._h, ptr(x), ptr(y), ptr(y_hat_c), ptr(y_static), ptr(y_hat_static_c),
+                                      float(adv_w), ptr(mask), B, T, int(train), float(mse_w), float(mge_w),
+                                      float(eps), C.byref(res), L.current_stream()))
+        if train:
+            optimizer_g._note_step(self, L.ROLE_G)
+        return res.loss_mse, res.loss_mge, res.loss_adv, res.loss_g
+
+    def _adv_width(self):
+        ss, hd, nW, adv, nmask, _ = self.signature
+        static = [s // nW if d else s for s, d in zip(ss, hd)]
+        if adv is None:
+            return sum(static)
+        return sum(s for s, a in zip(static, adv) if a) - (nmask if nmask > 0 else 0)
+
+    def flush_generator_grads(self):
+        check(lib.gt_flush_generator_grads(self._h, L.current_stream()))
+
+    def model_forward(self, model, x, R=None):
+        squeeze = x.dim() == 2
+        if squeeze:
+            x = x.unsqueeze(0)
+        x = _check_frames(x, "x", model.in_dim)
+        B, T, _ = x.shape
+        self.bind_model(L.ROLE_G, model, with_grads=False)
+        out = torch.empty(B, T, model.out_dim, device=x.device, dtype=torch.float32)
+        out2 = None
+        if model.include_parameter_generation():
+            if R is None:
+                raise RuntimeError("In2OutHighwayNet.forward needs R")
+            R = _check_frames(R, "R")
+            out2 = torch.empty(B, T, model.static_dim, device=x.device, dtype=torch.float32)
+        check(lib.gt_model_forward(self._h, L.ROLE_G, ptr(x), ptr(R), B, T, ptr(out), ptr(out2), L.current_stream()))
+        if out2 is not None:
+            return out, out2
+        return out.squeeze(0) if squeeze else out
+
+    # ---- stand-alone ops that need the stream config --------------------------------------
+    def mlpg_forward(self, y, R):
+        y = _check_frames(y, "inputs")
+        R = _check_frames(R, "R")
+        B, T, _ = y.shape
+        out = torch.empty(B, T, self.static_dim, device=y.device, dtype=torch.float32)
+        check(lib.gt_op_mlpg_forward(self._h, ptr(y), ptr(R), B, T, ptr(out), L.current_stream()))
+        return out
+
+    def mlpg_backward(self, g_static, R, full_dim):
+        g = _check_frames(g_static, "grad")
+        R = _check_frames(R, "R")
+        B, T, _ = g.shape
+        out = torch.empty(B, T, full_dim, device=g.device, dtype=torch.float32)
+        check(lib.gt_op_mlpg_backward(self._h, ptr(g), ptr(R), B, T, ptr(out), L.current_stream()))
+        return out
+
+
+_engines_by_sig = {}
+
+
+def engine_for(hp, model_g=None):
+    """One engine per (generator, hp signature); generators are the anchor because every step
+    starts with apply_generator (train.py:543)."""
+    sig = _hp_signature(hp)
+    if model_g is not None:
+        eng = getattr(model_g, "_step_engine", None)
+        if eng is None or eng.signature != sig:
+            eng = StepEngine(hp)
+            model_g._step_engine = eng
+        return eng
+    eng = _engines_by_sig.get(sig)
+    if eng is None:
+        eng = _engines_by_sig[sig] = StepEngine(hp)
+    return eng

@@ -1,0 +1,170 @@
+"""Generator / discriminator networks with the reference's constructor and module API
+(``gantts/models.py``), computed by the HIP engine.
+
+Each class is an ``nn.Module`` only for *plumbing*: parameters are ``nn.Parameter`` views into
+ONE flat float32 device buffer per network (state_dict order), so that
+  * ``state_dict()/load_state_dict()/parameters()/cuda()/train()/eval()`` and
+    ``torch.save`` checkpoints keep the reference's keys and (out, in) weight layout
+    (reference train.py:162-171, 651-658; SURVEY 5 "Checkpoint / resume"),
+  * the engine sees a single contiguous parameter / gradient / optimizer-state range
+    (fused clip-norm + optimizer kernel, one all-reduce bucket per network).
+No torch op touches the numbers: forward/backward/step run in libgantts_hip.so.
+"""
+import math
+import weakref
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+class AbstractModel(object):
+    """Interface for VC and TTS models (reference gantts/models.py:11-18)."""
+
+    def include_parameter_generation(self):
+        return False
+
+
+class _LinearParams(nn.Module):
+    """Holds ``weight`` (out, in) and ``bias`` (out) of one nn.Linear; never called."""
+
+    def __init__(self, out_dim, in_dim):
+        super(_LinearParams, self).__init__()
+        self.in_features, self.out_features = in_dim, out_dim
+        self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
+        self.bias = nn.Parameter(torch.empty(out_dim))
+
+    def extra_repr(self):
+        return "in_features=%d, out_features=%d" % (self.in_features, self.out_features)
+
+
+class _FlatNetwork(AbstractModel, nn.Module):
+    ARCH = None
+
+    def _finish_init(self):
+        """Re-homes all parameters into one flat buffer with nn.Linear's default init."""
+        params = list(self.parameters())
+        total = sum(p.numel() for p in params)
+        self._flat = torch.empty(total, dtype=torch.float32)
+        self._flat_grad = None
+        self._repoint(init=True)
+        self._engine = None          # private engine for plain forward calls
+        self._masks = {}             # (pass, layer) -> injected dropout mask tensor (tests)
+        self._bound_engines = {}     # id(engine) -> (weakref(engine), role): who must hear zero_grad()
+        self._version = 0            # bumped whenever buffers are re-homed (engines re-bind)
+
+    def _linears(self):
+        return [m for m in self.modules() if isinstance(m, _LinearParams)]
+
+    def _repoint(self, init=False):
+        off = 0
+        for lin in self._linears():
+            for name in ("weight", "bias"):
+                p = getattr(lin, name)
+                n = p.numel()
+                view = self._flat[off:off + n].view(p.shape)
+                if init:
+                    k = 1.0 / math.sqrt(lin.in_features)   # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in))
+                    view.uniform_(-k, k)
+                p.data = view
+                p._gt_owner = weakref.ref(self)
+                p.grad = None if self._flat_grad is None else self._flat_grad[off:off + n].view(p.shape)
+                off += n
+        self._version = getattr(self, "_version", 0) + 1
+
+    def _apply(self, fn, recurse=True):
+        # .cuda()/.cpu()/.to(): move the flat buffers, then re-create the parameter views
+        self._flat = fn(self._flat)
+        if self._flat.dtype != torch.float32:
+            raise TypeError("gantts_amd networks are float32 only")
+        if self._flat_grad is not None:
+            self._flat_grad = fn(self._flat_grad)
+        self._repoint()
+        return self
+
+    def flat_params(self):
+        return self._flat
+
+    def flat_grads(self):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+            self._repoint()
+        return self._flat_grad
+
+    def num_flat_params(self):
+        return self._flat.numel()
+
+    def set_dropout_masks(self, pass_index, masks):
+        """Parity hook: inject 0/1 keep-masks (one per hidden layer, shape (B,T,hidden)) for forward
+        pass ``pass_index`` (G: 0; D: 0 real / 1 fake of the D step, 2 fake of the G step)."""
+        for layer in range(self.num_hidden):
+            m = None if masks is None else masks[layer]
+            if m is not None:
+                m = m.to(self._flat.device, torch.float32).contiguous()
+            self._masks[(pass_index, layer)] = m
+        self._version += 1
+
+    def _desc(self, with_grads):
+        d = L.ModelDesc()
+        d.arch = self.ARCH
+        d.in_dim, d.out_dim = self.in_dim, self.out_dim
+        d.num_hidden, d.hidden_dim = self.num_hidden, self.hidden_dim
+        d.static_dim = getattr(self, "static_dim", 0)
+        d.dropout = float(self.dropout_p)
+        d.last_sigmoid = int(bool(getattr(self, "last_sigmoid", False)))
+        if not self._flat.is_cuda:
+            raise RuntimeError("gantts_amd: model is on %s -- call .cuda() first (the HIP engine has no CPU path)"
+                               % self._flat.device)
+        d.params = self._flat.data_ptr()
+        d.grads = self.flat_grads().data_ptr() if with_grads else None
+        d.n_params = self._flat.numel()
+        return d
+
+    def _own_engine(self):
+        from .engine import StepEngine
+        if self._engine is None:
+            self._engine = StepEngine.for_forward_only(self)
+        return self._engine
+
+
+class MLP(_FlatNetwork):
+    """Stack of Linear -> LeakyReLU(0.01) -> Dropout, final Linear, optional sigmoid
+    (reference gantts/models.py:121-141).  ``bidirectional`` is a dummy, as in the reference."""
+    ARCH = L.ARCH_MLP
+
+    def __init__(self, in_dim=118, out_dim=1, num_hidden=2, hidden_dim=256,
+                 dropout=0.5, last_sigmoid=True, bidirectional=None):
+        super(MLP, self).__init__()
+        self.in_dim, self.out_dim, self.num_hidden, self.hidden_dim = in_dim, out_dim, num_hidden, hidden_dim
+        self.dropout_p, self.last_sigmoid = dropout, last_sigmoid
+        ins = [in_dim] + [hidden_dim] * (num_hidden - 1)
+        self.layers = nn.ModuleList([_LinearParams(hidden_dim, i) for i in ins])
+        self.last_linear = _LinearParams(out_dim, hidden_dim)
+        self._finish_init()
+
+    def forward(self, x, lengths=None):
+        return self._own_engine().model_forward(self, x)
+
+
+class In2OutHighwayNet(_FlatNetwork):
+    """Input-to-output highway network for VC with MLPG inside the model
+    (reference gantts/models.py:21-69): returns ``(G(x), x_static + T(x) * MLPG(G(x)))``."""
+    ARCH = L.ARCH_IN2OUT
+
+    def __init__(self, in_dim=118, out_dim=118, static_dim=118 // 2,
+                 num_hidden=3, hidden_dim=512, dropout=0.5):
+        super(In2OutHighwayNet, self).__init__()
+        self.in_dim, self.out_dim, self.num_hidden, self.hidden_dim = in_dim, out_dim, num_hidden, hidden_dim
+        self.static_dim, self.dropout_p = static_dim, dropout
+        self.T = _LinearParams(static_dim, static_dim)
+        ins = [in_dim] + [hidden_dim] * (num_hidden - 1)
+        self.H = nn.ModuleList([_LinearParams(hidden_dim, i) for i in ins])
+        self.last_linear = _LinearParams(out_dim, hidden_dim)
+        self._finish_init()
+
+    def include_parameter_generation(self):
+        return True
+
+    def forward(self, x, R, lengths=None):
+        return self._own_engine().model_forward(self, x, R)

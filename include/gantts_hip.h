@@ -1,0 +1,203 @@
+/* gantts_hip.h -- C ABI of the MI355X-native GAN training engine (libgantts_hip.so).
+ *
+ * Drop-in boundary for the G+D adversarial training step of r9y9/gantts.  Every entry point
+ * cites the reference interface (file:line in the upstream tree) it stands in for; the Python
+ * host package `gantts_amd` binds these with ctypes and re-exposes the reference's own Python
+ * signatures.
+ *
+ * Conventions
+ *  - plain C: opaque handle, raw device pointers (HIP, float32 unless noted), sizes; no C++/torch types.
+ *  - every function returns 0 on success, non-zero on error; gt_last_error() gives the message
+ *    (thread-local).  HIP errors are mapped to GT_ERR_HIP; the library never aborts.
+ *  - all frame tensors are contiguous (B,T,D) row-major, feature dimension fastest
+ *    (reference train.py:145-159).  A "row" is one frame; rows = B*T.
+ *  - the caller owns inputs, outputs, parameters, gradients and optimizer state (so checkpoints
+ *    stay torch.save-compatible, reference train.py:162-171); the engine borrows the pointers for
+ *    the duration of a call and owns only its workspace (activation stash, slabs, scalars).
+ *  - calls on one handle are not re-entrant; kernels are enqueued on the `stream` argument
+ *    (a hipStream_t, may be NULL for the default stream); functions returning host scalars
+ *    synchronise that stream once before returning.
+ */
+#ifndef GANTTS_HIP_H_
+#define GANTTS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT_OK 0
+#define GT_ERR_INVALID 1      /* bad argument / unsupported configuration */
+#define GT_ERR_HIP 2          /* HIP runtime error */
+#define GT_ERR_STATE 3        /* call order violated (e.g. update_* before apply_generator) */
+#define GT_ERR_DIM 4          /* "You probably have specified wrong dimention params." (multistream.py:93-94) */
+
+#define GT_ROLE_G 0
+#define GT_ROLE_D 1
+
+#define GT_ARCH_MLP 0         /* gantts/models.py:121-141 */
+#define GT_ARCH_IN2OUT 1      /* gantts/models.py:21-69  (In2OutHighwayNet) */
+
+#define GT_OPT_ADAGRAD 0      /* torch.optim.Adagrad, train.py:796-799 with hparams.py:48-52,223-227 */
+#define GT_OPT_ADAM 1         /* torch.optim.Adam,    hparams.py:125-130 */
+
+#define GT_MAX_STREAMS 8
+
+typedef struct gt_engine gt_engine;
+
+/* hp.* fields read on the step path (train.py:61, 233-241, 248, 254, 299, 304, 352-353). */
+typedef struct {
+  int32_t n_streams;
+  int32_t stream_sizes[GT_MAX_STREAMS];          /* hp.stream_sizes (static+delta widths)        */
+  int32_t has_dynamic_features[GT_MAX_STREAMS];  /* hp.has_dynamic_features                       */
+  int32_t num_windows;                           /* len(hp.windows)                               */
+  int32_t adversarial_streams[GT_MAX_STREAMS];   /* hp.adversarial_streams; [0] = -1 means None   */
+  int32_t mask_nth_mgc_for_adv_loss;             /* hp.mask_nth_mgc_for_adv_loss                  */
+  int32_t discriminator_linguistic_condition;    /* hp.discriminator_linguistic_condition         */
+  int32_t cond_dim;                              /* width of x fed to D when conditioned (x, not cat(x,z): train.py:254-256) */
+} gt_stream_config;
+
+/* One network.  `params`/`grads` are flat float32 device buffers laid out in state_dict order:
+ *   MLP:    layers.0.weight (hidden x in) | layers.0.bias | ... | last_linear.weight | last_linear.bias
+ *   IN2OUT: T.weight (sd x sd) | T.bias | H.0.weight | H.0.bias | ... | last_linear.weight | last_linear.bias
+ * weights are (out, in) row-major exactly as nn.Linear stores them. */
+typedef struct {
+  int32_t arch;
+  int32_t in_dim, out_dim, num_hidden, hidden_dim;
+  int32_t static_dim;        /* IN2OUT only */
+  float dropout;
+  int32_t last_sigmoid;
+  float* params;
+  float* grads;
+  int64_t n_params;
+} gt_model_desc;
+
+typedef struct {
+  int32_t kind;              /* GT_OPT_* */
+  float lr, weight_decay, eps;
+  float lr_decay;            /* Adagrad */
+  float beta1, beta2;        /* Adam */
+  float max_grad_norm;       /* clip_grad_norm_ threshold, 1.0 in train.py:275,317 */
+  int64_t step;              /* number of steps already taken (restored from a checkpoint) */
+  float* state0;             /* Adagrad "sum" / Adam "exp_avg"     (flat, same layout as params) */
+  float* state1;             /* Adam "exp_avg_sq" (NULL for Adagrad) */
+} gt_optim_desc;
+
+typedef struct {             /* return values of update_discriminator, train.py:278-279 (same order) */
+  float loss_d, loss_fake_d, loss_real_d, real_correct_count, fake_correct_count;
+  float grad_norm;           /* pre-clip ||grad D||_2 (extra; 0 when phase != train) */
+} gt_d_result;
+
+typedef struct {             /* return values of update_generator, train.py:320 (same order) */
+  float loss_mse, loss_mge, loss_adv, loss_g;
+  float grad_norm;           /* pre-clip ||grad G||_2 of the accumulated gradient (extra) */
+} gt_g_result;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+const char* gt_last_error(void);
+const char* gt_version(void);
+int gt_engine_create(const gt_stream_config* cfg, gt_engine** out);
+void gt_engine_destroy(gt_engine* e);
+
+/* getattr(gantts.models, name)(**params) + .cuda()            (train.py:773-793) */
+int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc);
+/* getattr(optim, hp.optimizer_*)(model.parameters(), **params) (train.py:796-799) */
+int gt_bind_optimizer(gt_engine* e, int role, const gt_optim_desc* desc);
+/* model.train() / model.eval()                                 (train.py:481-486) */
+int gt_set_training(gt_engine* e, int role, int training);
+/* exp_lr_scheduler writes param_group["lr"]                     (train.py:323-333) */
+int gt_set_lr(gt_engine* e, int role, float lr);
+int gt_get_optimizer_step(gt_engine* e, int role, int64_t* step);
+int gt_set_seed(gt_engine* e, uint64_t seed);
+/* Parity hook: use the caller's 0/1 float mask ((rows, hidden) contiguous, device) instead of the
+ * Philox stream for dropout site `layer` of forward pass `pass` of `role`; NULL restores Philox.
+ * passes: G: 0 = apply_generator.  D: 0 = real rows of the D step, 1 = generated rows of the
+ * D step, 2 = generated rows of the G step (the order nn.Dropout is consumed in train.py:261-307). */
+int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, const float* mask);
+
+/* ---- hot path -------------------------------------------------------------------------- */
+/* optimizer.zero_grad()                                         (train.py:538-539) */
+int gt_zero_grad(gt_engine* e, int role);
+
+/* apply_generator(model_g, x, R, lengths) -> (y_hat, y_hat_static)   (train.py:336-355)
+ * x (B,T,in_dim of G); R dense (T, num_windows*T) from unit_variance_mlpg_matrix or NULL
+ * (train.py:510-515); outputs y_hat (B,T,out_dim), y_hat_static (B,T,static width). */
+int gt_apply_generator(gt_engine* e, const float* x, const float* R, int B, int T,
+                       float* y_hat, float* y_hat_static, void* stream);
+
+/* update_discriminator(model_d, optimizer_d, x, y_static, y_hat_static, lengths, mask, phase, eps)
+ * (train.py:245-279).  x is the conditioning input (cond_dim wide, may be NULL when not
+ * conditioned); mask (B,T) float; train != 0 <=> phase == "train".  When y_hat_static is the
+ * buffer the last gt_apply_generator wrote (the autograd graph of the reference), the D-loss
+ * gradient w.r.t. it is kept and added to G's gradient by gt_update_generator (train.py:265,274,316). */
+int gt_update_discriminator(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                            const float* mask, int B, int T, int train, float eps,
+                            gt_d_result* out, void* stream);
+
+/* update_generator(model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static, adv_w,
+ *                  lengths, mask, phase, mse_w, mge_w, eps)      (train.py:282-320) */
+int gt_update_generator(gt_engine* e, const float* x, const float* y, const float* y_hat,
+                        const float* y_static, const float* y_hat_static, float adv_w,
+                        const float* mask, int B, int T, int train, float mse_w, float mge_w, float eps,
+                        gt_g_result* out, void* stream);
+
+/* Split-phase forms for data parallelism (one process per GPU): *_begin runs forward+backward and
+ * leaves the LOCAL gradient sums in the bound grads buffer and the local loss sums in
+ * gt_scalar_buffer(); the host all-reduces both (RCCL), then *_end clips, steps and finalises.
+ * tv_global > 0 overrides sum(mask) as the loss normaliser (global valid-frame count). */
+int gt_set_loss_normalizer(gt_engine* e, float tv_global);
+int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                                  const float* mask, int B, int T, int train, float eps, void* stream);
+int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream);
+int gt_update_generator_begin(gt_engine* e, const float* x, const float* y, const float* y_hat,
+                              const float* y_static, const float* y_hat_static, float adv_w,
+                              const float* mask, int B, int T, int train, float mse_w, float mge_w, float eps,
+                              void* stream);
+int gt_update_generator_end(gt_engine* e, int train, float adv_w, float mse_w, float mge_w,
+                            gt_g_result* out, void* stream);
+/* device pointer + length (in doubles) of the additive loss/count sums of the current step */
+int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n_doubles);
+
+/* model(x, lengths=lengths) -- plain forward of a bound network (inference / reference-D spoofing
+ * rate, train.py:549-558; evaluation_tts.py:167,221).  For IN2OUT `out2` receives y_hat_static and
+ * R must be given; for MLP out2/R are ignored. */
+int gt_model_forward(gt_engine* e, int role, const float* x, const float* R, int B, int T,
+                     float* out, float* out2, void* stream);
+
+/* Materialise G's pending gradient (the D-loss leak) into G's grads buffer without stepping --
+ * parity/introspection helper mirroring `p.grad` after update_discriminator in the reference. */
+int gt_flush_generator_grads(gt_engine* e, void* stream);
+
+/* ---- stand-alone operators (same kernels as the engine; used by the host-side mirrors of
+ *      gantts.seqloss / gantts.multistream and by the parity tests) ------------------------ */
+/* sequence_mask(lengths, max_len)                                (gantts/seqloss.py:9-20); lengths int64 device */
+int gt_op_sequence_mask(const int64_t* lengths, int B, int T, float* mask, void* stream);
+/* MaskedMSELoss()(input, target, mask=mask)                      (gantts/seqloss.py:27-43); returns host scalar;
+ * grad_input (optional) receives d loss / d input */
+int gt_op_masked_mse(const float* input, const float* target, const float* mask, int B, int T, int D,
+                     float* loss_out, float* grad_input, void* stream);
+/* out[:, j] = in[:, idx[j]]  (select_streams / get_static_features / get_selected_static_stream:
+ * gantts/multistream.py:33-79, train.py:232-242); idx int32 device array */
+int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,
+                      int out_col_offset, int64_t rows, void* stream);
+/* multi_stream_mlpg(inputs, R, stream_sizes, has_dynamic_features) (gantts/multistream.py:82-123) and its
+ * transpose (autograd backward).  Uses the engine's stream config. */
+int gt_op_mlpg_forward(gt_engine* e, const float* y, const float* R, int B, int T, float* y_static, void* stream);
+int gt_op_mlpg_backward(gt_engine* e, const float* g_static, const float* R, int B, int T, float* g_y, void* stream);
+/* nn.Linear forward / backward with the fused activation used by the models
+ * (act: 0 none, 1 LeakyReLU(0.01) [+dropout mask], 2 sigmoid).  Y (rows,out), X (rows,in), W (out,in). */
+int gt_op_linear_forward(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy,
+                         int64_t rows, int in_dim, int out_dim, int act, const float* keep_mask, float p,
+                         void* stream);
+/* dX = (dY . W) [* f'(H_prev)],  dW = dY^T . X,  db = colsum(dY); any output may be NULL.
+ * workspace is managed internally (hipMallocAsync on `stream`). */
+int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, const float* W,
+                          int64_t rows, int in_dim, int out_dim,
+                          float* dX, int lddx, const float* H_prev, int act_prev, const float* keep_mask_prev, float p_prev,
+                          float* dW, float* db, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANTTS_HIP_H_ */

@@ -1,0 +1,265 @@
+"""-m gpu parity tests: the HIP path (through the C ABI, via the reference-shaped Python API)
+against (a) the golden fixtures generated from the REAL reference and (b) the CPU oracle on the
+same seeded inputs.  Tolerance: 1e-4 relative on float32 (BASELINE.json north_star); counts and
+stream-split / vuv indexing bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import gantts_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-4
+
+
+def _close(a, b, rtol=RTOL, atol=1e-6, msg=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(1e-30, float(np.abs(b).max()))
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    assert err <= atol + rtol * scale, "%s: max abs err %.3e (scale %.3e, rel %.3e)" % (msg, err, scale, err / scale)
+
+
+def test_library_loaded_is_the_hip_one():
+    import gantts_amd._lib as L
+    assert os.path.isfile(L.LIB_PATH)
+    assert b"gfx950" in L.lib.gt_version()
+
+
+@pytest.mark.parametrize("name", sorted(C.CASES))
+def test_step_matches_reference_golden(name):
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_hip_case(case)
+    for k in gold.files:
+        if k.startswith("g_leak_norm"):
+            continue
+        assert k in got, k
+        g, o = gold[k], got[k]
+        if "scalars" in k:
+            _close(o, g, rtol=RTOL, atol=1e-6, msg=k)
+            if k.startswith("d_scalars"):
+                assert o[3] == g[3] and o[4] == g[4], (k, o, g)   # classification counts exact
+        elif ".opt." in k:
+            _close(o, g, rtol=5e-4, atol=1e-9, msg=k)
+        else:
+            _close(o, g, rtol=RTOL, atol=1e-6, msg=k)
+    # vuv stream is a pass-through copy: bit-exact
+    if case["stream_sizes"] == [180, 3, 1, 3]:
+        assert np.array_equal(got["y_hat_static"][:, :, 61], got["y_hat"][:, :, 183])
+
+
+def test_leak_gradient_matches_reference():
+    """||G.grad|| right after update_discriminator alone (the un-detached D-loss leak, train.py:265,274)."""
+    import gantts_amd.train as T
+    from gantts_amd import optim, paramgen
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model, make_hp
+    name = "acoustic_d_warmup"
+    case = C.CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    T.hp = make_hp(case)
+    mg, md = build_model(case["g"], 11).eval(), build_model(case["d"], 22).eval()
+    od = optim.Adagrad(md.parameters(), **case["opt_d"][1])
+    x_np, y_np, lengths = C.make_batch(case)
+    x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
+    R = paramgen.unit_variance_mlpg_matrix_cuda(T.hp.windows, case["T"])
+    y_static = get_static_features(y, 3, T.hp.stream_sizes, T.hp.has_dynamic_features)
+    mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
+    y_hat, y_hat_static = T.apply_generator(mg, x, R, list(lengths))
+    T.update_discriminator(md, od, x, y_static, y_hat_static, list(lengths), mask, "train")
+    y_hat_static._gt_engine.flush_generator_grads()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in mg.parameters())))
+    assert gn == pytest.approx(float(gold["g_leak_norm_0"]), rel=2e-4)
+
+
+@pytest.mark.parametrize("rows,din,dout,act", [(77, 425, 512, 1), (1000, 512, 187, 0), (300, 483, 256, 1),
+                                               (129, 25, 25, 2), (4096, 256, 58, 0), (33, 7, 3, 1)])
+def test_linear_forward_backward_vs_torch(rows, din, dout, act):
+    import ctypes as Ct
+    from gantts_amd._lib import check, lib, ptr
+    rs = np.random.RandomState(rows + din)
+    X = torch.from_numpy(rs.randn(rows, din).astype(np.float32))
+    W = torch.from_numpy((rs.randn(dout, din) / np.sqrt(din)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(dout).astype(np.float32))
+    p = 0.5 if act == 1 else 0.0
+    keep = torch.from_numpy((rs.rand(rows, dout) >= 0.5).astype(np.float32)) if act == 1 else None
+    # torch reference
+    Xr, Wr, br = X.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = torch.nn.functional.linear(Xr, Wr, br)
+    if act == 1:
+        ref = torch.nn.functional.leaky_relu(z, 0.01) * keep / (1 - p)
+    elif act == 2:
+        ref = torch.sigmoid(z)
+    else:
+        ref = z
+    gY = torch.from_numpy(rs.randn(rows, dout).astype(np.float32))
+    ref.backward(gY)
+    Xd, Wd, bd = X.cuda(), W.cuda(), b.cuda()
+    Y = torch.empty(rows, dout, device="cuda")
+    s = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kd = keep.cuda() if keep is not None else None
+    check(lib.gt_op_linear_forward(ptr(Xd), din, ptr(Wd), ptr(bd), ptr(Y), dout, rows, din, dout, act, ptr(kd), p, s))
+    _close(Y.cpu().numpy(), ref.detach().numpy(), msg="Y")
+    # backward of the *linear* part: feed dZ = gY * f'(out) computed on the host, check dX/dW/db
+    with torch.no_grad():
+        if act == 1:
+            dZ = gY * torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, 0.01)) * keep / (1 - p)
+        elif act == 2:
+            dZ = gY * ref * (1 - ref)
+        else:
+            dZ = gY
+    dZd = dZ.contiguous().cuda()
+    dX, dW, db = torch.empty_like(Xd), torch.empty_like(Wd), torch.empty_like(bd)
+    check(lib.gt_op_linear_backward(ptr(dZd), dout, ptr(Xd), din, ptr(Wd), rows, din, dout, ptr(dX), din, None, 0, None,
+                                    0.0, ptr(dW), ptr(db), s))
+    torch.cuda.synchronize()
+    _close(dX.cpu().numpy(), Xr.grad.numpy(), msg="dX")
+    _close(dW.cpu().numpy(), Wr.grad.numpy(), msg="dW")
+    _close(db.cpu().numpy(), br.grad.numpy(), msg="db")
+
+
+def test_linear_backward_fused_activation_derivative():
+    """dX epilogue multiplies by f'(H_prev) of the producing layer (LeakyReLU + dropout keep mask)."""
+    import ctypes as Ct
+    from gantts_amd._lib import check, lib, ptr
+    rs = np.random.RandomState(5)
+    rows, din, dout = 200, 96, 40
+    H = rs.randn(rows, din).astype(np.float32)
+    keep = (rs.rand(rows, din) >= 0.5).astype(np.float32)
+    H = np.where(keep > 0, H, 0).astype(np.float32)
+    W = (rs.randn(dout, din) / 10).astype(np.float32)
+    dZ = rs.randn(rows, dout).astype(np.float32)
+    ref = (dZ.astype(np.float64) @ W.astype(np.float64)) * np.where(H > 0, 1.0, 0.01) * keep * 2.0
+    s = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = lambda a: torch.from_numpy(a).cuda()
+    dX = torch.empty(rows, din, device="cuda")
+    Hd, Wd, dZd, kd = t(H), t(W), t(dZ), t(keep)
+    check(lib.gt_op_linear_backward(ptr(dZd), dout, None, 0, ptr(Wd), rows, din, dout, ptr(dX), din, ptr(Hd), 1, ptr(kd),
+                                    0.5, None, None, s))
+    torch.cuda.synchronize()
+    _close(dX.cpu().numpy(), ref, msg="dX fused")
+
+
+@pytest.mark.parametrize("B,T", [(3, 7), (2, 100), (4, 513)])
+def test_multi_stream_mlpg_forward_backward_vs_dense(B, T):
+    from gantts_amd import paramgen
+    from gantts_amd.engine import engine_for
+    from gantts_amd.multistream import _HP, multi_stream_mlpg
+    ss, hd = [180, 3, 1, 3], [True, True, False, True]
+    R_np = paramgen.unit_variance_mlpg_matrix(C.WINDOWS, T)
+    R = torch.from_numpy(np.array(R_np)).cuda()
+    rs = np.random.RandomState(T)
+    y = torch.from_numpy(rs.randn(B, T, 187).astype(np.float32))
+    yr = y.clone().requires_grad_(True)
+    ref = O.multi_stream_mlpg(yr, torch.from_numpy(np.array(R_np)), ss, hd)
+    got = multi_stream_mlpg(y.cuda(), R, ss, hd)
+    _close(got.cpu().numpy(), ref.detach().numpy(), msg="mlpg fwd")
+    assert torch.equal(got[:, :, 61].cpu(), y[:, :, 183])          # vuv pass-through bit-exact
+    g = torch.from_numpy(rs.randn(B, T, 63).astype(np.float32))
+    ref.backward(g)
+    eng = engine_for(_HP(ss, hd, 3))
+    gy = eng.mlpg_backward(g.cuda(), R, 187)
+    _close(gy.cpu().numpy(), yr.grad.numpy(), msg="mlpg bwd")
+    with pytest.raises(RuntimeError):
+        multi_stream_mlpg(y[:, :, :100].cuda(), R, ss, hd)
+
+
+def test_stream_gathers_are_bit_exact():
+    # mirrors reference tests/test_gantts.py:60-129
+    from gantts_amd.multistream import get_static_features, get_static_stream_sizes, select_streams
+    ss = [60, 1, 1, 1]
+    x = torch.arange(0, 63).float().expand(32, 100, 63).contiguous().cuda()
+    assert select_streams(x, ss, [True, True, True, True]).shape == (32, 100, 63)
+    assert select_streams(x, ss, [True, False, False, False]).shape == (32, 100, 60)
+    assert select_streams(x, ss, [True, False, False, True]).shape == (32, 100, 61)
+    assert (select_streams(x, ss, [False, False, False, True]).squeeze(-1) == x[:, :, -1]).all()
+    assert (select_streams(x, ss, [False, False, True, False]).squeeze(-1) == x[:, :, -2]).all()
+    assert (select_streams(x, ss, [False, True, False, False]).squeeze(-1) == x[:, :, -3]).all()
+    y = select_streams(x, ss, [True, False, False, True])
+    assert (y[:, :, :60] == x[:, :, :60]).all() and (y[:, :, -1] == x[:, :, -1]).all()
+    assert np.all(get_static_stream_sizes([180, 3, 1, 3], [True, True, False, True], 3) == [60, 1, 1, 1])
+    z = torch.rand(8, 50, 187).cuda()
+    sf = get_static_features(z, 3, [180, 3, 1, 3], [True, True, False, True])
+    assert sf.shape == (8, 50, 63)
+    ref = O.get_static_features(z.cpu(), 3, [180, 3, 1, 3], [True, True, False, True])
+    assert torch.equal(sf.cpu(), ref)
+    assert get_static_features(z, 3, [180, 3, 1, 3], [True, True, False, True],
+                               streams=[True, False, False, True]).shape == (8, 50, 61)
+
+
+def test_sequence_mask_and_masked_mse():
+    from gantts_amd.seqloss import MaskedMSELoss, sequence_mask
+    lengths = torch.tensor([7, 5, 1, 0, 7])
+    m = sequence_mask(lengths.cuda())
+    assert torch.equal(m.cpu(), O.sequence_mask(lengths, 7))
+    a, b = torch.randn(5, 7, 11), torch.randn(5, 7, 11)
+    crit = MaskedMSELoss(compute_grad=True)
+    loss = crit(a.cuda(), b.cuda(), lengths=lengths.cuda())
+    ar = a.clone().requires_grad_(True)
+    ref = O.masked_mse(ar, b, O.sequence_mask(lengths, 7).unsqueeze(-1))
+    ref.backward()
+    assert float(loss) == pytest.approx(float(ref), rel=1e-5)
+    _close(crit.grad_input.cpu().numpy(), ar.grad.numpy(), msg="mse grad")
+    with pytest.raises(RuntimeError):
+        MaskedMSELoss()(a.cuda(), b.cuda())
+
+
+def test_model_forward_eval_matches_oracle_and_errors():
+    from gantts_amd import models
+    spec = dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
+    m = models.MLP(**{k: v for k, v in spec.items() if k != "kind"})
+    sd = C.make_weights(spec, 7)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    with pytest.raises(RuntimeError):
+        m(torch.rand(2, 5, 425))          # CPU tensors: fail loudly, no fallback
+    m = m.cuda().eval()
+    o = O.OracleMLP(**{k: v for k, v in spec.items() if k != "kind"})
+    o.load_state_dict(sd)
+    o.training = False
+    x = torch.rand(3, 41, 425)
+    _close(m(x.cuda()).cpu().numpy(), o(x).detach().numpy(), msg="MLP eval forward")
+    assert list(m.state_dict().keys()) == o.names
+
+
+def test_philox_dropout_statistics_and_determinism():
+    from gantts_amd import models
+    m = models.MLP(in_dim=16, out_dim=8, num_hidden=1, hidden_dim=2048, dropout=0.5, last_sigmoid=False).cuda().train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.zero_()
+        m.layers[0].bias.fill_(1.0)
+        m.last_linear.weight.fill_(1.0 / 2048)
+    x = torch.zeros(4, 64, 16, device="cuda")
+    out = m(x)                 # each output = mean over hidden of keep*2  -> ~1.0
+    assert abs(float(out.mean()) - 1.0) < 0.02
+    assert float(out.std()) > 1e-4          # masks differ between frames
+    out2 = m(x)
+    assert not torch.equal(out, out2)       # fresh mask per call
+
+
+def test_checkpoint_roundtrip_and_torch_compat(tmp_path):
+    import gantts_amd.train as T
+    from gantts_amd import models, optim
+    m = models.MLP(in_dim=12, out_dim=5, num_hidden=2, hidden_dim=16, last_sigmoid=False).cuda()
+    opt = optim.Adagrad(m.parameters(), lr=0.01, weight_decay=1e-7)
+    path = T.save_checkpoint(m, opt, 10, str(tmp_path), "Generator")
+    ck = torch.load(path, map_location="cpu")
+    # loadable by a plain torch module with the reference's layout
+    ref = torch.nn.ModuleDict({"layers": torch.nn.ModuleList([torch.nn.Linear(12, 16), torch.nn.Linear(16, 16)]),
+                               "last_linear": torch.nn.Linear(16, 5)})
+    ref.load_state_dict(ck["state_dict"])
+    topt = torch.optim.Adagrad(ref.parameters(), lr=0.01, weight_decay=1e-7)
+    topt.load_state_dict(ck["optimizer"])
+    m2 = models.MLP(in_dim=12, out_dim=5, num_hidden=2, hidden_dim=16, last_sigmoid=False).cuda()
+    opt2 = optim.Adagrad(m2.parameters())
+    assert T.load_checkpoint(m2, opt2, path) == 10
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    assert opt2.param_groups[0]["weight_decay"] == 1e-7
