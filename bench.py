@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Headline benchmark: acoustic frames/sec for one G+D GAN step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "cfg2"): TTS acoustic MLP G (425->512x3->187, LeakyReLU 0.01,
+dropout 0.5) + conditioned MLP D (483->256x3->1, dropout 0.5, sigmoid), Adagrad(lr 0.01, wd 1e-7),
+w_d=1, mse_w=0, mge_w=1, adv_w=1, B=32 sequences x T=512 frames per GPU, float32, all lengths = T.
+One step = zero_grad x2 -> apply_generator -> update_discriminator("train") -> update_generator("train")
+including both optimizer steps and the D2H of the 9 scalars (train.py:538-585); inputs are resident
+in HBM before the timed region.  Weak scaling: every rank processes its own 32x512 shard; gradients
+and loss sums are all-reduced over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the f32
+MFMA GEMM family, per-launch HIP-event timing on the launch stream) and `cpu_baseline` (the CPU
+oracle -- a torch-CPU restatement of the reference step -- timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+VARIANTS = ["fwd X.W^T BN64", "fwd X.W^T BN128", "bwd-data dZ.W BN64", "bwd-data dZ.W BN128",
+            "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128"]
+
+G_SPEC = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
+D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
+OPT = dict(lr=0.01, weight_decay=1e-7)
+
+
+def algorithmic_flops_per_frame():
+    """3g - g1 + 8d - d1 MACs per frame (minimal equivalent step)."""
+    def macs(spec):
+        ins = [spec["in_dim"]] + [spec["hidden_dim"]] * (spec["num_hidden"] - 1)
+        per = [i * spec["hidden_dim"] for i in ins] + [spec["hidden_dim"] * spec["out_dim"]]
+        return sum(per), per[0]
+    g, g1 = macs(G_SPEC)
+    d, d1 = macs(D_SPEC)
+    return 2.0 * (3 * g - g1 + 8 * d - d1)
+
+
+def make_hp():
+    from gantts_amd import hparams
+    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    hp.generator, hp.generator_params = "MLP", dict(G_SPEC)
+    hp.discriminator_params = dict(D_SPEC)
+    return hp
+
+
+def synthetic_batch(B, T, seed, device):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, T, 425, generator=g)
+    y = torch.randn(B, T, 187, generator=g)
+    vuv = (torch.rand(B, T, generator=g) > 0.5).float()
+    y[:, :, 183] = (vuv - 0.5) / 0.5
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(B, T, budget_s=20.0):
+    """Times the CPU oracle (torch-CPU restatement of train.py:245-320) on the same workload."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gantts_oracle as O
+    torch.manual_seed(0)
+    mg, md = O.OracleMLP(seed=1, **G_SPEC), O.OracleMLP(seed=2, **D_SPEC)
+    og, od = O.OracleAdagrad(mg.params, **OPT), O.OracleAdagrad(md.params, **OPT)
+    cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
+    x, y = synthetic_batch(B, T, 0, "cpu")
+    from gantts_amd import hparams, paramgen
+    R = torch.from_numpy(__import__("numpy").array(paramgen.unit_variance_mlpg_matrix(hparams.tts_acoustic.windows, T)))
+    lengths = [T] * B
+    mask = O.sequence_mask(lengths, T).unsqueeze(-1)
+    times = []
+    t_start = time.time()
+    for i in range(1 + 64):
+        t0 = time.time()
+        O.train_step(cfg, mg, md, og, od, x, y, R, lengths, mask, adv_w=1.0, mse_w=0.0, mge_w=1.0)
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if i >= 3 and time.time() - t_start > budget_s:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * T / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed steps (after 1 warm-up) of the same cfg2 workload B=%d T=%d fp32 dropout 0.5 "
+                      "through oracle/gantts_oracle.py (torch-CPU autograd restatement of train.py:245-320), "
+                      "median %.3f s/step" % (len(times), B, T, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import gantts_amd.train as T
+    from gantts_amd import _lib as L
+    from gantts_amd import models, optim, paramgen
+    from gantts_amd.engine import HipStepBackend
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.parallel import DataParallelStep
+    from gantts_amd.seqloss import sequence_mask
+
+    B, Tn = args.batch, args.frames
+    hp = make_hp()
+    T.hp = hp
+    torch.manual_seed(0)
+    mg = models.MLP(**G_SPEC).cuda().train()
+    md = models.MLP(**D_SPEC).cuda().train()
+    og, od = optim.Adagrad(mg.parameters(), **OPT), optim.Adagrad(md.parameters(), **OPT)
+    x, y = synthetic_batch(B, Tn, 1000 + rank, dev)        # every rank its own shard (weak scaling)
+    R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn, dev)
+    lengths = torch.full((B,), Tn, dtype=torch.long, device=dev)
+    cpu_lengths = [Tn] * B
+    y_static = get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features)
+    mask = sequence_mask(lengths).unsqueeze(-1)
+
+    if world > 1:
+        backend = HipStepBackend(hp, mg, md, og, od)
+        dp = DataParallelStep(backend)
+        dp.broadcast_parameters(mg.flat_params(), md.flat_params())
+        batch = dict(x=x, y=y, y_static=y_static, mask=mask, R=R)
+        tv_global = float(world * B * Tn)
+
+        def step():
+            return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, tv_global=tv_global)
+    else:
+        def step():
+            og.zero_grad()
+            od.zero_grad()
+            y_hat, y_hat_static = T.apply_generator(mg, x, R, cpu_lengths)
+            d = T.update_discriminator(md, od, x, y_static, y_hat_static, cpu_lengths, mask, "train")
+            g = T.update_generator(mg, md, og, x, y, y_hat, y_static, y_hat_static, 1.0, cpu_lengths, mask,
+                                   "train", mse_w=0.0, mge_w=1.0)
+            return d, g
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        last = step()
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides --------------------
+    profile = not args.no_roofline
+    if profile:
+        L.check(L.lib.gt_profile_enable(1))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.check(L.lib.gt_profile_enable(0))
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if profile:
+        import ctypes as C
+        ms, fl, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+        L.check(L.lib.gt_profile_read(ms, fl, cnt))
+        per = []
+        for v in range(6):
+            if cnt[v]:
+                per.append({"kernel": "gemm_f32_kernel<%s>" % VARIANTS[v], "launches_per_step": cnt[v] / args.steps,
+                            "avg_us": 1e3 * ms[v] / cnt[v], "tflops": fl[v] / (ms[v] * 1e-3) / 1e12,
+                            "share_of_step_ms": ms[v] / args.steps})
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        dom = max(per, key=lambda p: p["share_of_step_ms"])
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": dom["avg_us"],
+                    "gemm_family": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                    "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                    "ms_per_step": tot_ms / args.steps, "gflop_per_step": tot_fl / args.steps / 1e9},
+                    "variants": per}
+
+    if rank == 0:
+        frames = world * B * Tn * args.steps
+        value = frames / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        step_flops = algorithmic_flops_per_frame() * B * Tn
+        out = {"metric": "acoustic frames/sec per G+D GAN step (B=32,T=512)", "value": value, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "cfg2: TTS acoustic MLP G 425-512x3-187 + conditioned MLP D 483-256x3-1, "
+                                      "Adagrad, MGE+ADV loss, B=%d T=%d per GPU, fp32, dropout 0.5 (Philox)" % (B, Tn),
+                          "global_batch": world * B, "frames_per_step": world * B * Tn, "parallelism": "dp%d" % world},
+               "step_algorithmic_gflop": step_flops / 1e9,
+               "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+               "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, Tn)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,42 @@ extern "C" const char* gt_version(void) { return "gantts_hip 0.1 (gfx950, f32 MF
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------
+// optional per-launch timing of the GEMM family (HIP events on the launch stream); used by
+// bench.py for the live roofline figure.  Off by default: zero overhead on the normal path.
+// ------------------------------------------------------------------------------------------
+struct GemmProfiler {
+  bool on = false;
+  struct Rec { int kind, bn; double flops; hipEvent_t e0, e1; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+  }
+};
+static GemmProfiler g_prof;
+
+extern "C" int gt_profile_enable(int on) {
+  g_prof.on = on != 0;
+  return GT_OK;
+}
+// Drains the recorded launches into per-variant totals.  variant = kind*2 + (bn==128): 6 slots.
+// out_ms[v] = summed kernel time, out_flops[v] = summed algorithmic 2*M*N*K, out_count[v] = launches.
+extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_count) {
+  for (int v = 0; v < 6; ++v) { out_ms[v] = 0; out_flops[v] = 0; out_count[v] = 0; }
+  for (auto& r : g_prof.recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventElapsedTime failed");
+    const int v = r.kind * 2 + (r.bn == 128 ? 1 : 0);
+    out_ms[v] += ms; out_flops[v] += r.flops; out_count[v] += 1;
+    g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1);
+  }
+  g_prof.recs.clear();
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------
 template <int KIND, int BM, int BN>
@@ -70,8 +106,15 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
   hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
@@ -396,7 +439,7 @@ extern "C" int gt_zero_grad(gt_engine* e, int role) {
 extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {
   if (!e || !dev_ptr || !n) return fail(GT_ERR_INVALID, "bad argument");
   *dev_ptr = &e->sc()->s_real;
-  *n = 7;   // s_real, s_fake, s_adv, n_real_ok, n_fake_ok, s_mge, s_mse
+  *n = 7;   // D step: s_real, s_fake, n_real_ok, n_fake_ok | G step: s_adv, s_mge, s_mse
   return GT_OK;
 }
 

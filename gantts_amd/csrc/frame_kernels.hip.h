@@ -62,8 +62,10 @@ __device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int 
 struct StepScalars {
   float tv;          // sum(mask)  (valid frames, reference train.py:258,286)
   float inv_tv;
-  double s_real, s_fake, s_adv;   // sum(log(..)*mask)
+  // additive sums (all-reduced across ranks in data-parallel runs): D step [0..3], G step [4..6]
+  double s_real, s_fake;          // sum(log(..)*mask)
   double n_real_ok, n_fake_ok;    // correct counts
+  double s_adv;                   // sum(log(D(fake))*mask) of the G step
   double s_mge, s_mse;            // sum of squared masked differences
   double gnorm2_d, gnorm2_g;      // squared grad norms (pre-clip)
 };

@@ -197,6 +197,69 @@ class StepEngine(object):
             optimizer_g._note_step(self, L.ROLE_G)
         return res.loss_mse, res.loss_mge, res.loss_adv, res.loss_g
 
+    # ---- split-phase forms (data parallelism, gantts_amd/parallel.py) ------------------------
+    def scalar_sums(self, which=None):
+        """Zero-copy torch view of the additive float64 loss / count sums of the current step
+        (D step: [0:4], G step: [4:7])."""
+        p, n = C.c_void_p(), C.c_int()
+        check(lib.gt_scalar_buffer(self._h, C.byref(p), C.byref(n)))
+
+        class _Arr(object):
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f8", "data": (p.value, False), "version": 2}
+        t = torch.as_tensor(_Arr(), device="cuda")
+        return t if which is None else (t[0:4] if which == "D" else t[4:7])
+
+    def update_discriminator_begin(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
+        y_static = _check_frames(y_static, "y_static")
+        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        B, T, _ = y_static.shape
+        mask = self._mask2d(mask, B, T)
+        train = phase == "train"
+        self.bind_model(L.ROLE_D, model_d, with_grads=True)
+        if train:
+            self.bind_optimizer(L.ROLE_D, optimizer_d)
+        x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+        check(lib.gt_update_discriminator_begin(self._h, ptr(x), ptr(y_static), ptr(y_hat_static_c), ptr(mask), B, T,
+                                                int(train), float(eps), L.current_stream()))
+
+    def update_discriminator_end(self, optimizer_d, phase):
+        train = phase == "train"
+        res = L.DResult()
+        check(lib.gt_update_discriminator_end(self._h, int(train), C.byref(res), L.current_stream()))
+        if train:
+            optimizer_d._note_step(self, L.ROLE_D)
+        return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
+
+    def update_generator_begin(self, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
+                               adv_w, mask, phase, mse_w, mge_w, eps=1e-20):
+        y = _check_frames(y, "y", model_g.out_dim)
+        y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
+        y_static = _check_frames(y_static, "y_static")
+        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        B, T, _ = y.shape
+        mask = self._mask2d(mask, B, T)
+        train = phase == "train"
+        self.bind_model(L.ROLE_G, model_g, with_grads=True)
+        if train:
+            self.bind_optimizer(L.ROLE_G, optimizer_g)
+        if adv_w > 0:
+            self.bind_model(L.ROLE_D, model_d, with_grads=False)
+            x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+        else:
+            x = None
+        check(lib.gt_update_generator_begin(self._h, ptr(x), ptr(y), ptr(y_hat_c), ptr(y_static), ptr(y_hat_static_c),
+                                            float(adv_w), ptr(mask), B, T, int(train), float(mse_w), float(mge_w),
+                                            float(eps), L.current_stream()))
+
+    def update_generator_end(self, optimizer_g, adv_w, mse_w, mge_w, phase):
+        train = phase == "train"
+        res = L.GResult()
+        check(lib.gt_update_generator_end(self._h, int(train), float(adv_w), float(mse_w), float(mge_w),
+                                          C.byref(res), L.current_stream()))
+        if train:
+            optimizer_g._note_step(self, L.ROLE_G)
+        return res.loss_mse, res.loss_mge, res.loss_adv, res.loss_g
+
     def _adv_width(self):
         ss, hd, nW, adv, nmask, _ = self.signature
         static = [s // nW if d else s for s, d in zip(ss, hd)]
@@ -261,3 +324,47 @@ def engine_for(hp, model_g=None):
     if eng is None:
         eng = _engines_by_sig[sig] = StepEngine(hp)
     return eng
+
+
+class HipStepBackend(object):
+    """Adapter of one (G, D, optimizers, hp) set to the protocol ``DataParallelStep`` drives.
+    A batch is ``dict(x=, y=, y_static=, mask=, R=)`` of this rank's CUDA tensors."""
+
+    def __init__(self, hp, model_g, model_d, optimizer_g, optimizer_d):
+        self.hp, self.mg, self.md, self.og, self.od = hp, model_g, model_d, optimizer_g, optimizer_d
+        self.engine = engine_for(hp, model_g)
+        self._out = None
+
+    def mask_of(self, batch):
+        return batch["mask"]
+
+    def set_loss_normalizer(self, tv):
+        self.engine.set_loss_normalizer(tv)
+
+    def zero_grad(self):
+        self.og.zero_grad()
+        self.od.zero_grad()
+
+    def flat_grads(self, which):
+        return (self.mg if which == "G" else self.md).flat_grads()
+
+    def scalar_sums(self, which):
+        return self.engine.scalar_sums(which)
+
+    def apply_generator(self, batch):
+        self._out = self.engine.apply_generator(self.mg, batch.get("g_in", batch["x"]), batch.get("R"))
+        return self._out
+
+    def update_discriminator_begin(self, batch, phase):
+        self.engine.update_discriminator_begin(self.md, self.od, batch["x"], batch["y_static"], self._out[1],
+                                               batch["mask"], phase)
+
+    def update_discriminator_end(self, batch, phase):
+        return self.engine.update_discriminator_end(self.od, phase)
+
+    def update_generator_begin(self, batch, adv_w, mse_w, mge_w, phase):
+        self.engine.update_generator_begin(self.mg, self.md, self.og, batch["x"], batch["y"], self._out[0],
+                                           batch["y_static"], self._out[1], adv_w, batch["mask"], phase, mse_w, mge_w)
+
+    def update_generator_end(self, batch, adv_w, mse_w, mge_w, phase):
+        return self.engine.update_generator_end(self.og, adv_w, mse_w, mge_w, phase)

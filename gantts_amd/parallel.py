@@ -1,0 +1,68 @@
+"""Data-parallel G+D step: one process per GPU, minibatch sharded over ranks (whole sequences per
+rank), parameters / optimizer state replicated.  The reference has no multi-device code at all
+(SURVEY 5); this is new, built on ``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm;
+"gloo" in the CPU tests).
+
+Exchange steps per global step:
+  1. global valid-frame count Tv = sum over ranks of mask.sum()  -> loss normaliser on every rank
+     (losses divide by the GLOBAL Tv: train.py:258,269-270,286,308; seqloss.py:43);
+  2. D step: local forward+backward -> all-reduce(sum) of D's flat gradient + the 7 additive loss /
+     count sums -> identical clip-norm + optimizer step on every rank;
+  3. G step: same with G's flat gradient (the D->G "leak" gradient stays local: it is a
+     per-frame upstream gradient, already normalised by the global Tv).
+Gradients are single flat buffers (<= 19 MB), so each exchange is ONE all-reduce per network.
+
+The class only orchestrates; compute goes through a backend object with the split-phase methods
+of ``StepEngine`` (``*_begin`` / ``*_end``), which lets the CPU tests drive it with the oracle.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelStep(object):
+    def __init__(self, backend, process_group=None):
+        self.backend = backend
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t
+
+    def broadcast_parameters(self, *flat_buffers):
+        """Rank 0's parameters / optimizer state become everyone's (call once after construction)."""
+        if self.world > 1:
+            for t in flat_buffers:
+                dist.broadcast(t, src=0, group=self.pg)
+
+    def global_valid_frames(self, mask):
+        tv = mask.sum().reshape(1).double()
+        self._allreduce(tv)
+        return float(tv.item())
+
+    def step(self, batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=True, phase="train",
+             tv_global=None):
+        """One global step on this rank's shard.  ``batch`` is the backend's opaque local batch.
+        Returns (d_result or None, g_result or None), identical on all ranks."""
+        be = self.backend
+        if tv_global is None:
+            tv_global = self.global_valid_frames(be.mask_of(batch))
+        be.set_loss_normalizer(tv_global)
+        be.zero_grad()
+        be.apply_generator(batch)
+        d_res = g_res = None
+        train = phase == "train"
+        if update_d:
+            be.update_discriminator_begin(batch, phase)
+            if train:
+                self._allreduce(be.flat_grads("D"))
+            self._allreduce(be.scalar_sums("D"))
+            d_res = be.update_discriminator_end(batch, phase)
+        if update_g:
+            be.update_generator_begin(batch, adv_w, mse_w, mge_w, phase)
+            if train:
+                self._allreduce(be.flat_grads("G"))
+            self._allreduce(be.scalar_sums("G"))
+            g_res = be.update_generator_end(batch, adv_w, mse_w, mge_w, phase)
+        return d_res, g_res

@@ -197,6 +197,12 @@ int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, co
                           float* dX, int lddx, const float* H_prev, int act_prev, const float* keep_mask_prev, float p_prev,
                           float* dW, float* db, void* stream);
 
+/* ---- measurement (bench.py): HIP-event timing of every GEMM launch on its own stream --------
+ * variant index = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W),
+ * 2 backward-weight (dZ^T X).  flops are algorithmic 2*M*N*K of the unpadded problem. */
+int gt_profile_enable(int on);
+int gt_profile_read(double* ms_per_variant6, double* flops_per_variant6, int64_t* launches_per_variant6);
+
 #ifdef __cplusplus
 }
 #endif
