@@ -383,7 +383,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     CHK(upload_ints(ss, &e->d_sstride_i2o));
     if (sd != desc->static_dim) return fail(GT_ERR_DIM, "In2OutHighwayNet: out_dim/num_windows (%d) != static_dim (%d)", sd, desc->static_dim);
   }
-  e->g_pass_valid = false;
+  if (role == GT_ROLE_G) e->g_pass_valid = false;
   return GT_OK;
 }
 

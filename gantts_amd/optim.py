@@ -103,6 +103,8 @@ class _FlatOptimizer(object):
 
     def state_dict(self):
         state = {}
+        if self.KIND == L.OPT_ADAGRAD:
+            self._ensure_state()      # torch.optim.Adagrad creates "sum" at construction
         if self._state[0] is not None and (self._step > 0 or self.KIND == L.OPT_ADAGRAD):
             views = [self._views(s) for s in self._state[:len(self.STATE_KEYS)]]
             for i in range(len(self._params)):
