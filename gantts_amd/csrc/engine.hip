@@ -171,7 +171,8 @@ struct Scratch {  // growable device buffer
   template <typename T> T* as() { return (T*)p; }
 };
 
-// dW (+)= dZ^T X ; db (+)= colsum(dZ)   -- split over the frame dimension, fixed-order combine
+// dW (+)= dZ^T X ; db (+)= colsum(dZ)   -- split over the frame dimension, fixed-order combine.
+// The bias gradient rides along in the weight-gradient kernel (column sums of its A operand).
 static int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
                                   float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s) {
   if (dW) {
@@ -184,22 +185,29 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     int k_chunk = cdiv(cdiv(rows, nslab), GEMM_BK) * GEMM_BK;
     nslab = cdiv(rows, k_chunk);
     const long slab_stride = (long)out * in;
-    CHK(slabs.ensure((size_t)nslab * slab_stride * sizeof(float)));
+    CHK(slabs.ensure(((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float)));
+    float* bias_slabs = slabs.as<float>() + (size_t)nslab * slab_stride;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dZ; g.lda = lddz; g.B = X; g.ldb = ldx; g.C = slabs.as<float>(); g.ldc = in;
     g.M = out; g.N = in; g.K = (int)rows; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+    g.colsum_slab = db ? bias_slabs : nullptr;
     g.drop = no_drop();
     CHK(launch_gemm(GEMM_TN, g, nslab, s));
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slabs.as<float>(),
                        slab_stride, nslab, slab_stride, dW, accumulate ? 1 : 0);
     LAUNCH_CHECK();
-  }
-  if (db) {
-    const int rows_per_blk = 256;
+    if (db) {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, bias_slabs, (long)out, nslab, (long)out, db,
+                         accumulate ? 1 : 0);
+      LAUNCH_CHECK();
+    }
+  } else if (db) {
+    const int rows_per_blk = 128;
     const int nblk = cdiv(rows, rows_per_blk);
     CHK(colp.ensure((size_t)nblk * out * sizeof(float)));
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, s, dZ, lddz, rows, out, rows_per_blk, colp.as<float>());
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(out, 64)), dim3(256), 0, s, dZ, lddz, rows, out, rows_per_blk,
+                       colp.as<float>());
     LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, colp.as<float>(), nblk, out, db,
                        accumulate ? 1 : 0);
@@ -499,7 +507,7 @@ static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
 static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
                         float* ys, int ldys, int B, int T, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
-  const size_t lds = (size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC * sizeof(float);
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1)) * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     HIPCHK(hipFuncSetAttribute((const void*)mlpg_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -515,7 +523,12 @@ static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* sco
                          float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
                          const float* mask, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
-  const size_t lds = (size_t)(MLPG_TT + 2 * kb) * MLPG_CC * sizeof(float);
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1)) * sizeof(float);
+  static size_t lds_set_b = 0;
+  if (lds > lds_set_b) {
+    HIPCHK(hipFuncSetAttribute((const void*)mlpg_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set_b = lds;
+  }
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
   hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(256), lds, s, gs, ldgs, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
                      gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc());
@@ -686,7 +699,7 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s) {
   Net& D = e->net[GT_ROLE_D];
-  const int nblk = (int)std::min<long>(1024, (n_rows + 3) / 4);
+  const int nblk = (int)std::min<long>(512, (n_rows + 3) / 4);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
   CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
@@ -696,7 +709,7 @@ static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, 
                      e->headp.as<HeadPartials>(), e->headw.as<float>());
   LAUNCH_CHECK();
   const bool w = want_grad && want_w;
-  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0);
   LAUNCH_CHECK();
   return GT_OK;
@@ -808,7 +821,7 @@ static int sum_sqerr(gt_engine* e, const float* a, int lda, const float* b, int 
   hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, a, lda, b, ldb, mask, rows, D, e->partial.as<double>(),
                      g, ldg, gscale, e->sc());
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, e->partial.as<double>(), nblk, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, out);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -919,7 +932,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     hipLaunchKernelGGL(static_grad_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
                        e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, e->partial.as<double>(), e->sc());
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
     LAUNCH_CHECK();
   }
   if (tr) {
@@ -1027,7 +1040,7 @@ extern "C" int gt_op_masked_mse(const float* input, const float* target, const f
   const int nblk = (int)std::min<long>(1000, cdiv(N * D, RED_THREADS * 4));
   hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, input, D, target, D, mask, N, D, part, grad_input, D,
                      1.f, sc);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1), 0, s, part, nblk, &sc->s_mse);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, part, nblk, &sc->s_mse);
   StepScalars h;
   hipError_t err = hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s);
   if (err == hipSuccess) err = hipStreamSynchronize(s);

@@ -145,19 +145,21 @@ constexpr int MLPG_TT = 32;      // output frames per workgroup
 constexpr int MLPG_CC = 64;      // static columns per workgroup
 
 // y_static[b][t][c] = sum_w sum_j band[t][w][j] * y[b][t+j-kb][scol[c] + w*sstride[c]]
+// LDS: data tile [(TT+2kb)][nW][CC] + the TT band rows [TT][nW][nb]; the inner product then runs
+// on two LDS streams (band: wave-broadcast, data: lane <-> column, conflict-free).
 __global__ __launch_bounds__(256) void mlpg_forward_kernel(
     const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ ys, int ldys, int B, int T) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [(TT+2kb)][nW][CC]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int nb = 2 * kb + 1;
   const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
   const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
   const int rows = MLPG_TT + 2 * kb;
+  float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nb]
   const float* yb = y + (long)b * T * ldy;
-  // stage: frames t0-kb .. t0+TT+kb-1, for each window the nc needed columns (coalesced in c)
   for (int e = threadIdx.x; e < rows * nW * MLPG_CC; e += blockDim.x) {
     const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
     const int t = t0 - kb + r;
@@ -168,6 +170,10 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
     }
     sm[e] = v;
   }
+  for (int e = threadIdx.x; e < MLPG_TT * nW * nb; e += blockDim.x) {
+    const int t = t0 + e / (nW * nb);
+    sb[e] = t < T ? band[(long)t * nW * nb + e % (nW * nb)] : 0.f;
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < MLPG_TT * MLPG_CC; e += blockDim.x) {
     const int c = e % MLPG_CC, tl = e / MLPG_CC;
@@ -177,37 +183,51 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
     if (sstride[c0 + c] == 0) {
       out = sm[((tl + kb) * nW + 0) * MLPG_CC + c];
     } else {
-      float acc = 0.f;
-      const float* bt = band + (long)t * nW * nb;
-      for (int w = 0; w < nW; ++w)
-        for (int j = 0; j < nb; ++j) acc = fmaf(bt[w * nb + j], sm[((tl + j) * nW + w) * MLPG_CC + c], acc);
-      out = acc;
+      float acc0 = 0.f, acc1 = 0.f;
+      const float* bt = sb + tl * nW * nb;
+      for (int w = 0; w < nW; ++w) {
+        const float* bw = bt + w * nb;
+        const float* dw_ = sm + (tl * nW + w) * MLPG_CC + c;
+        int j = 0;
+        for (; j + 1 < nb; j += 2) {
+          acc0 = fmaf(bw[j], dw_[j * nW * MLPG_CC], acc0);
+          acc1 = fmaf(bw[j + 1], dw_[(j + 1) * nW * MLPG_CC], acc1);
+        }
+        if (j < nb) acc0 = fmaf(bw[j], dw_[j * nW * MLPG_CC], acc0);
+      }
+      out = acc0 + acc1;
     }
     ys[((long)b * T + t) * ldys + c0 + c] = out;
   }
 }
 
 // transpose of the above:  gy[b][t'][scol[c]+w*st] = sum_t band[t][w][t'-t+kb] * gs[b][t][c]
-// plus the masked-MSE gradient in the static+delta domain when mse_scale != 0:
+// plus the masked-MSE gradient in the static+delta domain when mse_w != 0:
 //   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
+// LDS: gs tile [(TT+2kb)][CC] + band rows of the same frames [(TT+2kb)][nW][nb].
 __global__ __launch_bounds__(256) void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ gy, int ldgy, int B, int T,
     float mse_w, const float* __restrict__ yhat, const float* __restrict__ ytgt, int ldt,
     const float* __restrict__ mask, const StepScalars* __restrict__ sc) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [(TT+2kb)][CC]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int nb = 2 * kb + 1;
   const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
   const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
   const int rows = MLPG_TT + 2 * kb;
+  float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nb]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
   for (int e = threadIdx.x; e < rows * MLPG_CC; e += blockDim.x) {
     const int c = e % MLPG_CC, r = e / MLPG_CC;
     const int t = t0 - kb + r;
     sm[e] = (c < nc && t >= 0 && t < T) ? gb[(long)t * ldgs + c0 + c] : 0.f;
+  }
+  for (int e = threadIdx.x; e < rows * nW * nb; e += blockDim.x) {
+    const int t = t0 - kb + e / (nW * nb);
+    sb[e] = (t >= 0 && t < T) ? band[(long)t * nW * nb + e % (nW * nb)] : 0.f;
   }
   __syncthreads();
   const float msk_scale = mse_w != 0.f ? 2.f * mse_w * sc->inv_tv : 0.f;
@@ -221,14 +241,17 @@ __global__ __launch_bounds__(256) void mlpg_backward_kernel(
     if (st == 0) {
       out = sm[(tl + kb) * MLPG_CC + c];
     } else {
-      float acc = 0.f;
-      // t = tp + o, o in [-kb, kb]; coefficient band[t][w][kb - o]; staged row of t is tl + kb + o
-      for (int o = -kb; o <= kb; ++o) {
-        const int t = tp + o;
-        if (t < 0 || t >= T) continue;
-        acc = fmaf(band[((long)t * nW + w) * nb + (kb - o)], sm[(tl + kb + o) * MLPG_CC + c], acc);
+      // frame t = tp + o (staged row tl + kb + o), coefficient band[t][w][kb - o], o in [-kb, kb]
+      float acc0 = 0.f, acc1 = 0.f;
+      const float* g0 = sm + tl * MLPG_CC + c;                 // row (tl + kb + o) with o = -kb
+      const float* b0 = sb + (tl * nW + w) * nb + (nb - 1);    // band row of the same frame, tap kb - o = 2kb
+      int q = 0;
+      for (; q + 1 < nb; q += 2) {
+        acc0 = fmaf(b0[q * (nW * nb - 1)], g0[q * MLPG_CC], acc0);
+        acc1 = fmaf(b0[(q + 1) * (nW * nb - 1)], g0[(q + 1) * MLPG_CC], acc1);
       }
-      out = acc;
+      if (q < nb) acc0 = fmaf(b0[q * (nW * nb - 1)], g0[q * MLPG_CC], acc0);
+      out = acc0 + acc1;
     }
     const int col = scol[c0 + c] + w * st;
     const long row = (long)b * T + tp;
@@ -349,22 +372,37 @@ __global__ __launch_bounds__(256) void d_head_kernel(
   }
 }
 
-// finalize head: sums HeadPartials in fixed order into StepScalars, writes dw/db of last_linear
-__global__ void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
-                                       int nblk, int K, int mode, StepScalars* sc,
-                                       float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (dw && k < K) {
+// finalize head: sums HeadPartials in a fixed order into StepScalars, writes dw/db of last_linear.
+// grid = ceil(K/64) workgroups of 256 threads; workgroup 0 also reduces the scalar partials.
+__global__ __launch_bounds__(256) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
+                                                              int nblk, int K, int mode, StepScalars* sc,
+                                                              float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  __shared__ float shw[4][64];
+  __shared__ double shd[16];
+  const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
+  if (dw) {
     float s = 0.f;
-    for (int i = 0; i < nblk; ++i) s += dw_partial[(long)i * K + k];
-    dw[k] = accumulate ? dw[k] + s : s;
+    if (k < K) for (int i = part; i < nblk; i += 4) s += dw_partial[(long)i * K + k];
+    shw[part][kl] = s;
+    __syncthreads();
+    if (part == 0 && k < K) {
+      const float tot = (shw[0][kl] + shw[1][kl]) + (shw[2][kl] + shw[3][kl]);
+      dw[k] = accumulate ? dw[k] + tot : tot;
+    }
   }
-  if (k == 0) {
-    double a = 0, b = 0, c = 0, d = 0, e = 0;
-    for (int i = 0; i < nblk; ++i) { a += hp[i].s_real; b += hp[i].s_fake; c += hp[i].n_real_ok; d += hp[i].n_fake_ok; e += hp[i].db; }
-    if (mode == HEAD_D_STEP) { sc->s_real = a; sc->s_fake = b; sc->n_real_ok = c; sc->n_fake_ok = d; }
-    else sc->s_adv = a;
-    if (db) db[0] = accumulate ? db[0] + (float)e : (float)e;
+  if (blockIdx.x == 0) {
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+      v[0] += hp[i].s_real; v[1] += hp[i].s_fake; v[2] += hp[i].n_real_ok; v[3] += hp[i].n_fake_ok; v[4] += hp[i].db;
+    }
+    double r[5];
+    for (int q = 0; q < 5; ++q) r[q] = block_sum_d(v[q], shd);
+    if (threadIdx.x == 0) {
+      if (mode == HEAD_D_STEP) { sc->s_real = r[0]; sc->s_fake = r[1]; sc->n_real_ok = r[2]; sc->n_fake_ok = r[3]; }
+      else sc->s_adv = r[0];
+      if (db) db[0] = accumulate ? db[0] + (float)r[4] : (float)r[4];
+    }
   }
 }
 
@@ -405,24 +443,28 @@ __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-__global__ void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *out = s;
-  }
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+  const double tot = block_sum_d(v, sh);
+  if (threadIdx.x == 0) *out = tot;
 }
 
-// column sums of a frame matrix (bias gradients): partial[blk][c] then a fixed-order finalize
+// column sums of a frame matrix (bias gradient when no weight gradient is requested):
+// workgroup = 64 columns x rows_per_blk rows, 4 row lanes; partial[blk_r][c] then a fixed-order finalize
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, long rows, int cols,
                                                              int rows_per_blk, float* __restrict__ partial) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
   const long r0 = (long)blockIdx.x * rows_per_blk;
   const long r1 = min(rows, r0 + rows_per_blk);
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
-    partial[(long)blockIdx.x * cols + c] = s;
-  }
+  float s = 0.f;
+  if (c < cols) for (long r = r0 + rl; r < r1; r += 4) s += X[r * ldx + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) partial[(long)blockIdx.x * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int cols, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -79,6 +79,7 @@ struct GemmArgs {
   // TN split
   int k_chunk;               // rows of K per slab (multiple of GEMM_BK)
   long slab_stride;
+  float* colsum_slab;        // TN: per-slab column sums of A (bias gradient), [nslab][M], or null
   int n_tiles_m, n_tiles_n;
 };
 
@@ -121,45 +122,77 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 
   float ra[A_PER_THR], rb[B_PER_THR];
 
-  auto load_tile = [&](int k0) {
-    // ---- A operand ----
+  // Per-thread element offsets of this thread's A_PER_THR / B_PER_THR operand elements inside
+  // the K-tile starting at k = 0, computed ONCE.  Rows/columns outside the matrix are clamped to
+  // the last valid one (their products land in accumulator rows/columns the epilogue never
+  // stores), so the steady-state loads are unconditional: no exec-mask branches, no per-load
+  // address arithmetic (base pointer advances by one K-tile per iteration).  Only the K tail is
+  // zero-filled (select after an in-bounds load).
+  uint32_t offA[A_PER_THR], offB[B_PER_THR];
+  // k index inside the tile of element i (k-contiguous: tid%32 for every i; otherwise tid/BM + i*(256/BM))
+  auto kkA = [&](int i) { return KIND == GEMM_TN ? (tid + i * GEMM_THREADS) / BM : tid % GEMM_BK; };
+  auto kkB = [&](int i) { return KIND == GEMM_NT ? tid % GEMM_BK : (tid + i * GEMM_THREADS) / BN; };
+#pragma unroll
+  for (int i = 0; i < A_PER_THR; ++i) {
+    const int e = tid + i * GEMM_THREADS;
     if (KIND == GEMM_TN) {  // m-contiguous: A[k*lda + m]
-#pragma unroll
-      for (int i = 0; i < A_PER_THR; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int mm = e % BM, kk = e / BM;
-        const int m = m0 + mm, k = k0 + kk;
-        ra[i] = (m < g.M && k < k_end) ? g.A[(long)k * g.lda + m] : 0.f;
-      }
-    } else {  // k-contiguous: A[m*lda + k]
-#pragma unroll
-      for (int i = 0; i < A_PER_THR; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int kk = e % GEMM_BK, mm = e / GEMM_BK;
-        const int m = m0 + mm, k = k0 + kk;
-        ra[i] = (m < g.M && k < k_end) ? g.A[(long)m * g.lda + k] : 0.f;
-      }
+      const int mm = e % BM, kk = e / BM;
+      offA[i] = (uint32_t)kk * (uint32_t)g.lda + (uint32_t)min(m0 + mm, g.M - 1);
+    } else {                // k-contiguous: A[m*lda + k]
+      const int kk = e % GEMM_BK, mm = e / GEMM_BK;
+      offA[i] = (uint32_t)min(m0 + mm, g.M - 1) * (uint32_t)g.lda + (uint32_t)kk;
     }
-    // ---- B operand ----
+  }
+#pragma unroll
+  for (int i = 0; i < B_PER_THR; ++i) {
+    const int e = tid + i * GEMM_THREADS;
     if (KIND == GEMM_NT) {  // k-contiguous: B[n*ldb + k]
+      const int kk = e % GEMM_BK, nn = e / GEMM_BK;
+      offB[i] = (uint32_t)min(n0 + nn, g.N - 1) * (uint32_t)g.ldb + (uint32_t)kk;
+    } else {                // n-contiguous: B[k*ldb + n]
+      const int nn = e % BN, kk = e / BN;
+      offB[i] = (uint32_t)kk * (uint32_t)g.ldb + (uint32_t)min(n0 + nn, g.N - 1);
+    }
+  }
+  const long stepA = (KIND == GEMM_TN) ? (long)GEMM_BK * g.lda : (long)GEMM_BK;
+  const long stepB = (KIND == GEMM_NT) ? (long)GEMM_BK : (long)GEMM_BK * g.ldb;
+  const float* pA = g.A + (KIND == GEMM_TN ? (long)k_begin * g.lda : (long)k_begin);
+  const float* pB = g.B + (KIND == GEMM_NT ? (long)k_begin : (long)k_begin * g.ldb);
+
+  auto load_tile = [&](int k0, bool tail) {
+    if (!tail) {
 #pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int kk = e % GEMM_BK, nn = e / GEMM_BK;
-        const int n = n0 + nn, k = k0 + kk;
-        rb[i] = (n < g.N && k < k_end) ? g.B[(long)n * g.ldb + k] : 0.f;
+      for (int i = 0; i < A_PER_THR; ++i) ra[i] = pA[offA[i]];
+#pragma unroll
+      for (int i = 0; i < B_PER_THR; ++i) rb[i] = pB[offB[i]];
+    } else {
+      // K tail: clamp k to the last valid index (keeps the address in bounds), then zero
+      const int krem = k_end - k0;   // valid k in this tile: [0, krem)
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) {
+        const int back = max(0, kkA(i) - (krem - 1));
+        const float v = pA[offA[i] - (uint32_t)back * (KIND == GEMM_TN ? (uint32_t)g.lda : 1u)];
+        ra[i] = kkA(i) < krem ? v : 0.f;
       }
-    } else {  // n-contiguous: B[k*ldb + n]
 #pragma unroll
       for (int i = 0; i < B_PER_THR; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int nn = e % BN, kk = e / BN;
-        const int n = n0 + nn, k = k0 + kk;
-        rb[i] = (n < g.N && k < k_end) ? g.B[(long)k * g.ldb + n] : 0.f;
+        const int back = max(0, kkB(i) - (krem - 1));
+        const float v = pB[offB[i] - (uint32_t)back * (KIND == GEMM_NT ? 1u : (uint32_t)g.ldb)];
+        rb[i] = kkB(i) < krem ? v : 0.f;
       }
     }
+    pA += stepA;
+    pB += stepB;
   };
+  // TN: column sums of the A operand (dZ) fall out of the loader for free -- element i of this
+  // thread always has the same column m = tid % BM (GEMM_THREADS % BM == 0).
+  float csum = 0.f;
+  const bool want_csum = KIND == GEMM_TN && g.colsum_slab != nullptr && tile_n == 0;
   auto store_tile = [&](int buf) {
+    if (KIND == GEMM_TN && want_csum) {
+#pragma unroll
+      for (int i = 0; i < A_PER_THR; ++i) csum += ra[i];
+    }
     float* as = As + buf * GEMM_BK * LDM;
     float* bs = Bs + buf * GEMM_BK * LDN;
 #pragma unroll
@@ -187,14 +220,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+  const bool has_tail = ((k_end - k_begin) % GEMM_BK) != 0;
   if (nk > 0) {
-    load_tile(k_begin);
+    load_tile(k_begin, has_tail && nk == 1);
     store_tile(0);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(k_begin + (kt + 1) * GEMM_BK);
+    if (kt + 1 < nk) load_tile(k_begin + (kt + 1) * GEMM_BK, has_tail && kt + 2 == nk);
     const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31;
     const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31;
 #pragma unroll
@@ -212,6 +246,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
+  }
+
+  if (KIND == GEMM_TN && want_csum) {
+    // all waves are past the last barrier of the K loop; reuse the LDS as scratch
+    smem[tid] = csum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M) {
+      float tot = 0.f;
+#pragma unroll
+      for (int j = 0; j < GEMM_THREADS / BM; ++j) tot += smem[tid + j * BM];
+      g.colsum_slab[(long)slab * g.M + m0 + tid] = tot;
+    }
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
