@@ -93,12 +93,12 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
 // ------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------
-template <int KIND, int BM, int BN>
+template <int KIND, int BM, int BN, bool VA, bool VB>
 static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = gemm_lds_bytes<BM, BN>();
+  const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, BM, BN>,
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -112,19 +112,31 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
 
+template <int KIND, int BN>
+static int launch_gemm_v(const GemmArgs& g, int nslab, hipStream_t s) {
+  // 16-byte operand loads need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
+  const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
+  const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
+  if (va && vb) return launch_gemm_t<KIND, 128, BN, true, true>(g, nslab, s);
+  if (va) return launch_gemm_t<KIND, 128, BN, true, false>(g, nslab, s);
+  if (vb) return launch_gemm_t<KIND, 128, BN, false, true>(g, nslab, s);
+  return launch_gemm_t<KIND, 128, BN, false, false>(g, nslab, s);
+}
+
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   const int bn = pick_bn(g.N);
   switch (kind) {
-    case GEMM_NT: return bn == 64 ? launch_gemm_t<GEMM_NT, 128, 64>(g, 1, s) : launch_gemm_t<GEMM_NT, 128, 128>(g, 1, s);
-    case GEMM_NN: return bn == 64 ? launch_gemm_t<GEMM_NN, 128, 64>(g, 1, s) : launch_gemm_t<GEMM_NN, 128, 128>(g, 1, s);
-    default: return bn == 64 ? launch_gemm_t<GEMM_TN, 128, 64>(g, nslab, s) : launch_gemm_t<GEMM_TN, 128, 128>(g, nslab, s);
+    case GEMM_NT: return bn == 64 ? launch_gemm_v<GEMM_NT, 64>(g, 1, s) : launch_gemm_v<GEMM_NT, 128>(g, 1, s);
+    case GEMM_NN: return bn == 64 ? launch_gemm_v<GEMM_NN, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 128>(g, 1, s);
+    default: return bn == 64 ? launch_gemm_v<GEMM_TN, 64>(g, nslab, s) : launch_gemm_v<GEMM_TN, 128>(g, nslab, s);
   }
 }
 

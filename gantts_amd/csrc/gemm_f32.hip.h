@@ -5,25 +5,33 @@
 //
 //   NT  Y  = act(X . W^T + b)          forward of nn.Linear      (reference gantts/models.py:129-141)
 //   NN  dX = (dZ . W) (.) f'(H)        backward-data, activation derivative of the producer fused
-//   TN  dW = dZ^T . X  (split over the frame dimension, deterministic partial slabs)
+//   TN  dW = dZ^T . X  (+ column sums of dZ = bias gradient), split over the frame dimension into
+//                       deterministic partial slabs
 //
 // Tile: BM x BN per 256-thread workgroup (4 waves, 2x2), each wave (BM/2)x(BN/2) in 32x32 MFMA
-// tiles; K step 32.  LDS image is k-major  As[k][m] / Bs[k][n]  with leading dimension BM+1
-// (== 1 mod 32): the MFMA operand fetch `As[k][m0 + lane%32]` is a conflict-free ds_read_b32 and
-// both loader orientations write conflict-free (k-contiguous sources scatter with bank = (k+m)%32,
-// m-contiguous sources write consecutive banks).  Double-buffered LDS, next tile's global loads
-// are issued before the MFMA block of the current tile (register staging), one barrier per K step.
-// f32 MFMA is 64 cycles per instruction per SIMD, so the loop is matrix-pipe bound by a wide
-// margin: per K step a wave issues 64 MFMAs (4096 cycles) against 64 ds_read_b32 + 32 global
-// dword loads + 32 ds_write_b32.  Dword (4 B) global loads are used on purpose: the frame
-// matrices have row strides of 425 / 483 / 187 / 63 floats, i.e. rows are not 16-byte aligned.
+// tiles; K step 32; 2 workgroups per CU.  LDS image is k-major  As[k][m] / Bs[k][n]; the MFMA
+// operand fetch `As[k][m0 + lane%32]` is a conflict-free ds_read_b32 for any pitch.  The pitch is
+// chosen per operand orientation so that the loader's LDS writes are conflict-free too:
+//   * k-contiguous source (rows of X / W): pitch BM+1 (== 1 mod 32): a lane holding k..k+3 of one
+//     row scatters 4 ds_write_b32 with bank = (k + m) % 32;
+//   * m-contiguous source (rows of dZ / H / W for the transposed products): pitch BM+4, a lane
+//     holding m..m+3 of one k row issues one aligned ds_write_b128.
+// Global loads are 16 B per lane when the operand's row pitch and base are 16-byte aligned
+// (hidden activations, most weights), 4 B per lane otherwise (row pitches 425 / 483 / 187 / 63 of
+// the reference's (B,T,D) tensors are not multiples of 4 floats).
+//
+// Schedule: f32 MFMA is 64 cycles per instruction per SIMD and issue is in-order, so everything
+// else is slotted into the MFMA shadow (see the K loop): next group's LDS fragments, slices of
+// the next K-tile's global loads, and slices of its LDS writes with counted vmcnt waits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace gt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_THREADS = 256;
@@ -83,13 +91,23 @@ struct GemmArgs {
   int n_tiles_m, n_tiles_n;
 };
 
+// LDS pitches per orientation (floats)
+template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
+template <int KIND, int BN> constexpr int gemm_ldn() { return KIND == GEMM_NT ? BN + 1 : BN + 4; }
 template <int KIND, int BM, int BN>
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * GEMM_BK * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float); }
+
+// VA / VB: operand is loaded 16 B per lane (requires 16-byte aligned base and pitch % 4 == 0)
+template <int KIND, int BM, int BN, bool VA, bool VB>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
-  constexpr int LDM = BM + 1, LDN = BN + 1;
-  constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
-  constexpr int TM = WM / 32, TN_ = WN / 32;  // MFMA tiles per wave
-  constexpr int A_PER_THR = BM * GEMM_BK / GEMM_THREADS;
-  constexpr int B_PER_THR = BN * GEMM_BK / GEMM_THREADS;
+  constexpr int LDM = gemm_ldm<KIND, BM>(), LDN = gemm_ldn<KIND, BN>();
+  constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
+  constexpr int TM = WM / 32, TN_ = WN / 32;    // MFMA tiles per wave
+  constexpr bool A_KC = KIND != GEMM_TN;        // A is k-contiguous in memory
+  constexpr bool B_KC = KIND == GEMM_NT;        // B is k-contiguous in memory
+  constexpr int VWA = VA ? 4 : 1, VWB = VB ? 4 : 1;
+  constexpr int UA = BM * GEMM_BK / GEMM_THREADS / VWA;   // load units (instructions) per thread per K-tile
+  constexpr int UB = BN * GEMM_BK / GEMM_THREADS / VWB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BK][LDM]
   float* Bs = smem + 2 * GEMM_BK * LDM;      // [2][BK][LDN]
@@ -120,94 +138,129 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
 
-  float ra[A_PER_THR], rb[B_PER_THR];
-
-  // Per-thread element offsets of this thread's A_PER_THR / B_PER_THR operand elements inside
-  // the K-tile starting at k = 0, computed ONCE.  Rows/columns outside the matrix are clamped to
-  // the last valid one (their products land in accumulator rows/columns the epilogue never
-  // stores), so the steady-state loads are unconditional: no exec-mask branches, no per-load
-  // address arithmetic (base pointer advances by one K-tile per iteration).  Only the K tail is
-  // zero-filled (select after an in-bounds load).
-  uint32_t offA[A_PER_THR], offB[B_PER_THR];
-  // k index inside the tile of element i (k-contiguous: tid%32 for every i; otherwise tid/BM + i*(256/BM))
-  auto kkA = [&](int i) { return KIND == GEMM_TN ? (tid + i * GEMM_THREADS) / BM : tid % GEMM_BK; };
-  auto kkB = [&](int i) { return KIND == GEMM_NT ? tid % GEMM_BK : (tid + i * GEMM_THREADS) / BN; };
-#pragma unroll
-  for (int i = 0; i < A_PER_THR; ++i) {
-    const int e = tid + i * GEMM_THREADS;
-    if (KIND == GEMM_TN) {  // m-contiguous: A[k*lda + m]
-      const int mm = e % BM, kk = e / BM;
-      offA[i] = (uint32_t)kk * (uint32_t)g.lda + (uint32_t)min(m0 + mm, g.M - 1);
-    } else {                // k-contiguous: A[m*lda + k]
-      const int kk = e % GEMM_BK, mm = e / GEMM_BK;
-      offA[i] = (uint32_t)min(m0 + mm, g.M - 1) * (uint32_t)g.lda + (uint32_t)kk;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < B_PER_THR; ++i) {
-    const int e = tid + i * GEMM_THREADS;
-    if (KIND == GEMM_NT) {  // k-contiguous: B[n*ldb + k]
-      const int kk = e % GEMM_BK, nn = e / GEMM_BK;
-      offB[i] = (uint32_t)min(n0 + nn, g.N - 1) * (uint32_t)g.ldb + (uint32_t)kk;
-    } else {                // n-contiguous: B[k*ldb + n]
-      const int nn = e % BN, kk = e / BN;
-      offB[i] = (uint32_t)kk * (uint32_t)g.ldb + (uint32_t)min(n0 + nn, g.N - 1);
-    }
-  }
-  const long stepA = (KIND == GEMM_TN) ? (long)GEMM_BK * g.lda : (long)GEMM_BK;
-  const long stepB = (KIND == GEMM_NT) ? (long)GEMM_BK : (long)GEMM_BK * g.ldb;
-  const float* pA = g.A + (KIND == GEMM_TN ? (long)k_begin * g.lda : (long)k_begin);
-  const float* pB = g.B + (KIND == GEMM_NT ? (long)k_begin : (long)k_begin * g.ldb);
-
-  auto load_tile = [&](int k0, bool tail) {
-    if (!tail) {
-#pragma unroll
-      for (int i = 0; i < A_PER_THR; ++i) ra[i] = pA[offA[i]];
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) rb[i] = pB[offB[i]];
-    } else {
-      // K tail: clamp k to the last valid index (keeps the address in bounds), then zero
-      const int krem = k_end - k0;   // valid k in this tile: [0, krem)
-#pragma unroll
-      for (int i = 0; i < A_PER_THR; ++i) {
-        const int back = max(0, kkA(i) - (krem - 1));
-        const float v = pA[offA[i] - (uint32_t)back * (KIND == GEMM_TN ? (uint32_t)g.lda : 1u)];
-        ra[i] = kkA(i) < krem ? v : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < B_PER_THR; ++i) {
-        const int back = max(0, kkB(i) - (krem - 1));
-        const float v = pB[offB[i] - (uint32_t)back * (KIND == GEMM_NT ? 1u : (uint32_t)g.ldb)];
-        rb[i] = kkB(i) < krem ? v : 0.f;
-      }
-    }
-    pA += stepA;
-    pB += stepB;
+  // ---- loader geometry.  Unit u of this thread covers VW consecutive elements along the
+  // operand's contiguous direction.  (kk, xx) = position inside the K-tile: k index, m/n index.
+  auto a_pos = [&](int u, int& kk, int& mm) {
+    const int e = tid + u * GEMM_THREADS;
+    if (A_KC) { kk = (e % (GEMM_BK / VWA)) * VWA; mm = e / (GEMM_BK / VWA); }
+    else      { mm = (e % (BM / VWA)) * VWA;      kk = e / (BM / VWA); }
   };
-  // TN: column sums of the A operand (dZ) fall out of the loader for free -- element i of this
-  // thread always has the same column m = tid % BM (GEMM_THREADS % BM == 0).
-  float csum = 0.f;
+  auto b_pos = [&](int u, int& kk, int& nn) {
+    const int e = tid + u * GEMM_THREADS;
+    if (B_KC) { kk = (e % (GEMM_BK / VWB)) * VWB; nn = e / (GEMM_BK / VWB); }
+    else      { nn = (e % (BN / VWB)) * VWB;      kk = e / (BN / VWB); }
+  };
+  // Element offsets inside the K-tile at k = 0, computed ONCE.  Rows/columns outside the matrix
+  // are clamped to the last valid position (their products land in accumulator rows/columns the
+  // epilogue never stores), so steady-state loads are unconditional: no exec-mask branches and no
+  // per-load address arithmetic (the base pointer advances by one K-tile per iteration).  Only
+  // the K tail is zero-filled (select after an in-bounds load).
+  uint32_t offA[UA], offB[UB];
+  const int mclamp = A_KC ? g.M - 1 : ((g.M - 1) / VWA) * VWA;   // last valid row / vector start
+  const int nclamp = B_KC ? g.N - 1 : ((g.N - 1) / VWB) * VWB;
+#pragma unroll
+  for (int u = 0; u < UA; ++u) {
+    int kk, mm; a_pos(u, kk, mm);
+    const int m = min(m0 + mm, mclamp);
+    offA[u] = A_KC ? (uint32_t)m * (uint32_t)g.lda + (uint32_t)kk : (uint32_t)kk * (uint32_t)g.lda + (uint32_t)m;
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    int kk, nn; b_pos(u, kk, nn);
+    const int n = min(n0 + nn, nclamp);
+    offB[u] = B_KC ? (uint32_t)n * (uint32_t)g.ldb + (uint32_t)kk : (uint32_t)kk * (uint32_t)g.ldb + (uint32_t)n;
+  }
+  const long stepA = A_KC ? (long)GEMM_BK : (long)GEMM_BK * g.lda;
+  const long stepB = B_KC ? (long)GEMM_BK : (long)GEMM_BK * g.ldb;
+  const float* pA = g.A + (A_KC ? (long)k_begin : (long)k_begin * g.lda);
+  const float* pB = g.B + (B_KC ? (long)k_begin : (long)k_begin * g.ldb);
+
+  float ra[UA * VWA], rb[UB * VWB];
+
+  // One unit of the next K-tile: global -> registers.  krem = number of valid k in that tile.
+  auto load_a = [&](int u, bool tail, int krem) {
+    int kk, mm; a_pos(u, kk, mm);
+    uint32_t off = offA[u];
+    if (tail) {  // keep the address inside the matrix: step back to the last valid k (vector start)
+      const int klast = A_KC ? ((krem - 1) / VWA) * VWA : krem - 1;
+      const int back = max(0, kk - klast);
+      off -= (uint32_t)back * (A_KC ? 1u : (uint32_t)g.lda);
+    }
+    if (VA) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pA + off);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ra[u * 4 + c] = v[c];
+    } else {
+      ra[u] = pA[off];
+    }
+    if (tail) {
+#pragma unroll
+      for (int c = 0; c < VWA; ++c) {
+        const int k = A_KC ? kk + c : kk;
+        if (k >= krem) ra[u * VWA + c] = 0.f;
+      }
+    }
+  };
+  auto load_b = [&](int u, bool tail, int krem) {
+    int kk, nn; b_pos(u, kk, nn);
+    uint32_t off = offB[u];
+    if (tail) {
+      const int klast = B_KC ? ((krem - 1) / VWB) * VWB : krem - 1;
+      const int back = max(0, kk - klast);
+      off -= (uint32_t)back * (B_KC ? 1u : (uint32_t)g.ldb);
+    }
+    if (VB) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pB + off);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rb[u * 4 + c] = v[c];
+    } else {
+      rb[u] = pB[off];
+    }
+    if (tail) {
+#pragma unroll
+      for (int c = 0; c < VWB; ++c) {
+        const int k = B_KC ? kk + c : kk;
+        if (k >= krem) rb[u * VWB + c] = 0.f;
+      }
+    }
+  };
+  // TN: column sums of the A operand (dZ) fall out of the loader for free -- every unit of this
+  // thread covers the same VWA columns (GEMM_THREADS is a multiple of BM / VWA).
+  float csum[VWA];
+#pragma unroll
+  for (int c = 0; c < VWA; ++c) csum[c] = 0.f;
   const bool want_csum = KIND == GEMM_TN && g.colsum_slab != nullptr && tile_n == 0;
-  auto store_tile = [&](int buf) {
+  // registers -> LDS
+  auto store_a = [&](int u, float* as) {
+    int kk, mm; a_pos(u, kk, mm);
+    if (A_KC) {
+#pragma unroll
+      for (int c = 0; c < VWA; ++c) as[(kk + c) * LDM + mm] = ra[u * VWA + c];
+    } else if (VA) {
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = ra[u * 4 + c];
+      *reinterpret_cast<f32x4*>(as + kk * LDM + mm) = v;
+    } else {
+      as[kk * LDM + mm] = ra[u];
+    }
     if (KIND == GEMM_TN && want_csum) {
 #pragma unroll
-      for (int i = 0; i < A_PER_THR; ++i) csum += ra[i];
+      for (int c = 0; c < VWA; ++c) csum[c] += ra[u * VWA + c];
     }
-    float* as = As + buf * GEMM_BK * LDM;
-    float* bs = Bs + buf * GEMM_BK * LDN;
+  };
+  auto store_b = [&](int u, float* bs) {
+    int kk, nn; b_pos(u, kk, nn);
+    if (B_KC) {
 #pragma unroll
-    for (int i = 0; i < A_PER_THR; ++i) {
-      const int e = tid + i * GEMM_THREADS;
-      int mm, kk;
-      if (KIND == GEMM_TN) { mm = e % BM; kk = e / BM; } else { kk = e % GEMM_BK; mm = e / GEMM_BK; }
-      as[kk * LDM + mm] = ra[i];
-    }
+      for (int c = 0; c < VWB; ++c) bs[(kk + c) * LDN + nn] = rb[u * VWB + c];
+    } else if (VB) {
+      f32x4 v;
 #pragma unroll
-    for (int i = 0; i < B_PER_THR; ++i) {
-      const int e = tid + i * GEMM_THREADS;
-      int nn, kk;
-      if (KIND == GEMM_NT) { kk = e % GEMM_BK; nn = e / GEMM_BK; } else { nn = e % BN; kk = e / BN; }
-      bs[kk * LDN + nn] = rb[i];
+      for (int c = 0; c < 4; ++c) v[c] = rb[u * 4 + c];
+      *reinterpret_cast<f32x4*>(bs + kk * LDN + nn) = v;
+    } else {
+      bs[kk * LDN + nn] = rb[u];
     }
   };
 
@@ -221,65 +274,157 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 
   const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
   const bool has_tail = ((k_end - k_begin) % GEMM_BK) != 0;
-  if (nk > 0) {
-    load_tile(k_begin, has_tail && nk == 1);
-    store_tile(0);
+  if (nk > 0) {   // prologue: tile 0 -> LDS buffer 0
+    const bool tail0 = has_tail && nk == 1;
+    const int krem0 = k_end - k_begin;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) load_a(u, tail0, krem0);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) load_b(u, tail0, krem0);
+    pA += stepA; pB += stepB;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) store_a(u, As);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) store_b(u, Bs);
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+
+  // K loop.  A K-tile is NG = 16 MFMA groups (one k-pair each, TM*TN_ MFMAs of 64 cycles).  The
+  // matrix pipe is the bottleneck resource, so everything else is slotted into its shadow:
+  //   * group g first issues the LDS fragment reads of group g+1 (register double buffer), so the
+  //     lgkmcnt wait in front of the next group's MFMAs is already satisfied;
+  //   * groups 0..NG/2-1 issue the NEXT tile's global loads, a slice per group,
+  //   * groups NG/2..NG-1 write those registers to the other LDS buffer (the loads have had
+  //     >= NG/2 groups, i.e. > 2000 cycles, to land: counted vmcnt waits, never 0 mid-loop).
+  // sched_barrier pins the group boundaries so the compiler keeps this interleave.  The tile
+  // body is instantiated three times (steady state / next tile is the K tail / last tile) so
+  // `prefetch` and `tail` are compile-time inside the MFMA stream: no branches there.
+  constexpr int NG = GEMM_BK / 2, NH = NG / 2;
+  auto k_tile = [&](int kt, auto PF, auto TL) {
+    constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(k_begin + (kt + 1) * GEMM_BK, has_tail && kt + 2 == nk);
-    const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31;
-    const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31;
+    const int krem = k_end - (k_begin + (kt + 1) * GEMM_BK);
+    const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31 + half * LDM;
+    const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31 + half * LDN;
+    float* as_w = As + (buf ^ 1) * GEMM_BK * LDM;
+    float* bs_w = Bs + (buf ^ 1) * GEMM_BK * LDN;
+    float a_cur[TM], b_cur[TN_], a_nxt[TM], b_nxt[TN_];
 #pragma unroll
-    for (int kk = 0; kk < GEMM_BK; kk += 2) {
-      float a[TM], b[TN_];
+    for (int i = 0; i < TM; ++i) a_cur[i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(kk + half) * LDM + i * 32];
+    for (int j = 0; j < TN_; ++j) b_cur[j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN_; ++j) b[j] = bs[(kk + half) * LDN + j * 32];
+    for (int gi = 0; gi < NG; ++gi) {
+#ifdef GT_ABLATE_NO_LDSREAD
+      if (gi + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { a_nxt[i] = a_cur[i]; asm volatile("" : "+v"(a_nxt[i])); }
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) { b_nxt[j] = b_cur[j]; asm volatile("" : "+v"(b_nxt[j])); }
+      }
+#else
+      if (gi + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_nxt[i] = as[(2 * gi + 2) * LDM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) b_nxt[j] = bs[(2 * gi + 2) * LDN + j * 32];
+      }
+#endif
+#ifdef GT_ABLATE_NO_GLOBAL
+      if (false) {
+#else
+      if (prefetch) {
+#endif
+        // unit u is loaded in group (u*NH)/U and stored in group NH + (u*NH)/U
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+          if ((u * NH) / UA == gi) load_a(u, tail, krem);
+          if (NH + (u * NH) / UA == gi) store_a(u, as_w);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if ((u * NH) / UB + (UB < NH ? 1 : 0) == gi) load_b(u, tail, krem);
+          if (NH + (u * NH) / UB + (UB < NH ? 1 : 0) == gi) store_b(u, bs_w);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+      if (gi + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) b_cur[j] = b_nxt[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (prefetch) { pA += stepA; pB += stepB; }
+#ifndef GT_ABLATE_NO_BARRIER
     __syncthreads();
+#endif
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) k_tile(kt, T_{}, F_{});                 // next tile is a full one
+  if (kt + 2 == nk) {                                               // next tile is the last one
+    if (has_tail) k_tile(kt, T_{}, T_{}); else k_tile(kt, T_{}, F_{});
+    ++kt;
   }
+  if (kt + 1 == nk) k_tile(kt, F_{}, F_{});                         // last tile: nothing to prefetch
 
   if (KIND == GEMM_TN && want_csum) {
-    // all waves are past the last barrier of the K loop; reuse the LDS as scratch
-    smem[tid] = csum;
+    // all waves are past the last barrier of the K loop; reuse the LDS as scratch.
+    // threads tid, tid + BM/VWA, ... own the same VWA columns starting at (tid % (BM/VWA)) * VWA
+    constexpr int OWN = BM / VWA;
+#pragma unroll
+    for (int c = 0; c < VWA; ++c) smem[tid * VWA + c] = csum[c];
     __syncthreads();
     if (tid < BM && m0 + tid < g.M) {
+      const int own = tid / VWA, c = tid % VWA;
       float tot = 0.f;
 #pragma unroll
-      for (int j = 0; j < GEMM_THREADS / BM; ++j) tot += smem[tid + j * BM];
+      for (int j = 0; j < GEMM_THREADS / OWN; ++j) tot += smem[(own + j * OWN) * VWA + c];
       g.colsum_slab[(long)slab * g.M + m0 + tid] = tot;
     }
   }
 
+#ifdef GT_ABLATE_NO_EPILOGUE
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN_; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[i][j][r];
+    g.C[(long)(m0 + wm * WM + l31) * g.ldc + n0 + wn * WN + half] = v;
+    return;
+  }
+#endif
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
+  const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
+  const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN_; ++j) {
       const int n = n0 + wn * WN + j * 32 + l31;
-      const bool n_ok = n < g.N;
+      const bool n_ok = full_tile || n < g.N;
       float bias = 0.f;
       if (KIND == GEMM_NT && g.bias && n_ok) bias = g.bias[n];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
         uint32_t rnd[4];
-        const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
         if (philox) philox4x32_10((uint32_t)(mrow >> 2), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;
-          if (!n_ok || m >= g.M) continue;
+          if (!full_tile && (!n_ok || m >= g.M)) continue;
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
             v += bias;
@@ -289,7 +434,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
               else if (g.drop.mode == DROP_BUFFER)
                 v = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
             } else if (g.act == ACT_SIGMOID) {
-              v = 1.f / (1.f + __expf(-v));
+              v = 1.f / (1.f + expf(-v));
             }
           } else if (KIND == GEMM_NN) {
             if (g.act == ACT_LEAKY_DROPOUT) {
@@ -312,8 +457,5 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     }
   }
 }
-
-template <int BM, int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * GEMM_BK * ((BM + 1) + (BN + 1)) * sizeof(float); }
 
 }  // namespace gt
