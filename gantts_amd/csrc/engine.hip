@@ -190,7 +190,7 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
   if (dW) {
     const int bn = pick_bn(in);
     const int tiles = cdiv(out, 128) * cdiv(in, bn);
-    int nslab = cdiv(768, tiles);
+    int nslab = std::max(1, 512 / tiles);   // <= 2 workgroups per CU x 256 CUs: one resident round
     const int max_slab = (int)((rows + 255) / 256);
     if (nslab > max_slab) nslab = max_slab;
     if (nslab < 1) nslab = 1;
@@ -206,8 +206,13 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     g.colsum_slab = db ? bias_slabs : nullptr;
     g.drop = no_drop();
     CHK(launch_gemm(GEMM_TN, g, nslab, s));
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slabs.as<float>(),
-                       slab_stride, nslab, slab_stride, dW, accumulate ? 1 : 0);
+    if (slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0) {
+      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(cdiv(slab_stride / 4, 256)), dim3(256), 0, s, slabs.as<float>(),
+                         slab_stride, nslab, slab_stride / 4, dW, accumulate ? 1 : 0);
+    } else {
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slabs.as<float>(),
+                         slab_stride, nslab, slab_stride, dW, accumulate ? 1 : 0);
+    }
     LAUNCH_CHECK();
     if (db) {
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, bias_slabs, (long)out, nslab, (long)out, db,
@@ -711,7 +716,7 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s) {
   Net& D = e->net[GT_ROLE_D];
-  const int nblk = (int)std::min<long>(512, (n_rows + 3) / 4);
+  const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
   CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
@@ -721,7 +726,7 @@ static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, 
                      e->headp.as<HeadPartials>(), e->headw.as<float>());
   LAUNCH_CHECK();
   const bool w = want_grad && want_w;
-  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0);
   LAUNCH_CHECK();
   return GT_OK;

@@ -160,14 +160,15 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
   const int rows = MLPG_TT + 2 * kb;
   float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nb]
   const float* yb = y + (long)b * T * ldy;
+  // blockDim.x is a multiple of MLPG_CC: this thread always handles column c = tid % MLPG_CC
+  const int c_own = threadIdx.x % MLPG_CC;
+  const bool c_ok = c_own < nc;
+  const int my_col = c_ok ? scol[c0 + c_own] : 0, my_st = c_ok ? sstride[c0 + c_own] : 0;
   for (int e = threadIdx.x; e < rows * nW * MLPG_CC; e += blockDim.x) {
-    const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
+    const int w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
     const int t = t0 - kb + r;
     float v = 0.f;
-    if (c < nc && t >= 0 && t < T) {
-      const int st = sstride[c0 + c];
-      if (st > 0 || w == 0) v = yb[(long)t * ldy + scol[c0 + c] + w * st];
-    }
+    if (c_ok && t >= 0 && t < T && (my_st > 0 || w == 0)) v = yb[(long)t * ldy + my_col + w * my_st];
     sm[e] = v;
   }
   for (int e = threadIdx.x; e < MLPG_TT * nW * nb; e += blockDim.x) {
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
     const int t = t0 + tl;
     if (c >= nc || t >= T) continue;
     float out;
-    if (sstride[c0 + c] == 0) {
+    if (my_st == 0) {
       out = sm[((tl + kb) * nW + 0) * MLPG_CC + c];
     } else {
       float acc0 = 0.f, acc1 = 0.f;
@@ -231,11 +232,13 @@ __global__ __launch_bounds__(256) void mlpg_backward_kernel(
   }
   __syncthreads();
   const float msk_scale = mse_w != 0.f ? 2.f * mse_w * sc->inv_tv : 0.f;
+  const int c_own = threadIdx.x % MLPG_CC;          // fixed per thread (blockDim.x % MLPG_CC == 0)
+  const int my_col = c_own < nc ? scol[c0 + c_own] : 0, my_st = c_own < nc ? sstride[c0 + c_own] : 0;
   for (int e = threadIdx.x; e < MLPG_TT * nW * MLPG_CC; e += blockDim.x) {
     const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, tl = e / (MLPG_CC * nW);
     const int tp = t0 + tl;
     if (c >= nc || tp >= T) continue;
-    const int st = sstride[c0 + c];
+    const int st = my_st;
     if (st == 0 && w > 0) continue;
     float out;
     if (st == 0) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void mlpg_backward_kernel(
       if (q < nb) acc0 = fmaf(b0[q * (nW * nb - 1)], g0[q * MLPG_CC], acc0);
       out = acc0 + acc1;
     }
-    const int col = scol[c0 + c] + w * st;
+    const int col = my_col + w * st;
     const long row = (long)b * T + tp;
     if (msk_scale != 0.f) {
       const float m = mask[row];
@@ -373,21 +376,31 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 }
 
 // finalize head: sums HeadPartials in a fixed order into StepScalars, writes dw/db of last_linear.
-// grid = ceil(K/64) workgroups of 256 threads; workgroup 0 also reduces the scalar partials.
-__global__ __launch_bounds__(256) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
-                                                              int nblk, int K, int mode, StepScalars* sc,
-                                                              float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-  __shared__ float shw[4][64];
+// grid = ceil(K/64) workgroups of 1024 threads (16 row-parts x 64 columns); workgroup 0 also
+// reduces the scalar partials.
+__global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
+                                                               int nblk, int K, int mode, StepScalars* sc,
+                                                               float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  __shared__ float shw[16][64];
   __shared__ double shd[16];
   const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + kl;
   if (dw) {
-    float s = 0.f;
-    if (k < K) for (int i = part; i < nblk; i += 4) s += dw_partial[(long)i * K + k];
-    shw[part][kl] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < K) {
+      int i = part;
+      for (; i + 48 < nblk; i += 64) {
+        s0 += dw_partial[(long)i * K + k];         s1 += dw_partial[(long)(i + 16) * K + k];
+        s2 += dw_partial[(long)(i + 32) * K + k];  s3 += dw_partial[(long)(i + 48) * K + k];
+      }
+      for (; i < nblk; i += 16) s0 += dw_partial[(long)i * K + k];
+    }
+    shw[part][kl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && k < K) {
-      const float tot = (shw[0][kl] + shw[1][kl]) + (shw[2][kl] + shw[3][kl]);
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += shw[q][kl];
       dw[k] = accumulate ? dw[k] + tot : tot;
     }
   }
@@ -475,6 +488,27 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nb
 }
 
 // dW = (accumulate ? dW : 0) + sum_s slab[s]   (deterministic split-K combine of the TN GEMM)
+// 16 B per lane, 8 slabs in flight per lane; slab_stride and n4*4 must keep 16-byte alignment.
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
+                                                           float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;
+  const long st4 = slab_stride / 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nslab; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(long)(k + q) * st4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; k < nslab; ++k) s += p[(long)k * st4];
+  f32x4* o = reinterpret_cast<f32x4*>(out) + i;
+  if (accumulate) s += *o;
+  *o = s;
+}
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n,
                                    float* __restrict__ out, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -512,9 +546,11 @@ __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
     const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o) {
   __shared__ float coef_sh;
+  __shared__ double shn[16];
+  double part = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += blockDim.x) part += norm_partial[i];
+  const double tot = block_sum_d(part, shn);      // same fixed order in every workgroup
   if (threadIdx.x == 0) {
-    double tot = 0;
-    for (int i = 0; i < n_partial; ++i) tot += norm_partial[i];
     if (blockIdx.x == 0 && norm2_out) *norm2_out = tot;
     float coef = 1.f;
     if (o.max_norm > 0.f) {
