@@ -388,11 +388,12 @@ def _adv_input(cfg, x, feats):
 
 
 def update_discriminator(cfg, model_d, optimizer_d, x, y_static, y_hat_static, lengths,
-                         mask, phase, eps=1e-20, drop=None):
-    """train.py:245-279.  y_hat_static is NOT detached: loss_d.backward also fills G grads."""
+                         mask, phase, eps=1e-20, drop=None, Tv=None, step=True):
+    """train.py:245-279.  y_hat_static is NOT detached: loss_d.backward also fills G grads.
+    Tv / step: hooks for the data-parallel test backend (global normaliser; stop before clip+step)."""
     real_in = _adv_input(cfg, x, y_static)
     fake_in = _adv_input(cfg, x, y_hat_static)
-    Tv = mask.sum().item()
+    Tv = mask.sum().item() if Tv is None else Tv
     D_real = model_d(real_in, lengths=lengths, drop=drop)
     real_correct = ((D_real > 0.5).float() * mask).sum().item()
     D_fake = model_d(fake_in, lengths=lengths, drop=drop)
@@ -402,17 +403,20 @@ def update_discriminator(cfg, model_d, optimizer_d, x, y_static, y_hat_static, l
     loss_d = loss_real + loss_fake
     if phase == "train":
         loss_d.backward(retain_graph=True)
-        clip_grad_norm_(model_d.params, 1.0)
-        optimizer_d.step()
+        if step:
+            clip_grad_norm_(model_d.params, 1.0)
+            optimizer_d.step()
     return loss_d.item(), loss_fake.item(), loss_real.item(), real_correct, fake_correct
 
 
 def update_generator(cfg, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
-                     adv_w, lengths, mask, phase, mse_w=None, mge_w=None, eps=1e-20, drop=None):
+                     adv_w, lengths, mask, phase, mse_w=None, mge_w=None, eps=1e-20, drop=None,
+                     Tv=None, step=True):
     """train.py:282-320.  D forward here uses the ALREADY UPDATED D weights."""
-    Tv = mask.sum().item()
-    loss_mge = masked_mse(y_hat_static, y_static, mask)
-    loss_mse = masked_mse(y_hat, y, mask)
+    local_tv = mask.sum()
+    Tv = local_tv.item() if Tv is None else Tv
+    loss_mge = masked_mse(y_hat_static, y_static, mask) * (local_tv / Tv)
+    loss_mse = masked_mse(y_hat, y, mask) * (local_tv / Tv)
     if adv_w > 0:
         fake_in = _adv_input(cfg, x, y_hat_static)
         loss_adv = -(torch.log(model_d(fake_in, lengths=lengths, drop=drop) + eps) * mask).sum() / Tv
@@ -421,8 +425,9 @@ def update_generator(cfg, model_g, model_d, optimizer_g, x, y, y_hat, y_static, 
     loss_g = (mse_w * loss_mse + mge_w * loss_mge) + adv_w * loss_adv
     if phase == "train":
         loss_g.backward()
-        clip_grad_norm_(model_g.params, 1.0)
-        optimizer_g.step()
+        if step:
+            clip_grad_norm_(model_g.params, 1.0)
+            optimizer_g.step()
     return loss_mse.item(), loss_mge.item(), loss_adv.item(), loss_g.item()
 
 

@@ -263,3 +263,147 @@ def test_checkpoint_roundtrip_and_torch_compat(tmp_path):
     for a, b in zip(m.parameters(), m2.parameters()):
         assert torch.equal(a, b)
     assert opt2.param_groups[0]["weight_decay"] == 1e-7
+
+
+def _dp_objects(case, rows):
+    """(backend, batch) of one emulated rank holding sequences `rows` of the case's batch."""
+    from gantts_amd import optim, paramgen
+    from gantts_amd.engine import HipStepBackend
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model, make_hp
+    hp = make_hp(case)
+    mg, md = build_model(case["g"], 11).eval(), build_model(case["d"], 22).eval()
+    og = getattr(optim, case["opt_g"][0])(mg.parameters(), **case["opt_g"][1])
+    od = getattr(optim, case["opt_d"][0])(md.parameters(), **case["opt_d"][1])
+    x_np, y_np, lengths = C.make_batch(case)
+    x, y = torch.from_numpy(x_np[rows]).cuda(), torch.from_numpy(y_np[rows]).cuda()
+    lens = torch.from_numpy(lengths[rows]).cuda()
+    batch = dict(x=x, y=y, R=paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, case["T"]),
+                 y_static=get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features),
+                 mask=sequence_mask(lens, case["T"]).unsqueeze(-1))
+    return HipStepBackend(hp, mg, md, og, od), batch
+
+
+def test_data_parallel_shards_equal_whole_batch_on_one_gpu():
+    """Two emulated ranks (B/2 sequences each, own engine + replicas) with the all-reduce done by
+    hand == the plain single-engine step on the whole batch: the split-phase C ABI keeps additive
+    sums, normalises by the GLOBAL valid-frame count and leaves identical replicas."""
+    from gantts_amd.parallel import DataParallelStep
+    from hip_runner import run_hip_case
+    case = C.CASES["acoustic_mlp"]
+    whole = run_hip_case(case)
+    ranks = [_dp_objects(case, np.arange(case["B"])[r::2]) for r in range(2)]
+    tv = float(sum(b["mask"].sum().item() for _, b in ranks))
+    hist = []
+    for step in range(case["steps"]):
+        for be, b in ranks:
+            be.set_loss_normalizer(tv)
+            be.zero_grad()
+            be.apply_generator(b)
+            be.update_discriminator_begin(b, "train")
+        for which, phase_end in (("D", "update_discriminator_end"),):
+            g = sum(be.flat_grads(which) for be, _ in ranks)
+            s = sum(be.scalar_sums(which) for be, _ in ranks)
+            for be, _ in ranks:
+                be.flat_grads(which).copy_(g)
+                be.scalar_sums(which).copy_(s)
+        d = [be.update_discriminator_end(b, "train") for be, b in ranks]
+        for be, b in ranks:
+            be.update_generator_begin(b, case["adv_w"], case["mse_w"], case["mge_w"], "train")
+        g = sum(be.flat_grads("G") for be, _ in ranks)
+        s = sum(be.scalar_sums("G") for be, _ in ranks)
+        for be, _ in ranks:
+            be.flat_grads("G").copy_(g)
+            be.scalar_sums("G").copy_(s)
+        gr = [be.update_generator_end(b, case["adv_w"], case["mse_w"], case["mge_w"], "train") for be, b in ranks]
+        assert d[0] == d[1] and gr[0] == gr[1]
+        hist.append((d[0], gr[0]))
+    for i, (d, g) in enumerate(hist):
+        _close(d, whole["d_scalars_%d" % i], msg="dp d step %d" % i)
+        _close(g, whole["g_scalars_%d" % i], msg="dp g step %d" % i)
+    for tag, idx in (("G", 0), ("D", 1)):
+        m0 = (ranks[0][0].mg, ranks[0][0].md)[idx]
+        m1 = (ranks[1][0].mg, ranks[1][0].md)[idx]
+        for (k, v0), v1 in zip(m0.state_dict().items(), m1.state_dict().values()):
+            assert torch.equal(v0, v1), k                       # replicas bit-identical
+            _close(v0.cpu().numpy(), whole["%s.%s" % (tag, k)], msg=k)
+    # world = 1 through the DP orchestrator == the plain path as well
+    be, b = _dp_objects(case, np.arange(case["B"]))
+    dp = DataParallelStep(be)
+    for i in range(case["steps"]):
+        d, g = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"])
+        _close(d, whole["d_scalars_%d" % i], msg="dp1 d")
+        _close(g, whole["g_scalars_%d" % i], msg="dp1 g")
+
+
+def test_full_size_cfg2_step_vs_oracle_and_determinism():
+    """BASELINE.json configs[1] at full size (B=32, T=512, 425->187, fp32), dropout off: one G+D step
+    against the CPU oracle, plus run-to-run bit-reproducibility of the HIP path."""
+    import gantts_amd.train as T
+    from gantts_amd import hparams, optim, paramgen
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model
+    import types
+    B, Tn = 32, 512
+    gs = dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
+    ds = dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
+    case = dict(B=B, T=Tn, din=425, dout=187, stream_sizes=[180, 3, 1, 3])
+    x_np, y_np, lengths = C.make_batch(case, seed=7)
+    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    T.hp = hp
+    R_np = np.array(paramgen.unit_variance_mlpg_matrix(hp.windows, Tn))
+
+    def hip_once():
+        mg, md = build_model(gs, 1).eval(), build_model(ds, 2).eval()
+        og, od = optim.Adagrad(mg.parameters(), lr=0.01, weight_decay=1e-7), optim.Adagrad(md.parameters(), lr=0.01, weight_decay=1e-7)
+        x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
+        R = torch.from_numpy(R_np).cuda()
+        ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
+        mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
+        og.zero_grad(), od.zero_grad()
+        yh, yhs = T.apply_generator(mg, x, R, list(lengths))
+        d = T.update_discriminator(md, od, x, ys, yhs, list(lengths), mask, "train")
+        d_grads = md.flat_grads().cpu().clone()   # D.grad as left by the D step (the G step's additions to it
+        # are discarded by the next zero_grad in the reference, train.py:538-539, and are not computed here)
+        g = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, list(lengths), mask, "train", mse_w=0.0, mge_w=1.0)
+        return (d, g, yhs.cpu(), mg.flat_params().cpu().clone(), md.flat_params().cpu().clone(),
+                mg.flat_grads().cpu().clone(), d_grads)
+
+    a, b = hip_once(), hip_once()
+    assert a[0] == b[0] and a[1] == b[1]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])   # bit-reproducible
+
+    mg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
+    md = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
+    mg.load_state_dict(C.make_weights(gs, 1)), md.load_state_dict(C.make_weights(ds, 2))
+    mg.training = md.training = False
+    og, od = O.OracleAdagrad(mg.params, lr=0.01, weight_decay=1e-7), O.OracleAdagrad(md.params, lr=0.01, weight_decay=1e-7)
+    cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
+    x, y = torch.from_numpy(x_np), torch.from_numpy(y_np)
+    omask = O.sequence_mask(lengths, Tn).unsqueeze(-1)
+    oys = O.get_static_features(y, 3, cfg.stream_sizes, cfg.has_dynamic_features)
+    oyh, oyhs = O.apply_generator(cfg, mg, x, torch.from_numpy(R_np), list(lengths))
+    out = {"y_hat_static": oyhs.detach()}
+    out["d"] = O.update_discriminator(cfg, md, od, x, oys, oyhs, list(lengths), omask, "train")
+    ref_d_grads = torch.cat([p.grad.reshape(-1) for p in md.params]).numpy().copy()
+    out["g"] = O.update_generator(cfg, mg, md, og, x, y, oyh, oys, oyhs, 1.0, list(lengths), omask, "train",
+                                  mse_w=0.0, mge_w=1.0)
+    _close(a[0], out["d"], msg="full-size D scalars")
+    assert a[0][3] == out["d"][3] and a[0][4] == out["d"][4]
+    _close(a[1], out["g"], msg="full-size G scalars")
+    _close(a[2].numpy(), out["y_hat_static"].numpy(), msg="full-size y_hat_static")
+    # gradients (clipped in place by clip_grad_norm_, like torch) agree to 1e-4 of their scale
+    _close(a[5].numpy(), torch.cat([p.grad.reshape(-1) for p in mg.params]).numpy(), rtol=2e-4, atol=1e-9, msg="G grads")
+    _close(a[6].numpy(), ref_d_grads, rtol=2e-4, atol=1e-9, msg="D grads")
+    # parameters after the step: the FIRST Adagrad step is lr*sign(g) (sum == g^2), i.e. discontinuous
+    # at g == 0, so the handful of entries whose gradient cancels to rounding noise may land 2*lr
+    # apart; everything else must agree tightly.
+    for got, params in ((a[3].numpy(), mg.params), (a[4].numpy(), md.params)):
+        ref = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+        gref = torch.cat([p.grad.reshape(-1) for p in params]).numpy()
+        bad = np.abs(got - ref) > 1e-5
+        assert bad.mean() < 1e-3, "too many mismatching parameters: %g" % bad.mean()
+        if bad.any():
+            assert np.abs(gref[bad]).max() < 1e-3 * np.abs(gref).max(), "mismatch on a well-conditioned gradient"

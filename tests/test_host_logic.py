@@ -1,0 +1,137 @@
+"""CPU-runnable tests of the host-side mirror of the reference interface (no GPU compute)."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import gantts_oracle as O
+
+
+def test_hparams_sets_and_parse():
+    from gantts_amd import hparams as H
+    assert H.tts_acoustic.stream_sizes == [180, 3, 1, 3]
+    assert H.tts_acoustic.has_dynamic_features == [True, True, False, True]
+    assert H.tts_acoustic.adversarial_streams == [True, False, False, False]
+    assert H.tts_acoustic.mask_nth_mgc_for_adv_loss == 2
+    assert H.tts_acoustic.optimizer_g_params == {"lr": 0.01, "weight_decay": 1e-7}
+    assert H.tts_duration.optimizer_d == "Adam" and H.tts_duration.optimizer_d_params["betas"] == (0.5, 0.9)
+    assert H.vc.generator == "In2OutHighwayNet" and H.vc.stream_sizes == [177]
+    assert len(H.vc.windows) == 3 and len(H.tts_duration.windows) == 1
+    hp = H.HParams(batch_size=20, nepoch=200, lr_decay_schedule=False, name="x")
+    hp.parse("batch_size=16,lr_decay_schedule=True")
+    assert hp.batch_size == 16 and hp.lr_decay_schedule is True
+    assert hp.parse("") is hp
+    with pytest.raises(ValueError):
+        hp.parse("nope=1")
+    s = H.hparams_debug_string(hp)
+    assert s.startswith("Hyperparameters:") and "  batch_size: 16" in s
+    assert H.tts_acoustic == H.tts_acoustic and H.tts_acoustic != H.vc     # identity comparisons (train.py:447)
+
+
+def test_reference_hparams_values_match_when_reference_present():
+    import os
+    if not os.path.isfile("/root/reference/hparams.py"):
+        pytest.skip("reference tree absent")
+    import ref_loader
+    _, ref, _ = ref_loader.load_reference()
+    from gantts_amd import hparams as H
+    for name in ("vc", "tts_duration", "tts_acoustic"):
+        a, b = getattr(H, name).values(), getattr(ref, name).values()
+        assert set(a) == set(b), name
+        for k in a:
+            if k == "windows":
+                assert len(a[k]) == len(b[k])
+                for (l1, u1, c1), (l2, u2, c2) in zip(a[k], b[k]):
+                    assert (l1, u1) == (l2, u2) and np.array_equal(c1, c2)
+            elif k == "question_path":
+                assert a[k].endswith("questions-radio_dnn_416.hed")
+            else:
+                assert a[k] == b[k], (name, k)
+
+
+def test_model_state_dict_layout_and_flat_buffer():
+    from gantts_amd import models
+    spec = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=64, dropout=0.5, last_sigmoid=False)
+    m = models.MLP(**spec)
+    names = [n for n, _ in C.param_shapes(dict(kind="MLP", **spec))]
+    assert list(m.state_dict().keys()) == names
+    for (n, shp), p in zip(C.param_shapes(dict(kind="MLP", **spec)), m.parameters()):
+        assert tuple(p.shape) == shp
+    flat = m.flat_params()
+    assert flat.numel() == sum(p.numel() for p in m.parameters())
+    off = 0
+    for p in m.parameters():           # parameters are views into the flat buffer, in order
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    w = C.make_weights(dict(kind="MLP", **spec), 3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    assert np.array_equal(flat[:64 * 425].view(64, 425).numpy(), w["layers.0.weight"])
+    k = 1 / np.sqrt(425)
+    m2 = models.MLP(**spec)
+    assert float(m2.layers[0].weight.abs().max()) <= k + 1e-7     # nn.Linear default init range
+    assert not m.include_parameter_generation()
+    i2o = models.In2OutHighwayNet(in_dim=75, out_dim=75, static_dim=25, hidden_dim=32)
+    assert i2o.include_parameter_generation()
+    assert list(i2o.state_dict().keys())[:4] == ["T.weight", "T.bias", "H.0.weight", "H.0.bias"]
+    m.eval()
+    assert not m.training
+    m.train()
+    assert m.training
+    with pytest.raises(TypeError):
+        models.MLP(nonsense=1)
+
+
+def test_optimizer_state_dict_is_torch_compatible():
+    from gantts_amd import models, optim
+    m = models.MLP(in_dim=6, out_dim=2, num_hidden=1, hidden_dim=4, last_sigmoid=False)
+    for cls, tcls, kw in ((optim.Adagrad, torch.optim.Adagrad, dict(lr=0.01, weight_decay=1e-7)),
+                          (optim.Adam, torch.optim.Adam, dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0))):
+        o = cls(m.parameters(), **kw)
+        sd = o.state_dict()
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2))
+        t = tcls(ref.parameters(), **kw)
+        assert sd["param_groups"][0]["params"] == t.state_dict()["param_groups"][0]["params"]
+        for k in kw:
+            assert sd["param_groups"][0][k] == kw[k]
+        t.load_state_dict(sd)                     # torch accepts our checkpoint format
+        o2 = cls(m.parameters())
+        o2.load_state_dict(t.state_dict())        # and we accept torch's
+        assert o2.param_groups[0]["lr"] == kw["lr"]
+        with pytest.raises(RuntimeError):
+            o.step()
+    with pytest.raises(TypeError):
+        optim.Adagrad(torch.nn.Linear(3, 3).parameters())
+    with pytest.raises(ValueError):
+        optim.Adagrad(list(m.parameters())[:2])
+
+
+def test_exp_lr_scheduler_and_stream_index_helpers():
+    import gantts_amd.train as T
+    from gantts_amd import models, optim
+    from gantts_amd.multistream import get_static_stream_sizes, static_columns
+    m = models.MLP(in_dim=6, out_dim=2, num_hidden=1, hidden_dim=4, last_sigmoid=False)
+    o = optim.Adagrad(m.parameters(), lr=0.01)
+    T.exp_lr_scheduler(o, 25, 200, init_lr=0.01, lr_decay_epoch=25)
+    assert o.param_groups[0]["lr"] == pytest.approx(0.001)
+    assert list(get_static_stream_sizes([180, 3, 1, 3], [True, True, False, True], 3)) == [60, 1, 1, 1]
+    ss, hd = [180, 3, 1, 3], [True, True, False, True]
+    cols = static_columns(3, ss, hd, None, 187)
+    x = torch.arange(187.).expand(1, 2, 187)
+    assert torch.equal(x[:, :, cols], O.get_static_features(x, 3, ss, hd))
+    assert static_columns(3, [75], [True], None, 75) == list(range(25))
+    assert static_columns(1, [5], [False], None, 5) == list(range(5))
+    from gantts_amd.engine import _hp_signature
+    from gantts_amd import hparams as H
+    sig = _hp_signature(H.tts_acoustic)
+    assert sig[0] == (180, 3, 1, 3) and sig[2] == 3 and sig[4] == 2 and sig[5] is True
+
+
+@pytest.mark.parametrize("T_", [1, 2, 7, 64, 300])
+def test_paramgen_matches_oracle_dense_inverse(T_):
+    from gantts_amd import paramgen
+    for n in (1, 2, 3):
+        a = paramgen.unit_variance_mlpg_matrix(C.WINDOWS[:n], T_)
+        b = O.unit_variance_mlpg_matrix(C.WINDOWS[:n], T_)
+        assert a.shape == (T_, n * T_) and a.dtype == np.float32
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    assert paramgen.unit_variance_mlpg_matrix(C.WINDOWS, T_) is paramgen.unit_variance_mlpg_matrix(C.WINDOWS, T_)
