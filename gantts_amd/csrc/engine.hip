@@ -215,7 +215,7 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     }
     LAUNCH_CHECK();
     if (db) {
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, bias_slabs, (long)out, nslab, (long)out, db,
+      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(out, 64)), dim3(1024), 0, s, bias_slabs, (long)out, nslab, out, db,
                          accumulate ? 1 : 0);
       LAUNCH_CHECK();
     }

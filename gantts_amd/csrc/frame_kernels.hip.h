@@ -509,6 +509,27 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restri
   if (accumulate) s += *o;
   *o = s;
 }
+// small-n variant (bias gradients): 64 columns x 16 slab lanes per workgroup, fixed-order combine
+__global__ __launch_bounds__(1024) void slab_reduce_small_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, int n,
+                                                                 float* __restrict__ out, int accumulate) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < n) {
+    int k = part;
+    for (; k + 16 < nslab; k += 32) { s0 += slabs[(long)k * slab_stride + c]; s1 += slabs[(long)(k + 16) * slab_stride + c]; }
+    for (; k < nslab; k += 16) s0 += slabs[(long)k * slab_stride + c];
+  }
+  sh[part][cl] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && c < n) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += sh[q][cl];
+    out[c] = accumulate ? out[c] + tot : tot;
+  }
+}
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n,
                                    float* __restrict__ out, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
