@@ -510,7 +510,7 @@ static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
   int kb = 0;
   for (int o = -(T - 1); o <= T - 1; ++o)
     if (off[o + T - 1] > 1e-9f * peak) kb = std::max(kb, abs(o));
-  if (kb > 64 && kb > T / 4)
+  if (kb > 63 || (kb > 48 && kb > T / 4))
     return fail(GT_ERR_INVALID, "MLPG matrix R is not banded (half-width %d of T=%d): only window sets whose "
                 "R = (W^T W)^-1 W^T decays (hparams.py:22-26) are supported", kb, T);
   const int nb = 2 * kb + 1;
@@ -721,9 +721,16 @@ static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, 
   CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
   const size_t lds = (size_t)4 * K * sizeof(float);
-  hipLaunchKernelGGL(d_head_kernel, dim3(nblk), dim3(256), lds, s, H, K, K, D.last.W, D.last.b, mask, (int)n_mask, (int)n_real,
-                     (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(),
-                     e->headp.as<HeadPartials>(), e->headw.as<float>());
+#define GT_HEAD_LAUNCH(KP_)                                                                                              \
+  hipLaunchKernelGGL(d_head_kernel<KP_>, dim3(nblk), dim3(256), lds, s, H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
+                     (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                     e->headp.as<HeadPartials>(), e->headw.as<float>())
+  if (K <= 128) GT_HEAD_LAUNCH(2);
+  else if (K <= 256) GT_HEAD_LAUNCH(4);
+  else if (K <= 512) GT_HEAD_LAUNCH(8);
+  else if (K <= 1024) GT_HEAD_LAUNCH(16);
+  else return fail(GT_ERR_INVALID, "discriminator hidden_dim > 1024 is not supported by the fused head kernel");
+#undef GT_HEAD_LAUNCH
   LAUNCH_CHECK();
   const bool w = want_grad && want_w;
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),

@@ -307,6 +307,9 @@ struct HeadPartials {   // one per workgroup; summed in fixed order afterwards
   double s_real, s_fake, n_real_ok, n_fake_ok, db;
 };
 
+// KP = hidden units per lane (K <= 64*KP): the row, the weight vector and the dw accumulators live
+// in registers; the next row is prefetched while the current one goes through the reduction chain.
+template <int KP>
 __global__ __launch_bounds__(256) void d_head_kernel(
     const float* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, int n_mask, int n_real, int n_rows, int mode, float eps,
@@ -319,14 +322,30 @@ __global__ __launch_bounds__(256) void d_head_kernel(
   const float inv_tv = sc->inv_tv;
   const float b0 = bias[0];
   double s_real = 0, s_fake = 0, n_rok = 0, n_fok = 0, dbs = 0;
-  const int kper = (K + 63) / 64;   // hidden units per lane (strided by 64)
-  // per-lane dw accumulators live in LDS rows (K can exceed register budget in general)
-  float* dwrow = smf + wv * K;
-  for (int k = lane; k < K; k += 64) dwrow[k] = 0.f;
-  for (int r = blockIdx.x * 4 + wv; r < n_rows; r += gridDim.x * 4) {
-    const float* h = H + (long)r * ldh;
+  float wreg[KP], dwacc[KP], hcur[KP], hnxt[KP];
+  int kidx[KP];
+#pragma unroll
+  for (int j = 0; j < KP; ++j) {
+    const int k = lane + 64 * j;
+    kidx[j] = min(k, K - 1);                       // clamped: loads stay in bounds, extra lanes use w = 0
+    wreg[j] = k < K ? w[k] : 0.f;
+    dwacc[j] = 0.f;
+  }
+  const int stride = gridDim.x * 4;
+  int r = blockIdx.x * 4 + wv;
+  if (r < n_rows) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) hcur[j] = H[(long)r * ldh + kidx[j]];
+  }
+  for (; r < n_rows; r += stride) {
+    const int rn = r + stride;
+    if (rn < n_rows) {
+#pragma unroll
+      for (int j = 0; j < KP; ++j) hnxt[j] = H[(long)rn * ldh + kidx[j]];
+    }
     float part = 0.f;
-    for (int k = lane; k < K; k += 64) part = fmaf(h[k], w[k], part);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) part = fmaf(hcur[j], wreg[j], part);
     const float z = wave_sum(part) + b0;
     const float D = 1.f / (1.f + expf(-z));
     const float m = mask[r % n_mask];
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     float dD;
     if (is_real) {
       const float l = logf(D + eps) * m;
-      if (mode == HEAD_G_ADV || r < n_real) { if (lane == 0) s_real += (double)l; }
+      if (lane == 0) s_real += (double)l;
       if (lane == 0 && mode == HEAD_D_STEP) n_rok += (D > 0.5f ? 1.0 : 0.0) * (double)m;
       dD = -m * inv_tv / (D + eps);
     } else {
@@ -347,18 +366,25 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     if (want_grad) {
       const float dz = dD * ((1.f - D) * D);
       if (lane == 0) dbs += (double)dz;
-      for (int k = lane; k < K; k += 64) {
-        const float hv = h[k];
-        dwrow[k] = fmaf(dz, hv, dwrow[k]);
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        const int k = lane + 64 * j;
+        const float hv = hcur[j];
+        dwacc[j] = fmaf(dz, hv, dwacc[j]);
         float f = 1.f;
-        if (has_act) f = leaky_drop_grad(hv, dropout_keep(drop, r, k), drop.mode == DROP_NONE ? 1.f : drop.scale);
-        dH[(long)r * lddh + k] = dz * w[k] * f;
+        if (has_act) f = leaky_drop_grad(hv, dropout_keep(drop, r, kidx[j]), drop.mode == DROP_NONE ? 1.f : drop.scale);
+        if (k < K) dH[(long)r * lddh + k] = dz * wreg[j] * f;
       }
     }
+#pragma unroll
+    for (int j = 0; j < KP; ++j) hcur[j] = hnxt[j];
   }
-  (void)kper;
   // reduce the scalar partials over the 4 waves
   if (lane == 0) { shd[0][wv] = s_real; shd[1][wv] = s_fake; shd[2][wv] = n_rok; shd[3][wv] = n_fok; shd[4][wv] = dbs; }
+  if (want_grad && dw_partial) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { const int k = lane + 64 * j; if (k < K) smf[wv * K + k] = dwacc[j]; }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     HeadPartials p;
