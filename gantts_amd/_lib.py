@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
-ARCH_MLP, ARCH_IN2OUT = 0, 1
+ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM = 0, 1, 2
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8
 
@@ -32,6 +32,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("arch", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32),
                 ("num_hidden", C.c_int32), ("hidden_dim", C.c_int32), ("static_dim", C.c_int32),
                 ("dropout", C.c_float), ("last_sigmoid", C.c_int32),
+                ("bidirectional", C.c_int32), ("reserved_", C.c_int32),
                 ("params", C.c_void_p), ("grads", C.c_void_p), ("n_params", C.c_int64)]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "gt_get_optimizer_step": (_I, [_P, _I, C.POINTER(_L)]),
     "gt_set_seed": (_I, [_P, C.c_uint64]),
     "gt_set_dropout_mask": (_I, [_P, _I, _I, _I, _P]),
+    "gt_set_lengths": (_I, [_P, C.POINTER(_L), _I]),
     "gt_zero_grad": (_I, [_P, _I]),
     "gt_apply_generator": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gt_update_discriminator": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, C.POINTER(DResult), _P]),

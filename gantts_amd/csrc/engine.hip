@@ -22,6 +22,7 @@
 #include "../../include/gantts_hip.h"
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
+#include "lstm_kernels.hip.h"
 
 using namespace gt;
 
@@ -237,12 +238,15 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
 // engine state
 // ------------------------------------------------------------------------------------------
 struct Lin { float *W, *b, *dW, *db; int in, out; };
+struct LstmDirP { float *Wih, *Whh, *bih, *bhh, *dWih, *dWhh, *dbih, *dbhh; };
+struct LstmLayerP { int in; LstmDirP d[2]; };
 
 struct Net {
   bool bound = false;
   gt_model_desc d;
   std::vector<Lin> hidden;
   Lin last, gate;
+  std::vector<LstmLayerP> lstm;   // GT_ARCH_LSTM; `last` is hidden2out
   bool training = true;
   bool grads_dirty = false;      // false after zero_grad: next backward overwrites instead of accumulating
   bool has_opt = false;
@@ -284,6 +288,10 @@ struct gt_engine {
   const float* fake_cat_x = nullptr; const float* fake_cat_yhs = nullptr;
   bool d_begin_done = false, g_begin_done = false, g_has_adv = false, g_used_mlpg = false;
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
+  // recurrent generator workspace (per layer) and the lengths of the current batch
+  std::vector<Scratch> l_xproj, l_gates, l_cst, l_out;
+  Scratch l_state, l_dout, l_hshift, d_lengths;
+  std::vector<int> h_lengths;
   StepScalars* sc() { return scal.as<StepScalars>(); }
   StepResults* res() { return (StepResults*)((char*)scal.p + 256); }
 };
@@ -350,6 +358,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& s : e->g_act) s.release();
   for (auto& s : e->d_act) s.release();
+  for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out}) for (auto& s : *v) s.release();
+  e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->d_lengths.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.band};
   for (auto* s : all) s->release();
@@ -361,6 +371,14 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
 
 static long expected_params(const gt_model_desc& d) {
   long n = 0;
+  if (d.arch == GT_ARCH_LSTM) {
+    const int H = d.hidden_dim, dirs = d.bidirectional ? 2 : 1;
+    for (int l = 0; l < d.num_hidden; ++l) {
+      const int in = l == 0 ? d.in_dim : H * dirs;
+      n += (long)dirs * (4L * H * in + 4L * H * H + 8L * H);
+    }
+    return n + (long)d.out_dim * H * dirs + d.out_dim;
+  }
   if (d.arch == GT_ARCH_IN2OUT) n += (long)d.static_dim * d.static_dim + d.static_dim;
   int in = d.in_dim;
   for (int l = 0; l < d.num_hidden; ++l) { n += (long)d.hidden_dim * in + d.hidden_dim; in = d.hidden_dim; }
@@ -370,12 +388,14 @@ static long expected_params(const gt_model_desc& d) {
 
 extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) {
   if (!e || !desc || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
-  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT) return fail(GT_ERR_INVALID, "unsupported arch %d", desc->arch);
+  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT && desc->arch != GT_ARCH_LSTM)
+    return fail(GT_ERR_INVALID, "unsupported arch %d", desc->arch);
   if (desc->num_hidden < 1 || desc->num_hidden > 16) return fail(GT_ERR_INVALID, "num_hidden must be in [1,16]");
   if (desc->dropout < 0.f || desc->dropout >= 1.f) return fail(GT_ERR_INVALID, "dropout must be in [0,1)");
   if (!desc->params) return fail(GT_ERR_INVALID, "params is null");
   if (desc->n_params != expected_params(*desc))
     return fail(GT_ERR_INVALID, "n_params %ld does not match the architecture (%ld)", (long)desc->n_params, expected_params(*desc));
+  if (desc->arch == GT_ARCH_LSTM && desc->hidden_dim < 1) return fail(GT_ERR_INVALID, "hidden_dim must be positive");
   if (role == GT_ROLE_D && (desc->arch != GT_ARCH_MLP || desc->out_dim != 1 || !desc->last_sigmoid))
     return fail(GT_ERR_INVALID, "discriminator must be MLP(out_dim=1, last_sigmoid=True) (hparams.py:56-64,230-239)");
   Net& n = e->net[role];
@@ -390,10 +410,31 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     l.b = p; l.db = g; p += out; if (g) g += out;
     return l;
   };
-  if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
-  int in = desc->in_dim;
-  for (int l = 0; l < desc->num_hidden; ++l) { n.hidden.push_back(take(desc->hidden_dim, in)); in = desc->hidden_dim; }
-  n.last = take(desc->out_dim, in);
+  n.lstm.clear();
+  if (desc->arch == GT_ARCH_LSTM) {
+    const int H = desc->hidden_dim, dirs = desc->bidirectional ? 2 : 1;
+    auto adv = [&](float*& wp, float*& gp, long cnt) { wp = p; gp = g; p += cnt; if (g) g += cnt; };
+    for (int l = 0; l < desc->num_hidden; ++l) {
+      LstmLayerP L;
+      memset(&L, 0, sizeof(L));
+      L.in = l == 0 ? desc->in_dim : H * dirs;
+      for (int dd = 0; dd < dirs; ++dd) {
+        adv(L.d[dd].Wih, L.d[dd].dWih, 4L * H * L.in);
+        adv(L.d[dd].Whh, L.d[dd].dWhh, 4L * H * H);
+        adv(L.d[dd].bih, L.d[dd].dbih, 4L * H);
+        adv(L.d[dd].bhh, L.d[dd].dbhh, 4L * H);
+      }
+      n.lstm.push_back(L);
+    }
+    n.last = take(desc->out_dim, H * dirs);
+    e->l_xproj.resize(desc->num_hidden); e->l_gates.resize(desc->num_hidden);
+    e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden);
+  } else {
+    if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
+    int in = desc->in_dim;
+    for (int l = 0; l < desc->num_hidden; ++l) { n.hidden.push_back(take(desc->hidden_dim, in)); in = desc->hidden_dim; }
+    n.last = take(desc->out_dim, in);
+  }
   n.bound = true;
   n.grads_dirty = false;
   auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
@@ -455,6 +496,18 @@ extern "C" int gt_set_loss_normalizer(gt_engine* e, float tv) {
   e->tv_override = tv;
   return GT_OK;
 }
+extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B) {
+  if (!e || !lengths_host || B < 1) return fail(GT_ERR_INVALID, "bad argument");
+  e->h_lengths.resize(B);
+  for (int b = 0; b < B; ++b) {
+    if (lengths_host[b] < 0 || lengths_host[b] > 0x3fffffff) return fail(GT_ERR_INVALID, "length out of range");
+    e->h_lengths[b] = (int)lengths_host[b];
+  }
+  CHK(e->d_lengths.ensure((size_t)B * sizeof(int)));
+  HIPCHK(hipMemcpy(e->d_lengths.p, e->h_lengths.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  return GT_OK;
+}
+
 extern "C" int gt_zero_grad(gt_engine* e, int role) {
   if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
   e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
@@ -628,15 +681,147 @@ static int check_common(gt_engine* e, int B, int T) {
   return GT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// recurrent generator (GT_ARCH_LSTM): forward / backward of the LSTM stack
+// ------------------------------------------------------------------------------------------
+static int lstm_check_lengths(gt_engine* e, int B, int T) {
+  if ((int)e->h_lengths.size() != B)
+    return fail(GT_ERR_STATE, "recurrent generator: call with lengths (gt_set_lengths) for this batch of %d sequences "
+                "(reference models.py:204-210 packs the batch by `lengths`)", B);
+  for (int b = 0; b < B; ++b)
+    if (e->h_lengths[b] > T) return fail(GT_ERR_INVALID, "length %d exceeds the padded length %d", e->h_lengths[b], T);
+  return GT_OK;
+}
+
+static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T, bool backward, const float* dout, hipStream_t s) {
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
+  const int Bpad = cdiv(B, 32) * 32;
+  const size_t st = (size_t)dirs * Bpad * H;              // floats per state array
+  CHK(e->l_state.ensure(5 * st * sizeof(float)));          // h0,h1,c0,c1 (ping-pong) + dc
+  float* base = e->l_state.as<float>();
+  HIPCHK(hipMemsetAsync(base, 0, 5 * st * sizeof(float), s));
+  static bool attr = false;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute((const void*)lstm_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
+    HIPCHK(hipFuncSetAttribute((const void*)lstm_bwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
+    attr = true;
+  }
+  LstmStepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.Bpad = Bpad;
+  a.lengths = e->d_lengths.as<int>();
+  for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
+  a.xproj = e->l_xproj[layer].as<float>();
+  a.gates = e->l_gates[layer].as<float>();
+  a.cst = e->l_cst[layer].as<float>();
+  a.out = e->l_out[layer].as<float>();
+  a.dout = dout;
+  a.dc_state = base + 4 * st;
+  for (int step = 0; step < T; ++step) {
+    a.step = step;
+    if (!backward) {
+      const int cur = step & 1;
+      a.h_prev = base + (size_t)cur * st;       a.c_prev = base + (2 + (size_t)cur) * st;
+      a.h_next = base + (size_t)(cur ^ 1) * st; a.c_next = base + (2 + (size_t)(cur ^ 1)) * st;
+      hipLaunchKernelGGL(lstm_fwd_step_kernel, dim3(cdiv(H, 8), dirs, cdiv(B, 32)), dim3(256), lstm_lds_bytes(), s, a);
+    } else {
+      hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3(cdiv(H, 32), dirs, cdiv(B, 32)), dim3(256), lstm_lds_bytes(), s, a);
+    }
+  }
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// x (N, in_dim) -> y_hat (N, out_dim); stashes X-projections / gates / cell states / layer outputs
+static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  CHK(lstm_check_lengths(e, B, T));
+  if (G.training && G.d.dropout > 0.f && G.d.num_hidden > 1)
+    return fail(GT_ERR_INVALID, "nn.LSTM inter-layer dropout > 0 in training mode is not supported yet");
+  const long N = (long)B * T;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
+  const float* in = x;
+  int ld_in = G.d.in_dim;
+  for (int l = 0; l < G.d.num_hidden; ++l) {
+    const LstmLayerP& L = G.lstm[l];
+    CHK(e->l_xproj[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
+    CHK(e->l_gates[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
+    CHK(e->l_cst[l].ensure((size_t)N * dirs * H * sizeof(float)));
+    CHK(e->l_out[l].ensure((size_t)N * dirs * H * sizeof(float)));
+    for (int d = 0; d < dirs; ++d)   // Xp[:, d*4H:(d+1)*4H] = X W_ih^T (biases are added in the step kernel)
+      CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, e->l_xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
+                         4 * H, ACT_NONE, no_drop(), s));
+    CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
+    in = e->l_out[l].as<float>();
+    ld_in = dirs * H;
+  }
+  return linear_forward(in, ld_in, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in, G.last.out,
+                        G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+}
+
+// gy (N, out_dim) = dL/dy_hat -> parameter gradients of hidden2out and of every LSTM layer
+static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = (long)B * T;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, Do = G.d.out_dim, Lc = G.d.num_hidden;
+  const bool acc = G.grads_dirty;
+  CHK(e->l_dout.ensure((size_t)2 * N * dirs * H * sizeof(float)));
+  CHK(e->l_hshift.ensure((size_t)N * H * sizeof(float)));
+  float* dout = e->l_dout.as<float>();                       // gradient w.r.t. the current layer's output
+  float* dout_other = dout + (size_t)N * dirs * H;
+  // hidden2out: dW = gy^T out_top, db, d out_top = gy W
+  CHK(linear_backward_weight(gy, Do, e->l_out[Lc - 1].as<float>(), dirs * H, N, Do, dirs * H, G.last.dW, G.last.db, acc, e->slabs,
+                             e->colp, s));
+  CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
+  for (int l = Lc - 1; l >= 0; --l) {
+    const LstmLayerP& L = G.lstm[l];
+    CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));     // dG overwrites l_xproj[l]
+    const float* dG = e->l_xproj[l].as<float>();
+    const float* Xl = l == 0 ? x : e->l_out[l - 1].as<float>();
+    const int ldx = l == 0 ? G.d.in_dim : dirs * H;
+    for (int d = 0; d < dirs; ++d) {
+      const float* dGd = dG + (size_t)d * 4 * H;
+      // dW_ih = dG_d^T X, db_ih = colsum(dG_d) (= db_hh)
+      CHK(linear_backward_weight(dGd, dirs * 4 * H, Xl, ldx, N, 4 * H, L.in, L.d[d].dWih, L.d[d].dbih, acc, e->slabs, e->colp, s));
+      // bias_ih and bias_hh always receive the same gradient: keep them equal by copy
+      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(4 * H, 64)), dim3(1024), 0, s, L.d[d].dbih, (long)4 * H, 1, 4 * H,
+                         L.d[d].dbhh, 0);
+      LAUNCH_CHECK();
+      // dW_hh = dG_d^T H_shift (h that entered each frame)
+      hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
+                         e->d_lengths.as<int>(), e->l_hshift.as<float>());
+      LAUNCH_CHECK();
+      CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, e->slabs,
+                                 e->colp, s));
+    }
+    if (l > 0) {   // gradient w.r.t. the layer below's output: sum over directions of dG_d W_ih_d
+      for (int d = 0; d < dirs; ++d) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = dG + (size_t)d * 4 * H; g.lda = dirs * 4 * H; g.B = L.d[d].Wih; g.ldb = L.in; g.C = dout_other; g.ldc = L.in;
+        g.M = (int)N; g.N = L.in; g.K = 4 * H; g.act = ACT_NONE; g.accumulate = d > 0 ? 1 : 0; g.drop = no_drop();
+        CHK(launch_gemm(GEMM_NN, g, 1, s));
+      }
+      std::swap(dout, dout_other);
+    }
+  }
+  return GT_OK;
+}
+
 static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
                              bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
   Net& G = e->net[GT_ROLE_G];
   const long N = (long)B * T;
   const int pass0[1] = {0};
-  CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
-  const Lin& Lh = G.hidden.back();
-  CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
-                     G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+  if (G.d.arch == GT_ARCH_LSTM) {
+    CHK(lstm_forward(e, x, B, T, y_hat, s));
+  } else {
+    CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+    const Lin& Lh = G.hidden.back();
+    CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                       G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+  }
   if (G.d.arch == GT_ARCH_IN2OUT) {
     if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
     const int sd = G.d.static_dim;
@@ -878,6 +1063,11 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
     LAUNCH_CHECK();
   }
+  if (G.d.arch == GT_ARCH_LSTM) {
+    CHK(lstm_backward(e, x, gy, B, T, s));
+    G.grads_dirty = true;
+    return GT_OK;
+  }
   // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
   const Lin& Lt = G.hidden.back();
   CHK(linear_backward_weight(gy, Do, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
@@ -1031,6 +1221,11 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
     if (!out2) return fail(GT_ERR_INVALID, "In2OutHighwayNet forward returns two tensors");
     e->g_pass_valid = false;
     return generator_forward(e, x, R, B, T, out, out2, false, s, specs);
+  }
+  if (n.d.arch == GT_ARCH_LSTM) {
+    if (role != GT_ROLE_G) return fail(GT_ERR_INVALID, "recurrent networks are supported in the generator slot only");
+    e->g_pass_valid = false;
+    return lstm_forward(e, x, B, T, out, s);
   }
   const int pass0[1] = {0};
   auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;

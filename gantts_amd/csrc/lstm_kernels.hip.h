@@ -1,0 +1,240 @@
+// Recurrent cells of LSTMRNN / GRURNN (reference gantts/models.py:170-213: nn.LSTM over
+// pack_padded_sequence, batch_first, optional bidirectional) for gfx950.
+//
+// Decomposition per layer (both directions together):
+//   1. X-projection for ALL frames at once:  Xp = X . W_ih^T          -> f32 MFMA GEMM (gemm_f32.hip.h)
+//   2. the recurrence, one launch per time step: gates = Xp[t] + b_ih + b_hh + h_{t-1} . W_hh^T,
+//      i,f,o = sigmoid, g = tanh, c_t = f c_{t-1} + i g, h_t = o tanh(c_t)        (this file)
+//   3. backward recurrence, one launch per time step (reverse order): dh_t = dOut_t + dG_{t+1} . W_hh,
+//      gate derivatives -> dG_t                                                      (this file)
+//   4. weight gradients for ALL frames at once: dW_ih = dG^T X, dW_hh = dG^T H_shift, db = colsum(dG),
+//      dX = dG . W_ih                                                               -> GEMMs again
+// Packed-sequence semantics: sequence b is active at frame t iff t < length[b]; outputs beyond the
+// length are zero (pad_packed_sequence) and the reverse direction starts from zero state at each
+// sequence's own last valid frame (state is held at zero while inactive).
+//
+// Step kernels: workgroup = (tile of hidden units, direction, 32 sequences); the per-step product
+// [32 x K] . [K x 32] runs on v_mfma_f32_32x32x2_f32 with K split over the 4 waves and staged
+// through LDS in chunks of 256 (k-major, pitch 33: conflict-free scatter and fragment reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_f32.hip.h"
+
+namespace gt {
+
+constexpr int LSTM_KC = 256;      // K chunk staged in LDS
+constexpr int LSTM_P = 33;        // LDS pitch
+constexpr size_t lstm_lds_bytes() { return (size_t)(2 * LSTM_KC * LSTM_P + 4 * 32 * LSTM_P) * sizeof(float); }
+
+struct LstmStepArgs {
+  int B, T, H, dirs;
+  int step;                       // launch index s = 0..T-1
+  const int* lengths;             // [B] device
+  // per direction (index 0 forward, 1 reverse)
+  const float* Whh[2];            // (4H, H) row-major
+  const float* bih[2];
+  const float* bhh[2];
+  // frame-major buffers, row = b*T + t
+  float* xproj;                   // [N][dirs*4H]  forward: X W_ih^T (in) ; backward: dG (out), same storage
+  float* gates;                   // [N][dirs*4H]  post-activation i,f,g,o (stash)
+  float* cst;                     // [N][dirs*H]   cell state (stash)
+  float* out;                     // [N][dirs*H]   h_t (zero beyond the length)
+  const float* dout;              // [N][dirs*H]   upstream gradient w.r.t. out (backward)
+  // running state, [dirs][Bpad][H]
+  const float* h_prev; const float* c_prev;
+  float* h_next; float* c_next;
+  float* dc_state;                // backward: running dL/dc, [dirs][Bpad][H]
+  int Bpad;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// acc += sA^T-fragment x sB-fragment over this wave's quarter of the staged chunk
+__device__ __forceinline__ void lstm_mma_chunk(f32x16& acc, const float* sA, const float* sB, int wave, int l31, int half) {
+  const int k0 = wave * (LSTM_KC / 4);
+#pragma unroll 8
+  for (int kk = 0; kk < LSTM_KC / 4; kk += 2) {
+    const float a = sA[(k0 + kk + half) * LSTM_P + l31];
+    const float b = sB[(k0 + kk + half) * LSTM_P + l31];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+}
+
+// cross-wave reduction of the 4 partial 32x32 tiles: red[w][row][col]
+__device__ __forceinline__ void lstm_store_partial(const f32x16& acc, float* red, int wave, int l31, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    red[(wave * 32 + row) * LSTM_P + l31] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward step.  grid = (ceil(H/8), dirs, ceil(B/32)); tile columns c = gate*8 + unit.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;                               // h_{t-1}^T  [KC][P]  (k, batch)
+  float* sB = sm + LSTM_KC * LSTM_P;            // W_hh tile  [KC][P]  (k, gate*8+unit)
+  float* red = sm + 2 * LSTM_KC * LSTM_P;       // [4][32][P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int H = a.H, T = a.T, d = blockIdx.y;
+  const int u0 = blockIdx.x * 8, b0 = blockIdx.z * 32;
+  const int t = d == 0 ? a.step : T - 1 - a.step;
+  const float* W = a.Whh[d];
+  const float* hp = a.h_prev + ((long)d * a.Bpad + b0) * H;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < H; kc += LSTM_KC) {
+    // stage h_{t-1}[b][kc..] and W_hh[gate*H + u0+u][kc..], zero beyond H / B / unit range
+    for (int e = tid; e < 32 * LSTM_KC; e += 256) {
+      const int k = e % LSTM_KC, r = e / LSTM_KC;
+      const int kg = kc + k;
+      float va = 0.f, vb = 0.f;
+      if (kg < H) {
+        if (b0 + r < a.B) va = hp[(long)r * H + kg];
+        const int gate = r >> 3, u = u0 + (r & 7);
+        if (u < H) vb = W[((long)gate * H + u) * H + kg];
+      }
+      sA[k * LSTM_P + r] = va;
+      sB[k * LSTM_P + r] = vb;
+    }
+    __syncthreads();
+    lstm_mma_chunk(acc, sA, sB, wave, l31, half);
+    __syncthreads();
+  }
+  lstm_store_partial(acc, red, wave, l31, half);
+  __syncthreads();
+  // one (sequence, unit) pair per thread: u fastest (8 consecutive floats per row)
+  const int u = tid & 7, bl = tid >> 3;
+  const int j = u0 + u, b = b0 + bl;
+  if (j >= H || b >= a.B) return;
+  const long row = (long)b * T + t;
+  const bool active = t < a.lengths[b];
+  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = g * 8 + u;
+    float s = (red[(0 * 32 + bl) * LSTM_P + c] + red[(1 * 32 + bl) * LSTM_P + c]) +
+              (red[(2 * 32 + bl) * LSTM_P + c] + red[(3 * 32 + bl) * LSTM_P + c]);
+    pre[g] = s + a.xproj[row * ld4 + d * 4 * H + g * H + j] + (a.bih[d][g * H + j] + a.bhh[d][g * H + j]);
+  }
+  const long sidx = ((long)d * a.Bpad + b) * H + j;
+  float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, h = 0.f;
+  if (active) {
+    ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+    c = fg * a.c_prev[sidx] + ig * gg;
+    h = og * tanhf(c);
+  }
+  a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
+  a.gates[row * ld4 + d * 4 * H + 1 * H + j] = fg;
+  a.gates[row * ld4 + d * 4 * H + 2 * H + j] = gg;
+  a.gates[row * ld4 + d * 4 * H + 3 * H + j] = og;
+  a.cst[row * ld1 + d * H + j] = c;
+  a.out[row * ld1 + d * H + j] = h;      // zero beyond the length (pad_packed_sequence)
+  a.h_next[sidx] = h;                    // state is held at zero while inactive
+  a.c_next[sidx] = c;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward step.  grid = (ceil(H/32), dirs, ceil(B/32)).  Direction 0 walks t = T-1..0,
+// direction 1 walks t = 0..T-1 (the reverse of each direction's forward order).
+//   dh = dOut[t] + dG[t_next] . W_hh      (t_next = the step processed by the previous launch)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;                               // dG_prev^T  [KC][P]  (k = gate column, batch)
+  float* sB = sm + LSTM_KC * LSTM_P;            // W_hh       [KC][P]  (k, unit)
+  float* red = sm + 2 * LSTM_KC * LSTM_P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int H = a.H, T = a.T, d = blockIdx.y;
+  const int u0 = blockIdx.x * 32, b0 = blockIdx.z * 32;
+  const int t = d == 0 ? T - 1 - a.step : a.step;
+  const int tprev = d == 0 ? t + 1 : t - 1;      // frame handled by the previous launch
+  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+  const float* W = a.Whh[d];
+  const int K = 4 * H;
+
+  if (a.step > 0) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kc = 0; kc < K; kc += LSTM_KC) {
+      for (int e = tid; e < 32 * LSTM_KC; e += 256) {       // dG_prev[b][kc + k]: k-contiguous rows
+        const int k = e % LSTM_KC, r = e / LSTM_KC;
+        float va = 0.f;
+        if (kc + k < K && b0 + r < a.B) va = a.xproj[((long)(b0 + r) * T + tprev) * ld4 + d * 4 * H + kc + k];
+        sA[k * LSTM_P + r] = va;
+      }
+      for (int e = tid; e < 32 * LSTM_KC; e += 256) {       // W_hh[kc + k][u0 + n]: n-contiguous rows
+        const int n = e & 31, k = e >> 5;
+        float vb = 0.f;
+        if (kc + k < K && u0 + n < H) vb = W[(long)(kc + k) * H + u0 + n];
+        sB[k * LSTM_P + n] = vb;
+      }
+      __syncthreads();
+      lstm_mma_chunk(acc, sA, sB, wave, l31, half);
+      __syncthreads();
+    }
+    lstm_store_partial(acc, red, wave, l31, half);
+    __syncthreads();
+  }
+  // 32 sequences x 32 units per workgroup, 4 pairs per thread, unit fastest
+  const int u = tid & 31;
+  const int j = u0 + u;
+  if (j >= H) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bl = (tid >> 5) + 8 * i;
+    const int b = b0 + bl;
+    if (b >= a.B) continue;
+    const long row = (long)b * T + t;
+    const int len = a.lengths[b];
+    const bool active = t < len;
+    float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
+    if (active) {
+      float dh = a.dout[row * ld1 + d * H + j];
+      if (a.step > 0)
+        dh += (red[(0 * 32 + bl) * LSTM_P + u] + red[(1 * 32 + bl) * LSTM_P + u]) +
+              (red[(2 * 32 + bl) * LSTM_P + u] + red[(3 * 32 + bl) * LSTM_P + u]);
+      const float ig = a.gates[row * ld4 + d * 4 * H + 0 * H + j], fg = a.gates[row * ld4 + d * 4 * H + 1 * H + j];
+      const float gg = a.gates[row * ld4 + d * 4 * H + 2 * H + j], og = a.gates[row * ld4 + d * 4 * H + 3 * H + j];
+      const float c = a.cst[row * ld1 + d * H + j];
+      float cp = 0.f;                                        // cell state entering this frame
+      if (d == 0) { if (t > 0) cp = a.cst[(row - 1) * ld1 + d * H + j]; }
+      else        { if (t + 1 < len) cp = a.cst[(row + 1) * ld1 + d * H + j]; }
+      const float tc = tanhf(c);
+      const float dc = a.dc_state[((long)d * a.Bpad + b) * H + j] + dh * og * (1.f - tc * tc);
+      dgo = dh * tc * (og * (1.f - og));
+      dgi = dc * gg * (ig * (1.f - ig));
+      dgf = dc * cp * (fg * (1.f - fg));
+      dgg = dc * ig * (1.f - gg * gg);
+      dcn = dc * fg;
+    }
+    a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
+    a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
+    a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
+    a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
+    a.dc_state[((long)d * a.Bpad + b) * H + j] = dcn;
+  }
+}
+
+// h_shift[row][j] = out[b][t -/+ 1][d*H + j] (the h that entered frame t in direction d), 0 at the start
+__global__ void lstm_shift_kernel(const float* __restrict__ out, int ld1, int d, int H, int B, int T,
+                                  const int* __restrict__ lengths, float* __restrict__ hs) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * T * H) return;
+  const int j = (int)(e % H);
+  const long row = e / H;
+  const int t = (int)(row % T), b = (int)(row / T);
+  float v = 0.f;
+  if (d == 0) { if (t > 0) v = out[(row - 1) * ld1 + j]; }
+  else        { if (t + 1 < lengths[b]) v = out[(row + 1) * ld1 + H + j]; }
+  hs[row * H + j] = v;
+}
+
+}  // namespace gt

@@ -130,10 +130,25 @@ class StepEngine(object):
         check(lib.gt_set_loss_normalizer(self._h, float(tv)))
 
     # ---- step functions -------------------------------------------------------------------
-    def apply_generator(self, model_g, x, R):
+    def set_lengths(self, lengths, B, T):
+        """`lengths` as the reference passes them (list of ints / 0-dim tensors, LongTensor, numpy)."""
+        if lengths is None:
+            vals = [T] * B
+        elif isinstance(lengths, torch.Tensor):
+            vals = [int(v) for v in lengths.detach().cpu().view(-1).tolist()]
+        else:
+            vals = [int(v) for v in lengths]
+        if len(vals) != B:
+            raise RuntimeError("lengths has %d entries for a batch of %d sequences" % (len(vals), B))
+        arr = (C.c_int64 * B)(*vals)
+        check(lib.gt_set_lengths(self._h, arr, B))
+
+    def apply_generator(self, model_g, x, R, lengths=None):
         x = _check_frames(x, "x", model_g.in_dim)
         B, T, _ = x.shape
         self.bind_model(L.ROLE_G, model_g, with_grads=True)
+        if getattr(model_g, "needs_lengths", False):
+            self.set_lengths(lengths, B, T)
         static_w = model_g.static_dim if model_g.include_parameter_generation() else self.static_dim
         y_hat = torch.empty(B, T, model_g.out_dim, device=x.device, dtype=torch.float32)
         y_hat_static = torch.empty(B, T, static_w, device=x.device, dtype=torch.float32)
@@ -270,13 +285,15 @@ class StepEngine(object):
     def flush_generator_grads(self):
         check(lib.gt_flush_generator_grads(self._h, L.current_stream()))
 
-    def model_forward(self, model, x, R=None):
+    def model_forward(self, model, x, R=None, lengths=None):
         squeeze = x.dim() == 2
         if squeeze:
             x = x.unsqueeze(0)
         x = _check_frames(x, "x", model.in_dim)
         B, T, _ = x.shape
         self.bind_model(L.ROLE_G, model, with_grads=False)
+        if getattr(model, "needs_lengths", False):
+            self.set_lengths(lengths, B, T)
         out = torch.empty(B, T, model.out_dim, device=x.device, dtype=torch.float32)
         out2 = None
         if model.include_parameter_generation():
@@ -352,7 +369,7 @@ class HipStepBackend(object):
         return self.engine.scalar_sums(which)
 
     def apply_generator(self, batch):
-        self._out = self.engine.apply_generator(self.mg, batch.get("g_in", batch["x"]), batch.get("R"))
+        self._out = self.engine.apply_generator(self.mg, batch.get("g_in", batch["x"]), batch.get("R"), batch.get("lengths"))
         return self._out
 
     def update_discriminator_begin(self, batch, phase):

@@ -35,8 +35,38 @@ class _LinearParams(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
         self.bias = nn.Parameter(torch.empty(out_dim))
 
+    def init_bound(self):
+        return 1.0 / math.sqrt(self.in_features)     # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in))
+
     def extra_repr(self):
         return "in_features=%d, out_features=%d" % (self.in_features, self.out_features)
+
+
+class _LSTMParams(nn.Module):
+    """Parameters of an ``nn.LSTM(batch_first=True)`` in torch's registration order and naming
+    (``weight_ih_l{k}[_reverse]``, ``weight_hh_l{k}..``, ``bias_ih_l{k}..``, ``bias_hh_l{k}..``;
+    gate order i, f, g, o); never called."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+        super(_LSTMParams, self).__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.bidirectional = bool(bidirectional)
+        dirs = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            n_in = input_size if layer == 0 else hidden_size * dirs
+            for d in range(dirs):
+                sfx = "_l%d%s" % (layer, "_reverse" if d else "")
+                self.register_parameter("weight_ih" + sfx, nn.Parameter(torch.empty(4 * hidden_size, n_in)))
+                self.register_parameter("weight_hh" + sfx, nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
+                self.register_parameter("bias_ih" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
+                self.register_parameter("bias_hh" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
+
+    def init_bound(self):
+        return 1.0 / math.sqrt(self.hidden_size)      # nn.LSTM.reset_parameters
+
+    def extra_repr(self):
+        return "%d, %d, num_layers=%d, batch_first=True, bidirectional=%s" % (
+            self.input_size, self.hidden_size, self.num_layers, self.bidirectional)
 
 
 class _FlatNetwork(AbstractModel, nn.Module):
@@ -54,18 +84,17 @@ class _FlatNetwork(AbstractModel, nn.Module):
         self._bound_engines = {}     # id(engine) -> (weakref(engine), role): who must hear zero_grad()
         self._version = 0            # bumped whenever buffers are re-homed (engines re-bind)
 
-    def _linears(self):
-        return [m for m in self.modules() if isinstance(m, _LinearParams)]
+    def _holders(self):
+        return [m for m in self.modules() if isinstance(m, (_LinearParams, _LSTMParams))]
 
     def _repoint(self, init=False):
         off = 0
-        for lin in self._linears():
-            for name in ("weight", "bias"):
-                p = getattr(lin, name)
+        for holder in self._holders():
+            for name, p in holder._parameters.items():     # registration order == state_dict order
                 n = p.numel()
                 view = self._flat[off:off + n].view(p.shape)
                 if init:
-                    k = 1.0 / math.sqrt(lin.in_features)   # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in))
+                    k = holder.init_bound()
                     view.uniform_(-k, k)
                 p.data = view
                 p._gt_owner = weakref.ref(self)
@@ -113,6 +142,7 @@ class _FlatNetwork(AbstractModel, nn.Module):
         d.static_dim = getattr(self, "static_dim", 0)
         d.dropout = float(self.dropout_p)
         d.last_sigmoid = int(bool(getattr(self, "last_sigmoid", False)))
+        d.bidirectional = int(getattr(self, "num_direction", 1) == 2)
         if not self._flat.is_cuda:
             raise RuntimeError("gantts_amd: model is on %s -- call .cuda() first (the HIP engine has no CPU path)"
                                % self._flat.device)
@@ -168,3 +198,36 @@ class In2OutHighwayNet(_FlatNetwork):
 
     def forward(self, x, R, lengths=None):
         return self._own_engine().model_forward(self, x, R)
+
+
+class LSTMRNN(_FlatNetwork):
+    """``pack_padded_sequence -> nn.LSTM(in, H, num_hidden, batch_first, bidirectional, dropout) ->
+    pad_packed_sequence -> hidden2out -> optional sigmoid`` (reference gantts/models.py:193-213).
+    ``forward(sequence, lengths)``: a sequence is active at frame t iff t < length; outputs beyond a
+    length are zero before hidden2out, the reverse direction starts at each sequence's last valid
+    frame.  Unlike pack_padded_sequence the batch does not have to be sorted by length."""
+    ARCH = L.ARCH_LSTM
+    RNN_ATTR = "lstm"
+    needs_lengths = True
+
+    def __init__(self, in_dim=118, out_dim=118, num_hidden=2, hidden_dim=256,
+                 bidirectional=False, dropout=0, last_sigmoid=False):
+        super(LSTMRNN, self).__init__()
+        self.in_dim, self.out_dim, self.num_hidden, self.hidden_dim = in_dim, out_dim, num_hidden, hidden_dim
+        self.num_direction = 2 if bidirectional else 1
+        self.dropout_p, self.last_sigmoid = dropout, last_sigmoid
+        setattr(self, self.RNN_ATTR, _LSTMParams(in_dim, hidden_dim, num_hidden, bidirectional))
+        self.hidden2out = _LinearParams(out_dim, hidden_dim * self.num_direction)
+        self._finish_init()
+
+    def set_dropout_masks(self, pass_index, masks):
+        raise NotImplementedError("dropout mask injection is not available for recurrent generators")
+
+    def forward(self, sequence, lengths):
+        return self._own_engine().model_forward(self, sequence, lengths=lengths)
+
+
+class GRURNN(LSTMRNN):
+    """Named GRU in the reference but built on ``nn.LSTM`` under the attribute name ``gru``
+    (gantts/models.py:170-190); state_dict keys are ``gru.weight_ih_l0`` ..."""
+    RNN_ATTR = "gru"

@@ -43,7 +43,7 @@ def apply_generator(model_g, x, R, lengths):
     """Returns ``(y_hat, y_hat_static)``; for generic models y_hat_static = multi_stream_mlpg(y_hat)."""
     if not model_g.include_parameter_generation():
         assert hp.has_dynamic_features is not None
-    return engine_for(hp, model_g).apply_generator(model_g, x, R)
+    return engine_for(hp, model_g).apply_generator(model_g, x, R, lengths)
 
 
 def _engine_of(t, model_g=None):

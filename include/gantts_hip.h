@@ -38,6 +38,7 @@ extern "C" {
 
 #define GT_ARCH_MLP 0         /* gantts/models.py:121-141 */
 #define GT_ARCH_IN2OUT 1      /* gantts/models.py:21-69  (In2OutHighwayNet) */
+#define GT_ARCH_LSTM 2        /* gantts/models.py:170-213 (LSTMRNN, GRURNN: nn.LSTM + hidden2out) */
 
 #define GT_OPT_ADAGRAD 0      /* torch.optim.Adagrad, train.py:796-799 with hparams.py:48-52,223-227 */
 #define GT_OPT_ADAM 1         /* torch.optim.Adam,    hparams.py:125-130 */
@@ -61,13 +62,18 @@ typedef struct {
 /* One network.  `params`/`grads` are flat float32 device buffers laid out in state_dict order:
  *   MLP:    layers.0.weight (hidden x in) | layers.0.bias | ... | last_linear.weight | last_linear.bias
  *   IN2OUT: T.weight (sd x sd) | T.bias | H.0.weight | H.0.bias | ... | last_linear.weight | last_linear.bias
- * weights are (out, in) row-major exactly as nn.Linear stores them. */
+ *   LSTM:   for layer k, for direction d (forward, then reverse when bidirectional):
+ *             weight_ih (4H x in_k) | weight_hh (4H x H) | bias_ih (4H) | bias_hh (4H)     (gate order i,f,g,o)
+ *           then hidden2out.weight (out x H*dirs) | hidden2out.bias        (torch.nn.LSTM parameter order)
+ * weights are (out, in) row-major exactly as nn.Linear / nn.LSTM store them. */
 typedef struct {
   int32_t arch;
   int32_t in_dim, out_dim, num_hidden, hidden_dim;
   int32_t static_dim;        /* IN2OUT only */
   float dropout;
   int32_t last_sigmoid;
+  int32_t bidirectional;     /* LSTM only */
+  int32_t reserved_;
   float* params;
   float* grads;
   int64_t n_params;
@@ -115,6 +121,12 @@ int gt_set_seed(gt_engine* e, uint64_t seed);
  * passes: G: 0 = apply_generator.  D: 0 = real rows of the D step, 1 = generated rows of the
  * D step, 2 = generated rows of the G step (the order nn.Dropout is consumed in train.py:261-307). */
 int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, const float* mask);
+
+/* Sequence lengths of the NEXT batch (host int64 array, as the `lengths` list the reference passes to
+ * model(x, lengths=lengths), train.py:344; models.py:204-210 pack_padded_sequence).  Needed by the
+ * recurrent generators only; MLP ignores lengths like the reference.  Unlike pack_padded_sequence the
+ * batch need not be sorted. */
+int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B);
 
 /* ---- hot path -------------------------------------------------------------------------- */
 /* optimizer.zero_grad()                                         (train.py:538-539) */

@@ -8,6 +8,9 @@ What it restates (reference file:line, relative to the upstream tree):
 
 * ``MLP``                       gantts/models.py:121-141
 * ``In2OutHighwayNet``          gantts/models.py:21-69
+* ``LSTMRNN`` / ``GRURNN``      gantts/models.py:170-213 (nn.LSTM over packed sequences, restated
+                                as an explicit masked time loop; pinned by the golden case
+                                ``acoustic_lstm`` generated from the real reference)
 * ``sequence_mask`` / masked MSE gantts/seqloss.py:9-43
 * stream index arithmetic       gantts/multistream.py:33-123
 * ``apply_generator``           train.py:336-355
@@ -277,6 +280,73 @@ class OracleIn2OutHighwayNet(object):
         h = F.linear(h, self.params[-2], self.params[-1])
         Gx = unit_variance_mlpg(R, h)
         return h, x_static + Tx * Gx
+
+    __call__ = forward
+
+
+class OracleLSTMRNN(object):
+    """gantts/models.py:193-213 (LSTMRNN; GRURNN :170-190 is the same network under the attribute
+    name ``gru``).  pack_padded_sequence -> nn.LSTM(batch_first, bidirectional, dropout) ->
+    pad_packed_sequence -> hidden2out -> optional sigmoid, restated with an explicit time loop:
+    a sequence is active at frame t iff t < length; the reverse direction therefore starts at each
+    sequence's own last valid frame with zero state; outputs beyond the length are zero (so
+    hidden2out yields its bias there).  Gate order i, f, g, o; keys lstm.weight_ih_l{k}[_reverse] ..."""
+
+    def __init__(self, in_dim=118, out_dim=118, num_hidden=2, hidden_dim=256, bidirectional=False,
+                 dropout=0, last_sigmoid=False, seed=0, prefix="lstm"):
+        gen = torch.Generator().manual_seed(seed)
+        self.H, self.L, self.dirs = hidden_dim, num_hidden, 2 if bidirectional else 1
+        self.p, self.last_sigmoid = float(dropout), last_sigmoid
+        k = 1.0 / math.sqrt(hidden_dim)
+        self.names, self.params = [], []
+        for l in range(num_hidden):
+            n_in = in_dim if l == 0 else hidden_dim * self.dirs
+            for d in range(self.dirs):
+                sfx = "_l%d%s" % (l, "_reverse" if d else "")
+                for nm, shape in (("weight_ih", (4 * hidden_dim, n_in)), ("weight_hh", (4 * hidden_dim, hidden_dim)),
+                                  ("bias_ih", (4 * hidden_dim,)), ("bias_hh", (4 * hidden_dim,))):
+                    self.names.append("%s.%s%s" % (prefix, nm, sfx))
+                    self.params.append((torch.rand(*shape, generator=gen) * 2 - 1) * k)
+        W, b = linear_init(out_dim, hidden_dim * self.dirs, gen)
+        self.names += ["hidden2out.weight", "hidden2out.bias"]
+        self.params += [W, b]
+        for p in self.params:
+            p.requires_grad_(True)
+        self.training = True
+
+    def include_parameter_generation(self):
+        return False
+
+    state_dict = OracleMLP.state_dict
+    load_state_dict = OracleMLP.load_state_dict
+
+    def forward(self, x, lengths=None, drop=None):
+        B, T, _ = x.shape
+        lens = torch.as_tensor([int(v) for v in lengths]) if lengths is not None else torch.full((B,), T)
+        H, idx = self.H, 0
+        inp = x
+        for l in range(self.L):
+            outs = []
+            for d in range(self.dirs):
+                Wih, Whh, bih, bhh = self.params[idx:idx + 4]
+                idx += 4
+                xp = F.linear(inp, Wih, bih + bhh)
+                h, c = x.new_zeros(B, H), x.new_zeros(B, H)
+                seq = [None] * T
+                for t in (range(T - 1, -1, -1) if d else range(T)):
+                    act = (t < lens).to(x.dtype).unsqueeze(1)
+                    g = xp[:, t] + F.linear(h, Whh)
+                    i, f, gg, o = g[:, :H].sigmoid(), g[:, H:2 * H].sigmoid(), g[:, 2 * H:3 * H].tanh(), g[:, 3 * H:].sigmoid()
+                    c = act * (f * c + i * gg)
+                    h = act * (o * c.tanh())
+                    seq[t] = h
+                outs.append(torch.stack(seq, 1))
+            inp = torch.cat(outs, -1)
+            if self.training and self.p > 0 and l + 1 < self.L:
+                drop = drop or _DropoutSource()
+                inp = inp * drop.next(inp, self.p) / (1.0 - self.p)
+        out = F.linear(inp, self.params[-2], self.params[-1])
+        return torch.sigmoid(out) if self.last_sigmoid else out
 
     __call__ = forward
 

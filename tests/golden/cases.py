@@ -82,6 +82,32 @@ CASES = {
         opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
         windows=1, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # cfg3 family at reduced size: BiLSTM generator (packed variable lengths) + conditioned MLP D
+    "acoustic_lstm": dict(
+        hp="tts_acoustic", B=4, T=21, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="LSTMRNN", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=16,
+               bidirectional=True, dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # unidirectional single-layer variant under the GRURNN name (an nn.LSTM as attribute `gru`)
+    "acoustic_grurnn_uni": dict(
+        hp="tts_acoustic", B=3, T=17, din=20, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="GRURNN", in_dim=20, out_dim=187, num_hidden=1, hidden_dim=24,
+               bidirectional=False, dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=78, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     # curriculum stages (train_gan.sh): D warm-up only / G only with w_d=0
     "acoustic_d_warmup": dict(
         hp="tts_acoustic", B=3, T=20, din=30, dout=187,
@@ -130,13 +156,23 @@ def param_shapes(spec):
                     ("H.%d.bias" % i, (spec["hidden_dim"],))]
         out += [("last_linear.weight", (spec["out_dim"], spec["hidden_dim"])),
                 ("last_linear.bias", (spec["out_dim"],))]
+    elif kind in ("LSTMRNN", "GRURNN"):
+        prefix = "lstm" if kind == "LSTMRNN" else "gru"
+        H, dirs = spec["hidden_dim"], 2 if spec["bidirectional"] else 1
+        for l in range(spec["num_hidden"]):
+            n_in = spec["in_dim"] if l == 0 else H * dirs
+            for d in range(dirs):
+                sfx = "_l%d%s" % (l, "_reverse" if d else "")
+                out += [("%s.weight_ih%s" % (prefix, sfx), (4 * H, n_in)), ("%s.weight_hh%s" % (prefix, sfx), (4 * H, H)),
+                        ("%s.bias_ih%s" % (prefix, sfx), (4 * H,)), ("%s.bias_hh%s" % (prefix, sfx), (4 * H,))]
+        out += [("hidden2out.weight", (spec["out_dim"], H * dirs)), ("hidden2out.bias", (spec["out_dim"],))]
     else:
         raise ValueError(kind)
     return out
 
 
 def make_weights(spec, seed):
-    """U(+-1/sqrt(fan_in)) like nn.Linear's default init, from numpy RandomState."""
+    """U(+-1/sqrt(fan_in)) like nn.Linear's default init (U(+-1/sqrt(H)) for LSTM tensors), from numpy RandomState."""
     rs = np.random.RandomState(seed)
     sd = {}
     shapes = param_shapes(spec)
@@ -144,6 +180,8 @@ def make_weights(spec, seed):
     for name, shape in shapes:
         if name.endswith("weight"):
             fan_in = shape[1]
+        if ".weight_ih" in name or ".weight_hh" in name or ".bias_ih" in name or ".bias_hh" in name:
+            fan_in = spec["hidden_dim"]
         k = 1.0 / math.sqrt(fan_in)
         sd[name] = ((rs.rand(*shape) * 2 - 1) * k).astype(np.float32)
     return sd

@@ -8,7 +8,10 @@ import gantts_oracle as O
 
 def build_oracle_model(spec, seed):
     kw = {k: v for k, v in spec.items() if k != "kind"}
-    cls = {"MLP": O.OracleMLP, "In2OutHighwayNet": O.OracleIn2OutHighwayNet}[spec["kind"]]
+    cls = {"MLP": O.OracleMLP, "In2OutHighwayNet": O.OracleIn2OutHighwayNet,
+           "LSTMRNN": O.OracleLSTMRNN, "GRURNN": O.OracleLSTMRNN}[spec["kind"]]
+    if spec["kind"] == "GRURNN":
+        kw["prefix"] = "gru"
     m = cls(**kw)
     m.load_state_dict(C.make_weights(spec, seed))
     return m

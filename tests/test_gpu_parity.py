@@ -407,3 +407,33 @@ def test_full_size_cfg2_step_vs_oracle_and_determinism():
         assert bad.mean() < 1e-3, "too many mismatching parameters: %g" % bad.mean()
         if bad.any():
             assert np.abs(gref[bad]).max() < 1e-3 * np.abs(gref).max(), "mismatch on a well-conditioned gradient"
+
+
+@pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])
+def test_lstmrnn_forward_matches_oracle_unsorted_lengths(B, T, din, H, L, bi):
+    """LSTMRNN.forward(sequence, lengths) vs the oracle's masked time loop (== nn.LSTM over packed
+    sequences, pinned by the golden case); lengths deliberately NOT sorted, B > 32 covers 2 batch tiles."""
+    from gantts_amd import models
+    spec = dict(kind="LSTMRNN", in_dim=din, out_dim=11, num_hidden=L, hidden_dim=H, bidirectional=bi, dropout=0.0,
+                last_sigmoid=False)
+    sd = C.make_weights(spec, B + T)
+    m = models.LSTMRNN(**{k: v for k, v in spec.items() if k != "kind"})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda().eval()
+    o = O.OracleLSTMRNN(**{k: v for k, v in spec.items() if k != "kind"})
+    o.load_state_dict(sd)
+    o.training = False
+    rs = np.random.RandomState(B)
+    x = torch.from_numpy(rs.randn(B, T, din).astype(np.float32))
+    lengths = rs.randint(1, T + 1, size=B)
+    lengths[rs.randint(B)] = T
+    got = m(x.cuda(), list(lengths)).cpu().numpy()
+    ref = o(x, list(lengths)).detach().numpy()
+    _close(got, ref, msg="LSTMRNN forward")
+    # frames beyond each length see zero LSTM output -> exactly the hidden2out bias
+    b = int(np.argmin(lengths))
+    if lengths[b] < T:
+        np.testing.assert_allclose(got[b, lengths[b]:], np.broadcast_to(sd["hidden2out.bias"], got[b, lengths[b]:].shape),
+                                   rtol=0, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        m(x.cuda(), list(lengths[:-1]))
