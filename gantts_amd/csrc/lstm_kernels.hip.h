@@ -50,6 +50,50 @@ struct LstmStepArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Stage a 32-row, k-contiguous panel (row r at src + roff(r), valid iff rvalid(r)) transposed into
+// LDS [k][row] (pitch 33): branch-free (clamped address + select), 8 loads in flight per lane,
+// 16 B per lane when `vec` (pitch and base 16-byte aligned), else 4 B.
+template <typename RowOff, typename RowOk>
+__device__ __forceinline__ void lstm_stage_kc(float* sdst, const float* __restrict__ src, int kc, int kmax, bool vec,
+                                              RowOff roff, RowOk rvalid) {
+  const int tid = threadIdx.x;
+  if (vec) {
+    constexpr int PER = 32 * LSTM_KC / 4 / 256;            // float4 per thread = 8
+    f32x4 v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid + q * 256;
+      const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+      const int kg = min(kc + k4, kmax - 4);
+      v[q] = *reinterpret_cast<const f32x4*>(src + roff(r) + kg);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid + q * 256;
+      const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+      const bool ok = rvalid(r) && kc + k4 < kmax;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sdst[(k4 + c) * LSTM_P + r] = ok ? v[q][c] : 0.f;
+    }
+  } else {
+    for (int e0 = tid; e0 < 32 * LSTM_KC; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * 256;
+        const int k = e % LSTM_KC, r = e / LSTM_KC;
+        v[q] = src[roff(r) + min(kc + k, kmax - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * 256;
+        const int k = e % LSTM_KC, r = e / LSTM_KC;
+        sdst[k * LSTM_P + r] = (rvalid(r) && kc + k < kmax) ? v[q] : 0.f;
+      }
+    }
+  }
+}
+
 // acc += sA^T-fragment x sB-fragment over this wave's quarter of the staged chunk
 __device__ __forceinline__ void lstm_mma_chunk(f32x16& acc, const float* sA, const float* sB, int wave, int l31, int half) {
   const int k0 = wave * (LSTM_KC / 4);
@@ -85,29 +129,31 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a
   const float* W = a.Whh[d];
   const float* hp = a.h_prev + ((long)d * a.Bpad + b0) * H;
 
+  const bool vec = (H % 4) == 0;     // rows of h / W_hh are then 16-byte aligned
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int kc = 0; kc < H; kc += LSTM_KC) {
-    // stage h_{t-1}[b][kc..] and W_hh[gate*H + u0+u][kc..], zero beyond H / B / unit range
-    for (int e = tid; e < 32 * LSTM_KC; e += 256) {
-      const int k = e % LSTM_KC, r = e / LSTM_KC;
-      const int kg = kc + k;
-      float va = 0.f, vb = 0.f;
-      if (kg < H) {
-        if (b0 + r < a.B) va = hp[(long)r * H + kg];
-        const int gate = r >> 3, u = u0 + (r & 7);
-        if (u < H) vb = W[((long)gate * H + u) * H + kg];
-      }
-      sA[k * LSTM_P + r] = va;
-      sB[k * LSTM_P + r] = vb;
-    }
+    // stage h_{t-1}[b][kc..] and W_hh[gate*H + u0+u][kc..], zero beyond H / unit range
+    // (the state arrays are padded to 32 sequences and zero there, so every row is readable)
+#ifndef GT_ABLATE_LSTM_NO_STAGE
+    lstm_stage_kc(sA, hp, kc, H, vec, [&](int r) { return (long)r * H; }, [&](int r) { return true; });
+    lstm_stage_kc(sB, W, kc, H, vec,
+                  [&](int r) { return ((long)(r >> 3) * H + min(u0 + (r & 7), H - 1)) * H; },
+                  [&](int r) { return u0 + (r & 7) < H; });
+#endif
     __syncthreads();
+#ifndef GT_ABLATE_LSTM_NO_MMA
     lstm_mma_chunk(acc, sA, sB, wave, l31, half);
+#endif
     __syncthreads();
   }
   lstm_store_partial(acc, red, wave, l31, half);
   __syncthreads();
+#ifdef GT_ABLATE_LSTM_NO_GATES
+  if (tid == 0) a.out[blockIdx.x] = red[3];
+  return;
+#endif
   // one (sequence, unit) pair per thread: u fastest (8 consecutive floats per row)
   const int u = tid & 7, bl = tid >> 3;
   const int j = u0 + u, b = b0 + bl;
@@ -159,26 +205,67 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmStepArgs a
   const float* W = a.Whh[d];
   const int K = 4 * H;
 
+  const bool vec = (H % 4) == 0;
   if (a.step > 0) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kc = 0; kc < K; kc += LSTM_KC) {
-      for (int e = tid; e < 32 * LSTM_KC; e += 256) {       // dG_prev[b][kc + k]: k-contiguous rows
-        const int k = e % LSTM_KC, r = e / LSTM_KC;
-        float va = 0.f;
-        if (kc + k < K && b0 + r < a.B) va = a.xproj[((long)(b0 + r) * T + tprev) * ld4 + d * 4 * H + kc + k];
-        sA[k * LSTM_P + r] = va;
+    const float* dGp = a.xproj + (long)tprev * ld4 + d * 4 * H;       // dG of the previous launch's frame
+    auto arow = [&](int r) { return (long)min(b0 + r, a.B - 1) * T * ld4; };
+    if (vec) {
+      // software pipeline over the K chunks: the loads of chunk c+1 (A: dG_prev rows, 16 B/lane;
+      // B: W_hh rows of 32 units, 4 B/lane) are in flight while chunk c runs on the matrix pipe
+      f32x4 va[8];
+      float vb[32];
+      auto load_ab = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = tid + q * 256;
+          const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+          va[q] = *reinterpret_cast<const f32x4*>(dGp + arow(r) + min(kc + k4, K - 4));
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int e = tid + q * 256;
+          const int n = e & 31, k = e >> 5;
+          vb[q] = W[(long)min(kc + k, K - 1) * H + min(u0 + n, H - 1)];
+        }
+      };
+      auto store_ab = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = tid + q * 256;
+          const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+          const bool ok = b0 + r < a.B && kc + k4 < K;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sA[(k4 + c) * LSTM_P + r] = ok ? va[q][c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int e = tid + q * 256;
+          const int n = e & 31, k = e >> 5;
+          sB[k * LSTM_P + n] = (kc + k < K && u0 + n < H) ? vb[q] : 0.f;
+        }
+      };
+      load_ab(0);
+      for (int kc = 0; kc < K; kc += LSTM_KC) {
+        store_ab(kc);
+        __syncthreads();
+        if (kc + LSTM_KC < K) load_ab(kc + LSTM_KC);
+        lstm_mma_chunk(acc, sA, sB, wave, l31, half);
+        __syncthreads();
       }
-      for (int e = tid; e < 32 * LSTM_KC; e += 256) {       // W_hh[kc + k][u0 + n]: n-contiguous rows
-        const int n = e & 31, k = e >> 5;
-        float vb = 0.f;
-        if (kc + k < K && u0 + n < H) vb = W[(long)(kc + k) * H + u0 + n];
-        sB[k * LSTM_P + n] = vb;
+    } else {
+      for (int kc = 0; kc < K; kc += LSTM_KC) {
+        lstm_stage_kc(sA, dGp, kc, K, false, arow, [&](int r) { return b0 + r < a.B; });
+        for (int e = tid; e < 32 * LSTM_KC; e += 256) {
+          const int n = e & 31, k = e >> 5;
+          sB[k * LSTM_P + n] = (kc + k < K && u0 + n < H) ? W[(long)(kc + k) * H + u0 + n] : 0.f;
+        }
+        __syncthreads();
+        lstm_mma_chunk(acc, sA, sB, wave, l31, half);
+        __syncthreads();
       }
-      __syncthreads();
-      lstm_mma_chunk(acc, sA, sB, wave, l31, half);
-      __syncthreads();
     }
     lstm_store_partial(acc, red, wave, l31, half);
     __syncthreads();
