@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
-ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM = 0, 1, 2
+ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU = 0, 1, 2, 3
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8
 
@@ -32,7 +32,8 @@ class ModelDesc(C.Structure):
     _fields_ = [("arch", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32),
                 ("num_hidden", C.c_int32), ("hidden_dim", C.c_int32), ("static_dim", C.c_int32),
                 ("dropout", C.c_float), ("last_sigmoid", C.c_int32),
-                ("bidirectional", C.c_int32), ("reserved_", C.c_int32),
+                ("bidirectional", C.c_int32), ("use_relu", C.c_int32),
+                ("rnn_dropout", C.c_float), ("reserved_", C.c_int32),
                 ("params", C.c_void_p), ("grads", C.c_void_p), ("n_params", C.c_int64)]
 
 

@@ -24,6 +24,7 @@
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
 #include "lstm_kernels.hip.h"
+#include "sru_kernels.hip.h"
 
 using namespace gt;
 
@@ -241,6 +242,7 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
 struct Lin { float *W, *b, *dW, *db; int in, out; };
 struct LstmDirP { float *Wih, *Whh, *bih, *bhh, *dWih, *dWhh, *dbih, *dbhh; };
 struct LstmLayerP { int in; LstmDirP d[2]; };
+struct SruLayerP { int in, k; float *W, *b, *dW, *db; };
 
 struct Net {
   bool bound = false;
@@ -248,6 +250,7 @@ struct Net {
   std::vector<Lin> hidden;
   Lin last, gate;
   std::vector<LstmLayerP> lstm;   // GT_ARCH_LSTM; `last` is hidden2out
+  std::vector<SruLayerP> sru;     // GT_ARCH_SRU;  `last` is hidden2out
   bool training = true;
   bool grads_dirty = false;      // false after zero_grad: next backward overwrites instead of accumulating
   bool has_opt = false;
@@ -292,6 +295,8 @@ struct gt_engine {
   // recurrent generator workspace (per layer) and the lengths of the current batch
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out;
   Scratch l_state, l_dout, l_hshift, d_lengths;
+  std::vector<Scratch> s_u, s_h, s_c, s_xdrop;     // SRU per-layer stashes
+  Scratch s_du, s_dx, s_dbias;
   std::vector<int> h_lengths;
   StepScalars* sc() { return scal.as<StepScalars>(); }
   StepResults* res() { return (StepResults*)((char*)scal.p + 256); }
@@ -361,6 +366,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   for (auto& s : e->d_act) s.release();
   for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out}) for (auto& s : *v) s.release();
   e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->d_lengths.release();
+  for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop}) for (auto& s : *v) s.release();
+  e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.band};
   for (auto* s : all) s->release();
@@ -380,6 +387,14 @@ static long expected_params(const gt_model_desc& d) {
     }
     return n + (long)d.out_dim * H * dirs + d.out_dim;
   }
+  if (d.arch == GT_ARCH_SRU) {
+    const int ncols = d.hidden_dim * (d.bidirectional ? 2 : 1);
+    for (int l = 0; l < d.num_hidden; ++l) {
+      const int in = l == 0 ? d.in_dim : ncols;
+      n += (long)in * ncols * (in == ncols ? 3 : 4) + 2L * ncols;
+    }
+    return n + (long)d.out_dim * ncols + d.out_dim;
+  }
   if (d.arch == GT_ARCH_IN2OUT) n += (long)d.static_dim * d.static_dim + d.static_dim;
   int in = d.in_dim;
   for (int l = 0; l < d.num_hidden; ++l) { n += (long)d.hidden_dim * in + d.hidden_dim; in = d.hidden_dim; }
@@ -389,7 +404,7 @@ static long expected_params(const gt_model_desc& d) {
 
 extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) {
   if (!e || !desc || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
-  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT && desc->arch != GT_ARCH_LSTM)
+  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT && desc->arch != GT_ARCH_LSTM && desc->arch != GT_ARCH_SRU)
     return fail(GT_ERR_INVALID, "unsupported arch %d", desc->arch);
   if (desc->num_hidden < 1 || desc->num_hidden > 16) return fail(GT_ERR_INVALID, "num_hidden must be in [1,16]");
   if (desc->dropout < 0.f || desc->dropout >= 1.f) return fail(GT_ERR_INVALID, "dropout must be in [0,1)");
@@ -412,6 +427,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     return l;
   };
   n.lstm.clear();
+  n.sru.clear();
   if (desc->arch == GT_ARCH_LSTM) {
     const int H = desc->hidden_dim, dirs = desc->bidirectional ? 2 : 1;
     auto adv = [&](float*& wp, float*& gp, long cnt) { wp = p; gp = g; p += cnt; if (g) g += cnt; };
@@ -430,6 +446,22 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     n.last = take(desc->out_dim, H * dirs);
     e->l_xproj.resize(desc->num_hidden); e->l_gates.resize(desc->num_hidden);
     e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden);
+  } else if (desc->arch == GT_ARCH_SRU) {
+    if (desc->rnn_dropout < 0.f || desc->rnn_dropout >= 1.f) return fail(GT_ERR_INVALID, "rnn_dropout must be in [0,1)");
+    const int ncols = desc->hidden_dim * (desc->bidirectional ? 2 : 1);
+    n.sru.clear();
+    for (int l = 0; l < desc->num_hidden; ++l) {
+      SruLayerP L;
+      L.in = l == 0 ? desc->in_dim : ncols;
+      L.k = L.in == ncols ? 3 : 4;
+      const long nw = (long)L.in * ncols * L.k;
+      L.W = p; L.dW = g; p += nw; if (g) g += nw;
+      L.b = p; L.db = g; p += 2 * ncols; if (g) g += 2 * ncols;
+      n.sru.push_back(L);
+    }
+    n.last = take(desc->out_dim, ncols);
+    e->s_u.resize(desc->num_hidden); e->s_h.resize(desc->num_hidden);
+    e->s_c.resize(desc->num_hidden); e->s_xdrop.resize(desc->num_hidden);
   } else {
     if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
     int in = desc->in_dim;
@@ -810,6 +842,137 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
   return GT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// recurrent generator (GT_ARCH_SRU)
+// ------------------------------------------------------------------------------------------
+static void sru_keys(gt_engine* e, int layer, int which, uint32_t* k0, uint32_t* k1) {
+  const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which);
+  *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
+  *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site;
+}
+static uint32_t drop_thresh(float p) {
+  const double th = (double)p * 4294967296.0;
+  return th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+}
+
+static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const float* in, int ld_in) {
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, ncols = H * dirs;
+  const SruLayerP& L = G.sru[l];
+  SruArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.k = L.k; a.act = G.d.use_relu ? SRU_RELU : SRU_TANH;
+  a.U = e->s_u[l].as<float>(); a.ldu = ncols * L.k;
+  a.x = in; a.ldx = ld_in;
+  a.bias = L.b;
+  a.h = e->s_h[l].as<float>(); a.c = e->s_c[l].as<float>();
+  if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {   // the last layer has dropout 0 (SRU.__init__)
+    a.use_mask = 1; a.keep_scale = 1.f / (1.f - G.d.dropout); a.thresh = drop_thresh(G.d.dropout);
+    sru_keys(e, l, 1, &a.key0, &a.key1);
+  }
+  return a;
+}
+
+static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = (long)B * T;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, ncols = H * dirs;
+  const float* in = x;
+  int ld_in = G.d.in_dim;
+  for (int l = 0; l < G.d.num_hidden; ++l) {
+    const SruLayerP& L = G.sru[l];
+    CHK(e->s_u[l].ensure((size_t)N * ncols * L.k * sizeof(float)));
+    CHK(e->s_h[l].ensure((size_t)N * ncols * sizeof(float)));
+    CHK(e->s_c[l].ensure((size_t)N * ncols * sizeof(float)));
+    const float* xin = in;
+    int ld_xin = ld_in;
+    if (G.training && G.d.rnn_dropout > 0.f) {      // variational input dropout, mask shared over time
+      CHK(e->s_xdrop[l].ensure((size_t)N * L.in * sizeof(float)));
+      uint32_t k0, k1;
+      sru_keys(e, l, 0, &k0, &k1);
+      hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, in, ld_in, e->s_xdrop[l].as<float>(),
+                         L.in, B, T, L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, 0,
+                         (const float*)nullptr, 0);
+      LAUNCH_CHECK();
+      xin = e->s_xdrop[l].as<float>();
+      ld_xin = L.in;
+    }
+    {  // U = xin W   (W is (n_in, ncols*k): n-contiguous rows -> NN orientation)
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = xin; g.lda = ld_xin; g.B = L.W; g.ldb = ncols * L.k; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
+      g.M = (int)N; g.N = ncols * L.k; g.K = L.in; g.act = ACT_NONE; g.drop = no_drop();
+      CHK(launch_gemm(GEMM_NN, g, 1, s));
+    }
+    SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
+    hipLaunchKernelGGL(sru_fwd_kernel, dim3(cdiv((long)B * ncols, 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    in = e->s_h[l].as<float>();
+    ld_in = ncols;
+  }
+  return linear_forward(in, ld_in, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in, G.last.out,
+                        G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+}
+
+static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, int T, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = (long)B * T;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, ncols = H * dirs, Do = G.d.out_dim, Lc = G.d.num_hidden;
+  const bool acc = G.grads_dirty;
+  int kmax = 3, inmax = ncols;
+  for (auto& L : G.sru) { kmax = std::max(kmax, L.k); inmax = std::max(inmax, L.in); }
+  CHK(e->l_dout.ensure((size_t)2 * N * std::max(ncols, inmax) * sizeof(float)));
+  CHK(e->s_du.ensure((size_t)N * ncols * kmax * sizeof(float)));
+  CHK(e->s_dx.ensure((size_t)N * ncols * sizeof(float)));
+  CHK(e->s_dbias.ensure((size_t)B * 2 * ncols * sizeof(float)));
+  float* dh = e->l_dout.as<float>();
+  float* dh_other = dh + (size_t)N * std::max(ncols, inmax);
+  CHK(linear_backward_weight(gy, Do, e->s_h[Lc - 1].as<float>(), ncols, N, Do, ncols, G.last.dW, G.last.db, acc, e->slabs, e->colp, s));
+  CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dh, ncols, N, Do, ncols, ACT_NONE, nullptr, 0, no_drop(), s));
+  for (int l = Lc - 1; l >= 0; --l) {
+    const SruLayerP& L = G.sru[l];
+    const float* in = l == 0 ? x : e->s_h[l - 1].as<float>();
+    const int ld_in = l == 0 ? G.d.in_dim : ncols;
+    const bool rdrop = G.training && G.d.rnn_dropout > 0.f;
+    SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
+    a.dh = dh; a.dU = e->s_du.as<float>();
+    // k == 3: the highway gradient goes straight to the layer input.  Without input dropout it is
+    // written into the next dh buffer and the GEMM below accumulates onto it.
+    float* dx_res = L.k == 3 ? (rdrop ? e->s_dx.as<float>() : dh_other) : nullptr;
+    a.dx = dx_res; a.lddx = ncols;
+    a.dbias_part = e->s_dbias.as<float>();
+    hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(2 * ncols, 64)), dim3(1024), 0, s, e->s_dbias.as<float>(), (long)2 * ncols, B,
+                       2 * ncols, L.db, acc ? 1 : 0);
+    LAUNCH_CHECK();
+    const float* xin = rdrop ? e->s_xdrop[l].as<float>() : in;
+    const int ld_xin = rdrop ? L.in : ld_in;
+    // dW = xin^T dU   (TN: A = xin is m-contiguous over n_in, B = dU)
+    CHK(linear_backward_weight(xin, ld_xin, e->s_du.as<float>(), ncols * L.k, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs,
+                               e->colp, s));
+    if (l > 0) {
+      // d in = (dU W^T) (.) mask_in + highway term     (NT: B[n = i][k = c] = W[i*ldw + c])
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = e->s_du.as<float>(); g.lda = ncols * L.k; g.B = L.W; g.ldb = ncols * L.k; g.C = dh_other; g.ldc = L.in;
+      g.M = (int)N; g.N = L.in; g.K = ncols * L.k; g.act = ACT_NONE; g.drop = no_drop();
+      g.accumulate = (L.k == 3 && !rdrop) ? 1 : 0;
+      CHK(launch_gemm(GEMM_NT, g, 1, s));
+      if (rdrop) {
+        uint32_t k0, k1;
+        sru_keys(e, l, 0, &k0, &k1);
+        hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, dh_other, L.in, dh_other, L.in, B, T,
+                           L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, L.k == 3 ? 1 : 0,
+                           (const float*)e->s_dx.as<float>(), ncols);
+        LAUNCH_CHECK();
+      }
+      std::swap(dh, dh_other);
+    }
+  }
+  return GT_OK;
+}
+
 static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
                              bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
   Net& G = e->net[GT_ROLE_G];
@@ -817,6 +980,8 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
   const int pass0[1] = {0};
   if (G.d.arch == GT_ARCH_LSTM) {
     CHK(lstm_forward(e, x, B, T, y_hat, s));
+  } else if (G.d.arch == GT_ARCH_SRU) {
+    CHK(sru_forward(e, x, B, T, y_hat, s));
   } else {
     CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
     const Lin& Lh = G.hidden.back();
@@ -1064,8 +1229,8 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
     LAUNCH_CHECK();
   }
-  if (G.d.arch == GT_ARCH_LSTM) {
-    CHK(lstm_backward(e, x, gy, B, T, s));
+  if (G.d.arch == GT_ARCH_LSTM || G.d.arch == GT_ARCH_SRU) {
+    CHK(G.d.arch == GT_ARCH_LSTM ? lstm_backward(e, x, gy, B, T, s) : sru_backward(e, x, gy, B, T, s));
     G.grads_dirty = true;
     return GT_OK;
   }
@@ -1223,10 +1388,10 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
     e->g_pass_valid = false;
     return generator_forward(e, x, R, B, T, out, out2, false, s, specs);
   }
-  if (n.d.arch == GT_ARCH_LSTM) {
+  if (n.d.arch == GT_ARCH_LSTM || n.d.arch == GT_ARCH_SRU) {
     if (role != GT_ROLE_G) return fail(GT_ERR_INVALID, "recurrent networks are supported in the generator slot only");
     e->g_pass_valid = false;
-    return lstm_forward(e, x, B, T, out, s);
+    return n.d.arch == GT_ARCH_LSTM ? lstm_forward(e, x, B, T, out, s) : sru_forward(e, x, B, T, out, s);
   }
   const int pass0[1] = {0};
   auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;

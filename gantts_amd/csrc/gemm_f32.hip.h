@@ -83,7 +83,7 @@ struct GemmArgs {
   const float* bias;         // NT: [N] or null
   int act;                   // Act
   const float* H; int ldh;   // NN: producer's stored activation (for f'), or null
-  int accumulate;            // NN: C += result (sum over the two LSTM directions)
+  int accumulate;            // NT/NN: C += result (sum over LSTM directions / SRU highway term)
   DropoutSpec drop;
   // TN split
   int k_chunk;               // rows of K per slab (multiple of GEMM_BK)
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
               v *= h * (1.f - h);
             }
           }
-          if (KIND == GEMM_NN && g.accumulate) v += C[(long)m * g.ldc + n];
+          if (KIND != GEMM_TN && g.accumulate) v += C[(long)m * g.ldc + n];
           C[(long)m * g.ldc + n] = v;
         }
       }

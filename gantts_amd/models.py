@@ -35,7 +35,7 @@ class _LinearParams(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_dim, in_dim))
         self.bias = nn.Parameter(torch.empty(out_dim))
 
-    def init_bound(self):
+    def init_bound(self, name=None):
         return 1.0 / math.sqrt(self.in_features)     # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(in))
 
     def extra_repr(self):
@@ -61,12 +61,40 @@ class _LSTMParams(nn.Module):
                 self.register_parameter("bias_ih" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
                 self.register_parameter("bias_hh" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
 
-    def init_bound(self):
+    def init_bound(self, name=None):
         return 1.0 / math.sqrt(self.hidden_size)      # nn.LSTM.reset_parameters
 
     def extra_repr(self):
         return "%d, %d, num_layers=%d, batch_first=True, bidirectional=%s" % (
             self.input_size, self.hidden_size, self.num_layers, self.bidirectional)
+
+
+class _SRUCellParams(nn.Module):
+    """``weight`` (n_in, ncols*k) and ``bias`` (2*ncols) of one SRU cell in the layout of the 2017
+    ``cuda_functional.SRUCell`` the reference imports (gantts/models.py:150): k = 3 when
+    n_in == ncols else 4; init U(+-sqrt(3/n_in)), zero bias; never called."""
+
+    def __init__(self, n_in, n_out, bidirectional):
+        super(_SRUCellParams, self).__init__()
+        self.n_in, self.n_out, self.bidirectional = n_in, n_out, bool(bidirectional)
+        ncols = n_out * (2 if bidirectional else 1)
+        self.k = 3 if n_in == ncols else 4
+        self.weight = nn.Parameter(torch.empty(n_in, ncols * self.k))
+        self.bias = nn.Parameter(torch.empty(2 * ncols))
+
+    def init_bound(self, name=None):
+        return math.sqrt(3.0 / self.n_in) if name == "weight" else 0.0
+
+    def extra_repr(self):
+        return "n_in=%d, n_out=%d, k=%d, bidirectional=%s" % (self.n_in, self.n_out, self.k, self.bidirectional)
+
+
+class _SRUStack(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+        super(_SRUStack, self).__init__()
+        ncols = hidden_size * (2 if bidirectional else 1)
+        self.rnn_lst = nn.ModuleList([_SRUCellParams(input_size if i == 0 else ncols, hidden_size, bidirectional)
+                                      for i in range(num_layers)])
 
 
 class _FlatNetwork(AbstractModel, nn.Module):
@@ -85,7 +113,7 @@ class _FlatNetwork(AbstractModel, nn.Module):
         self._version = 0            # bumped whenever buffers are re-homed (engines re-bind)
 
     def _holders(self):
-        return [m for m in self.modules() if isinstance(m, (_LinearParams, _LSTMParams))]
+        return [m for m in self.modules() if isinstance(m, (_LinearParams, _LSTMParams, _SRUCellParams))]
 
     def _repoint(self, init=False):
         off = 0
@@ -94,8 +122,8 @@ class _FlatNetwork(AbstractModel, nn.Module):
                 n = p.numel()
                 view = self._flat[off:off + n].view(p.shape)
                 if init:
-                    k = holder.init_bound()
-                    view.uniform_(-k, k)
+                    k = holder.init_bound(name)
+                    view.uniform_(-k, k) if k > 0 else view.zero_()
                 p.data = view
                 p._gt_owner = weakref.ref(self)
                 p.grad = None if self._flat_grad is None else self._flat_grad[off:off + n].view(p.shape)
@@ -143,6 +171,8 @@ class _FlatNetwork(AbstractModel, nn.Module):
         d.dropout = float(self.dropout_p)
         d.last_sigmoid = int(bool(getattr(self, "last_sigmoid", False)))
         d.bidirectional = int(getattr(self, "num_direction", 1) == 2)
+        d.use_relu = int(bool(getattr(self, "use_relu", 0)))
+        d.rnn_dropout = float(getattr(self, "rnn_dropout", 0.0))
         if not self._flat.is_cuda:
             raise RuntimeError("gantts_amd: model is on %s -- call .cuda() first (the HIP engine has no CPU path)"
                                % self._flat.device)
@@ -231,3 +261,31 @@ class GRURNN(LSTMRNN):
     """Named GRU in the reference but built on ``nn.LSTM`` under the attribute name ``gru``
     (gantts/models.py:170-190); state_dict keys are ``gru.weight_ih_l0`` ..."""
     RNN_ATTR = "gru"
+
+
+class SRURNN(_FlatNetwork):
+    """``SRU(in_dim, hidden_dim, num_hidden, bidirectional, dropout, use_relu, rnn_dropout)`` on the
+    time-major view of the batch, then ``hidden2out`` and an optional sigmoid (reference
+    gantts/models.py:144-167; the default generator of both TTS hparams sets, hparams.py:111-124,
+    211-222).  The SRU cell itself is third-party code the reference does not vendor
+    (github.com/taolei87/sru): this class follows its 2017 ``cuda_functional`` layout (state_dict keys
+    ``gru.rnn_lst.{i}.weight/bias``) and recurrence; ``lengths`` are ignored like in the reference."""
+    ARCH = L.ARCH_SRU
+
+    def __init__(self, in_dim=118, out_dim=118, num_hidden=2, hidden_dim=256,
+                 bidirectional=False, dropout=0, last_sigmoid=False,
+                 use_relu=0, rnn_dropout=0.0):
+        super(SRURNN, self).__init__()
+        self.in_dim, self.out_dim, self.num_hidden, self.hidden_dim = in_dim, out_dim, num_hidden, hidden_dim
+        self.num_direction = 2 if bidirectional else 1
+        self.dropout_p, self.last_sigmoid = dropout, last_sigmoid
+        self.use_relu, self.rnn_dropout = use_relu, rnn_dropout
+        self.gru = _SRUStack(in_dim, hidden_dim, num_hidden, bidirectional)
+        self.hidden2out = _LinearParams(out_dim, hidden_dim * self.num_direction)
+        self._finish_init()
+
+    def set_dropout_masks(self, pass_index, masks):
+        raise NotImplementedError("dropout mask injection is not available for recurrent generators")
+
+    def forward(self, sequence, lengths=None):
+        return self._own_engine().model_forward(self, sequence)

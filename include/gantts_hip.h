@@ -39,6 +39,7 @@ extern "C" {
 #define GT_ARCH_MLP 0         /* gantts/models.py:121-141 */
 #define GT_ARCH_IN2OUT 1      /* gantts/models.py:21-69  (In2OutHighwayNet) */
 #define GT_ARCH_LSTM 2        /* gantts/models.py:170-213 (LSTMRNN, GRURNN: nn.LSTM + hidden2out) */
+#define GT_ARCH_SRU 3         /* gantts/models.py:144-167 (SRURNN: third-party SRU cells + hidden2out) */
 
 #define GT_OPT_ADAGRAD 0      /* torch.optim.Adagrad, train.py:796-799 with hparams.py:48-52,223-227 */
 #define GT_OPT_ADAM 1         /* torch.optim.Adam,    hparams.py:125-130 */
@@ -65,14 +66,19 @@ typedef struct {
  *   LSTM:   for layer k, for direction d (forward, then reverse when bidirectional):
  *             weight_ih (4H x in_k) | weight_hh (4H x H) | bias_ih (4H) | bias_hh (4H)     (gate order i,f,g,o)
  *           then hidden2out.weight (out x H*dirs) | hidden2out.bias        (torch.nn.LSTM parameter order)
- * weights are (out, in) row-major exactly as nn.Linear / nn.LSTM store them. */
+ *   SRU:    for layer i: rnn_lst.i.weight (n_in x ncols*k, ncols = H*dirs, k = 3 if n_in == ncols else 4,
+ *           column j owns entries j*k..j*k+k-1) | rnn_lst.i.bias (2*ncols = b_f | b_r);
+ *           then hidden2out.weight (out x ncols) | hidden2out.bias
+ * Linear / LSTM weights are (out, in) row-major exactly as torch stores them; SRU weights are (in, out). */
 typedef struct {
   int32_t arch;
   int32_t in_dim, out_dim, num_hidden, hidden_dim;
   int32_t static_dim;        /* IN2OUT only */
   float dropout;
   int32_t last_sigmoid;
-  int32_t bidirectional;     /* LSTM only */
+  int32_t bidirectional;     /* LSTM, SRU */
+  int32_t use_relu;          /* SRU: g = relu (1) or tanh (0), models.py:152-154 */
+  float rnn_dropout;         /* SRU: variational input dropout (training) */
   int32_t reserved_;
   float* params;
   float* grads;

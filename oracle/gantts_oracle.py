@@ -19,6 +19,8 @@ What it restates (reference file:line, relative to the upstream tree):
 * ``clip_grad_norm_`` + ``torch.optim.Adagrad/Adam`` as used at train.py:275-276,
   317-318, 796-799 (restated from the published update rules, checked against
   ``torch.optim`` in tests/test_oracle.py)
+* ``SRURNN``                    gantts/models.py:144-167 over the un-vendored third-party SRU cell:
+                                **parity unpinned** (see OracleSRURNN)
 * ``unit_variance_mlpg_matrix`` / ``unit_variance_mlpg`` -- third-party nnmnkwii
   (>= 0.0.14, reference setup.py:58-68, NOT vendored under /root/reference).
   Restated from its published definition: W = vstack of per-window band matrices with
@@ -345,6 +347,93 @@ class OracleLSTMRNN(object):
             if self.training and self.p > 0 and l + 1 < self.L:
                 drop = drop or _DropoutSource()
                 inp = inp * drop.next(inp, self.p) / (1.0 - self.p)
+        out = F.linear(inp, self.params[-2], self.params[-1])
+        return torch.sigmoid(out) if self.last_sigmoid else out
+
+    __call__ = forward
+
+
+class OracleSRURNN(object):
+    """gantts/models.py:144-167 (SRURNN) on top of the THIRD-PARTY, un-vendored SRU cell
+    (`cuda_functional.SRU` of github.com/taolei87/sru, 2017 layout; no version pinned anywhere in
+    the reference, CUDA-only, no reference test touches it) => **parity unpinned**: restated from
+    the published recurrence (Lei et al. 2017, arXiv:1709.02755, and SURVEY Appendix B) and checked
+    for self-consistency only (finite-difference gradients, tests/test_oracle.py).
+
+    Per layer (n_in -> H per direction, ncols = H*dirs, k = 3 if n_in == ncols else 4):
+        U = x @ weight                       weight (n_in, ncols*k), column j owns U[..., j*k : (j+1)*k]
+        f = sigmoid(u1 + b_f[j]); r = sigmoid(u2 + b_r[j])          bias = [b_f (ncols) | b_r (ncols)]
+        c_t = (c_{t-1} - u0) * f + u0
+        h_t = (g(c_t) * mask_h - x') * r + x'      x' = x_t[j] if k == 3 else u3; g = relu / tanh / identity
+    columns j >= H of a bidirectional layer run backwards in time.  `lengths` are ignored (padded
+    frames run through the recurrence).  Training only: `rnn_dropout` = one Bernoulli mask (B, n_in)
+    shared over time on x before the GEMM; `dropout` = mask (B, ncols) on g(c) (not on the last layer)."""
+
+    def __init__(self, in_dim=118, out_dim=118, num_hidden=2, hidden_dim=256, bidirectional=False,
+                 dropout=0, last_sigmoid=False, use_relu=0, rnn_dropout=0.0, seed=0):
+        gen = torch.Generator().manual_seed(seed)
+        self.H, self.L, self.dirs = hidden_dim, num_hidden, 2 if bidirectional else 1
+        self.p, self.rnn_p, self.act = float(dropout), float(rnn_dropout), ("relu" if use_relu else "tanh")
+        self.last_sigmoid = last_sigmoid
+        ncols = hidden_dim * self.dirs
+        self.names, self.params, self.ks = [], [], []
+        for l in range(num_hidden):
+            n_in = in_dim if l == 0 else ncols
+            k = 3 if n_in == ncols else 4
+            self.ks.append(k)
+            r = math.sqrt(3.0 / n_in)
+            self.names += ["gru.rnn_lst.%d.weight" % l, "gru.rnn_lst.%d.bias" % l]
+            self.params += [(torch.rand(n_in, ncols * k, generator=gen) * 2 - 1) * r, torch.zeros(2 * ncols)]
+        W, b = linear_init(out_dim, ncols, gen)
+        self.names += ["hidden2out.weight", "hidden2out.bias"]
+        self.params += [W, b]
+        for p in self.params:
+            p.requires_grad_(True)
+        self.training = True
+
+    def include_parameter_generation(self):
+        return False
+
+    state_dict = OracleMLP.state_dict
+    load_state_dict = OracleMLP.load_state_dict
+
+    def _g(self, c):
+        return torch.relu(c) if self.act == "relu" else torch.tanh(c)
+
+    def forward(self, x, lengths=None, drop=None):
+        B, T, _ = x.shape
+        H, ncols = self.H, self.H * self.dirs
+        inp = x
+        for l in range(self.L):
+            W, bias = self.params[2 * l], self.params[2 * l + 1]
+            k = self.ks[l]
+            xin = inp
+            if self.training and self.rnn_p > 0:
+                drop = drop or _DropoutSource()
+                xin = inp * (drop.next(inp[:, 0], self.rnn_p) / (1.0 - self.rnn_p)).unsqueeze(1)
+            U = (xin @ W).view(B, T, ncols, k)
+            mask_h = None
+            if self.training and self.p > 0 and l + 1 < self.L:
+                drop = drop or _DropoutSource()
+                mask_h = drop.next(inp.new_zeros(B, ncols), self.p) / (1.0 - self.p)
+            bf, br = bias[:ncols], bias[ncols:]
+            outs = []
+            for d in range(self.dirs):
+                sl = slice(d * H, (d + 1) * H)
+                c = x.new_zeros(B, H)
+                seq = [None] * T
+                for t in (range(T - 1, -1, -1) if d else range(T)):
+                    u = U[:, t, sl]
+                    f = torch.sigmoid(u[..., 1] + bf[sl])
+                    r = torch.sigmoid(u[..., 2] + br[sl])
+                    c = (c - u[..., 0]) * f + u[..., 0]
+                    val = self._g(c)
+                    if mask_h is not None:
+                        val = val * mask_h[:, sl]
+                    xp = inp[:, t, sl] if k == 3 else u[..., 3]
+                    seq[t] = (val - xp) * r + xp
+                outs.append(torch.stack(seq, 1))
+            inp = torch.cat(outs, -1)
         out = F.linear(inp, self.params[-2], self.params[-1])
         return torch.sigmoid(out) if self.last_sigmoid else out
 

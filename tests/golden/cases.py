@@ -136,6 +136,38 @@ CASES = {
 }
 
 
+# Cases with NO reference-generated fixture: the SRU cell is third-party code that is neither vendored in
+# the reference nor runnable here (CUDA-only), so these are checked HIP-vs-oracle only (parity unpinned).
+ORACLE_ONLY_CASES = {
+    # cfg4 family at reduced size: bidirectional SRU generator (default hparams generator), 3 dynamic streams
+    "vc_sru_multistream": dict(
+        hp="tts_acoustic", B=3, T=19, din=20, dout=183,
+        stream_sizes=[177, 3, 3], has_dynamic_features=[True, True, True],
+        adversarial_streams=[True, False, False], mask_nth_mgc=0, cond=False,
+        g=dict(kind="SRURNN", in_dim=20, out_dim=183, num_hidden=3, hidden_dim=12,
+               bidirectional=True, dropout=0.0, last_sigmoid=False, use_relu=1, rnn_dropout=0.0),
+        d=dict(kind="MLP", in_dim=59, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+    # unidirectional tanh SRU whose first layer already has n_in == ncols (k = 3 everywhere)
+    "acoustic_sru_uni_k3": dict(
+        hp="tts_acoustic", B=2, T=23, din=16, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="SRURNN", in_dim=16, out_dim=187, num_hidden=2, hidden_dim=16,
+               bidirectional=False, dropout=0.0, last_sigmoid=False, use_relu=0, rnn_dropout=0.0),
+        d=dict(kind="MLP", in_dim=74, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.5, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
+}
+
+
 def param_shapes(spec):
     """(name, shape) in state_dict / parameters() order for a model spec."""
     kind = spec["kind"]
@@ -166,6 +198,14 @@ def param_shapes(spec):
                 out += [("%s.weight_ih%s" % (prefix, sfx), (4 * H, n_in)), ("%s.weight_hh%s" % (prefix, sfx), (4 * H, H)),
                         ("%s.bias_ih%s" % (prefix, sfx), (4 * H,)), ("%s.bias_hh%s" % (prefix, sfx), (4 * H,))]
         out += [("hidden2out.weight", (spec["out_dim"], H * dirs)), ("hidden2out.bias", (spec["out_dim"],))]
+    elif kind == "SRURNN":
+        H, dirs = spec["hidden_dim"], 2 if spec["bidirectional"] else 1
+        ncols = H * dirs
+        for l in range(spec["num_hidden"]):
+            n_in = spec["in_dim"] if l == 0 else ncols
+            k = 3 if n_in == ncols else 4
+            out += [("gru.rnn_lst.%d.weight" % l, (n_in, ncols * k)), ("gru.rnn_lst.%d.bias" % l, (2 * ncols,))]
+        out += [("hidden2out.weight", (spec["out_dim"], ncols)), ("hidden2out.bias", (spec["out_dim"],))]
     else:
         raise ValueError(kind)
     return out
@@ -183,6 +223,8 @@ def make_weights(spec, seed):
         if ".weight_ih" in name or ".weight_hh" in name or ".bias_ih" in name or ".bias_hh" in name:
             fan_in = spec["hidden_dim"]
         k = 1.0 / math.sqrt(fan_in)
+        if "rnn_lst" in name:        # SRU: U(+-sqrt(3/n_in)) weights, small non-zero biases for the test
+            k = math.sqrt(3.0 / shape[0]) if name.endswith("weight") else 0.5
         sd[name] = ((rs.rand(*shape) * 2 - 1) * k).astype(np.float32)
     return sd
 

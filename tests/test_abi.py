@@ -37,7 +37,7 @@ def test_ctypes_structs_match_header_layout():
     from gantts_amd import _lib
     assert C.sizeof(_lib.StreamConfig) == 4 * (1 + 8 + 8 + 1 + 8 + 3)
     assert C.sizeof(_lib.DResult) == 24 and C.sizeof(_lib.GResult) == 20
-    assert _lib.ModelDesc.params.offset == 40 and C.sizeof(_lib.ModelDesc) == 64
+    assert _lib.ModelDesc.params.offset == 48 and C.sizeof(_lib.ModelDesc) == 72
     assert _lib.OptimDesc.step.offset == 32 and C.sizeof(_lib.OptimDesc) == 56
 
 

@@ -131,3 +131,33 @@ def test_oracle_live_against_reference_models():
     x = torch.rand(2, 9, 20)
     assert torch.allclose(ref(x), mine(x), atol=1e-7)
     assert list(ref.state_dict().keys()) == mine.names
+
+
+def test_sru_restatement_gradients_by_finite_differences():
+    """The SRU cell is third-party and un-vendored (parity unpinned): the restatement is checked for
+    self-consistency -- autograd gradients of the recurrence against central differences in float64."""
+    torch.manual_seed(0)
+    m = O.OracleSRURNN(in_dim=5, out_dim=4, num_hidden=2, hidden_dim=3, bidirectional=True, use_relu=0)
+    m.training = False
+    m.params = [p.detach().double().requires_grad_(True) for p in m.params]
+    with torch.no_grad():
+        m.params[1].uniform_(-0.5, 0.5)
+        m.params[3].uniform_(-0.5, 0.5)
+    x = torch.randn(2, 6, 5, dtype=torch.float64)
+    w = torch.randn(2, 6, 4, dtype=torch.float64)
+    loss = (m(x) * w).sum()
+    grads = torch.autograd.grad(loss, m.params)
+    for p, g in zip(m.params, grads):
+        flat = p.detach().view(-1)
+        for idx in torch.randperm(flat.numel())[:6].tolist():
+            old = float(flat[idx])
+            flat[idx] = old + 1e-6
+            lp = float((m(x) * w).sum())
+            flat[idx] = old - 1e-6
+            lm = float((m(x) * w).sum())
+            flat[idx] = old
+            assert (lp - lm) / 2e-6 == pytest.approx(float(g.view(-1)[idx]), rel=1e-5, abs=1e-8)
+    # k = 3 layers use the layer input itself as the highway term, k = 4 a fourth projection
+    assert m.ks == [4, 3]
+    assert m.names[:2] == ["gru.rnn_lst.0.weight", "gru.rnn_lst.0.bias"]
+    assert tuple(m.params[0].shape) == (5, 6 * 4) and tuple(m.params[2].shape) == (6, 6 * 3)
