@@ -210,17 +210,20 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     g.drop = no_drop();
     CHK(launch_gemm(GEMM_TN, g, nslab, s));
     if (slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0) {
-      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(cdiv(slab_stride / 4, 256)), dim3(256), 0, s, slabs.as<float>(),
-                         slab_stride, nslab, slab_stride / 4, dW, accumulate ? 1 : 0);
+      const int main_blocks = cdiv(slab_stride / 4, 256);
+      const int bias_blocks = db ? cdiv(out, 256) : 0;
+      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slabs.as<float>(), slab_stride, nslab,
+                         slab_stride / 4, dW, accumulate ? 1 : 0, (const float*)bias_slabs, out, db, main_blocks);
+      LAUNCH_CHECK();
     } else {
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slabs.as<float>(),
                          slab_stride, nslab, slab_stride, dW, accumulate ? 1 : 0);
-    }
-    LAUNCH_CHECK();
-    if (db) {
-      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(out, 64)), dim3(1024), 0, s, bias_slabs, (long)out, nslab, out, db,
-                         accumulate ? 1 : 0);
       LAUNCH_CHECK();
+      if (db) {
+        hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(out, 64)), dim3(1024), 0, s, bias_slabs, (long)out, nslab, out, db,
+                           accumulate ? 1 : 0);
+        LAUNCH_CHECK();
+      }
     }
   } else if (db) {
     const int rows_per_blk = 128;
@@ -291,6 +294,7 @@ struct gt_engine {
   bool g_pass_valid = false, leak_pending = false, fake_cat_valid = false;
   const float* fake_cat_x = nullptr; const float* fake_cat_yhs = nullptr;
   bool d_begin_done = false, g_begin_done = false, g_has_adv = false, g_used_mlpg = false;
+  const float* tv_mask = nullptr; long tv_n = 0; float tv_ovr = 0.f;   // sum(mask) already on the device for this step
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
   // recurrent generator workspace (per layer) and the lengths of the current batch
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out;
@@ -313,7 +317,7 @@ static int upload_ints(const std::vector<int>& v, int** dptr) {
 extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if (!cfg || !out) return fail(GT_ERR_INVALID, "null argument");
   if (cfg->n_streams < 1 || cfg->n_streams > GT_MAX_STREAMS) return fail(GT_ERR_INVALID, "n_streams out of range");
-  if (cfg->num_windows < 1) return fail(GT_ERR_INVALID, "num_windows must be >= 1");
+  if (cfg->num_windows < 1 || cfg->num_windows > MLPG_MAXW) return fail(GT_ERR_INVALID, "num_windows must be in [1,%d]", MLPG_MAXW);
   gt_engine* e = new gt_engine();
   e->cfg = *cfg;
   // static layout: get_static_stream_sizes (multistream.py:46-53) + per-column source map
@@ -544,6 +548,7 @@ extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B) 
 extern "C" int gt_zero_grad(gt_engine* e, int role) {
   if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
   e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
+  e->tv_mask = nullptr;
   if (role == GT_ROLE_G) e->leak_pending = false;
   return GT_OK;
 }
@@ -610,7 +615,7 @@ static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
 static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
                         float* ys, int ldys, int B, int T, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
-  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1)) * sizeof(float);
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     HIPCHK(hipFuncSetAttribute((const void*)mlpg_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -626,7 +631,7 @@ static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* sco
                          float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
                          const float* mask, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
-  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1)) * sizeof(float);
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
   static size_t lds_set_b = 0;
   if (lds > lds_set_b) {
     HIPCHK(hipFuncSetAttribute((const void*)mlpg_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -704,6 +709,15 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
                                no_drop(), s));
     }
   }
+  return GT_OK;
+}
+
+// tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask)
+static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
+  if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
+  LAUNCH_CHECK();
+  e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
   return GT_OK;
 }
 
@@ -1031,6 +1045,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
   e->fake_cat_valid = false;
+  e->tv_mask = nullptr;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
   e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
   e->g_pass_valid = true;
@@ -1130,8 +1145,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   hipStream_t s = (hipStream_t)stream;
   const long N = (long)B * T;
   const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
-  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
-  LAUNCH_CHECK();
+  CHK(ensure_tv(e, mask, N, s));
   CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
   CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
   CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
@@ -1268,8 +1282,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   const int Do = G.d.out_dim;
   const int Ds = G.d.arch == GT_ARCH_IN2OUT ? G.d.static_dim : e->Ds;
-  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
-  LAUNCH_CHECK();
+  CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
   const bool direct = G.d.arch != GT_ARCH_IN2OUT && !e->g_used_mlpg;
   if (!(tr && direct && mse_w != 0.f))

@@ -145,67 +145,96 @@ constexpr int MLPG_TT = 32;      // output frames per workgroup
 constexpr int MLPG_CC = 64;      // static columns per workgroup
 
 // y_static[b][t][c] = sum_w sum_j band[t][w][j] * y[b][t+j-kb][scol[c] + w*sstride[c]]
-// LDS: data tile [(TT+2kb)][nW][CC] + the TT band rows [TT][nW][nb]; the inner product then runs
-// on two LDS streams (band: wave-broadcast, data: lane <-> column, conflict-free).
+//
+// Workgroup = (sequence b, MLPG_TT = 32 output frames, MLPG_CC = 64 static columns).  LDS holds the
+// (T,D) tile with its +-kb halo, [(TT+2kb)][nW][CC], and the TT band rows, zero-padded by
+// MLPG_PAD taps on both sides, [TT][nW][nb+2*PAD].  Each lane owns a 2-column x 4-frame register
+// block: one ds_read_b64 of data feeds 8 FMAs, the 4 coefficients are wave-broadcast reads
+// (0.6 LDS instructions per FMA instead of 2 for the one-output-per-lane form).
+constexpr int MLPG_PAD = 3;      // = frames per lane - 1
+constexpr int MLPG_MAXW = 4;
+
 __global__ __launch_bounds__(256) void mlpg_forward_kernel(
     const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ ys, int ldys, int B, int T) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int nb = 2 * kb + 1;
+  const int nb = 2 * kb + 1, nbp = nb + 2 * MLPG_PAD;
   const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
   const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
   const int rows = MLPG_TT + 2 * kb;
-  float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nb]
+  float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nbp]
   const float* yb = y + (long)b * T * ldy;
-  // blockDim.x is a multiple of MLPG_CC: this thread always handles column c = tid % MLPG_CC
-  const int c_own = threadIdx.x % MLPG_CC;
-  const bool c_ok = c_own < nc;
-  const int my_col = c_ok ? scol[c0 + c_own] : 0, my_st = c_ok ? sstride[c0 + c_own] : 0;
-  for (int e = threadIdx.x; e < rows * nW * MLPG_CC; e += blockDim.x) {
-    const int w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
-    const int t = t0 - kb + r;
-    float v = 0.f;
-    if (c_ok && t >= 0 && t < T && (my_st > 0 || w == 0)) v = yb[(long)t * ldy + my_col + w * my_st];
-    sm[e] = v;
+  {  // stage the data tile: this thread always loads column c = tid % CC (blockDim % CC == 0)
+    const int c_own = threadIdx.x % MLPG_CC;
+    const bool c_ok = c_own < nc;
+    const int my_col = c_ok ? scol[c0 + c_own] : 0, my_st = c_ok ? sstride[c0 + c_own] : 0;
+    const int total = rows * nW * MLPG_CC;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = min(e0 + q * (int)blockDim.x, total - 1);
+        const int w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
+        const int t = t0 - kb + r;
+        const int tc = min(max(t, 0), T - 1);
+        const float x = yb[(long)tc * ldy + my_col + (my_st > 0 ? w * my_st : 0)];
+        v[q] = (c_ok && t >= 0 && t < T && (my_st > 0 || w == 0)) ? x : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * (int)blockDim.x;
+        if (e < total) sm[e] = v[q];
+      }
+    }
   }
-  for (int e = threadIdx.x; e < MLPG_TT * nW * nb; e += blockDim.x) {
-    const int t = t0 + e / (nW * nb);
-    sb[e] = t < T ? band[(long)t * nW * nb + e % (nW * nb)] : 0.f;
+  for (int e = threadIdx.x; e < MLPG_TT * nW * nbp; e += blockDim.x) {
+    const int jp = e % nbp, tw = e / nbp;                      // tw = tl*nW + w
+    const int t = t0 + tw / nW, j = jp - MLPG_PAD;
+    sb[e] = (t < T && j >= 0 && j < nb) ? band[((long)t * nW + tw % nW) * nb + j] : 0.f;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < MLPG_TT * MLPG_CC; e += blockDim.x) {
-    const int c = e % MLPG_CC, tl = e / MLPG_CC;
-    const int t = t0 + tl;
-    if (c >= nc || t >= T) continue;
-    float out;
-    if (my_st == 0) {
-      out = sm[((tl + kb) * nW + 0) * MLPG_CC + c];
-    } else {
-      float acc0 = 0.f, acc1 = 0.f;
-      const float* bt = sb + tl * nW * nb;
-      for (int w = 0; w < nW; ++w) {
-        const float* bw = bt + w * nb;
-        const float* dw_ = sm + (tl * nW + w) * MLPG_CC + c;
-        int j = 0;
-        for (; j + 1 < nb; j += 2) {
-          acc0 = fmaf(bw[j], dw_[j * nW * MLPG_CC], acc0);
-          acc1 = fmaf(bw[j + 1], dw_[(j + 1) * nW * MLPG_CC], acc1);
-        }
-        if (j < nb) acc0 = fmaf(bw[j], dw_[j * nW * MLPG_CC], acc0);
+  const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;     // column pair, frame group (4 frames)
+  const int tl0 = fg * 4;
+  float acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.f;
+  for (int w = 0; w < nW; ++w) {
+    const float* dcol = sm + w * MLPG_CC + 2 * cp;             // + r*nW*CC
+    const float* cf = sb + (tl0 * nW + w) * nbp + MLPG_PAD;     // + i*nW*nbp + (r - tl0 - i)
+    for (int r = tl0; r < tl0 + 3 + nb; ++r) {
+      const float2 d = *reinterpret_cast<const float2*>(dcol + r * nW * MLPG_CC);
+      const int j0 = r - tl0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float cfi = cf[i * nW * nbp + j0 - i];
+        acc[i][0] = fmaf(cfi, d.x, acc[i][0]);
+        acc[i][1] = fmaf(cfi, d.y, acc[i][1]);
       }
-      out = acc0 + acc1;
     }
-    ys[((long)b * T + t) * ldys + c0 + c] = out;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = 2 * cp + q;
+    if (c >= nc) continue;
+    const bool pass = sstride[c0 + c] == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + tl0 + i;
+      if (t >= T) continue;
+      const float out = pass ? sm[((tl0 + i + kb) * nW + 0) * MLPG_CC + c] : acc[i][q];   // pass-through: bit-exact copy
+      ys[((long)b * T + t) * ldys + c0 + c] = out;
+    }
   }
 }
 
 // transpose of the above:  gy[b][t'][scol[c]+w*st] = sum_t band[t][w][t'-t+kb] * gs[b][t][c]
 // plus the masked-MSE gradient in the static+delta domain when mse_w != 0:
 //   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
-// LDS: gs tile [(TT+2kb)][CC] + band rows of the same frames [(TT+2kb)][nW][nb].
+// LDS: gs tile [(TT+2kb)][CC] + the band rows of the same frames, padded, [(TT+2kb)][nW][nb+2*PAD].
+// Lane = 2 columns x 4 frames x all windows: one ds_read_b64 of gs feeds 8*nW FMAs.
 __global__ __launch_bounds__(256) void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
@@ -213,56 +242,86 @@ __global__ __launch_bounds__(256) void mlpg_backward_kernel(
     float mse_w, const float* __restrict__ yhat, const float* __restrict__ ytgt, int ldt,
     const float* __restrict__ mask, const StepScalars* __restrict__ sc) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int nb = 2 * kb + 1;
+  const int nb = 2 * kb + 1, nbp = nb + 2 * MLPG_PAD;
   const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
   const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
   const int rows = MLPG_TT + 2 * kb;
-  float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nb]; frames outside [0,T) are zero
+  float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nbp]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
-  for (int e = threadIdx.x; e < rows * MLPG_CC; e += blockDim.x) {
-    const int c = e % MLPG_CC, r = e / MLPG_CC;
-    const int t = t0 - kb + r;
-    sm[e] = (c < nc && t >= 0 && t < T) ? gb[(long)t * ldgs + c0 + c] : 0.f;
+  {
+    const int total = rows * MLPG_CC;
+    const int cb = threadIdx.x % MLPG_CC;
+    const bool cb_ok = cb < nc;
+    const int ccl = cb_ok ? c0 + cb : c0;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = min(e0 + q * (int)blockDim.x, total - 1);
+        const int t = t0 - kb + e / MLPG_CC;
+        const int tc = min(max(t, 0), T - 1);
+        const float x = gb[(long)tc * ldgs + ccl];
+        v[q] = (cb_ok && t >= 0 && t < T) ? x : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * (int)blockDim.x;
+        if (e < total) sm[e] = v[q];
+      }
+    }
   }
-  for (int e = threadIdx.x; e < rows * nW * nb; e += blockDim.x) {
-    const int t = t0 - kb + e / (nW * nb);
-    sb[e] = (t >= 0 && t < T) ? band[(long)t * nW * nb + e % (nW * nb)] : 0.f;
+  for (int e = threadIdx.x; e < rows * nW * nbp; e += blockDim.x) {
+    const int jp = e % nbp, rw = e / nbp;                      // rw = r*nW + w
+    const int t = t0 - kb + rw / nW, j = jp - MLPG_PAD;
+    sb[e] = (t >= 0 && t < T && j >= 0 && j < nb) ? band[((long)t * nW + rw % nW) * nb + j] : 0.f;
   }
   __syncthreads();
-  const float msk_scale = mse_w != 0.f ? 2.f * mse_w * sc->inv_tv : 0.f;
-  const int c_own = threadIdx.x % MLPG_CC;          // fixed per thread (blockDim.x % MLPG_CC == 0)
-  const int my_col = c_own < nc ? scol[c0 + c_own] : 0, my_st = c_own < nc ? sstride[c0 + c_own] : 0;
-  for (int e = threadIdx.x; e < MLPG_TT * nW * MLPG_CC; e += blockDim.x) {
-    const int c = e % MLPG_CC, w = (e / MLPG_CC) % nW, tl = e / (MLPG_CC * nW);
-    const int tp = t0 + tl;
-    if (c >= nc || tp >= T) continue;
-    const int st = my_st;
-    if (st == 0 && w > 0) continue;
-    float out;
-    if (st == 0) {
-      out = sm[(tl + kb) * MLPG_CC + c];
-    } else {
-      // frame t = tp + o (staged row tl + kb + o), coefficient band[t][w][kb - o], o in [-kb, kb]
-      float acc0 = 0.f, acc1 = 0.f;
-      const float* g0 = sm + tl * MLPG_CC + c;                 // row (tl + kb + o) with o = -kb
-      const float* b0 = sb + (tl * nW + w) * nb + (nb - 1);    // band row of the same frame, tap kb - o = 2kb
-      int q = 0;
-      for (; q + 1 < nb; q += 2) {
-        acc0 = fmaf(b0[q * (nW * nb - 1)], g0[q * MLPG_CC], acc0);
-        acc1 = fmaf(b0[(q + 1) * (nW * nb - 1)], g0[(q + 1) * MLPG_CC], acc1);
+  const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;
+  const int tl0 = fg * 4;
+  float acc[MLPG_MAXW][4][2];
+#pragma unroll
+  for (int w = 0; w < MLPG_MAXW; ++w)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[w][i][0] = acc[w][i][1] = 0.f;
+  // staged row r holds frame t = t0 - kb + r; it reaches output frame tl (t' = t0 + tl) with
+  // q = r - tl in [0, nb) through the coefficient band[t][w][nb - 1 - q]
+  for (int r = tl0; r < tl0 + 3 + nb; ++r) {
+    const float2 d = *reinterpret_cast<const float2*>(sm + r * MLPG_CC + 2 * cp);
+    const float* cf = sb + (long)r * nW * nbp + MLPG_PAD + (nb - 1) - (r - tl0);   // + w*nbp + i
+#pragma unroll
+    for (int w = 0; w < MLPG_MAXW; ++w) {
+      if (w >= nW) break;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float cfi = cf[w * nbp + i];
+        acc[w][i][0] = fmaf(cfi, d.x, acc[w][i][0]);
+        acc[w][i][1] = fmaf(cfi, d.y, acc[w][i][1]);
       }
-      if (q < nb) acc0 = fmaf(b0[q * (nW * nb - 1)], g0[q * MLPG_CC], acc0);
-      out = acc0 + acc1;
     }
-    const int col = my_col + w * st;
-    const long row = (long)b * T + tp;
-    if (msk_scale != 0.f) {
-      const float m = mask[row];
-      out += msk_scale * (yhat[row * ldt + col] * m - ytgt[row * ldt + col] * m) * m;
+  }
+  const float msk_scale = mse_w != 0.f ? 2.f * mse_w * sc->inv_tv : 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = 2 * cp + q;
+    if (c >= nc) continue;
+    const int col0 = scol[c0 + c], st = sstride[c0 + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tp = t0 + tl0 + i;
+      if (tp >= T) continue;
+      const long row = (long)b * T + tp;
+      const float m = msk_scale != 0.f ? mask[row] : 0.f;
+#pragma unroll
+      for (int w = 0; w < MLPG_MAXW; ++w) {
+        if (w >= nW || (st == 0 && w > 0)) break;
+        float out = st == 0 ? sm[(tl0 + i + kb) * MLPG_CC + c] : acc[w][i][q];
+        const int col = col0 + w * st;
+        if (msk_scale != 0.f) out += msk_scale * (yhat[row * ldt + col] * m - ytgt[row * ldt + col] * m) * m;
+        gy[row * ldgy + col] = out;
+      }
     }
-    gy[row * ldgy + col] = out;
   }
 }
 
@@ -516,7 +575,23 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nb
 // dW = (accumulate ? dW : 0) + sum_s slab[s]   (deterministic split-K combine of the TN GEMM)
 // 16 B per lane, 8 slabs in flight per lane; slab_stride and n4*4 must keep 16-byte alignment.
 __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
-                                                           float* __restrict__ out, int accumulate) {
+                                                           float* __restrict__ out, int accumulate,
+                                                           const float* __restrict__ bslabs, int nb, float* __restrict__ bout, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {
+    // trailing workgroups: the bias-gradient slabs [nslab][nb] ride along in the same launch
+    const int c = (blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    if (c >= nb) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nslab; k += 4) {
+      s0 += bslabs[(long)k * nb + c];       s1 += bslabs[(long)(k + 1) * nb + c];
+      s2 += bslabs[(long)(k + 2) * nb + c]; s3 += bslabs[(long)(k + 3) * nb + c];
+    }
+    for (; k < nslab; ++k) s0 += bslabs[(long)k * nb + c];
+    const float tot = (s0 + s1) + (s2 + s3);
+    bout[c] = accumulate ? bout[c] + tot : tot;
+    return;
+  }
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;

@@ -19,11 +19,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--gen", default="lstm", choices=["lstm", "sru"])
 args = ap.parse_args()
 B, Tn = args.batch, args.frames
 hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
 T.hp = hp
-mg = models.LSTMRNN(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True, dropout=0.0).cuda().train()
+if args.gen == "lstm":
+    mg = models.LSTMRNN(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True, dropout=0.0).cuda().train()
+else:   # hparams.tts_acoustic default generator (hparams.py:211-222)
+    mg = models.SRURNN(in_dim=425, out_dim=187, num_hidden=6, hidden_dim=512, bidirectional=True, dropout=0.2,
+                       use_relu=1, rnn_dropout=0.2).cuda().train()
 md = models.MLP(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True).cuda().train()
 og, od = optim.Adagrad(mg.parameters(), lr=0.01, weight_decay=1e-7), optim.Adagrad(md.parameters(), lr=0.01, weight_decay=1e-7)
 g = torch.Generator().manual_seed(0)
@@ -52,4 +57,4 @@ for _ in range(args.steps):
     out = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print("cfg3 fp32 BiLSTM 3x256 B=%d T=%d: %.1f ms/step, %.0f padded frames/s, scalars %s" % (B, Tn, dt * 1e3, B * Tn / dt, out))
+print("%s fp32 B=%d T=%d: %.1f ms/step, %.0f padded frames/s, scalars %s" % ("cfg3 BiLSTM 3x256" if args.gen == "lstm" else "SRU 6x512 bi (hparams default G)", B, Tn, dt * 1e3, B * Tn / dt, out))
