@@ -295,6 +295,11 @@ struct gt_engine {
   const float* fake_cat_x = nullptr; const float* fake_cat_yhs = nullptr;
   bool d_begin_done = false, g_begin_done = false, g_has_adv = false, g_used_mlpg = false;
   const float* tv_mask = nullptr; long tv_n = 0; float tv_ovr = 0.f;   // sum(mask) already on the device for this step
+  // early results (single-GPU fused entry points): the step scalars are final right after the loss
+  // kernels, long before backward + optimizer finish; they are copied out then, and the call returns
+  // as soon as THAT copy has landed, leaving the rest of the step queued on the stream.
+  bool early = false, early_done = false;
+  hipEvent_t ev_res = nullptr;
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
   // recurrent generator workspace (per layer) and the lengths of the current batch
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out;
@@ -378,6 +383,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
   for (int* p : ints) if (p) (void)hipFree(p);
   if (e->h_res) (void)hipHostFree(e->h_res);
+  if (e->ev_res) (void)hipEventDestroy(e->ev_res);
   delete e;
 }
 
@@ -1130,6 +1136,13 @@ static int fetch_results(gt_engine* e, hipStream_t s) {
   HIPCHK(hipStreamSynchronize(s));
   return GT_OK;
 }
+static int post_early_results(gt_engine* e, hipStream_t s) {
+  if (!e->ev_res) HIPCHK(hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
+  HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(e->ev_res, s));
+  e->early_done = true;
+  return GT_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // update_discriminator
@@ -1159,6 +1172,13 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
                e->d_specs.back(), true, s));
+  e->early_done = false;
+  if (e->early) {   // losses and counts are final here; gradient norm is not (reported as 0)
+    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
+    LAUNCH_CHECK();
+    CHK(post_early_results(e, s));
+  }
   if (tr) {
     // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
     // (the autograd graph in the reference, train.py:265) and a generator with grads exists
@@ -1183,11 +1203,17 @@ extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result*
   if (!e->d_begin_done) return fail(GT_ERR_STATE, "gt_update_discriminator_end without _begin");
   hipStream_t s = (hipStream_t)stream;
   e->d_begin_done = false;
-  HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
-  if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
-  hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
-  LAUNCH_CHECK();
-  CHK(fetch_results(e, s));
+  if (e->early_done) {
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    HIPCHK(hipEventSynchronize(e->ev_res));       // only the scalar copy; backward + step stay queued
+    e->early_done = false;
+  } else {
+    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
+    LAUNCH_CHECK();
+    CHK(fetch_results(e, s));
+  }
   out->loss_d = e->h_res->loss_d; out->loss_fake_d = e->h_res->loss_fake_d; out->loss_real_d = e->h_res->loss_real_d;
   out->real_correct_count = e->h_res->real_correct; out->fake_correct_count = e->h_res->fake_correct;
   out->grad_norm = e->h_res->gnorm_d;
@@ -1196,7 +1222,11 @@ extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result*
 
 extern "C" int gt_update_discriminator(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                        const float* mask, int B, int T, int train, float eps, gt_d_result* out, void* stream) {
-  CHK(gt_update_discriminator_begin(e, x, y_static, y_hat_static, mask, B, T, train, eps, stream));
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->early = true;
+  int r = gt_update_discriminator_begin(e, x, y_static, y_hat_static, mask, B, T, train, eps, stream);
+  e->early = false;
+  if (r != GT_OK) { e->early_done = false; return r; }
   return gt_update_discriminator_end(e, train, out, stream);
 }
 
@@ -1328,6 +1358,13 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
     LAUNCH_CHECK();
   }
+  e->early_done = false;
+  if (e->early && !(tr && direct && mse_w != 0.f)) {   // all four losses are final here
+    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
+    LAUNCH_CHECK();
+    CHK(post_early_results(e, s));
+  }
   if (tr) {
     CHK(generator_backward(e, e->last_x, y, y_hat, mask, mse_w, s));  // G's own input (cat(x, z), train.py:542)
     e->leak_pending = false;
@@ -1342,11 +1379,17 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
   if (!e->g_begin_done) return fail(GT_ERR_STATE, "gt_update_generator_end without _begin");
   hipStream_t s = (hipStream_t)stream;
   e->g_begin_done = false;
-  HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
-  if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
-  hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
-  LAUNCH_CHECK();
-  CHK(fetch_results(e, s));
+  if (e->early_done) {
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    HIPCHK(hipEventSynchronize(e->ev_res));
+    e->early_done = false;
+  } else {
+    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
+    LAUNCH_CHECK();
+    CHK(fetch_results(e, s));
+  }
   out->loss_mse = e->h_res->loss_mse; out->loss_mge = e->h_res->loss_mge; out->loss_adv = e->h_res->loss_adv;
   out->loss_g = e->h_res->loss_g; out->grad_norm = e->h_res->gnorm_g;
   return GT_OK;
@@ -1355,7 +1398,11 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
 extern "C" int gt_update_generator(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* y_static,
                                    const float* y_hat_static, float adv_w, const float* mask, int B, int T, int train,
                                    float mse_w, float mge_w, float eps, gt_g_result* out, void* stream) {
-  CHK(gt_update_generator_begin(e, x, y, y_hat, y_static, y_hat_static, adv_w, mask, B, T, train, mse_w, mge_w, eps, stream));
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->early = true;
+  int r = gt_update_generator_begin(e, x, y, y_hat, y_static, y_hat_static, adv_w, mask, B, T, train, mse_w, mge_w, eps, stream);
+  e->early = false;
+  if (r != GT_OK) { e->early_done = false; return r; }
   return gt_update_generator_end(e, train, adv_w, mse_w, mge_w, out, stream);
 }
 

@@ -15,8 +15,10 @@
  *    stay torch.save-compatible, reference train.py:162-171); the engine borrows the pointers for
  *    the duration of a call and owns only its workspace (activation stash, slabs, scalars).
  *  - calls on one handle are not re-entrant; kernels are enqueued on the `stream` argument
- *    (a hipStream_t, may be NULL for the default stream); functions returning host scalars
- *    synchronise that stream once before returning.
+ *    (a hipStream_t, may be NULL for the default stream); functions returning host scalars wait only
+ *    for those scalars (an event after the loss kernels): the backward pass and the optimizer step of
+ *    the same call may still be executing on the stream when the call returns -- stream order keeps
+ *    every later call (and any reader on the same stream) correct.
  */
 #ifndef GANTTS_HIP_H_
 #define GANTTS_HIP_H_
@@ -98,12 +100,13 @@ typedef struct {
 
 typedef struct {             /* return values of update_discriminator, train.py:278-279 (same order) */
   float loss_d, loss_fake_d, loss_real_d, real_correct_count, fake_correct_count;
-  float grad_norm;           /* pre-clip ||grad D||_2 (extra; 0 when phase != train) */
+  float grad_norm;           /* pre-clip ||grad D||_2 from the split-phase gt_update_discriminator_end; 0 from the fused call,
+                              * which returns before the backward pass has finished */
 } gt_d_result;
 
 typedef struct {             /* return values of update_generator, train.py:320 (same order) */
   float loss_mse, loss_mge, loss_adv, loss_g;
-  float grad_norm;           /* pre-clip ||grad G||_2 of the accumulated gradient (extra) */
+  float grad_norm;           /* pre-clip ||grad G||_2 of the accumulated gradient (split-phase form only, see above) */
 } gt_g_result;
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
