@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -117,8 +118,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dp:
+        # RCCL's NCCL_DEBUG=VERSION banner goes to stdout by default: keep stdout for the ONE JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -145,9 +149,9 @@ def main():
     y_static = get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features)
     mask = sequence_mask(lengths).unsqueeze(-1)
 
-    if world > 1:
+    if world > 1 or args.force_dp:
         backend = HipStepBackend(hp, mg, md, og, od)
-        dp = DataParallelStep(backend)
+        dp = DataParallelStep(backend, always_reduce=args.force_dp)
         dp.broadcast_parameters(mg.flat_params(), md.flat_params())
         batch = dict(x=x, y=y, y_static=y_static, mask=mask, R=R)
         tv_global = float(world * B * Tn)
@@ -165,7 +169,7 @@ def main():
             return d, g
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.force_dp:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -236,8 +240,8 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, Tn)
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

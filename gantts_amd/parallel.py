@@ -20,13 +20,14 @@ import torch.distributed as dist
 
 
 class DataParallelStep(object):
-    def __init__(self, backend, process_group=None):
+    def __init__(self, backend, process_group=None, always_reduce=False):
         self.backend = backend
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.always_reduce = always_reduce and dist.is_initialized()   # exercise the collectives with one rank
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return t
 
