@@ -119,8 +119,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_dp:
-        # RCCL's NCCL_DEBUG=VERSION banner goes to stdout by default: keep stdout for the ONE JSON line
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -240,6 +238,10 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, Tn)
+        # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio (block-buffered when piped): flush it
+        # first so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()
