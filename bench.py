@@ -221,6 +221,11 @@ def main():
                     "sampled_steps": profiled_steps,
                     "variants": per}
 
+    # every rank flushes its C stdio (RCCL's NCCL_DEBUG=VERSION banner is block-buffered when piped)
+    # before rank 0 prints, so the JSON line is the last line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    barrier()
     if rank == 0:
         frames = world * B * Tn * args.steps
         value = frames / elapsed
@@ -238,10 +243,6 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, Tn)
-        # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio (block-buffered when piped): flush it
-        # first so that the JSON line is the LAST line of stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()
