@@ -122,24 +122,31 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
 }
 static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
 
-template <int KIND, int BN>
+template <int KIND, int BM, int BN>
 static int launch_gemm_v(const GemmArgs& g, int nslab, hipStream_t s) {
   // 16-byte operand loads need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
   const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
   const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
-  if (va && vb) return launch_gemm_t<KIND, 128, BN, true, true>(g, nslab, s);
-  if (va) return launch_gemm_t<KIND, 128, BN, true, false>(g, nslab, s);
-  if (vb) return launch_gemm_t<KIND, 128, BN, false, true>(g, nslab, s);
-  return launch_gemm_t<KIND, 128, BN, false, false>(g, nslab, s);
+  if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true>(g, nslab, s);
+  if (va) return launch_gemm_t<KIND, BM, BN, true, false>(g, nslab, s);
+  if (vb) return launch_gemm_t<KIND, BM, BN, false, true>(g, nslab, s);
+  return launch_gemm_t<KIND, BM, BN, false, false>(g, nslab, s);
 }
 
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   const int bn = pick_bn(g.N);
+  // 128-row tiles unless that leaves CUs without a second resident workgroup: forward / backward-data
+  // launches with <= 256 tiles (the N-row D passes of the G step, the 58-column leak) use 64-row tiles
+  const bool small = kind != GEMM_TN && (long)cdiv(g.M, 128) * cdiv(g.N, bn) <= 256 && g.M > 64;
   switch (kind) {
-    case GEMM_NT: return bn == 64 ? launch_gemm_v<GEMM_NT, 64>(g, 1, s) : launch_gemm_v<GEMM_NT, 128>(g, 1, s);
-    case GEMM_NN: return bn == 64 ? launch_gemm_v<GEMM_NN, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 128>(g, 1, s);
-    default: return bn == 64 ? launch_gemm_v<GEMM_TN, 64>(g, nslab, s) : launch_gemm_v<GEMM_TN, 128>(g, nslab, s);
+    case GEMM_NT:
+      if (small) return bn == 64 ? launch_gemm_v<GEMM_NT, 64, 64>(g, 1, s) : launch_gemm_v<GEMM_NT, 64, 128>(g, 1, s);
+      return bn == 64 ? launch_gemm_v<GEMM_NT, 128, 64>(g, 1, s) : launch_gemm_v<GEMM_NT, 128, 128>(g, 1, s);
+    case GEMM_NN:
+      if (small) return bn == 64 ? launch_gemm_v<GEMM_NN, 64, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 64, 128>(g, 1, s);
+      return bn == 64 ? launch_gemm_v<GEMM_NN, 128, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 128, 128>(g, 1, s);
+    default: return bn == 64 ? launch_gemm_v<GEMM_TN, 128, 64>(g, nslab, s) : launch_gemm_v<GEMM_TN, 128, 128>(g, nslab, s);
   }
 }
 
