@@ -136,9 +136,16 @@ static int launch_gemm_v(const GemmArgs& g, int nslab, hipStream_t s) {
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   const int bn = pick_bn(g.N);
-  // 128-row tiles unless that leaves CUs without a second resident workgroup: forward / backward-data
-  // launches with <= 256 tiles (the N-row D passes of the G step, the 58-column leak) use 64-row tiles
-  const bool small = kind != GEMM_TN && (long)cdiv(g.M, 128) * cdiv(g.N, bn) <= 256 && g.M > 64;
+  // Tile height by a residency model: 128-row tiles keep 2 workgroups per CU resident (512 at once),
+  // 64-row tiles 3-4 (LDS-limited: 768 with 128 columns, 1024 with 64) at ~0.55x the work each.
+  // Cost = resident rounds x work per tile; e.g. 384 tiles (187-wide output) or 1024 tiles (2N x 483)
+  // finish sooner as 64-row tiles, exactly 512 tiles do not.
+  bool small = false;
+  if (kind != GEMM_TN && g.M > 64) {
+    const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, bn), t64 = (long)cdiv(g.M, 64) * cdiv(g.N, bn);
+    const double c128 = (double)cdiv(t128, 512), c64 = 0.55 * (double)cdiv(t64, bn == 64 ? 1024 : 768);
+    small = c64 < c128;
+  }
   switch (kind) {
     case GEMM_NT:
       if (small) return bn == 64 ? launch_gemm_v<GEMM_NT, 64, 64>(g, 1, s) : launch_gemm_v<GEMM_NT, 64, 128>(g, 1, s);
