@@ -257,6 +257,8 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
 // engine state
 // ------------------------------------------------------------------------------------------
 struct Lin { float *W, *b, *dW, *db; int in, out; };
+static inline bool is_i2o(int arch) { return arch == GT_ARCH_IN2OUT || arch == GT_ARCH_IN2OUT_RNN; }
+static inline bool has_lstm_body(int arch) { return arch == GT_ARCH_LSTM || arch == GT_ARCH_IN2OUT_RNN; }
 struct LstmDirP { float *Wih, *Whh, *bih, *bhh, *dWih, *dWhh, *dbih, *dbhh; };
 struct LstmLayerP { int in; LstmDirP d[2]; };
 struct SruLayerP { int in, k; float *W, *b, *dW, *db; };
@@ -316,7 +318,8 @@ struct gt_engine {
   hipEvent_t ev_res = nullptr;
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
   // recurrent generator workspace (per layer) and the lengths of the current batch
-  std::vector<Scratch> l_xproj, l_gates, l_cst, l_out;
+  std::vector<Scratch> l_xproj, l_gates, l_cst, l_out, l_outd;   // l_outd: inter-layer-dropped outputs
+  Scratch i2o_gout;                                              // In2OutRNNHighwayNet: hidden2out output G(x)
   Scratch l_state, l_dout, l_hshift, d_lengths;
   std::vector<Scratch> s_u, s_h, s_c, s_xdrop;     // SRU per-layer stashes
   Scratch s_du, s_dx, s_dbias;
@@ -387,7 +390,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& s : e->g_act) s.release();
   for (auto& s : e->d_act) s.release();
-  for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out}) for (auto& s : *v) s.release();
+  for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
+  e->i2o_gout.release();
   e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->d_lengths.release();
   for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop}) for (auto& s : *v) s.release();
   e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
@@ -403,8 +407,9 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
 
 static long expected_params(const gt_model_desc& d) {
   long n = 0;
-  if (d.arch == GT_ARCH_LSTM) {
+  if (has_lstm_body(d.arch)) {
     const int H = d.hidden_dim, dirs = d.bidirectional ? 2 : 1;
+    if (d.arch == GT_ARCH_IN2OUT_RNN) n += (long)d.static_dim * d.static_dim + d.static_dim;
     for (int l = 0; l < d.num_hidden; ++l) {
       const int in = l == 0 ? d.in_dim : H * dirs;
       n += (long)dirs * (4L * H * in + 4L * H * H + 8L * H);
@@ -428,7 +433,7 @@ static long expected_params(const gt_model_desc& d) {
 
 extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) {
   if (!e || !desc || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
-  if (desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_IN2OUT && desc->arch != GT_ARCH_LSTM && desc->arch != GT_ARCH_SRU)
+  if (desc->arch < GT_ARCH_MLP || desc->arch > GT_ARCH_IN2OUT_RNN)
     return fail(GT_ERR_INVALID, "unsupported arch %d", desc->arch);
   if (desc->num_hidden < 1 || desc->num_hidden > 16) return fail(GT_ERR_INVALID, "num_hidden must be in [1,16]");
   if (desc->dropout < 0.f || desc->dropout >= 1.f) return fail(GT_ERR_INVALID, "dropout must be in [0,1)");
@@ -452,8 +457,13 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
   };
   n.lstm.clear();
   n.sru.clear();
-  if (desc->arch == GT_ARCH_LSTM) {
+  if (has_lstm_body(desc->arch)) {
     const int H = desc->hidden_dim, dirs = desc->bidirectional ? 2 : 1;
+    if (desc->arch == GT_ARCH_IN2OUT_RNN) {
+      if (desc->in_dim != desc->out_dim)
+        return fail(GT_ERR_DIM, "In2OutRNNHighwayNet returns its input as y_hat (models.py:118): in_dim must equal out_dim");
+      n.gate = take(desc->static_dim, desc->static_dim);
+    }
     auto adv = [&](float*& wp, float*& gp, long cnt) { wp = p; gp = g; p += cnt; if (g) g += cnt; };
     for (int l = 0; l < desc->num_hidden; ++l) {
       LstmLayerP L;
@@ -469,7 +479,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     }
     n.last = take(desc->out_dim, H * dirs);
     e->l_xproj.resize(desc->num_hidden); e->l_gates.resize(desc->num_hidden);
-    e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden);
+    e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden); e->l_outd.resize(desc->num_hidden);
   } else if (desc->arch == GT_ARCH_SRU) {
     if (desc->rnn_dropout < 0.f || desc->rnn_dropout >= 1.f) return fail(GT_ERR_INVALID, "rnn_dropout must be in [0,1)");
     const int ncols = desc->hidden_dim * (desc->bidirectional ? 2 : 1);
@@ -496,8 +506,8 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
   n.grads_dirty = false;
   auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
   acts.resize(desc->num_hidden);
-  if (role == GT_ROLE_G && desc->arch == GT_ARCH_IN2OUT) {
-    // single dynamic stream of width out_dim (models.py:66)
+  if (role == GT_ROLE_G && is_i2o(desc->arch)) {
+    // single dynamic stream of width out_dim (models.py:66,115)
     const int sd = desc->out_dim / e->cfg.num_windows;
     std::vector<int> sc(sd), ss(sd, sd);
     for (int c = 0; c < sd; ++c) sc[c] = c;
@@ -804,8 +814,6 @@ static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T
 static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];
   CHK(lstm_check_lengths(e, B, T));
-  if (G.training && G.d.dropout > 0.f && G.d.num_hidden > 1)
-    return fail(GT_ERR_INVALID, "nn.LSTM inter-layer dropout > 0 in training mode is not supported yet");
   const long N = (long)B * T;
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   const float* in = x;
@@ -822,6 +830,15 @@ static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat
     CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
     in = e->l_out[l].as<float>();
     ld_in = dirs * H;
+    if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {
+      // nn.LSTM(dropout=p): dropout on the outputs of every layer but the last (training only)
+      CHK(e->l_outd[l].ensure((size_t)N * dirs * H * sizeof(float)));
+      const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l, G.inj[0][l], dirs * H);
+      hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, in, e->l_outd[l].as<float>(), N,
+                         dirs * H, ds);
+      LAUNCH_CHECK();
+      in = e->l_outd[l].as<float>();
+    }
   }
   return linear_forward(in, ld_in, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in, G.last.out,
                         G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
@@ -845,7 +862,8 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
     const LstmLayerP& L = G.lstm[l];
     CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));     // dG overwrites l_xproj[l]
     const float* dG = e->l_xproj[l].as<float>();
-    const float* Xl = l == 0 ? x : e->l_out[l - 1].as<float>();
+    const bool dropped_in = l > 0 && G.training && G.d.dropout > 0.f;
+    const float* Xl = l == 0 ? x : (dropped_in ? e->l_outd[l - 1].as<float>() : e->l_out[l - 1].as<float>());
     const int ldx = l == 0 ? G.d.in_dim : dirs * H;
     for (int d = 0; d < dirs; ++d) {
       const float* dGd = dG + (size_t)d * 4 * H;
@@ -869,6 +887,11 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
         g.A = dG + (size_t)d * 4 * H; g.lda = dirs * 4 * H; g.B = L.d[d].Wih; g.ldb = L.in; g.C = dout_other; g.ldc = L.in;
         g.M = (int)N; g.N = L.in; g.K = 4 * H; g.act = ACT_NONE; g.accumulate = d > 0 ? 1 : 0; g.drop = no_drop();
         CHK(launch_gemm(GEMM_NN, g, 1, s));
+      }
+      if (dropped_in) {   // through the inter-layer dropout of layer l-1 (same Philox site as the forward)
+        const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l - 1, G.inj[0][l - 1], dirs * H);
+        hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, dout_other, dout_other, N, dirs * H, ds);
+        LAUNCH_CHECK();
       }
       std::swap(dout, dout_other);
     }
@@ -1012,8 +1035,17 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
   Net& G = e->net[GT_ROLE_G];
   const long N = (long)B * T;
   const int pass0[1] = {0};
+  const float* gsrc = y_hat;            // what MLPG is applied to
   if (G.d.arch == GT_ARCH_LSTM) {
     CHK(lstm_forward(e, x, B, T, y_hat, s));
+  } else if (G.d.arch == GT_ARCH_IN2OUT_RNN) {
+    // G(x) = hidden2out(LSTM(x)) stays internal; the model returns its INPUT as y_hat (models.py:118)
+    CHK(e->i2o_gout.ensure((size_t)N * G.d.out_dim * sizeof(float)));
+    CHK(lstm_forward(e, x, B, T, e->i2o_gout.as<float>(), s));
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * G.d.in_dim, 256)), dim3(256), 0, s, x, G.d.in_dim, 0, (const int*)nullptr,
+                       y_hat, G.d.in_dim, 0, (int)N, G.d.in_dim);
+    LAUNCH_CHECK();
+    gsrc = e->i2o_gout.as<float>();
   } else if (G.d.arch == GT_ARCH_SRU) {
     CHK(sru_forward(e, x, B, T, y_hat, s));
   } else {
@@ -1022,7 +1054,7 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
     CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
                        G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
   }
-  if (G.d.arch == GT_ARCH_IN2OUT) {
+  if (is_i2o(G.d.arch)) {
     if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
     const int sd = G.d.static_dim;
     CHK(ensure_band(e, R, T, s));
@@ -1030,7 +1062,7 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
     CHK(e->gx.ensure((size_t)N * sd * sizeof(float)));
     // T(x) = sigmoid(T x_static), x_static = x[:, :, :static_dim]   (models.py:57-60)
     CHK(linear_forward(x, G.d.in_dim, G.gate.W, sd, G.gate.b, e->tx.as<float>(), sd, N, sd, sd, ACT_SIGMOID, no_drop(), s));
-    CHK(mlpg_forward(e, y_hat, G.d.out_dim, e->d_scol_i2o, e->d_sstride_i2o, sd, e->gx.as<float>(), sd, B, T, s));
+    CHK(mlpg_forward(e, gsrc, G.d.out_dim, e->d_scol_i2o, e->d_sstride_i2o, sd, e->gx.as<float>(), sd, B, T, s));
     if (stash) e->g_used_mlpg = true;
     hipLaunchKernelGGL(highway_forward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, x, G.d.in_dim, e->tx.as<float>(), sd,
                        e->gx.as<float>(), sd, y_hat_static, sd, N, sd);
@@ -1268,8 +1300,9 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   CHK(e->gy.ensure((size_t)N * Do * sizeof(float)));
   float* gy = e->gy.as<float>();
   const float* gs = e->gs.as<float>();
-  if (G.d.arch == GT_ARCH_IN2OUT) {
+  if (is_i2o(G.d.arch)) {
     const int sd = G.d.static_dim;
+    if (G.d.arch == GT_ARCH_IN2OUT_RNN) mse_w = 0.f;   // y_hat is the input x there: the MSE term has no path into G
     CHK(e->dgx.ensure((size_t)N * sd * sizeof(float)));
     CHK(e->dtz.ensure((size_t)N * sd * sizeof(float)));
     hipLaunchKernelGGL(highway_backward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, gs, sd, e->tx.as<float>(), sd,
@@ -1287,8 +1320,8 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
     LAUNCH_CHECK();
   }
-  if (G.d.arch == GT_ARCH_LSTM || G.d.arch == GT_ARCH_SRU) {
-    CHK(G.d.arch == GT_ARCH_LSTM ? lstm_backward(e, x, gy, B, T, s) : sru_backward(e, x, gy, B, T, s));
+  if (has_lstm_body(G.d.arch) || G.d.arch == GT_ARCH_SRU) {
+    CHK(has_lstm_body(G.d.arch) ? lstm_backward(e, x, gy, B, T, s) : sru_backward(e, x, gy, B, T, s));
     G.grads_dirty = true;
     return GT_OK;
   }
@@ -1325,10 +1358,10 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (G.d.last_sigmoid) return fail(GT_ERR_INVALID, "training a generator with last_sigmoid=True is not supported");
   }
   const int Do = G.d.out_dim;
-  const int Ds = G.d.arch == GT_ARCH_IN2OUT ? G.d.static_dim : e->Ds;
+  const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
-  const bool direct = G.d.arch != GT_ARCH_IN2OUT && !e->g_used_mlpg;
+  const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
   if (!(tr && direct && mse_w != 0.f))
     CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s));
   // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
@@ -1426,7 +1459,7 @@ extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
   if (!G.bound || !G.d.grads || !e->g_pass_valid) return fail(GT_ERR_STATE, "no generator pass to back-propagate");
   hipStream_t s = (hipStream_t)stream;
   const long N = e->N;
-  const int Ds = G.d.arch == GT_ARCH_IN2OUT ? G.d.static_dim : e->Ds;
+  const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
   CHK(e->gs.ensure((size_t)N * Ds * sizeof(float)));
   HIPCHK(hipMemsetAsync(e->gs.p, 0, (size_t)N * Ds * sizeof(float), s));
   if (e->leak_pending) {
@@ -1457,7 +1490,7 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
   const long N = (long)B * T;
   e->step_counter++;
   std::vector<DropoutSpec> specs;
-  if (role == GT_ROLE_G && n.d.arch == GT_ARCH_IN2OUT) {
+  if (role == GT_ROLE_G && is_i2o(n.d.arch)) {
     if (!out2) return fail(GT_ERR_INVALID, "In2OutHighwayNet forward returns two tensors");
     e->g_pass_valid = false;
     return generator_forward(e, x, R, B, T, out, out2, false, s, specs);

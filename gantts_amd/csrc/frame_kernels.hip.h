@@ -711,6 +711,15 @@ __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
   }
 }
 
+// out[r][c] = in[r][c] * keep(r, c) / (1 - p)   (nn.LSTM inter-layer dropout and its backward; in == out allowed)
+__global__ void dropout_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, DropoutSpec d) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const long r = e / cols;
+  const int c = (int)(e - r * cols);
+  out[e] = dropout_keep(d, (int)r, c) ? in[e] * d.scale : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------
 // In2OutHighwayNet combine (reference gantts/models.py:57-69):
 //   y_hat_static = x_static + Tx * Gx      ;  backward: dGx = g*Tx, dTz = g*Gx*Tx*(1-Tx)

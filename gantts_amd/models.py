@@ -156,7 +156,7 @@ class _FlatNetwork(AbstractModel, nn.Module):
         """Parity hook: inject 0/1 keep-masks (one per hidden layer, shape (B,T,hidden)) for forward
         pass ``pass_index`` (G: 0; D: 0 real / 1 fake of the D step, 2 fake of the G step)."""
         for layer in range(self.num_hidden):
-            m = None if masks is None else masks[layer]
+            m = None if masks is None or layer >= len(masks) else masks[layer]
             if m is not None:
                 m = m.to(self._flat.device, torch.float32).contiguous()
             self._masks[(pass_index, layer)] = m
@@ -251,10 +251,48 @@ class LSTMRNN(_FlatNetwork):
         self._finish_init()
 
     def set_dropout_masks(self, pass_index, masks):
-        raise NotImplementedError("dropout mask injection is not available for recurrent generators")
+        """Parity hook for nn.LSTM's inter-layer dropout: ``masks[l]`` (B,T,H*dirs) 0/1 keep-mask on
+        the outputs of layer ``l`` (l < num_hidden-1); entries for the last layer are ignored."""
+        if pass_index != 0:
+            raise ValueError("recurrent generators have a single forward pass (index 0)")
+        for layer in range(self.num_hidden):
+            m = None if masks is None or layer >= len(masks) else masks[layer]
+            if m is not None:
+                m = m.to(self._flat.device, torch.float32).contiguous()
+            self._masks[(0, layer)] = m
+        self._version += 1
 
     def forward(self, sequence, lengths):
         return self._own_engine().model_forward(self, sequence, lengths=lengths)
+
+
+class In2OutRNNHighwayNet(LSTMRNN):
+    """Recurrent input-to-output highway network (reference gantts/models.py:72-118):
+    ``Tx = sigmoid(T(x_static))``, ``Gx = MLPG(R, hidden2out(LSTM(x, lengths)))`` and the model
+    returns ``(x, x_static + Tx * Gx)`` -- the first output is the INPUT itself (models.py:118), so
+    the MSE term of update_generator has no path into the weights.  state_dict keys ``T.*``,
+    ``lstm.*``, ``hidden2out.*``."""
+    ARCH = L.ARCH_IN2OUT_RNN
+
+    def __init__(self, in_dim=118, out_dim=118, static_dim=118 // 2,
+                 num_hidden=3, hidden_dim=512, bidirectional=False, dropout=0.5):
+        _FlatNetwork.__init__(self)
+        if in_dim != out_dim:
+            raise ValueError("In2OutRNNHighwayNet returns its input as y_hat: in_dim must equal out_dim")
+        self.in_dim, self.out_dim, self.num_hidden, self.hidden_dim = in_dim, out_dim, num_hidden, hidden_dim
+        self.static_dim = static_dim
+        self.num_direction = 2 if bidirectional else 1
+        self.dropout_p, self.last_sigmoid = dropout, False
+        self.T = _LinearParams(static_dim, static_dim)
+        self.lstm = _LSTMParams(in_dim, hidden_dim, num_hidden, bidirectional)
+        self.hidden2out = _LinearParams(out_dim, hidden_dim * self.num_direction)
+        self._finish_init()
+
+    def include_parameter_generation(self):
+        return True
+
+    def forward(self, x, R, lengths=None):
+        return self._own_engine().model_forward(self, x, R, lengths=lengths)
 
 
 class GRURNN(LSTMRNN):

@@ -42,6 +42,7 @@ extern "C" {
 #define GT_ARCH_IN2OUT 1      /* gantts/models.py:21-69  (In2OutHighwayNet) */
 #define GT_ARCH_LSTM 2        /* gantts/models.py:170-213 (LSTMRNN, GRURNN: nn.LSTM + hidden2out) */
 #define GT_ARCH_SRU 3         /* gantts/models.py:144-167 (SRURNN: third-party SRU cells + hidden2out) */
+#define GT_ARCH_IN2OUT_RNN 4  /* gantts/models.py:72-118 (In2OutRNNHighwayNet: T gate | lstm.* | hidden2out.*) */
 
 #define GT_OPT_ADAGRAD 0      /* torch.optim.Adagrad, train.py:796-799 with hparams.py:48-52,223-227 */
 #define GT_OPT_ADAM 1         /* torch.optim.Adam,    hparams.py:125-130 */

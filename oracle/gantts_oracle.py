@@ -322,10 +322,11 @@ class OracleLSTMRNN(object):
     state_dict = OracleMLP.state_dict
     load_state_dict = OracleMLP.load_state_dict
 
-    def forward(self, x, lengths=None, drop=None):
+    def _recurrent(self, x, lengths, drop, idx=0):
+        """nn.LSTM over the packed batch; returns the padded (B,T,H*dirs) outputs."""
         B, T, _ = x.shape
         lens = torch.as_tensor([int(v) for v in lengths]) if lengths is not None else torch.full((B,), T)
-        H, idx = self.H, 0
+        H = self.H
         inp = x
         for l in range(self.L):
             outs = []
@@ -347,8 +348,36 @@ class OracleLSTMRNN(object):
             if self.training and self.p > 0 and l + 1 < self.L:
                 drop = drop or _DropoutSource()
                 inp = inp * drop.next(inp, self.p) / (1.0 - self.p)
-        out = F.linear(inp, self.params[-2], self.params[-1])
+        return inp
+
+    def forward(self, x, lengths=None, drop=None):
+        out = F.linear(self._recurrent(x, lengths, drop), self.params[-2], self.params[-1])
         return torch.sigmoid(out) if self.last_sigmoid else out
+
+    __call__ = forward
+
+
+class OracleIn2OutRNNHighwayNet(OracleLSTMRNN):
+    """gantts/models.py:72-118.  keys: T.*, lstm.*, hidden2out.*.  Returns (x, x_static + T(x) *
+    MLPG(hidden2out(LSTM(x)))) -- the first output is the input itself (:118)."""
+
+    def __init__(self, in_dim=118, out_dim=118, static_dim=59, num_hidden=3, hidden_dim=512,
+                 bidirectional=False, dropout=0.5, seed=0):
+        OracleLSTMRNN.__init__(self, in_dim, out_dim, num_hidden, hidden_dim, bidirectional, dropout, False, seed)
+        gen = torch.Generator().manual_seed(seed + 7919)
+        self.static_dim = static_dim
+        W, b = linear_init(static_dim, static_dim, gen)
+        self.names = ["T.weight", "T.bias"] + self.names
+        self.params = [W.requires_grad_(True), b.requires_grad_(True)] + self.params
+
+    def include_parameter_generation(self):
+        return True
+
+    def forward(self, x, R, lengths=None, drop=None):
+        x_static = x[:, :, :self.static_dim]
+        Tx = torch.sigmoid(F.linear(x_static, self.params[0], self.params[1]))
+        out = F.linear(self._recurrent(x, lengths, drop, idx=2), self.params[-2], self.params[-1])
+        return x, x_static + Tx * unit_variance_mlpg(R, out)
 
     __call__ = forward
 

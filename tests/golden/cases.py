@@ -69,6 +69,19 @@ CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
         windows=3, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # VC recurrent highway generator (gantts/models.py:72-118): returns its input as y_hat, BiLSTM body
+    "vc_in2out_rnn": dict(
+        hp="vc", B=3, T=40, din=75, dout=75,
+        stream_sizes=[75], has_dynamic_features=[True],
+        adversarial_streams=[True], mask_nth_mgc=0, cond=False,
+        g=dict(kind="In2OutRNNHighwayNet", in_dim=75, out_dim=75, static_dim=25,
+               num_hidden=2, hidden_dim=24, bidirectional=True, dropout=0.5),
+        d=dict(kind="MLP", in_dim=25, out_dim=1, num_hidden=2, hidden_dim=32,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=0)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
+        windows=3, steps=3, adv_w=1.0, mse_w=1.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     # duration model: no dynamic features (R=None), Adam, conditioned D
     "duration_mlp": dict(
         hp="tts_duration", B=5, T=17, din=60, dout=5,
@@ -139,6 +152,32 @@ CASES = {
 # Cases with NO reference-generated fixture: the SRU cell is third-party code that is neither vendored in
 # the reference nor runnable here (CUDA-only), so these are checked HIP-vs-oracle only (parity unpinned).
 ORACLE_ONLY_CASES = {
+    # nn.LSTM inter-layer dropout (training mode) cannot be mask-injected into the real reference
+    # (it lives inside _VF.lstm): HIP vs oracle with injected masks; eval-mode parity is in CASES.
+    "acoustic_lstm_dropout": dict(
+        hp="tts_acoustic", B=4, T=18, din=22, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="LSTMRNN", in_dim=22, out_dim=187, num_hidden=3, hidden_dim=12,
+               bidirectional=True, dropout=0.3, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=80, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
+    "vc_in2out_rnn_dropout": dict(
+        hp="vc", B=3, T=33, din=75, dout=75,
+        stream_sizes=[75], has_dynamic_features=[True],
+        adversarial_streams=[True], mask_nth_mgc=0, cond=False,
+        g=dict(kind="In2OutRNNHighwayNet", in_dim=75, out_dim=75, static_dim=25,
+               num_hidden=3, hidden_dim=20, bidirectional=False, dropout=0.5),
+        d=dict(kind="MLP", in_dim=25, out_dim=1, num_hidden=2, hidden_dim=32,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
     # cfg4 family at reduced size: bidirectional SRU generator (default hparams generator), 3 dynamic streams
     "vc_sru_multistream": dict(
         hp="tts_acoustic", B=3, T=19, din=20, dout=183,
@@ -188,8 +227,10 @@ def param_shapes(spec):
                     ("H.%d.bias" % i, (spec["hidden_dim"],))]
         out += [("last_linear.weight", (spec["out_dim"], spec["hidden_dim"])),
                 ("last_linear.bias", (spec["out_dim"],))]
-    elif kind in ("LSTMRNN", "GRURNN"):
-        prefix = "lstm" if kind == "LSTMRNN" else "gru"
+    elif kind in ("LSTMRNN", "GRURNN", "In2OutRNNHighwayNet"):
+        prefix = "gru" if kind == "GRURNN" else "lstm"
+        if kind == "In2OutRNNHighwayNet":
+            out += [("T.weight", (spec["static_dim"],) * 2), ("T.bias", (spec["static_dim"],))]
         H, dirs = spec["hidden_dim"], 2 if spec["bidirectional"] else 1
         for l in range(spec["num_hidden"]):
             n_in = spec["in_dim"] if l == 0 else H * dirs
@@ -254,6 +295,9 @@ def make_batch(case, seed=1234):
 
 
 def hidden_sites(spec):
+    """Widths of the dropout sites of one forward pass."""
+    if spec["kind"] in ("LSTMRNN", "GRURNN", "In2OutRNNHighwayNet"):   # nn.LSTM: between layers only
+        return [spec["hidden_dim"] * (2 if spec["bidirectional"] else 1)] * (spec["num_hidden"] - 1)
     return [spec["hidden_dim"]] * spec["num_hidden"]
 
 

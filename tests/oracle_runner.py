@@ -9,7 +9,8 @@ import gantts_oracle as O
 def build_oracle_model(spec, seed):
     kw = {k: v for k, v in spec.items() if k != "kind"}
     cls = {"MLP": O.OracleMLP, "In2OutHighwayNet": O.OracleIn2OutHighwayNet,
-           "LSTMRNN": O.OracleLSTMRNN, "GRURNN": O.OracleLSTMRNN, "SRURNN": O.OracleSRURNN}[spec["kind"]]
+           "LSTMRNN": O.OracleLSTMRNN, "GRURNN": O.OracleLSTMRNN, "SRURNN": O.OracleSRURNN,
+           "In2OutRNNHighwayNet": O.OracleIn2OutRNNHighwayNet}[spec["kind"]]
     if spec["kind"] == "GRURNN":
         kw["prefix"] = "gru"
     m = cls(**kw)

@@ -440,9 +440,10 @@ def test_lstmrnn_forward_matches_oracle_unsorted_lengths(B, T, din, H, L, bi):
 
 
 @pytest.mark.parametrize("name", sorted(C.ORACLE_ONLY_CASES))
-def test_sru_step_matches_oracle(name):
-    """SRURNN generator: full G+D steps against the CPU oracle (no reference-generated fixture exists:
-    the SRU cell is un-vendored third-party CUDA code -> parity unpinned)."""
+def test_oracle_only_step_matches_oracle(name):
+    """Full G+D steps against the CPU oracle where no reference-generated fixture can exist: SRURNN
+    (un-vendored third-party CUDA cell -> parity unpinned) and nn.LSTM inter-layer
+    dropout in training mode (masks cannot be injected into _VF.lstm; eval mode is pinned in CASES)."""
     from hip_runner import run_hip_case
     from oracle_runner import run_oracle_case
     case = C.ORACLE_ONLY_CASES[name]
