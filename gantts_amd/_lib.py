@@ -57,6 +57,11 @@ class GResult(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> (restype, argtypes); every symbol declared in include/gantts_hip.h
+class DistortionSums(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("s_mcd", "s_bap", "s_f0", "n_voiced", "n_vuv_err", "s_mse", "n_frames")]
+
+
 SIGNATURES = {
     "gt_last_error": (C.c_char_p, []),
     "gt_version": (C.c_char_p, []),
@@ -84,6 +89,8 @@ SIGNATURES = {
     "gt_flush_generator_grads": (_I, [_P, _P]),
     "gt_op_sequence_mask": (_I, [_P, _I, _I, _P, _P]),
     "gt_op_masked_mse": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(_F), _P, _P]),
+    "gt_compute_distortions": (_I, [_P, _P, _I, _P, _P, _I, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_L), _I, _I,
+                                    C.POINTER(DistortionSums), _P]),
     "gt_op_gather_cols": (_I, [_P, _I, _P, _I, _P, _I, _I, _L, _P]),
     "gt_op_mlpg_forward": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "gt_op_mlpg_backward": (_I, [_P, _P, _P, _I, _I, _P, _P]),

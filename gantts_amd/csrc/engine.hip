@@ -1542,6 +1542,55 @@ extern "C" int gt_op_masked_mse(const float* input, const float* target, const f
   return GT_OK;
 }
 
+extern "C" int gt_compute_distortions(const float* y_static, const float* y_hat_static, int Ds, const void* stat_mean,
+                                      const void* stat_std, int stats_f64, const int32_t* col_stat_host,
+                                      const int32_t* col_role_host, int vuv_col, const int64_t* lengths_host, int B, int T,
+                                      gt_distortion_sums* out, void* stream) {
+  if (!y_static || !y_hat_static || !stat_mean || !stat_std || !col_stat_host || !col_role_host || !out)
+    return fail(GT_ERR_INVALID, "null argument");
+  if (Ds < 1 || B < 1 || T < 1 || vuv_col >= Ds) return fail(GT_ERR_DIM, "bad sizes: Ds=%d B=%d T=%d vuv_col=%d", Ds, B, T, vuv_col);
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  const int nblk = (int)std::min<long>(1024, cdiv(N, 4));
+  std::vector<int> host(2 * Ds + B);
+  for (int c = 0; c < Ds; ++c) {
+    if (col_stat_host[c] < 0) return fail(GT_ERR_INVALID, "negative statistics index");
+    host[c] = col_stat_host[c];
+    host[Ds + c] = col_role_host[c];
+  }
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = lengths_host ? lengths_host[b] : T;
+    if (n < 0 || n > T) return fail(GT_ERR_INVALID, "length %lld outside [0, T=%d]", (long long)n, T);
+    host[2 * Ds + b] = (int)n;
+  }
+  void* ws = nullptr;
+  const size_t off_part = ((host.size() * sizeof(int) + 255) / 256) * 256;
+  const size_t off_out = off_part + (size_t)nblk * DIST_NSUM * sizeof(double);
+  HIPCHK(hipMalloc(&ws, off_out + DIST_NSUM * sizeof(double)));
+  int* d_int = (int*)ws;
+  double* part = (double*)((char*)ws + off_part);
+  double* d_out = (double*)((char*)ws + off_out);
+  hipError_t err = hipMemcpyAsync(d_int, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) {
+    if (stats_f64)
+      hipLaunchKernelGGL(distortion_kernel<double>, dim3(nblk), dim3(256), 0, s, y_static, y_hat_static, Ds, (const double*)stat_mean,
+                         (const double*)stat_std, d_int, d_int + Ds, vuv_col, d_int + 2 * Ds, B, T, part);
+    else
+      hipLaunchKernelGGL(distortion_kernel<float>, dim3(nblk), dim3(256), 0, s, y_static, y_hat_static, Ds, (const float*)stat_mean,
+                         (const float*)stat_std, d_int, d_int + Ds, vuv_col, d_int + 2 * Ds, B, T, part);
+    hipLaunchKernelGGL(distortion_finalize_kernel, dim3(1), dim3(64 * DIST_NSUM), 0, s, part, nblk, d_out);
+    err = hipGetLastError();
+  }
+  double h[DIST_NSUM];
+  if (err == hipSuccess) err = hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);   // also keeps `host` alive until the H2D is done
+  (void)hipFree(ws);
+  if (err != hipSuccess) return fail(GT_ERR_HIP, "compute_distortions: %s", hipGetErrorString(err));
+  out->s_mcd = h[0]; out->s_bap = h[1]; out->s_f0 = h[2]; out->n_voiced = h[3];
+  out->n_vuv_err = h[4]; out->s_mse = h[5]; out->n_frames = h[6];
+  return GT_OK;
+}
+
 extern "C" int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,
                                  int out_col_offset, int64_t rows, void* stream) {
   if (!in || !out || n_idx < 0 || rows < 0) return fail(GT_ERR_INVALID, "bad argument");

@@ -721,6 +721,89 @@ __global__ void dropout_apply_kernel(const float* __restrict__ in, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// Distortion metrics of the training loop (reference train.py:358-432: inv_scale + split_streams +
+// nnmnkwii.metrics.{melcd, lf0_mean_squared_error, vuv_error, mean_squared_error}) as ONE masked
+// reduction over the valid frames of (y_static, y_hat_static): 2*Ds*4 B/frame of HBM reads, nothing
+// written but 7 doubles.  One wave per frame, lanes <-> columns.  Column roles and the index of each
+// column's statistics (static+dynamic domain, train.py:361-372) come from the host.
+//   S = arithmetic type of the inverse scaling (float for f32 statistics, double for f64 ones: torch
+//   promotes f32 features * 1-D f64 statistics to f64).  The vuv column is always f32: its statistics
+//   are 0-dim tensors (train.py:373), which do not promote.  mul and add are rounded separately
+//   (no fma contraction) so that the vuv > 0.5 binarisation is bit-exact.
+// ---------------------------------------------------------------------------------------
+enum DistRole { DIST_MCD = 0, DIST_BAP = 1, DIST_LF0 = 2, DIST_VUV = 3, DIST_MSE = 4 };
+constexpr int DIST_NSUM = 7;   // s_mcd, s_bap, s_f0, n_voiced, n_vuv_err, s_mse, n_frames
+
+__device__ __forceinline__ float inv_scale_rn(float x, float s, float m) { return __fadd_rn(__fmul_rn(x, s), m); }
+__device__ __forceinline__ double inv_scale_rn(double x, double s, double m) { return __dadd_rn(__dmul_rn(x, s), m); }
+__device__ __forceinline__ float dist_exp(float v) { return expf(v); }
+__device__ __forceinline__ double dist_exp(double v) { return exp(v); }
+
+template <typename S>
+__global__ __launch_bounds__(256) void distortion_kernel(const float* __restrict__ y, const float* __restrict__ yh, int Ds,
+                                                         const S* __restrict__ mean, const S* __restrict__ stdv,
+                                                         const int* __restrict__ col_stat, const int* __restrict__ col_role,
+                                                         int vuv_col, const int* __restrict__ lengths, int B, int T,
+                                                         double* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const long N = (long)B * T;
+  double acc[DIST_NSUM];
+#pragma unroll
+  for (int i = 0; i < DIST_NSUM; ++i) acc[i] = 0.0;
+  float vs = 0.f, vm = 0.f;
+  if (vuv_col >= 0) { vs = (float)stdv[col_stat[vuv_col]]; vm = (float)mean[col_stat[vuv_col]]; }
+  for (long f = (long)blockIdx.x * nwave + wave; f < N; f += (long)gridDim.x * nwave) {
+    const int b = (int)(f / T), t = (int)(f - (long)b * T);
+    if (t >= lengths[b]) continue;                       // wave-uniform
+    const float* yr = y + f * Ds;
+    const float* hr = yh + f * Ds;
+    bool va = false, vb = false;
+    if (vuv_col >= 0) {
+      va = inv_scale_rn(yr[vuv_col], vs, vm) > 0.5f;     // train.py:375-377
+      vb = inv_scale_rn(hr[vuv_col], vs, vm) > 0.5f;
+    }
+    double q_mcd = 0.0, q_bap = 0.0, q_f0 = 0.0, q_mse = 0.0;
+    for (int c = lane; c < Ds; c += 64) {
+      const int role = col_role[c];
+      if (role < 0 || role == DIST_VUV) continue;
+      const int si = col_stat[c];
+      S a = inv_scale_rn((S)yr[c], stdv[si], mean[si]);
+      S h = inv_scale_rn((S)hr[c], stdv[si], mean[si]);
+      if (role == DIST_LF0) {
+        if (!(va && vb)) continue;
+        a = dist_exp(a); h = dist_exp(h);                // linear_domain=True (train.py:407)
+      }
+      const S z = a - h;
+      const double zz = (double)(z * z);
+      if (role == DIST_MCD) q_mcd += zz; else if (role == DIST_BAP) q_bap += zz;
+      else if (role == DIST_LF0) q_f0 += zz; else q_mse += zz;
+    }
+    q_mcd = wave_sum_d(q_mcd); q_bap = wave_sum_d(q_bap); q_f0 = wave_sum_d(q_f0); q_mse = wave_sum_d(q_mse);
+    acc[0] += sqrt(q_mcd); acc[1] += sqrt(q_bap); acc[2] += q_f0;
+    acc[3] += (va && vb) ? 1.0 : 0.0; acc[4] += (va != vb) ? 1.0 : 0.0;
+    acc[5] += q_mse; acc[6] += 1.0;
+  }
+  __shared__ double sh[4][DIST_NSUM];
+  if (lane == 0)
+    for (int i = 0; i < DIST_NSUM; ++i) sh[wave][i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < DIST_NSUM) {
+    double r = 0.0;
+    for (int w = 0; w < nwave; ++w) r += sh[w][threadIdx.x];
+    partials[(long)blockIdx.x * DIST_NSUM + threadIdx.x] = r;
+  }
+}
+
+// out[i] = sum over blocks of partials[blk][i], fixed order; grid 1 x 64*DIST_NSUM threads (one wave per sum)
+__global__ void distortion_finalize_kernel(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;
+  double r = 0.0;
+  for (int k = lane; k < nblk; k += 64) r += partials[(long)k * DIST_NSUM + i];
+  r = wave_sum_d(r);
+  if (lane == 0) out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------
 // In2OutHighwayNet combine (reference gantts/models.py:57-69):
 //   y_hat_static = x_static + Tx * Gx      ;  backward: dGx = g*Tx, dTz = g*Gx*Tx*(1-Tx)
 // ---------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ by ``apply_generator`` remember their engine, so ``update_discriminator`` can ke
 d loss_d / d y_hat_static (which the reference leaks into G's .grad, train.py:265,274) for the
 following ``update_generator``.
 """
+import math
 from os.path import join
 
 import torch
@@ -68,6 +69,121 @@ def update_generator(model_g, model_d, optimizer_g,
     eng = _engine_of(y_hat_static, model_g)
     return eng.update_generator(model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
                                 adv_w, mask, phase, mse_w, mge_w, eps)
+
+
+# ---- distortion metrics of the training loop (train.py:358-432) --------------------------------
+_LOGDB_CONST = 10.0 / math.log(10.0) * math.sqrt(2.0)      # nnmnkwii.metrics.melcd
+ROLE_MCD, ROLE_BAP, ROLE_LF0, ROLE_VUV, ROLE_MSE, ROLE_NONE = 0, 1, 2, 3, 4, -1
+
+
+def _acoustic_columns():
+    """Per static column of the acoustic layout: (role, index of its statistics).  The statistics
+    are indexed in the static+dynamic domain: mgc at 0, lf0 at mgc_dim, vuv after lf0, bap after
+    vuv, each for the first ``dim // num_windows`` entries of its stream (train.py:358-372)."""
+    mgc_dim, lf0_dim, vuv_dim, bap_dim = hp.stream_sizes
+    nw = len(hp.windows)
+    smgc, slf0, svuv, sbap = [int(v) for v in
+                              get_static_stream_sizes(hp.stream_sizes, hp.has_dynamic_features, nw)]
+    lf0_0, vuv_0, bap_0 = mgc_dim, mgc_dim + lf0_dim, mgc_dim + lf0_dim + vuv_dim
+    if mgc_dim // nw != smgc or lf0_dim // nw != slf0 or bap_dim // nw != sbap:
+        # the reference's broadcast of Y_mean[:dim // len(windows)] against the static slice fails here too
+        raise RuntimeError("stream statistics do not match the static stream sizes")
+    roles, stats = [], []
+    for j in range(smgc):                       # "mcd" skips the 0-th (energy) coefficient: mgc[:, :, 1:]
+        roles.append(ROLE_NONE if j == 0 else ROLE_MCD)
+        stats.append(j)
+    for j in range(slf0):
+        roles.append(ROLE_LF0)
+        stats.append(lf0_0 + j)
+    roles.append(ROLE_VUV)                      # vuv = y_static[:, :, vuv_start_idx]: ONE column
+    stats.append(vuv_0)
+    for j in range(svuv - 1):                   # never read by the reference
+        roles.append(ROLE_NONE)
+        stats.append(vuv_0)
+    nbap = smgc + slf0 + svuv
+    for j in range(sbap):
+        roles.append(ROLE_BAP)
+        stats.append(bap_0 + j)
+    return roles, stats, smgc + slf0, nbap
+
+
+def _distortion_sums(y_static, y_hat_static, Y_data_mean, Y_data_std, roles, stats, vuv_col, lengths):
+    from . import _lib as L
+    import ctypes as C
+    if y_static.dim() == 2:
+        y_static, y_hat_static = y_static.unsqueeze(0), y_hat_static.unsqueeze(0)
+    y = y_static.detach().to(torch.float32).contiguous()
+    yh = y_hat_static.detach().to(torch.float32).contiguous()
+    if not (y.is_cuda and yh.is_cuda):
+        raise RuntimeError("gantts_amd: compute_distortions needs CUDA(HIP) tensors (the HIP engine has no CPU path)")
+    if y.shape != yh.shape or y.size(-1) != len(roles):
+        raise RuntimeError("You probably have specified wrong dimention params.")
+    B, T, Ds = y.shape
+    f64 = Y_data_mean.dtype == torch.float64 or Y_data_std.dtype == torch.float64
+    dt = torch.float64 if f64 else torch.float32
+    mean = Y_data_mean.detach().to(y.device, dt).contiguous().view(-1)
+    std = Y_data_std.detach().to(y.device, dt).contiguous().view(-1)
+    if max(stats) >= mean.numel() or mean.numel() != std.numel():
+        raise RuntimeError("Y_data_mean / Y_data_std are shorter than the feature layout")
+    lens = None
+    if lengths is not None:
+        vals = [int(v) for v in (lengths.detach().cpu().view(-1).tolist() if isinstance(lengths, torch.Tensor) else lengths)]
+        if len(vals) != B:
+            raise RuntimeError("lengths has %d entries for a batch of %d sequences" % (len(vals), B))
+        lens = (C.c_int64 * B)(*vals)
+    out = L.DistortionSums()
+    L.check(L.lib.gt_compute_distortions(L.ptr(y), L.ptr(yh), Ds, L.ptr(mean), L.ptr(std), int(f64),
+                                         (C.c_int * Ds)(*stats), (C.c_int * Ds)(*roles), vuv_col, lens, B, T,
+                                         C.byref(out), L.current_stream()))
+    return out
+
+
+def inv_scale(mgc, lf0, vuv, bap, Y_mean, Y_std, binalize_vuv=True):
+    """train.py:358-380 on device tensors (plain torch indexing; used by the evaluation scripts --
+    the per-step metric path is the fused kernel behind ``compute_distortions``)."""
+    mgc_dim, lf0_dim, vuv_dim, bap_dim = hp.stream_sizes
+    nw = len(hp.windows)
+    lf0_0, vuv_0, bap_0 = mgc_dim, mgc_dim + lf0_dim, mgc_dim + lf0_dim + vuv_dim
+    mgc = mgc * Y_std[:mgc_dim // nw] + Y_mean[:mgc_dim // nw]
+    lf0 = lf0 * Y_std[lf0_0:lf0_0 + lf0_dim // nw] + Y_mean[lf0_0:lf0_0 + lf0_dim // nw]
+    bap = bap * Y_std[bap_0:bap_0 + bap_dim // nw] + Y_mean[bap_0:bap_0 + bap_dim // nw]
+    vuv = vuv * Y_std[vuv_0] + Y_mean[vuv_0]
+    if binalize_vuv:
+        vuv = (vuv > 0.5).long()
+    return mgc, lf0, vuv, bap
+
+
+def split_streams(y_static, Y_data_mean, Y_data_std):
+    """train.py:383-396"""
+    smgc, slf0, svuv, sbap = [int(v) for v in
+                              get_static_stream_sizes(hp.stream_sizes, hp.has_dynamic_features, len(hp.windows))]
+    lf0_0, vuv_0, bap_0 = smgc, smgc + slf0, smgc + slf0 + svuv
+    return inv_scale(y_static[:, :, :lf0_0], y_static[:, :, lf0_0:vuv_0], y_static[:, :, vuv_0],
+                     y_static[:, :, bap_0:], Y_data_mean, Y_data_std)
+
+
+def compute_distortions(y_static, y_hat_static, Y_data_mean, Y_data_std, lengths=None):
+    """train.py:399-432: {"mcd", "bap_mcd", "f0_rmse", "vuv_err"} (acoustic), {"dur_rmse"} (duration) or
+    {"mcd"} (vc), from ONE fused masked reduction on the device and one D2H of 7 doubles instead of
+    the reference's per-sequence python loops."""
+    Ds = y_static.size(-1)
+    if hp.name == "acoustic":
+        roles, stats, vuv_col, _ = _acoustic_columns()
+        r = _distortion_sums(y_static, y_hat_static, Y_data_mean, Y_data_std, roles, stats, vuv_col, lengths)
+        f0_mse = r.s_f0 / r.n_voiced if r.n_voiced > 0 else float("nan")     # ZeroDivisionError -> nan (:408-409)
+        return {"mcd": _LOGDB_CONST * r.s_mcd / r.n_frames,
+                "bap_mcd": _LOGDB_CONST * r.s_bap / r.n_frames / 10.0,
+                "f0_rmse": math.sqrt(f0_mse) if f0_mse == f0_mse else float("nan"),
+                "vuv_err": r.n_vuv_err / r.n_frames}
+    if hp.name == "duration":
+        r = _distortion_sums(y_static, y_hat_static, Y_data_mean, Y_data_std, [ROLE_MSE] * Ds, list(range(Ds)), -1, lengths)
+        return {"dur_rmse": math.sqrt(r.s_mse / (r.n_frames * Ds))}
+    if hp.name == "vc":
+        if Ds != hp.order:
+            raise RuntimeError("vc distortion expects static_dim == hp.order (train.py:423)")
+        r = _distortion_sums(y_static, y_hat_static, Y_data_mean, Y_data_std, [ROLE_MCD] * Ds, list(range(Ds)), -1, lengths)
+        return {"mcd": _LOGDB_CONST * r.s_mcd / r.n_frames}
+    assert False
 
 
 def exp_lr_scheduler(optimizer, epoch, nepoch, init_lr=0.0001, lr_decay_epoch=100):

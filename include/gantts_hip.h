@@ -203,6 +203,25 @@ int gt_op_masked_mse(const float* input, const float* target, const float* mask,
  * gantts/multistream.py:33-79, train.py:232-242); idx int32 device array */
 int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,
                       int out_col_offset, int64_t rows, void* stream);
+/* compute_distortions(y_static, y_hat_static, Y_data_mean, Y_data_std, lengths)  (train.py:399-432, with
+ * split_streams / inv_scale :358-396 and nnmnkwii.metrics underneath) as one masked reduction over the valid
+ * frames.  col_role[c] (host, Ds entries): 0 mel-cepstrum column of "mcd", 1 column of "bap_mcd", 2 lf0,
+ * 3 vuv, 4 plain squared error ("dur_rmse"), -1 ignored; col_stat[c] (host): index of column c's
+ * statistics inside stat_mean / stat_std (device; float, or double when stats_f64).  vuv_col = -1 if none.
+ * lengths_host may be NULL (every sequence has T frames).  The caller forms the reference's ratios. */
+typedef struct gt_distortion_sums {
+  double s_mcd;      /* sum over valid frames of ||mgc - mgc_hat||_2 (inverse-scaled)            */
+  double s_bap;      /* same for the bap columns                                                 */
+  double s_f0;       /* sum of (exp(lf0) - exp(lf0_hat))^2 over frames voiced in both            */
+  double n_voiced;   /* frames voiced in both (vuv binarised with > 0.5, train.py:375-377)        */
+  double n_vuv_err;  /* frames whose binary vuv decisions differ                                 */
+  double s_mse;      /* sum of squared errors of the role-4 columns                              */
+  double n_frames;   /* valid frames                                                              */
+} gt_distortion_sums;
+int gt_compute_distortions(const float* y_static, const float* y_hat_static, int Ds, const void* stat_mean,
+                           const void* stat_std, int stats_f64, const int32_t* col_stat_host,
+                           const int32_t* col_role_host, int vuv_col, const int64_t* lengths_host, int B, int T,
+                           gt_distortion_sums* out, void* stream);
 /* multi_stream_mlpg(inputs, R, stream_sizes, has_dynamic_features) (gantts/multistream.py:82-123) and its
  * transpose (autograd backward).  Uses the engine's stream config. */
 int gt_op_mlpg_forward(gt_engine* e, const float* y, const float* R, int B, int T, float* y_static, void* stream);

@@ -636,3 +636,119 @@ def train_step(cfg, model_g, model_d, opt_g, opt_d, x, y, R, lengths, mask,
                                     y_hat_static, adv_w, lengths, mask, phase,
                                     mse_w=mse_w, mge_w=mge_w, drop=drop_d)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Distortion metrics of the training loop (reference train.py:358-432).
+#
+# The four metric functions live in the THIRD-PARTY, un-vendored nnmnkwii (>= 0.0.14 per reference
+# setup.py:58-68; `from nnmnkwii import metrics`, train.py:51): restated here from that package's
+# published definitions -> **parity unpinned** for their numeric conventions (no reference test or
+# fixture touches them).  The stream split / inverse scaling / vuv binarisation around them IS
+# reference code (train.py:358-396) and is pinned through tests/golden/distortions.npz, generated by
+# the real train.compute_distortions with these metric restatements plugged in as the nnmnkwii stub.
+# ---------------------------------------------------------------------------------------------
+_LOGDB_CONST = 10.0 / math.log(10.0) * math.sqrt(2.0)
+
+
+def _len_list(lengths, B, T):
+    if lengths is None:
+        return [T] * B
+    if isinstance(lengths, torch.Tensor):
+        return [int(v) for v in lengths.view(-1).tolist()]
+    return [int(v) for v in lengths]
+
+
+def melcd(X, Y, lengths=None):
+    """nnmnkwii.metrics.melcd: (10/ln10)*sqrt(2) * mean over valid frames of ||x_t - y_t||_2."""
+    if X.dim() == 2:
+        X, Y = X.unsqueeze(-1), Y.unsqueeze(-1)
+    s, Tn = 0.0, 0
+    for x, y, n in zip(X, Y, _len_list(lengths, X.size(0), X.size(1))):
+        z = x[:n] - y[:n]
+        s += float(torch.sqrt((z * z).sum(-1)).sum())
+        Tn += n
+    return _LOGDB_CONST * s / float(Tn)
+
+
+def mean_squared_error(X, Y, lengths=None):
+    """nnmnkwii.metrics.mean_squared_error: sum of squared errors over valid frames / (frames * D).
+    (The reference takes sqrt() of it for "dur_rmse", train.py:420.)"""
+    s, Tn = 0.0, 0
+    for x, y, n in zip(X, Y, _len_list(lengths, X.size(0), X.size(1))):
+        z = x[:n] - y[:n]
+        s += float((z * z).sum())
+        Tn += n
+    return s / float(Tn * X.shape[-1])
+
+
+def lf0_mean_squared_error(src_f0, src_vuv, tgt_f0, tgt_vuv, lengths=None, linear_domain=False):
+    """nnmnkwii.metrics.lf0_mean_squared_error: MSE over frames voiced in BOTH; ZeroDivisionError if none."""
+    s, Tn = 0.0, 0
+    for x, xv, y, yv, n in zip(src_f0, src_vuv, tgt_f0, tgt_vuv, _len_list(lengths, src_f0.size(0), src_f0.size(1))):
+        voiced = (xv[:n] + yv[:n]) >= 2
+        Tn += int(voiced.sum())
+        x, y = x[:n][voiced], y[:n][voiced]
+        if linear_domain:
+            x, y = torch.exp(x), torch.exp(y)
+        z = x - y
+        s += float((z * z).sum())
+    return float(s) / float(Tn)      # python float division: ZeroDivisionError when nothing is voiced
+
+
+def vuv_error(src_vuv, tgt_vuv, lengths=None):
+    """nnmnkwii.metrics.vuv_error: fraction of valid frames whose binary decisions differ."""
+    s, Tn = 0, 0
+    for x, y, n in zip(src_vuv, tgt_vuv, _len_list(lengths, src_vuv.size(0), src_vuv.size(1))):
+        s += int((x[:n] != y[:n]).sum())
+        Tn += n
+    return float(s) / float(Tn)
+
+
+def _inv_scale(x, m, s):
+    return x * s + m      # nnmnkwii.preprocessing.inv_scale
+
+
+def split_streams(cfg, y_static, Y_mean, Y_std):
+    """train.py:358-396 (inv_scale + split_streams).  Statistics are indexed in the static+dynamic
+    domain (lf0 at mgc_dim, vuv after lf0, bap after vuv), the features in the static domain;
+    vuv is binarised (> 0.5 -> 1, else 0) to int64."""
+    mgc_dim, lf0_dim, vuv_dim, bap_dim = cfg.stream_sizes
+    nw = cfg.num_windows
+    lf0_0 = mgc_dim
+    vuv_0 = lf0_0 + lf0_dim
+    bap_0 = vuv_0 + vuv_dim
+    smgc, slf0, svuv, sbap = get_static_stream_sizes(cfg.stream_sizes, cfg.has_dynamic_features, nw)
+    mgc = y_static[:, :, :smgc]
+    lf0 = y_static[:, :, smgc:smgc + slf0]
+    vuv = y_static[:, :, smgc + slf0]
+    bap = y_static[:, :, smgc + slf0 + svuv:]
+    mgc = _inv_scale(mgc, Y_mean[:mgc_dim // nw], Y_std[:mgc_dim // nw])
+    lf0 = _inv_scale(lf0, Y_mean[lf0_0:lf0_0 + lf0_dim // nw], Y_std[lf0_0:lf0_0 + lf0_dim // nw])
+    bap = _inv_scale(bap, Y_mean[bap_0:bap_0 + bap_dim // nw], Y_std[bap_0:bap_0 + bap_dim // nw])
+    vuv = _inv_scale(vuv, Y_mean[vuv_0], Y_std[vuv_0])
+    vuv = (vuv > 0.5).long()
+    return mgc, lf0, vuv, bap
+
+
+def compute_distortions(cfg, name, y_static, y_hat_static, Y_mean, Y_std, lengths=None):
+    """train.py:399-432.  name = hp.name ("acoustic" | "duration" | "vc")."""
+    if name == "acoustic":
+        mgc, lf0, vuv, bap = split_streams(cfg, y_static, Y_mean, Y_std)
+        mgc_h, lf0_h, vuv_h, bap_h = split_streams(cfg, y_hat_static, Y_mean, Y_std)
+        try:
+            f0_mse = lf0_mean_squared_error(lf0, vuv, lf0_h, vuv_h, lengths=lengths, linear_domain=True)
+        except ZeroDivisionError:
+            f0_mse = float("nan")
+        return {"mcd": melcd(mgc[:, :, 1:], mgc_h[:, :, 1:], lengths=lengths),
+                "bap_mcd": melcd(bap, bap_h, lengths=lengths) / 10.0,
+                "f0_rmse": float(np.sqrt(f0_mse)),
+                "vuv_err": vuv_error(vuv, vuv_h, lengths=lengths)}
+    if name == "duration":
+        a, b = _inv_scale(y_static, Y_mean, Y_std), _inv_scale(y_hat_static, Y_mean, Y_std)
+        return {"dur_rmse": math.sqrt(mean_squared_error(a, b, lengths=lengths))}
+    if name == "vc":
+        sd = y_static.size(-1)      # == hp.order (train.py:423)
+        a, b = _inv_scale(y_static, Y_mean[:sd], Y_std[:sd]), _inv_scale(y_hat_static, Y_mean[:sd], Y_std[:sd])
+        return {"mcd": melcd(a, b, lengths=lengths)}
+    raise AssertionError(name)

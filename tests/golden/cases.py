@@ -315,3 +315,52 @@ def make_dropout_masks(case, step, seed=99):
     g = draw(case["g"])
     d = draw(case["d"]) + draw(case["d"]) + draw(case["d"])
     return g, d
+
+
+# ---------------------------------------------------------------------------------------------
+# Distortion metrics (reference train.py:358-432): inputs for tests/golden/distortions.npz
+# ---------------------------------------------------------------------------------------------
+DISTORTION_CASES = {
+    "acoustic_f32": dict(name="acoustic", hp="tts_acoustic", B=4, T=37, stream_sizes=[180, 3, 1, 3],
+                         has_dynamic_features=[True, True, False, True], windows=3, stats="float32", voiced=True),
+    "acoustic_f64": dict(name="acoustic", hp="tts_acoustic", B=3, T=29, stream_sizes=[180, 3, 1, 3],
+                         has_dynamic_features=[True, True, False, True], windows=3, stats="float64", voiced=True),
+    "acoustic_unvoiced": dict(name="acoustic", hp="tts_acoustic", B=2, T=16, stream_sizes=[180, 3, 1, 3],
+                              has_dynamic_features=[True, True, False, True], windows=3, stats="float32", voiced=False),
+    "acoustic_small_streams": dict(name="acoustic", hp="tts_acoustic", B=3, T=23, stream_sizes=[30, 3, 1, 15],
+                                   has_dynamic_features=[True, True, False, True], windows=3, stats="float32", voiced=True),
+    "duration": dict(name="duration", hp="tts_duration", B=5, T=21, stream_sizes=[5],
+                     has_dynamic_features=[False], windows=1, stats="float32", voiced=True),
+    "vc": dict(name="vc", hp="vc", B=3, T=41, stream_sizes=[75], has_dynamic_features=[True],
+               windows=3, stats="float64", voiced=True),
+}
+
+
+def static_sizes(case):
+    nw = case["windows"]
+    return [s // nw if d else s for s, d in zip(case["stream_sizes"], case["has_dynamic_features"])]
+
+
+def make_distortion_inputs(case, seed=4321):
+    """(y_static, y_hat_static, Y_mean, Y_std, lengths): normalised features, statistics in the
+    static+dynamic domain; the vuv column inverse-scales to values scattered around 0.5."""
+    rs = np.random.RandomState(seed)
+    B, T = case["B"], case["T"]
+    Ds, D = sum(static_sizes(case)), sum(case["stream_sizes"])
+    y = rs.randn(B, T, Ds).astype(np.float32)
+    yh = (y + 0.4 * rs.randn(B, T, Ds)).astype(np.float32)
+    mean = rs.randn(D) * 0.5
+    std = 0.5 + 1.5 * rs.rand(D)
+    if case["name"] == "acoustic":
+        mgc, lf0, vuv, bap = case["stream_sizes"]
+        smgc, slf0 = static_sizes(case)[:2]
+        mean[mgc:mgc + lf0] = 5.0 + 0.1 * rs.randn(lf0)      # log-F0
+        std[mgc:mgc + lf0] = 0.25
+        mean[mgc + lf0], std[mgc + lf0] = 0.55, 0.45            # vuv
+        if not case["voiced"]:
+            y[:, :, smgc + slf0] = -2.0                         # reference: every frame unvoiced
+        # a few values that land exactly on / next to the 0.5 threshold after inverse scaling
+        yh[0, :4, smgc + slf0] = np.array([(0.5 - 0.55) / 0.45, -0.1111111, -0.1111112, -0.111111], np.float32)
+    lengths = make_lengths(B, T, seed + 1)
+    dt = np.float32 if case["stats"] == "float32" else np.float64
+    return y, yh, mean.astype(dt), std.astype(dt), lengths

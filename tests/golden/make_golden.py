@@ -128,8 +128,43 @@ def run_case(name, case):
         hp.__dict__.update(saved)
 
 
+def run_distortions():
+    """The real train.compute_distortions / split_streams (train.py:358-432) on seeded inputs; the
+    nnmnkwii.metrics functions underneath are the restatements of oracle/gantts_oracle.py."""
+    train, hparams, gantts = ref_loader.load_reference()
+    out = {}
+    for name, case in C.DISTORTION_CASES.items():
+        hp = getattr(hparams, case["hp"])
+        saved = dict(hp.__dict__)
+        try:
+            hp.__dict__.update(stream_sizes=case["stream_sizes"], has_dynamic_features=case["has_dynamic_features"],
+                               windows=C.WINDOWS[:case["windows"]], order=sum(C.static_sizes(case)))
+            train.hp = hp
+            y, yh, mean, std, lengths = C.make_distortion_inputs(case)
+            ty, tyh, tm, ts = (torch.from_numpy(a) for a in (y, yh, mean, std))
+            d = train.compute_distortions(ty, tyh, tm, ts, torch.from_numpy(lengths))
+            for k, v in d.items():
+                out["%s.%s" % (name, k)] = np.float64(v)
+            if case["name"] == "acoustic":
+                for tag, t in (("y", ty), ("yh", tyh)):
+                    mgc, lf0, vuv, bap = train.split_streams(t, tm, ts)
+                    out["%s.split.%s.vuv" % (name, tag)] = vuv.numpy().copy()
+                    out["%s.split.%s.lf0" % (name, tag)] = lf0.numpy().copy()
+        finally:
+            hp.__dict__.clear()
+            hp.__dict__.update(saved)
+    path = os.path.join(HERE, "distortions.npz")
+    np.savez_compressed(path, **out)
+    print("distortions -> %s" % os.path.relpath(path, ROOT))
+    for k in sorted(out):
+        if ".split." not in k:
+            print("    %-36s %r" % (k, float(out[k])))
+
+
 def main():
     only = sys.argv[1:]
+    if not only or "distortions" in only:
+        run_distortions()
     for name, case in C.CASES.items():
         if only and name not in only:
             continue

@@ -457,3 +457,78 @@ def test_oracle_only_step_matches_oracle(name):
             _close(got[k], r, rtol=5e-4, atol=1e-9, msg=k)
         else:
             _close(got[k], r, msg=k)
+
+
+def _dist_hp(case):
+    import types
+    from gantts_amd import hparams
+    hp = types.SimpleNamespace(**getattr(hparams, case["hp"]).values())
+    hp.stream_sizes, hp.has_dynamic_features = case["stream_sizes"], case["has_dynamic_features"]
+    hp.windows = C.WINDOWS[:case["windows"]]
+    hp.order = sum(C.static_sizes(case))
+    return hp
+
+
+@pytest.mark.parametrize("name", sorted(C.DISTORTION_CASES))
+def test_compute_distortions_matches_reference_golden(name):
+    """Fused device reduction (gt_compute_distortions) vs the real train.compute_distortions fixture;
+    the binarised vuv stream and the vuv error COUNT are bit-exact."""
+    import gantts_amd.train as T
+    gold = np.load(os.path.join(GOLDEN, "distortions.npz"))
+    case = C.DISTORTION_CASES[name]
+    T.hp = _dist_hp(case)
+    y, yh, mean, std, lengths = C.make_distortion_inputs(case)
+    ty, tyh = torch.from_numpy(y).cuda(), torch.from_numpy(yh).cuda()
+    tm, ts = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+    for lens in (torch.from_numpy(lengths), list(lengths)):
+        got = T.compute_distortions(ty, tyh, tm, ts, lens)
+        keys = [k for k in gold.files if k.startswith(name + ".") and ".split." not in k]
+        assert sorted(k.split(".", 1)[1] for k in keys) == sorted(got)
+        for k in keys:
+            g, o = float(gold[k]), got[k.split(".", 1)[1]]
+            if np.isnan(g):
+                assert np.isnan(o), k
+            elif k.endswith("vuv_err"):
+                assert o == g, (k, o, g)                       # integer count / integer frames
+            else:
+                assert abs(o - g) <= 1e-5 * abs(g), (k, o, g)
+    if case["name"] == "acoustic":
+        for tag, t in (("y", ty), ("yh", tyh)):
+            _, lf0, vuv, _ = T.split_streams(t, tm, ts)
+            assert vuv.dtype == torch.int64
+            np.testing.assert_array_equal(vuv.cpu().numpy(), gold["%s.split.%s.vuv" % (name, tag)])
+
+
+def test_compute_distortions_full_size_properties():
+    """cfg2 size (B=32, T=512, Ds=63): identical inputs -> all-zero distortions; no lengths == full
+    lengths; the kernel's vuv mismatch count equals a host count over the binarised streams; the
+    result does not depend on what lies beyond the lengths."""
+    import types
+    import gantts_amd.train as T
+    from gantts_amd import hparams
+    T.hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    g = torch.Generator().manual_seed(5)
+    B, Tn = 32, 512
+    y = torch.randn(B, Tn, 63, generator=g)
+    yh = y + 0.3 * torch.randn(B, Tn, 63, generator=g)
+    mean, std = torch.randn(187, generator=g) * 0.3, 0.5 + torch.rand(187, generator=g)
+    mean[180], std[180], mean[183], std[183] = 5.0, 0.2, 0.5, 0.5
+    lengths = torch.randint(Tn // 2, Tn + 1, (B,), generator=g)
+    yc, yhc, mc, sc = y.cuda(), yh.cuda(), mean.cuda(), std.cuda()
+    same = T.compute_distortions(yc, yc, mc, sc, lengths)
+    assert same["mcd"] == 0 and same["bap_mcd"] == 0 and same["vuv_err"] == 0 and same["f0_rmse"] == 0
+    full = T.compute_distortions(yc, yhc, mc, sc, None)
+    assert full == T.compute_distortions(yc, yhc, mc, sc, [Tn] * B)
+    d = T.compute_distortions(yc, yhc, mc, sc, lengths)
+    ref = O.compute_distortions(O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3), "acoustic", y, yh, mean, std,
+                                lengths.tolist())
+    for k in ref:
+        assert abs(d[k] - ref[k]) <= 1e-5 * abs(ref[k]), (k, d[k], ref[k])
+    assert d["vuv_err"] == ref["vuv_err"]
+    _, _, va, _ = T.split_streams(yc, mc, sc)
+    _, _, vb, _ = T.split_streams(yhc, mc, sc)
+    m = (torch.arange(Tn)[None, :] < lengths[:, None]).cuda()
+    assert d["vuv_err"] == float(((va != vb) & m).sum().item()) / float(lengths.sum().item())
+    yh2 = yhc.clone()
+    yh2[~m] = 1e6
+    assert T.compute_distortions(yc, yh2, mc, sc, lengths) == d

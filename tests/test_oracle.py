@@ -161,3 +161,42 @@ def test_sru_restatement_gradients_by_finite_differences():
     assert m.ks == [4, 3]
     assert m.names[:2] == ["gru.rnn_lst.0.weight", "gru.rnn_lst.0.bias"]
     assert tuple(m.params[0].shape) == (5, 6 * 4) and tuple(m.params[2].shape) == (6, 6 * 3)
+
+
+def _dist_cfg(case):
+    return O.StreamConfig(case["stream_sizes"], case["has_dynamic_features"], case["windows"])
+
+
+@pytest.mark.parametrize("name", sorted(C.DISTORTION_CASES))
+def test_distortions_match_reference_golden(name):
+    """oracle.compute_distortions / split_streams vs the real train.compute_distortions (train.py:358-432)."""
+    gold = np.load(os.path.join(GOLDEN, "distortions.npz"))
+    case = C.DISTORTION_CASES[name]
+    y, yh, mean, std, lengths = C.make_distortion_inputs(case)
+    ty, tyh, tm, ts = (torch.from_numpy(a) for a in (y, yh, mean, std))
+    got = O.compute_distortions(_dist_cfg(case), case["name"], ty, tyh, tm, ts, list(lengths))
+    keys = [k for k in gold.files if k.startswith(name + ".") and ".split." not in k]
+    assert sorted(k.split(".", 1)[1] for k in keys) == sorted(got)
+    for k in keys:
+        g, o = float(gold[k]), got[k.split(".", 1)[1]]
+        assert (np.isnan(g) and np.isnan(o)) or abs(o - g) <= 1e-9 * max(1.0, abs(g)), (k, o, g)
+    if case["name"] == "acoustic":
+        for tag, t in (("y", ty), ("yh", tyh)):
+            _, lf0, vuv, _ = O.split_streams(_dist_cfg(case), t, tm, ts)
+            assert vuv.dtype == torch.int64
+            np.testing.assert_array_equal(vuv.numpy(), gold["%s.split.%s.vuv" % (name, tag)])     # bit-exact
+            np.testing.assert_array_equal(lf0.numpy(), gold["%s.split.%s.lf0" % (name, tag)])
+
+
+def test_distortion_metrics_without_lengths_use_every_frame():
+    rs = np.random.RandomState(0)
+    X, Y = torch.from_numpy(rs.randn(3, 11, 4)), torch.from_numpy(rs.randn(3, 11, 4))
+    assert abs(O.melcd(X, Y) - O.melcd(X, Y, [11, 11, 11])) < 1e-12
+    z = (X - Y).numpy()
+    assert abs(O.melcd(X, Y) - O._LOGDB_CONST * np.sqrt((z * z).sum(-1)).mean()) < 1e-12
+    assert abs(O.mean_squared_error(X, Y) - (z * z).mean()) < 1e-12
+    v = torch.from_numpy((rs.rand(3, 11) > 0.5).astype(np.int64))
+    w = torch.from_numpy((rs.rand(3, 11) > 0.5).astype(np.int64))
+    assert abs(O.vuv_error(v, w) - float((v != w).double().mean())) < 1e-12
+    with pytest.raises(ZeroDivisionError):
+        O.lf0_mean_squared_error(X[:, :, :1], torch.zeros(3, 11, dtype=torch.long), Y[:, :, :1], w)
