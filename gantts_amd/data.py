@@ -1,0 +1,319 @@
+"""Batch pipeline of the training loop (reference train.py:64-229, 494-524).
+
+Host side (same names and on-disk format as the reference):
+
+* ``NPYDataSource`` -- one float32 ``(T_i, D)`` ``.npy`` per utterance, sorted by file name; the last 5
+  files are the real test set, the rest is split with ``train_test_split(test_size=0.112,
+  random_state=1234)`` (train.py:64-93).
+* ``FileSourceDataset`` / ``MemoryCacheDataset`` -- stand-ins for the two nnmnkwii dataset wrappers
+  the reference imports (train.py:50-51; nnmnkwii is third-party and un-vendored).
+* ``VCDataset`` / ``TTSDataset`` -- normalisation per utterance (train.py:96-135): mean/variance
+  scaling of the acoustic side, min-max scaling to [0.01, 0.99] of the linguistic side, optional
+  delta recomputation (gantts/multistream.py:15-30).
+* ``collate_fn`` -- zero padding to the longest utterance of the batch (train.py:139-159; the
+  reference's ``np.int`` no longer exists in numpy 2 -> int64 here).
+* ``scale / inv_scale / minmax_scale_params / minmax_scale / meanvar / minmax / delta_features`` --
+  the few nnmnkwii.preprocessing functions on this path, restated from their published definitions.
+
+Device side (the part that matters at >10^6 frames/s): ``DevicePrefetcher`` wraps any iterable of
+``(x, y, lengths)`` host batches and hands out batches that are already resident in HBM, sorted by
+length (train.py:494-501) -- batch k+1 is staged into pinned memory and copied on a side stream
+while step k runs on the compute stream, so the step never waits for PCIe.
+"""
+import os
+from os.path import join, splitext
+
+import numpy as np
+import torch
+
+test_size = 0.112      # train.py:64 (1000 training utterances for cmu arctic)
+random_state = 1234    # train.py:65
+
+
+# ---- nnmnkwii.preprocessing (un-vendored third party), the functions train.py touches ------------
+def scale(x, data_mean, data_std):
+    return (x - data_mean) / data_std
+
+
+def inv_scale(x, data_mean, data_std):
+    return data_std * x + data_mean
+
+
+def minmax_scale_params(data_min, data_max, feature_range=(0, 1)):
+    data_range = data_max - data_min
+    data_range = np.where(data_range == 0.0, 1.0, data_range)      # constant columns: scale 1
+    scale_ = (feature_range[1] - feature_range[0]) / data_range
+    min_ = feature_range[0] - data_min * scale_
+    return min_, scale_
+
+
+def minmax_scale(x, data_min=None, data_max=None, feature_range=(0, 1), scale_=None, min_=None):
+    if scale_ is None or min_ is None:
+        min_, scale_ = minmax_scale_params(data_min, data_max, feature_range)
+    return x * scale_ + min_
+
+
+def meanvar(dataset, lengths=None, mean_=0.0, var_=0.0, last_sample_count=0, return_last_sample_count=False):
+    """Streaming mean / variance over all frames of a dataset of (T_i, D) arrays (Chan et al.
+    pairwise update, the scheme sklearn's incremental mean/variance uses)."""
+    n = float(last_sample_count)
+    mean, m2 = np.asarray(mean_, dtype=np.float64), np.asarray(var_, dtype=np.float64) * n
+    for idx in range(len(dataset)):
+        x = np.asarray(dataset[idx], dtype=np.float64)
+        if lengths is not None:
+            x = x[:lengths[idx]]
+        k = float(len(x))
+        if k == 0:
+            continue
+        xm = x.mean(0)
+        xv = ((x - xm) ** 2).sum(0)
+        delta = xm - mean
+        tot = n + k
+        mean = mean + delta * (k / tot)
+        m2 = m2 + xv + delta ** 2 * (n * k / tot)
+        n = tot
+    var = m2 / max(n, 1.0)
+    if return_last_sample_count:
+        return mean, var, int(n)
+    return mean, var
+
+
+def minmax(dataset, lengths=None):
+    lo, hi = None, None
+    for idx in range(len(dataset)):
+        x = np.asarray(dataset[idx])
+        if lengths is not None:
+            x = x[:lengths[idx]]
+        a, b = x.min(0), x.max(0)
+        lo = a if lo is None else np.minimum(lo, a)
+        hi = b if hi is None else np.maximum(hi, b)
+    return lo, hi
+
+
+def delta_features(x, windows):
+    """[static | delta | delta-delta]: each window correlated along time with zeros beyond the edges."""
+    T, D = x.shape
+    out = np.empty((T, D * len(windows)), dtype=x.dtype)
+    for i, (_, _, coef) in enumerate(windows):
+        coef = np.asarray(coef, dtype=x.dtype)
+        for d in range(D):
+            out[:, i * D + d] = np.correlate(x[:, d], coef, mode="same")
+    return out
+
+
+def recompute_delta_features(Y, Y_data_mean, Y_data_std, windows, stream_sizes=[180, 3, 1, 3],
+                             has_dynamic_features=[True, True, False, True]):
+    """gantts/multistream.py:15-30: rebuilds the dynamic columns of every dynamic stream from its
+    (already normalised) static columns, in place.  The statistics arguments are unused there too."""
+    from .multistream import get_static_stream_sizes
+    starts = np.hstack(([0], np.cumsum(stream_sizes)[:-1]))
+    ends = np.cumsum(stream_sizes)
+    statics = get_static_stream_sizes(stream_sizes, has_dynamic_features, len(windows))
+    for s, e, n, dyn in zip(starts, ends, statics, has_dynamic_features):
+        if dyn:
+            Y[:, s:e] = delta_features(Y[:, s:s + int(n)], windows)
+    return Y
+
+
+# ---- datasets ---------------------------------------------------------------------------------
+class NPYDataSource(object):
+    """train.py:71-93"""
+
+    def __init__(self, dirname, train=True, max_files=None, test=False):
+        self.dirname, self.train, self.test, self.max_files = dirname, train, test, max_files
+
+    def collect_files(self):
+        from sklearn.model_selection import train_test_split
+        npy_files = sorted(join(self.dirname, f) for f in os.listdir(self.dirname) if splitext(f)[-1] == ".npy")
+        if self.test:                                  # last 5 is for real testset
+            return npy_files[len(npy_files) - 5:]
+        npy_files = npy_files[:len(npy_files) - 5]
+        if self.max_files is not None and self.max_files > 0:
+            npy_files = npy_files[:self.max_files]
+        train_files, test_files = train_test_split(npy_files, test_size=test_size, random_state=random_state)
+        return train_files if self.train else test_files
+
+    def collect_features(self, path):
+        return np.load(path)
+
+
+class FileSourceDataset(object):
+    """Lazy list of per-utterance arrays behind a data source (nnmnkwii.datasets.FileSourceDataset)."""
+
+    def __init__(self, file_data_source):
+        self.file_data_source = file_data_source
+        self.collected_files = list(file_data_source.collect_files())
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return [self[i] for i in range(*idx.indices(len(self)))]
+        return self.file_data_source.collect_features(self.collected_files[idx])
+
+    def __len__(self):
+        return len(self.collected_files)
+
+
+class MemoryCacheDataset(object):
+    """Keeps up to ``cache_size`` loaded utterances (nnmnkwii.datasets.MemoryCacheDataset)."""
+
+    def __init__(self, dataset, cache_size=777):
+        self.dataset, self.cache_size = dataset, cache_size
+        self.cached = {}
+
+    def __getitem__(self, idx):
+        if idx not in self.cached:
+            if len(self.cached) >= self.cache_size:
+                self.cached.pop(next(iter(self.cached)))       # oldest first
+            self.cached[idx] = self.dataset[idx]
+        return self.cached[idx]
+
+    def __len__(self):
+        return len(self.dataset)
+
+
+class VCDataset(object):
+    """train.py:96-108"""
+
+    def __init__(self, X, Y, data_mean, data_std):
+        self.X, self.Y, self.data_mean, self.data_std = X, Y, data_mean, data_std
+
+    def __getitem__(self, idx):
+        return scale(self.X[idx], self.data_mean, self.data_std), scale(self.Y[idx], self.data_mean, self.data_std)
+
+    def __len__(self):
+        return len(self.X)
+
+
+class TTSDataset(object):
+    """train.py:111-135.  ``hp`` (module-global in the reference) is passed in."""
+
+    def __init__(self, X, Y, X_data_min, X_data_max, Y_data_mean, Y_data_std, hp=None):
+        self.X, self.Y = X, Y
+        self.X_data_min, self.X_data_scale = minmax_scale_params(X_data_min, X_data_max, feature_range=(0.01, 0.99))
+        self.Y_data_mean, self.Y_data_std = Y_data_mean, Y_data_std
+        self.hp = hp
+
+    def __getitem__(self, idx):
+        x = minmax_scale(self.X[idx], min_=self.X_data_min, scale_=self.X_data_scale, feature_range=(0.01, 0.99))
+        y = scale(self.Y[idx], self.Y_data_mean, self.Y_data_std)
+        hp = self.hp
+        if hp is not None and getattr(hp, "recompute_delta_features", False):
+            y = recompute_delta_features(y, self.Y_data_mean, self.Y_data_std, hp.windows, hp.stream_sizes,
+                                         hp.has_dynamic_features)
+        return x, y
+
+    def __len__(self):
+        return len(self.X)
+
+
+def _pad_2d(x, max_len):
+    return np.pad(x, [(0, max_len - len(x)), (0, 0)], mode="constant", constant_values=0)
+
+
+def collate_fn(batch):
+    """train.py:145-159: ``(x_batch (B,T,Din) f32, y_batch (B,T,Dout) f32, lengths (B,) int64)``."""
+    input_lengths = np.array([len(x[0]) for x in batch], dtype=np.int64)
+    max_len = int(np.max(input_lengths))
+    x_batch = np.array([_pad_2d(x[0], max_len) for x in batch], dtype=np.float32)
+    y_batch = np.array([_pad_2d(x[1], max_len) for x in batch], dtype=np.float32)
+    return torch.from_numpy(x_batch), torch.from_numpy(y_batch), torch.from_numpy(input_lengths)
+
+
+def _loaders(train_dataset, test_dataset, hp):
+    from torch.utils import data as data_utils
+    kw = dict(batch_size=hp.batch_size, num_workers=hp.num_workers, pin_memory=hp.pin_memory, collate_fn=collate_fn)
+    return {"train": data_utils.DataLoader(train_dataset, shuffle=True, **kw),
+            "test": data_utils.DataLoader(test_dataset, shuffle=False, **kw)}
+
+
+def get_vc_data_loaders(X, Y, data_mean, data_std, hp):
+    """train.py:174-200 (the reference has a ``data_var``/``data_std`` name slip at :174/:182; std is meant)."""
+    mk = lambda ph: VCDataset(MemoryCacheDataset(X[ph], cache_size=hp.cache_size),
+                              MemoryCacheDataset(Y[ph], cache_size=hp.cache_size), data_mean, data_std)
+    return _loaders(mk("train"), mk("test"), hp)
+
+
+def get_tts_data_loaders(X, Y, X_data_min, X_data_max, Y_data_mean, Y_data_std, hp):
+    """train.py:203-229"""
+    mk = lambda ph: TTSDataset(MemoryCacheDataset(X[ph], cache_size=hp.cache_size),
+                               MemoryCacheDataset(Y[ph], cache_size=hp.cache_size),
+                               X_data_min, X_data_max, Y_data_mean, Y_data_std, hp=hp)
+    return _loaders(mk("train"), mk("test"), hp)
+
+
+# ---- device side --------------------------------------------------------------------------------
+class DeviceBatch(object):
+    """One length-sorted batch resident on the device (what train_loop consumes per step)."""
+    __slots__ = ("x", "y", "lengths", "cpu_lengths", "max_len", "ready")
+
+    def __init__(self, x, y, lengths, cpu_lengths, ready):
+        self.x, self.y, self.lengths, self.cpu_lengths = x, y, lengths, cpu_lengths
+        self.max_len = int(cpu_lengths[0]) if len(cpu_lengths) else 0
+        self.ready = ready
+
+
+class DevicePrefetcher(object):
+    """Iterates ``loader`` one batch ahead: sorts by length (descending, stable -- what torch.sort
+    gives the reference at train.py:495-501), trims the padding to the longest sequence, stages the
+    batch in pinned host buffers and copies it on a dedicated stream; ``__next__`` makes the compute
+    stream wait on that copy's event (no host sync)."""
+
+    def __init__(self, loader, device="cuda", depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._pinned, self._slot_copied = {}, {}
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _pin(self, key, t):
+        buf = self._pinned.get(key)
+        if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+            buf = torch.empty(t.numel(), dtype=t.dtype).pin_memory() if self.copy_stream is not None else torch.empty(t.numel(), dtype=t.dtype)
+            self._pinned[key] = buf
+        v = buf[:t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+
+    def _stage(self, slot, batch):
+        x, y, lengths = batch
+        lengths = torch.as_tensor(lengths).view(-1).long()
+        sorted_lengths, indices = torch.sort(lengths, dim=0, descending=True)
+        max_len = int(sorted_lengths[0])
+        x, y = x[indices][:, :max_len], y[indices][:, :max_len]
+        cpu_lengths = [int(v) for v in sorted_lengths.tolist()]
+        if self.copy_stream is None:
+            return DeviceBatch(x.contiguous(), y.contiguous(), sorted_lengths, cpu_lengths, None)
+        prev = self._slot_copied.get(slot)
+        if prev is not None:
+            prev.synchronize()          # the slot's previous H2D must have drained before the host overwrites it
+        hx, hy = self._pin((slot, "x"), x.contiguous()), self._pin((slot, "y"), y.contiguous())
+        with torch.cuda.stream(self.copy_stream):
+            dx = hx.to(self.device, non_blocking=True)
+            dy = hy.to(self.device, non_blocking=True)
+            dl = sorted_lengths.to(self.device)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._slot_copied[slot] = ev
+        return DeviceBatch(dx, dy, dl, cpu_lengths, ev)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        queue, slot = [], 0
+        for batch in it:
+            if self.copy_stream is not None and len(queue) >= self.depth:
+                out = queue.pop(0)
+                yield self._release(out)
+            queue.append(self._stage(slot % (self.depth + 1), batch))
+            slot += 1
+            if self.copy_stream is None:
+                yield self._release(queue.pop(0))
+        while queue:
+            yield self._release(queue.pop(0))
+
+    def _release(self, b):
+        if b.ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(b.ready)
+            for t in (b.x, b.y, b.lengths):
+                t.record_stream(torch.cuda.current_stream(self.device))
+        return b

@@ -364,3 +364,68 @@ def make_distortion_inputs(case, seed=4321):
     lengths = make_lengths(B, T, seed + 1)
     dt = np.float32 if case["stats"] == "float32" else np.float64
     return y, yh, mean.astype(dt), std.astype(dt), lengths
+
+
+# ---------------------------------------------------------------------------------------------
+# Whole training loop (reference train.py:435-643) on a tiny in-memory dataset: tests/golden/train_loop_*.npz
+# Dropout is 0 everywhere (train_loop switches the models to .train()) and no generator noise, so the
+# run is deterministic; everything else (length sort, curriculum weight, lr schedule, test phase,
+# distortion metrics, accuracies, spoofing rate) is exercised as the reference does it.
+# ---------------------------------------------------------------------------------------------
+TRAIN_LOOP_CASES = {
+    "train_loop_acoustic": dict(
+        hp="tts_acoustic", din=30, dout=187, stream_sizes=[180, 3, 1, 3],
+        has_dynamic_features=[True, True, False, True], adversarial_streams=[True, False, False, False],
+        mask_nth_mgc=2, cond=False, windows=3, nepoch=3, lr_decay_schedule=True, lr_decay_epoch=2,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32, dropout=0.0, last_sigmoid=False),
+        # the spoofing-rate branch feeds the reference D without the linguistic condition (train.py:551-555):
+        # it only runs with discriminator_linguistic_condition=False
+        d=dict(kind="MLP", in_dim=58, out_dim=1, num_hidden=2, hidden_dim=16, dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)), opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        batches=dict(train=[(4, 24), (4, 19), (3, 22)], test=[(3, 17), (2, 21)]),
+        w_d=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=True, reference_d=True, stats="float32"),
+    "train_loop_vc": dict(
+        hp="vc", din=75, dout=75, stream_sizes=[75], has_dynamic_features=[True], adversarial_streams=None,
+        mask_nth_mgc=0, cond=False, windows=3, nepoch=2, lr_decay_schedule=False, lr_decay_epoch=10, order=25,
+        g=dict(kind="In2OutHighwayNet", in_dim=75, out_dim=75, static_dim=25, num_hidden=2, hidden_dim=32, dropout=0.0),
+        d=dict(kind="MLP", in_dim=25, out_dim=1, num_hidden=2, hidden_dim=16, dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=0)), opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
+        batches=dict(train=[(3, 30), (3, 26)], test=[(2, 23)]),
+        w_d=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=True, reference_d=False, stats="float64"),
+    "train_loop_d_warmup": dict(
+        hp="tts_acoustic", din=30, dout=187, stream_sizes=[180, 3, 1, 3],
+        has_dynamic_features=[True, True, False, True], adversarial_streams=[True, False, False, False],
+        mask_nth_mgc=2, cond=True, windows=3, nepoch=2, lr_decay_schedule=False, lr_decay_epoch=25,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32, dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=16, dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)), opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        batches=dict(train=[(4, 20), (2, 25)], test=[(3, 18)]),
+        w_d=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=False, reference_d=False, stats="float32"),
+}
+
+
+def make_train_loop_data(case, seed=777):
+    """{"train": [(x, y, lengths), ...], "test": [...]} (collated, UNsorted lengths, zero padded) and the
+    output statistics in the static+dynamic domain."""
+    rs = np.random.RandomState(seed)
+    din, dout = case["din"], case["dout"]
+    out = {}
+    for phase in ("train", "test"):
+        out[phase] = []
+        for (B, T) in case["batches"][phase]:
+            lens = rs.randint(max(1, T // 2), T + 1, size=B)
+            lens[rs.randint(B)] = T
+            x = (0.01 + 0.98 * rs.rand(B, T, din)).astype(np.float32)
+            y = rs.randn(B, T, dout).astype(np.float32)
+            if case["stream_sizes"] == [180, 3, 1, 3]:
+                y[:, :, 183] = ((rs.rand(B, T) > 0.5).astype(np.float32) - 0.5) / 0.5
+            for b, n in enumerate(lens):
+                x[b, n:] = 0
+                y[b, n:] = 0
+            out[phase].append((x, y, lens.astype(np.int64)))
+    dt = np.float32 if case["stats"] == "float32" else np.float64
+    mean = (rs.randn(dout) * 0.3).astype(dt)
+    std = (0.5 + rs.rand(dout)).astype(dt)
+    if case["stream_sizes"] == [180, 3, 1, 3]:
+        mean[180], std[180], mean[183], std[183] = 5.0, 0.2, 0.5, 0.5
+    return out, mean, std

@@ -161,8 +161,78 @@ def run_distortions():
             print("    %-36s %r" % (k, float(out[k])))
 
 
+class _Loader(list):
+    """What train_loop needs from a DataLoader: iteration, len() and .dataset statistics."""
+
+
+def run_train_loop(name, case):
+    import types
+    train, hparams, gantts = ref_loader.load_reference()
+    hp = getattr(hparams, case["hp"])
+    saved = dict(hp.__dict__)
+    try:
+        hp.__dict__.update(
+            stream_sizes=case["stream_sizes"], has_dynamic_features=case["has_dynamic_features"],
+            windows=C.WINDOWS[:case["windows"]], adversarial_streams=case["adversarial_streams"],
+            mask_nth_mgc_for_adv_loss=case["mask_nth_mgc"], discriminator_linguistic_condition=case["cond"],
+            nepoch=case["nepoch"], lr_decay_schedule=case["lr_decay_schedule"], lr_decay_epoch=case["lr_decay_epoch"],
+            generator_add_noise=False, optimizer_g_params=dict(case["opt_g"][1]), optimizer_d_params=dict(case["opt_d"][1]))
+        if "order" in case:
+            hp.__dict__["order"] = case["order"]
+        train.hp = hp
+        train.global_epoch = 0
+
+        def build(spec, seed):
+            kw = {k: v for k, v in spec.items() if k != "kind"}
+            m = getattr(gantts.models, spec["kind"])(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed).items()})
+            return m
+
+        model_g, model_d = build(case["g"], 11), build(case["d"], 22)
+        ref_d = build(case["d"], 33) if case["reference_d"] else None
+        og = getattr(torch.optim, case["opt_g"][0])(model_g.parameters(), **case["opt_g"][1])
+        od = getattr(torch.optim, case["opt_d"][0])(model_d.parameters(), **case["opt_d"][1])
+        data, mean, std = C.make_train_loop_data(case)
+        loaders = {}
+        for phase in ("train", "test"):
+            ld = _Loader((torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(l)) for x, y, l in data[phase])
+            if case["hp"] == "vc":
+                ld.dataset = types.SimpleNamespace(data_mean=mean, data_std=std)
+            else:
+                ld.dataset = types.SimpleNamespace(Y_data_mean=mean, Y_data_std=std)
+            loaders[phase] = ld
+        logs = []
+        train.log_value = lambda n, v, e: logs.append((n, float(v), int(e)))
+        train.tqdm = lambda it: it
+        rc = train.train_loop((model_g, model_d), (og, od), loaders, w_d=case["w_d"], mse_w=case["mse_w"],
+                              mge_w=case["mge_w"], update_d=case["update_d"], update_g=case["update_g"],
+                              reference_discriminator=ref_d)
+        assert rc == 0
+        out = {"log.names": np.array([n for n, _, _ in logs]), "log.values": np.array([v for _, v, _ in logs]),
+               "log.epochs": np.array([e for _, _, e in logs]),
+               "lr_g": np.float64(og.param_groups[0]["lr"]), "lr_d": np.float64(od.param_groups[0]["lr"])}
+        for k, v in model_g.state_dict().items():
+            out["G." + k] = v.numpy().copy()
+        for k, v in model_d.state_dict().items():
+            out["D." + k] = v.numpy().copy()
+        return out
+    finally:
+        hp.__dict__.clear()
+        hp.__dict__.update(saved)
+
+
 def main():
     only = sys.argv[1:]
+    for name, case in C.TRAIN_LOOP_CASES.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        out = run_train_loop(name, case)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-28s -> %s (%d log values)" % (name, os.path.relpath(path, ROOT), len(out["log.values"])))
+        for n, v, e in list(zip(out["log.names"], out["log.values"], out["log.epochs"]))[-12:]:
+            print("    [%d] %-28s %.6f" % (e, n, v))
     if not only or "distortions" in only:
         run_distortions()
     for name, case in C.CASES.items():
