@@ -752,3 +752,56 @@ def compute_distortions(cfg, name, y_static, y_hat_static, Y_mean, Y_std, length
         a, b = _inv_scale(y_static, Y_mean[:sd], Y_std[:sd]), _inv_scale(y_hat_static, Y_mean[:sd], Y_std[:sd])
         return {"mcd": melcd(a, b, lengths=lengths)}
     raise AssertionError(name)
+
+
+# ---------------------------------------------------------------------------------------------
+# Inference path (reference evaluation_tts.py:47-100, 133-221; evaluation_vc.py:40-92)
+# ---------------------------------------------------------------------------------------------
+def mlpg(mean_frames, variance_frames, windows):
+    """nnmnkwii.paramgen.mlpg (un-vendored; restated from its published definition, parity unpinned):
+    maximum-likelihood static trajectory c = (W' P W)^-1 W' P mu per static dimension, P = diagonal
+    precisions.  mean_frames (T, D) in [static | delta | delta-delta] layout, variance_frames (T, D) or
+    (D,), result (T, D // len(windows)) in float64.  Dense float64 solve (test sizes only)."""
+    mu = np.asarray(mean_frames, dtype=np.float64)
+    T, D = mu.shape
+    nw = len(windows)
+    sd = D // nw
+    var = np.asarray(variance_frames, dtype=np.float64)
+    if var.ndim == 1:
+        var = np.tile(var, (T, 1))
+    Ws = [_window_matrix(l, u, c, T) for (l, u, c) in windows]
+    out = np.empty((T, sd))
+    for d in range(sd):
+        A, b = np.zeros((T, T)), np.zeros(T)
+        for w, Ww in enumerate(Ws):
+            p = 1.0 / var[:, w * sd + d]
+            A += Ww.T @ (p[:, None] * Ww)
+            b += Ww.T @ (p * mu[:, w * sd + d])
+        out[:, d] = np.linalg.solve(A, b)
+    return out
+
+
+def gen_parameters(stream_sizes, windows, y_predicted, Y_mean, Y_std):
+    """evaluation_tts.py:47-83, the ``mge_training=True`` branch (the other branch multiplies a dict,
+    :86, and cannot run): split -> per-stream MLPG on the NORMALISED features with unit variance ->
+    inverse scaling with statistics indexed in the static+dynamic domain; vuv is only inverse-scaled."""
+    mgc_dim, lf0_dim, vuv_dim, bap_dim = stream_sizes
+    nw = len(windows)
+    lf0_0, vuv_0, bap_0 = mgc_dim, mgc_dim + lf0_dim, mgc_dim + lf0_dim + vuv_dim
+    mgc, lf0 = y_predicted[:, :lf0_0], y_predicted[:, lf0_0:vuv_0]
+    vuv, bap = y_predicted[:, vuv_0], y_predicted[:, bap_0:]
+    mgc = mlpg(mgc, np.ones(mgc.shape[-1]), windows)
+    lf0 = mlpg(lf0, np.ones(lf0.shape[-1]), windows)
+    bap = mlpg(bap, np.ones(bap.shape[-1]), windows)
+    mgc = _inv_scale(mgc, Y_mean[:mgc_dim // nw], Y_std[:mgc_dim // nw])
+    lf0 = _inv_scale(lf0, Y_mean[lf0_0:lf0_0 + lf0_dim // nw], Y_std[lf0_0:lf0_0 + lf0_dim // nw])
+    bap = _inv_scale(bap, Y_mean[bap_0:bap_0 + bap_dim // nw], Y_std[bap_0:bap_0 + bap_dim // nw])
+    vuv = _inv_scale(vuv, Y_mean[vuv_0], Y_std[vuv_0])
+    return mgc, lf0, vuv, bap
+
+
+def predict_durations(duration_pred, Y_mean, Y_std):
+    """evaluation_tts.py:170-176: denormalise, round to frames, at least one frame per state."""
+    d = np.round(_inv_scale(np.asarray(duration_pred), Y_mean, Y_std))
+    d[d <= 0] = 1
+    return d

@@ -429,3 +429,36 @@ def make_train_loop_data(case, seed=777):
     if case["stream_sizes"] == [180, 3, 1, 3]:
         mean[180], std[180], mean[183], std[183] = 5.0, 0.2, 0.5, 0.5
     return out, mean, std
+
+
+# ---------------------------------------------------------------------------------------------
+# Inference path (reference evaluation_tts.py / evaluation_vc.py): tests/golden/inference.npz
+# ---------------------------------------------------------------------------------------------
+INFERENCE = dict(
+    T_acoustic=57, T_states=23, din=40, T_vc=44,
+    acoustic=dict(kind="LSTMRNN", in_dim=40, out_dim=187, num_hidden=2, hidden_dim=24, bidirectional=True,
+                  dropout=0.0, last_sigmoid=False),
+    acoustic_mlp=dict(kind="MLP", in_dim=40, out_dim=187, num_hidden=2, hidden_dim=48, dropout=0.5, last_sigmoid=False),
+    duration=dict(kind="MLP", in_dim=40, out_dim=5, num_hidden=2, hidden_dim=32, dropout=0.5, last_sigmoid=False),
+    vc=dict(kind="In2OutHighwayNet", in_dim=75, out_dim=75, static_dim=25, num_hidden=2, hidden_dim=40, dropout=0.5),
+)
+
+
+def make_inference_inputs(seed=2468):
+    rs = np.random.RandomState(seed)
+    I = INFERENCE
+    out = {}
+    for ty, T in (("acoustic", I["T_acoustic"]), ("duration", I["T_states"])):
+        lo = rs.randn(I["din"]) - 2.0
+        hi = lo + 0.5 + 3.0 * rs.rand(I["din"])
+        out["X_min_" + ty], out["X_max_" + ty] = lo, hi
+        out["feats_" + ty] = (lo + (hi - lo) * rs.rand(T, I["din"])).astype(np.float32)
+    out["Y_mean_acoustic"] = rs.randn(187) * 0.4
+    out["Y_std_acoustic"] = 0.5 + rs.rand(187)
+    out["Y_mean_duration"] = 4.0 + rs.rand(5) * 6.0
+    out["Y_std_duration"] = 1.0 + 4.0 * rs.rand(5)
+    c = np.cumsum(rs.randn(I["T_vc"], 25) * 0.2, axis=0)               # smooth-ish static mel-cepstrum
+    out["vc_static"] = c.astype(np.float32)
+    out["vc_mean"] = rs.randn(75) * 0.3
+    out["vc_std"] = 0.5 + rs.rand(75)
+    return out

@@ -221,8 +221,63 @@ def run_train_loop(name, case):
         hp.__dict__.update(saved)
 
 
+def run_inference():
+    """Eval-mode generator forwards with the real gantts.models classes, the real
+    evaluation_tts.gen_parameters (evaluation_tts.py:47-100) and the lines of gen_duration /
+    test_vc_from_path that sit between the front end / vocoder and the model."""
+    train, hparams, gantts = ref_loader.load_reference()
+    ev = ref_loader.load_reference_evaluation_tts()
+    import gantts_oracle as O
+    from nnmnkwii.paramgen import unit_variance_mlpg_matrix
+    I, inp = C.INFERENCE, C.make_inference_inputs()
+    out = {}
+
+    def build(spec, seed):
+        kw = {k: v for k, v in spec.items() if k != "kind"}
+        m = getattr(gantts.models, spec["kind"])(**kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed).items()})
+        return m.eval()
+
+    def mm(x, lo, hi):       # nnmnkwii.preprocessing.minmax_scale(x, min, max, feature_range=(0.01, 0.99))
+        return (x - lo) / (hi - lo) * (0.99 - 0.01) + 0.01
+
+    with torch.no_grad():
+        for tag, spec in (("lstm", I["acoustic"]), ("mlp", I["acoustic_mlp"])):
+            x = torch.from_numpy(mm(inp["feats_acoustic"], inp["X_min_acoustic"], inp["X_max_acoustic"])).float()
+            xl = len(x)
+            pred = build(spec, 41)(x.view(1, -1, x.size(-1)), [xl]).numpy().reshape(-1, 187)
+            out["acoustic_predicted." + tag] = pred
+            mgc, lf0, vuv, bap = ev.gen_parameters(pred, {"acoustic": inp["Y_mean_acoustic"]}, {"acoustic": inp["Y_std_acoustic"]})
+            for n, v in (("mgc", mgc), ("lf0", lf0), ("vuv", vuv), ("bap", bap)):
+                out["%s.%s" % (n, tag)] = np.asarray(v)
+        x = torch.from_numpy(mm(inp["feats_duration"], inp["X_min_duration"], inp["X_max_duration"])).float()
+        pred = build(I["duration"], 42)(x.view(1, -1, x.size(-1)), [len(x)]).numpy().reshape(-1, 5)
+        d = np.round(pred * inp["Y_std_duration"] + inp["Y_mean_duration"])      # evaluation_tts.py:171-172
+        d[d <= 0] = 1
+        out["durations"] = d
+        # evaluation_vc.py:56-92
+        hp = hparams.vc
+        mc = O.unit_variance_mlpg_matrix  # (silence linters)
+        W = np.vstack([O._window_matrix(l, u, c, I["T_vc"]) for (l, u, c) in C.WINDOWS])
+        st = inp["vc_static"].astype(np.float64)
+        mc = (W @ st).reshape(3, I["T_vc"], 25).transpose(1, 0, 2).reshape(I["T_vc"], 75).astype(np.float32)   # P.delta_features
+        mc_scaled = torch.from_numpy(((mc - inp["vc_mean"]) / inp["vc_std"]).astype(np.float32)).view(1, I["T_vc"], 75)
+        R = torch.from_numpy(unit_variance_mlpg_matrix(C.WINDOWS, I["T_vc"]))
+        y_hat, y_hat_static = build(I["vc"], 43)(mc_scaled, R, lengths=[I["T_vc"]])
+        pred = y_hat_static.numpy().reshape(-1, 25)
+        pred = pred * inp["vc_std"][:25] + inp["vc_mean"][:25]
+        out["vc_mc"] = mc
+        out["vc_outputs"] = pred
+        out["vc_diff"] = pred - mc[:, :25]
+    path = os.path.join(HERE, "inference.npz")
+    np.savez_compressed(path, **out)
+    print("inference -> %s: %s" % (os.path.relpath(path, ROOT), {k: v.shape for k, v in out.items()}))
+
+
 def main():
     only = sys.argv[1:]
+    if not only or "inference" in only:
+        run_inference()
     for name, case in C.TRAIN_LOOP_CASES.items():
         if only and name not in only:
             continue

@@ -593,3 +593,39 @@ def test_train_loop_matches_reference_golden(name):
     for tag, m in (("G", mg), ("D", md)):
         for k, v in m.state_dict().items():
             _close(v.cpu().numpy(), gold[tag + "." + k], rtol=2e-4, atol=2e-6, msg=name + ":" + tag + "." + k)
+
+
+def test_inference_path_matches_reference_golden():
+    """gantts_amd.inference (eval-mode forwards + banded multi-stream MLPG + inverse scaling) against
+    outputs of the real reference models / evaluation_tts.gen_parameters / evaluation_vc lines."""
+    from gantts_amd import inference as INF
+    from hip_runner import build_model
+    gold = np.load(os.path.join(GOLDEN, "inference.npz"))
+    I, inp = C.INFERENCE, C.make_inference_inputs()
+    X_min = {"acoustic": inp["X_min_acoustic"], "duration": inp["X_min_duration"]}
+    X_max = {"acoustic": inp["X_max_acoustic"], "duration": inp["X_max_duration"]}
+    Y_mean = {"acoustic": inp["Y_mean_acoustic"], "duration": inp["Y_mean_duration"]}
+    Y_std = {"acoustic": inp["Y_std_acoustic"], "duration": inp["Y_std_duration"]}
+    for tag, spec in (("lstm", I["acoustic"]), ("mlp", I["acoustic_mlp"])):
+        model = build_model(spec, 41)
+        pred = INF.predict_acoustic(model, inp["feats_acoustic"], X_min, X_max)
+        _close(pred, gold["acoustic_predicted." + tag], msg="acoustic_predicted." + tag)
+        assert not model.training
+        got = INF.gen_parameters(pred, Y_mean, Y_std)
+        for n, v in zip(("mgc", "lf0", "vuv", "bap"), got):
+            g = gold["%s.%s" % (n, tag)]
+            assert v.shape == g.shape, n
+            _close(v, g, msg="%s.%s" % (n, tag))
+        # from the reference's own prediction: isolates MLPG + inverse scaling
+        got = INF.gen_parameters(gold["acoustic_predicted." + tag], Y_mean, Y_std)
+        for n, v in zip(("mgc", "lf0", "vuv", "bap"), got):
+            _close(v, gold["%s.%s" % (n, tag)], rtol=2e-5, msg="%s.%s (ref input)" % (n, tag))
+    d = INF.predict_duration(build_model(I["duration"], 42), inp["feats_duration"], X_min, X_max, Y_mean, Y_std)
+    assert d.shape == gold["durations"].shape and d.min() >= 1
+    assert (d != gold["durations"]).sum() <= 1, "rounded durations differ in more than one borderline entry"
+    inputs, outputs, diff = INF.vc_convert(build_model(I["vc"], 43), gold["vc_mc"], inp["vc_mean"], inp["vc_std"], diffvc=True)
+    np.testing.assert_array_equal(inputs, gold["vc_mc"][:, :25])
+    _close(outputs, gold["vc_outputs"], msg="vc_outputs")
+    _close(diff, gold["vc_diff"], rtol=1e-4, atol=1e-5, msg="vc_diff")
+    with pytest.raises(NotImplementedError):
+        INF.gen_parameters(gold["acoustic_predicted.mlp"], Y_mean, Y_std, mge_training=False)

@@ -200,3 +200,28 @@ def test_distortion_metrics_without_lengths_use_every_frame():
     assert abs(O.vuv_error(v, w) - float((v != w).double().mean())) < 1e-12
     with pytest.raises(ZeroDivisionError):
         O.lf0_mean_squared_error(X[:, :, :1], torch.zeros(3, 11, dtype=torch.long), Y[:, :, :1], w)
+
+
+def test_inference_restatements_match_reference_golden():
+    """oracle.gen_parameters vs the real evaluation_tts.gen_parameters outputs; generic mlpg() with unit
+    variance == the unit-variance matrix form; weighted mlpg solves its normal equations."""
+    gold = np.load(os.path.join(GOLDEN, "inference.npz"))
+    inp = C.make_inference_inputs()
+    for tag in ("lstm", "mlp"):
+        got = O.gen_parameters([180, 3, 1, 3], C.WINDOWS, gold["acoustic_predicted." + tag],
+                               inp["Y_mean_acoustic"], inp["Y_std_acoustic"])
+        for n, v in zip(("mgc", "lf0", "vuv", "bap"), got):
+            np.testing.assert_allclose(v, gold["%s.%s" % (n, tag)], rtol=1e-10, atol=1e-10, err_msg=n)
+    rs = np.random.RandomState(0)
+    mu = rs.randn(19, 6)
+    R = O.unit_variance_mlpg_matrix(C.WINDOWS, 19).astype(np.float64)
+    want = R @ mu.reshape(19, 3, 2).transpose(1, 0, 2).reshape(57, 2)
+    np.testing.assert_allclose(O.mlpg(mu, np.ones(6), C.WINDOWS), want, atol=2e-6)
+    var = 0.2 + rs.rand(19, 6)
+    c = O.mlpg(mu, var, C.WINDOWS)
+    Ws = [O._window_matrix(l, u, w, 19) for (l, u, w) in C.WINDOWS]
+    for d in range(2):      # gradient of the weighted least-squares objective vanishes at the solution
+        g = sum(Ww.T @ ((Ww @ c[:, d] - mu[:, w * 2 + d]) / var[:, w * 2 + d]) for w, Ww in enumerate(Ws))
+        assert np.abs(g).max() < 1e-9
+    d = O.predict_durations(np.array([[-3.0, 0.2, 0.26]]), np.array([1.0, 1.0, 1.0]), np.array([1.0, 1.0, 2.0]))
+    np.testing.assert_array_equal(d, [[1.0, 1.0, 2.0]])
