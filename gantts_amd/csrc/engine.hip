@@ -123,8 +123,11 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
 static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
 
 template <int KIND, int BM, int BN>
-static int launch_gemm_v(const GemmArgs& g, int nslab, hipStream_t s) {
-  // 16-byte operand loads need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
+static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
+  GemmArgs g = g_in;
+  // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
+  g.wide_store = KIND != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
+                 (KIND != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
   const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
   const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
   if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true>(g, nslab, s);

@@ -84,6 +84,8 @@ struct GemmArgs {
   int act;                   // Act
   const float* H; int ldh;   // NN: producer's stored activation (for f'), or null
   int accumulate;            // NT/NN: C += result (sum over LSTM directions / SRU highway term)
+  int wide_store;            // NT/NN: C (and H) 16-byte aligned with pitch % 4 == 0 -> full tiles are written
+                             // row-wise with 16 B stores through an LDS transpose (set by the launcher)
   DropoutSpec drop;
   // TN split
   int k_chunk;               // rows of K per slab (multiple of GEMM_BK)
@@ -409,6 +411,80 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
   const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
   const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+
+  if (KIND != GEMM_TN && full_tile && g.wide_store) {
+    // Wide path: everything that is keyed by the MFMA layout (bias column, the 4 Philox words of rows
+    // mrow..mrow+3) is applied in the C layout, the 32 x WN strip is transposed through a wave-private
+    // LDS region, and the strip leaves row-wise: 16 B per lane, WN*4-byte contiguous row segments
+    // (4x fewer store instructions, full-line writes).  H (NN: f' of the producer) is read the same way.
+    constexpr int EP = WN + 4;                    // pitch (floats), keeps 16 B alignment
+    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN>(), "epilogue staging exceeds the LDS image");
+    constexpr int LPR = WN / 4;                   // lanes per row
+    constexpr int RPI = 64 / LPR;                 // rows per store instruction
+    __syncthreads();                              // the K loop's LDS image is dead from here on
+    float* stg = smem + wave * (32 * EP);
+    const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        float bias = 0.f;
+        if (KIND == GEMM_NT && g.bias) bias = g.bias[n];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
+          uint32_t rnd[4];
+          if (philox) philox4x32_10((uint32_t)(mrow >> 2), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            float v = acc[i][j][q * 4 + s4];
+            if (KIND == GEMM_NT) {
+              v += bias;
+              if (g.act == ACT_LEAKY_DROPOUT) {
+                v = leaky(v);
+                if (g.drop.mode == DROP_PHILOX) v = rnd[s4] >= g.drop.thresh ? v * g.drop.scale : 0.f;
+                else if (g.drop.mode == DROP_BUFFER)
+                  v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
+              } else if (g.act == ACT_SIGMOID) {
+                v = 1.f / (1.f + expf(-v));
+              }
+            } else if (g.act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
+              if (g.drop.mode == DROP_PHILOX) v = rnd[s4] >= g.drop.thresh ? v * g.drop.scale : 0.f;
+              else if (g.drop.mode == DROP_BUFFER)
+                v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
+            }
+            stg[(8 * q + 4 * half + s4) * EP + j * 32 + l31] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + srow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EP + sc4);
+        const long m = m0 + wm * WM + i * 32 + row;
+        const int n = n0 + wn * WN + sc4;
+        if (KIND == GEMM_NN && g.act != ACT_NONE) {
+          const f32x4 h = *reinterpret_cast<const f32x4*>(g.H + m * g.ldh + n);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            v[c] *= g.act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
+        }
+        float* dst = C + m * g.ldc + n;
+        if (g.accumulate) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += o[c];
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll

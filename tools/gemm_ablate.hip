@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
   hipMemset(A, 0x3c, (size_t)M * K * 4); hipMemset(B, 0x3c, (size_t)N * K * 4); hipMemset(bias, 0, N * 4);
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = Cc; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = ACT_NONE;
-  g.drop.mode = DROP_NONE; g.drop.scale = 1.f; g.n_tiles_m = M / 128; g.n_tiles_n = N / 128;
+  g.drop.mode = DROP_NONE; g.drop.scale = 1.f; g.wide_store = getenv("NOWIDE") ? 0 : 1; g.n_tiles_m = M / 128; g.n_tiles_n = N / 128;
   const size_t lds = gemm_lds_bytes<GEMM_NT, 128, 128>();
   hipFuncSetAttribute((const void*)gemm_f32_kernel<GEMM_NT, 128, 128, VEC, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
