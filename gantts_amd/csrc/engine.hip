@@ -603,8 +603,8 @@ static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const 
     d.mode = DROP_BUFFER; d.mask = stacked_mask; d.ld_mask = ld;
   } else {
     d.mode = DROP_PHILOX;
-    double th = (double)n.d.dropout * 4294967296.0;
-    d.thresh = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+    const double th = (double)n.d.dropout * 65536.0 + 0.5;       // 16-bit pieces (gemm_f32.hip.h: philox_keep)
+    d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
     const uint64_t site = e->step_counter * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
     d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
     d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;

@@ -46,11 +46,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 }
 
 __device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int col) {
-  if (d.mode == DROP_PHILOX) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)(row >> 2), (uint32_t)col, d.key0, d.key1, r);
-    return r[row & 3] >= d.thresh;
-  }
+  if (d.mode == DROP_PHILOX) return philox_keep(d.key0, d.key1, d.thresh, row, col);
   if (d.mode == DROP_BUFFER) return d.mask[(long)row * d.ld_mask + col] != 0.f;
   return true;
 }

@@ -44,7 +44,7 @@ struct DropoutSpec {
   int mode;           // DropMode
   float p;            // drop probability
   float scale;        // 1/(1-p)
-  uint32_t thresh;    // keep iff philox word >= thresh  (thresh = p * 2^32)
+  uint32_t thresh;    // keep iff 16-bit philox piece >= thresh  (thresh = p * 2^16)
   uint32_t key0, key1;  // philox key: (seed, site/step)
   const float* mask;  // DROP_BUFFER: [rows][ld_mask] 0/1 floats
   int ld_mask;
@@ -63,6 +63,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Dropout keep bits from 16-bit pieces: ONE Philox call decides 8 elements of a column -- the rows that
+// share (row >> 4, (row >> 2) & 1), i.e. exactly the 8 rows of a 16-row group that one lane of the
+// 32x32 MFMA C layout owns (rows 8q + 4*half + s, q in {0,1}).  Layout-independent definition:
+//   counter = (2*(row>>4) + ((row>>2)&1), col),  piece = 4*((row>>3)&1) + (row&3),  keep iff piece >= p*2^16
+__device__ __forceinline__ uint32_t philox_piece(const uint32_t r[4], int piece) {
+  return (r[piece >> 1] >> ((piece & 1) * 16)) & 0xffffu;
+}
+__device__ __forceinline__ bool philox_keep(uint32_t key0, uint32_t key1, uint32_t thresh, int row, int col) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)(2 * (row >> 4) + ((row >> 2) & 1)), (uint32_t)col, key0, key1, r);
+  return philox_piece(r, 4 * ((row >> 3) & 1) + (row & 3)) >= thresh;
 }
 
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : 0.01f * z; }
@@ -431,26 +444,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         const int n = n0 + wn * WN + j * 32 + l31;
         float bias = 0.f;
         if (KIND == GEMM_NT && g.bias) bias = g.bias[n];
+        uint32_t rnd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
-          uint32_t rnd[4];
-          if (philox) philox4x32_10((uint32_t)(mrow >> 2), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+          if (philox && (q & 1) == 0)
+            philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
+            const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
             float v = acc[i][j][q * 4 + s4];
             if (KIND == GEMM_NT) {
               v += bias;
               if (g.act == ACT_LEAKY_DROPOUT) {
                 v = leaky(v);
-                if (g.drop.mode == DROP_PHILOX) v = rnd[s4] >= g.drop.thresh ? v * g.drop.scale : 0.f;
+                if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
                 else if (g.drop.mode == DROP_BUFFER)
                   v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
               } else if (g.act == ACT_SIGMOID) {
                 v = 1.f / (1.f + expf(-v));
               }
             } else if (g.act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
-              if (g.drop.mode == DROP_PHILOX) v = rnd[s4] >= g.drop.thresh ? v * g.drop.scale : 0.f;
+              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
               else if (g.drop.mode == DROP_BUFFER)
                 v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
             }
@@ -493,21 +508,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
       const bool n_ok = full_tile || n < g.N;
       float bias = 0.f;
       if (KIND == GEMM_NT && g.bias && n_ok) bias = g.bias[n];
+      uint32_t rnd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
-        uint32_t rnd[4];
-        if (philox) philox4x32_10((uint32_t)(mrow >> 2), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+        if (philox && (q & 1) == 0)
+          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;
+          const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
           if (!full_tile && (!n_ok || m >= g.M)) continue;
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
             v += bias;
             if (g.act == ACT_LEAKY_DROPOUT) {
               v = leaky(v);
-              if (g.drop.mode == DROP_PHILOX) v = rnd[s] >= g.drop.thresh ? v * g.drop.scale : 0.f;
+              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
               else if (g.drop.mode == DROP_BUFFER)
                 v = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
             } else if (g.act == ACT_SIGMOID) {
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
               const float h = g.H[(long)m * g.ldh + n];
               bool keep = true;
               float scale = 1.f;
-              if (g.drop.mode == DROP_PHILOX) { keep = rnd[s] >= g.drop.thresh; scale = g.drop.scale; }
+              if (g.drop.mode == DROP_PHILOX) { keep = keep_px; scale = g.drop.scale; }
               else if (g.drop.mode == DROP_BUFFER) {
                 keep = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f; scale = g.drop.scale;
               }

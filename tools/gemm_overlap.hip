@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
           GemmArgs g; memset(&g, 0, sizeof(g));
           g.A = A + (size_t)p * rows * K; g.lda = K; g.B = B; g.ldb = K; g.C = Cc + (size_t)p * rows * N; g.ldc = N;
           g.M = rows; g.N = N; g.K = K; g.bias = bias; g.act = act ? ACT_LEAKY_DROPOUT : ACT_NONE;
-          g.drop.mode = act ? DROP_PHILOX : DROP_NONE; g.drop.scale = 2.f; g.drop.p = 0.5f; g.drop.thresh = 0x80000000u;
+          g.drop.mode = act ? DROP_PHILOX : DROP_NONE; g.drop.scale = 2.f; g.drop.p = 0.5f; g.drop.thresh = 0x8000u;
           g.drop.key0 = 123; g.drop.key1 = 456;
           g.wide_store = getenv("NOWIDE") ? 0 : 1; g.n_tiles_m = rows / 128; g.n_tiles_n = N / 128;
           hipLaunchKernelGGL(kern, dim3(g.n_tiles_m * g.n_tiles_n), dim3(256), lds, st[p], g);
