@@ -82,6 +82,33 @@ CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
         windows=3, steps=3, adv_w=1.0, mse_w=1.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # discriminator wide enough (hidden 128, 3 layers) for the row-panel chain kernels: injected dropout masks,
+    # conditioned D, ragged panel tail (2*B*T = 138 rows), real/fake halves sharing the x part of layer 0
+    "acoustic_chain_d": dict(
+        hp="tts_acoustic", B=3, T=23, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32,
+               dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=3, hidden_dim=128,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=3, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
+    # same without conditioning and without dropout (eval-mode modules), Adam
+    "acoustic_chain_d_uncond": dict(
+        hp="tts_acoustic", B=2, T=40, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=False,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32,
+               dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=58, out_dim=1, num_hidden=2, hidden_dim=128,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     # duration model: no dynamic features (R=None), Adam, conditioned D
     "duration_mlp": dict(
         hp="tts_duration", B=5, T=17, din=60, dout=5,
