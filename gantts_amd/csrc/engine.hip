@@ -762,7 +762,7 @@ static bool chain_ok(const Net& n) {
   const int L = (int)n.hidden.size();
   if (L < 2 || L > CH_MAXS) return false;
   const int H = n.hidden[0].out;
-  if (H != 128 && H != 256 && H != 512) return false;
+  if (H != 128 && H != 256) return false;
   for (int l = 0; l < L; ++l) {
     if (n.hidden[l].out != H) return false;
     if (l > 0 && n.hidden[l].in != H) return false;
@@ -777,7 +777,7 @@ static bool chain_ok(const Net& n) {
 template <int TN_, bool FWD>
 static int launch_chain_t(const ChainArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = chain_lds_bytes(a.H, FWD ? a.K0p : 0);
+  const size_t lds = chain_lds_bytes(a.H, FWD ? a.K0p : 0, FWD);
   auto kern = FWD ? chain_fwd_kernel<TN_> : chain_bwd_kernel<TN_>;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
@@ -789,11 +789,10 @@ static int launch_chain_t(const ChainArgs& a, hipStream_t s) {
 }
 static int launch_chain(bool fwd, const ChainArgs& a, hipStream_t s) {
   if (a.rows <= 0) return GT_OK;
-  if (chain_lds_bytes(a.H, fwd ? a.K0p : 0) > 160 * 1024 - 512) return fail(GT_ERR_DIM, "panel chain: first-layer depth %d too large", a.K0);
+  if (chain_lds_bytes(a.H, fwd ? a.K0p : 0, fwd) > 160 * 1024 - 512) return fail(GT_ERR_DIM, "panel chain: first-layer depth %d too large", a.K0);
   switch (a.H) {
     case 128: return fwd ? launch_chain_t<1, true>(a, s) : launch_chain_t<1, false>(a, s);
     case 256: return fwd ? launch_chain_t<2, true>(a, s) : launch_chain_t<2, false>(a, s);
-    case 512: return fwd ? launch_chain_t<4, true>(a, s) : launch_chain_t<4, false>(a, s);
   }
   return fail(GT_ERR_DIM, "panel chain: unsupported hidden width %d", a.H);
 }

@@ -20,11 +20,12 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 3; ++i) { hipMalloc(&act[i], maxrows * H * 4); hipMalloc(&dz[i], maxrows * H * 4); hipMemset(act[i], 0x3c, maxrows * H * 4); hipMemset(dz[i], 0x3c, maxrows * H * 4); }
   hipFuncSetAttribute((const void*)chain_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
   hipFuncSetAttribute((const void*)chain_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  long long* dbg; hipMalloc(&dbg, 1024 * 16 * 8); hipMemset(dbg, 0, 1024 * 16 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (long rows : {16384L, 32768L}) {
     for (int fwd = 1; fwd >= 0; --fwd) {
       ChainArgs a; memset(&a, 0, sizeof(a));
-      a.rows = rows; a.H = H;
+      a.rows = rows; a.H = H; a.dbg = dbg;
       DropoutSpec d; memset(&d, 0, sizeof(d)); d.mode = getenv("NODROP") ? DROP_NONE : DROP_PHILOX; d.p = 0.5f; d.scale = 2.f; d.thresh = 0x8000u; d.key0 = 1; d.key1 = 2;
       double flops;
       if (fwd) {
@@ -36,7 +37,7 @@ int main(int argc, char** argv) {
         for (int l = 0; l < 2; ++l) { a.st[l].W = W; a.st[l].ldw = H; a.st[l].Hact = act[l]; a.st[l].ldh = H; a.st[l].out = dz[l]; a.st[l].ldo = H; a.st[l].act = getenv("NOACT") ? ACT_NONE : ACT_LEAKY_DROPOUT; a.st[l].drop = d; }
         flops = 2.0 * rows * H * (2.0 * H);
       }
-      const size_t lds = chain_lds_bytes(H, fwd ? K0p : 0);
+      const size_t lds = chain_lds_bytes(H, fwd ? K0p : 0, fwd != 0);
       for (int i = 0; i < 3; ++i) CHAIN_LAUNCH(fwd, a, lds);
       hipEventRecord(e0);
       const int it = 20;
@@ -44,6 +45,10 @@ int main(int argc, char** argv) {
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double us = ms * 1e3 / it;
+#ifdef CH_DEBUG_TIMING
+      { long long h[1024 * 16]; hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int wg : {0, 255, (int)(rows / 64) - 1}) { printf("  wg %4d stamps (cycles since first):", wg); for (int i = 1; i < 16 && h[wg * 16 + i]; ++i) printf(" %lld", h[wg * 16 + i] - h[wg * 16]); printf("   | start offset vs wg0 %lld\n", h[wg * 16] - h[0]); } }
+#endif
       printf("%s rows=%ld: %.1f us  %.1f TFLOP/s  (%s)\n", fwd ? "fwd(3 stages)" : "bwd(2 stages)", rows, us, flops / (us * 1e-6) / 1e12, hipGetErrorString(hipGetLastError()));
     }
   }
