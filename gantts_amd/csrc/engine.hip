@@ -662,7 +662,7 @@ static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, 
     lds_set = lds;
   }
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(256), lds, s, y, ldy, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
                      ys, ldys, B, T);
   LAUNCH_CHECK();
   return GT_OK;
@@ -678,7 +678,7 @@ static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* sco
     lds_set_b = lds;
   }
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(256), lds, s, gs, ldgs, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
                      gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc());
   LAUNCH_CHECK();
   return GT_OK;

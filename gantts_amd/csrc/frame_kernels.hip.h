@@ -149,8 +149,9 @@ constexpr int MLPG_CC = 64;      // static columns per workgroup
 // (0.6 LDS instructions per FMA instead of 2 for the one-output-per-lane form).
 constexpr int MLPG_PAD = 3;      // = frames per lane - 1
 constexpr int MLPG_MAXW = 4;
+constexpr int MLPG_THREADS = 1024; // all 16 waves stage the tile and band rows, waves 0-3 compute
 
-__global__ __launch_bounds__(256) void mlpg_forward_kernel(
+__global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ ys, int ldys, int B, int T) {
@@ -186,12 +187,28 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
       }
     }
   }
-  for (int e = threadIdx.x; e < MLPG_TT * nW * nbp; e += blockDim.x) {
-    const int jp = e % nbp, tw = e / nbp;                      // tw = tl*nW + w
-    const int t = t0 + tw / nW, j = jp - MLPG_PAD;
-    sb[e] = (t < T && j >= 0 && j < nb) ? band[((long)t * nW + tw % nW) * nb + j] : 0.f;
+  {  // band rows: 8 independent loads in flight per thread (a load->store loop would pay the latency per element)
+    const int total = MLPG_TT * nW * nbp;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = min(e0 + q * (int)blockDim.x, total - 1);
+        const int jp = e % nbp, tw = e / nbp;                    // tw = tl*nW + w
+        const int t = t0 + tw / nW, j = jp - MLPG_PAD;
+        const bool ok = t < T && j >= 0 && j < nb;
+        const float x = band[((long)min(t, T - 1) * nW + tw % nW) * nb + min(max(j, 0), nb - 1)];
+        v[q] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * (int)blockDim.x;
+        if (e < total) sb[e] = v[q];
+      }
+    }
   }
   __syncthreads();
+  if (threadIdx.x >= 256) return;        // every wave stages (memory-level parallelism), four compute
   const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;     // column pair, frame group (4 frames)
   const int tl0 = fg * 4;
   float acc[4][2];
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void mlpg_forward_kernel(
 //   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
 // LDS: gs tile [(TT+2kb)][CC] + the band rows of the same frames, padded, [(TT+2kb)][nW][nb+2*PAD].
 // Lane = 2 columns x 4 frames x all windows: one ds_read_b64 of gs feeds 8*nW FMAs.
-__global__ __launch_bounds__(256) void mlpg_backward_kernel(
+__global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ gy, int ldgy, int B, int T,
@@ -268,12 +285,28 @@ __global__ __launch_bounds__(256) void mlpg_backward_kernel(
       }
     }
   }
-  for (int e = threadIdx.x; e < rows * nW * nbp; e += blockDim.x) {
-    const int jp = e % nbp, rw = e / nbp;                      // rw = r*nW + w
-    const int t = t0 - kb + rw / nW, j = jp - MLPG_PAD;
-    sb[e] = (t >= 0 && t < T && j >= 0 && j < nb) ? band[((long)t * nW + rw % nW) * nb + j] : 0.f;
+  {
+    const int total = rows * nW * nbp;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = min(e0 + q * (int)blockDim.x, total - 1);
+        const int jp = e % nbp, rw = e / nbp;                    // rw = r*nW + w
+        const int t = t0 - kb + rw / nW, j = jp - MLPG_PAD;
+        const bool ok = t >= 0 && t < T && j >= 0 && j < nb;
+        const float x = band[((long)min(max(t, 0), T - 1) * nW + rw % nW) * nb + min(max(j, 0), nb - 1)];
+        v[q] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * (int)blockDim.x;
+        if (e < total) sb[e] = v[q];
+      }
+    }
   }
   __syncthreads();
+  if (threadIdx.x >= 256) return;
   const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;
   const int tl0 = fg * 4;
   float acc[MLPG_MAXW][4][2];
