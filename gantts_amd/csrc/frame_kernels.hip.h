@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
   const float inv_tv = sc->inv_tv;
   const float b0 = bias[0];
   double s_real = 0, s_fake = 0, n_rok = 0, n_fok = 0, dbs = 0;
-  float wreg[KP], dwacc[KP], hcur[KP], hnxt[KP];
+  float wreg[KP], dwacc[KP];
   int kidx[KP];
 #pragma unroll
   for (int j = 0; j < KP; ++j) {
@@ -419,53 +419,74 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     wreg[j] = k < K ? w[k] : 0.f;
     dwacc[j] = 0.f;
   }
-  const int stride = gridDim.x * 4;
-  int r = blockIdx.x * 4 + wv;
-  if (r < n_rows) {
+  // A wave owns ITEMS of 8 rows: the rows of a 16-row group that share one Philox call per column
+  // (rows 16g + 8q + 4h + s, q in {0,1}, s in 0..3; gemm_f32.hip.h: philox_keep) -- one call per lane and
+  // column slot instead of one per element.  All 8 rows of an item are requested up front.
+  const int n_items = ((n_rows + 15) / 16) * 2;
+  for (int item = blockIdx.x * 4 + wv; item < n_items; item += gridDim.x * 4) {
+    const int g = item >> 1, h = item & 1;
+    float hrow[8][KP];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) hcur[j] = H[(long)r * ldh + kidx[j]];
-  }
-  for (; r < n_rows; r += stride) {
-    const int rn = r + stride;
-    if (rn < n_rows) {
+    for (int ri = 0; ri < 8; ++ri) {
+      const int r = min(16 * g + 8 * (ri >> 2) + 4 * h + (ri & 3), n_rows - 1);
 #pragma unroll
-      for (int j = 0; j < KP; ++j) hnxt[j] = H[(long)rn * ldh + kidx[j]];
+      for (int j = 0; j < KP; ++j) hrow[ri][j] = H[(long)r * ldh + kidx[j]];
     }
-    float part = 0.f;
+    uint32_t keepb[KP];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) part = fmaf(hcur[j], wreg[j], part);
-    const float z = wave_sum(part) + b0;
-    const float D = 1.f / (1.f + expf(-z));
-    const float m = mask[r % n_mask];
-    const bool is_real = (mode == HEAD_G_ADV) || (r < n_real);
-    float dD;
-    if (is_real) {
-      const float l = logf(D + eps) * m;
-      if (lane == 0) s_real += (double)l;
-      if (lane == 0 && mode == HEAD_D_STEP) n_rok += (D > 0.5f ? 1.0 : 0.0) * (double)m;
-      dD = -m * inv_tv / (D + eps);
-    } else {
-      const float om = (1.f - D) + eps;
-      const float l = logf(om) * m;
-      if (lane == 0) { s_fake += (double)l; n_fok += (D < 0.5f ? 1.0 : 0.0) * (double)m; }
-      dD = m * inv_tv / om;
-    }
-    if (lane == 0 && Dout) Dout[r] = D;
-    if (want_grad) {
-      const float dz = dD * ((1.f - D) * D);
-      if (lane == 0) dbs += (double)dz;
+    for (int j = 0; j < KP; ++j) {
+      keepb[j] = 0xffu;
+      if (want_grad && has_act && drop.mode == DROP_PHILOX) {
+        uint32_t rnd[4];
+        philox4x32_10((uint32_t)(2 * g + h), (uint32_t)kidx[j], drop.key0, drop.key1, rnd);
+        uint32_t bits = 0;
 #pragma unroll
-      for (int j = 0; j < KP; ++j) {
-        const int k = lane + 64 * j;
-        const float hv = hcur[j];
-        dwacc[j] = fmaf(dz, hv, dwacc[j]);
-        float f = 1.f;
-        if (has_act) f = leaky_drop_grad(hv, dropout_keep(drop, r, kidx[j]), drop.mode == DROP_NONE ? 1.f : drop.scale);
-        if (k < K) dH[(long)r * lddh + k] = dz * wreg[j] * f;
+        for (int p = 0; p < 8; ++p) bits |= (philox_piece(rnd, p) >= drop.thresh ? 1u : 0u) << p;
+        keepb[j] = bits;
       }
     }
 #pragma unroll
-    for (int j = 0; j < KP; ++j) hcur[j] = hnxt[j];
+    for (int ri = 0; ri < 8; ++ri) {
+      const int r = 16 * g + 8 * (ri >> 2) + 4 * h + (ri & 3);
+      if (r >= n_rows) continue;                   // wave-uniform
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < KP; ++j) part = fmaf(hrow[ri][j], wreg[j], part);
+      const float z = wave_sum(part) + b0;
+      const float D = 1.f / (1.f + expf(-z));
+      const float m = mask[r % n_mask];
+      const bool is_real = (mode == HEAD_G_ADV) || (r < n_real);
+      float dD;
+      if (is_real) {
+        const float l = logf(D + eps) * m;
+        if (lane == 0) s_real += (double)l;
+        if (lane == 0 && mode == HEAD_D_STEP) n_rok += (D > 0.5f ? 1.0 : 0.0) * (double)m;
+        dD = -m * inv_tv / (D + eps);
+      } else {
+        const float om = (1.f - D) + eps;
+        const float l = logf(om) * m;
+        if (lane == 0) { s_fake += (double)l; n_fok += (D < 0.5f ? 1.0 : 0.0) * (double)m; }
+        dD = m * inv_tv / om;
+      }
+      if (lane == 0 && Dout) Dout[r] = D;
+      if (want_grad) {
+        const float dz = dD * ((1.f - D) * D);
+        if (lane == 0) dbs += (double)dz;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          const int k = lane + 64 * j;
+          const float hv = hrow[ri][j];
+          dwacc[j] = fmaf(dz, hv, dwacc[j]);
+          float f = 1.f;
+          if (has_act) {
+            bool keep = ((keepb[j] >> ri) & 1u) != 0u;
+            if (drop.mode == DROP_BUFFER) keep = drop.mask[(long)r * drop.ld_mask + kidx[j]] != 0.f;
+            f = leaky_drop_grad(hv, keep, drop.mode == DROP_NONE ? 1.f : drop.scale);
+          }
+          if (k < K) dH[(long)r * lddh + k] = dz * wreg[j] * f;
+        }
+      }
+    }
   }
   // reduce the scalar partials over the 4 waves
   if (lane == 0) { shd[0][wv] = s_real; shd[1][wv] = s_fake; shd[2][wv] = n_rok; shd[3][wv] = n_fok; shd[4][wv] = dbs; }
