@@ -1362,8 +1362,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
                e->d_specs.back(), true, s));
   e->early_done = false;
   if (e->early) {   // losses and counts are final here; gradient norm is not (reported as 0)
-    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
-    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), 1);
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));
   }
@@ -1410,9 +1409,8 @@ extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result*
     HIPCHK(hipEventSynchronize(e->ev_res));       // only the scalar copy; backward + step stay queued
     e->early_done = false;
   } else {
-    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_d, 0, sizeof(double), s));
     if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
-    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res());
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), train ? 0 : 1);
     LAUNCH_CHECK();
     CHK(fetch_results(e, s));
   }
@@ -1581,8 +1579,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   e->early_done = false;
   if (e->early && !(tr && direct && mse_w != 0.f)) {   // all four losses are final here
-    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
-    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1);
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));
   }
@@ -1605,9 +1602,9 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
     HIPCHK(hipEventSynchronize(e->ev_res));
     e->early_done = false;
   } else {
-    HIPCHK(hipMemsetAsync(&e->sc()->gnorm2_g, 0, sizeof(double), s));
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
-    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0);
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
+                       train ? 0 : 1);
     LAUNCH_CHECK();
     CHK(fetch_results(e, s));
   }

@@ -70,7 +70,13 @@ struct StepScalars {
 __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, StepScalars* sc) {
   __shared__ double sh[16];
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)mask[i];
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // 0/1 values: float partial sums of <= n/4096 terms are exact
+  int i = threadIdx.x;
+  for (; i + 3 * (int)blockDim.x < n; i += 4 * blockDim.x) {
+    p0 += mask[i]; p1 += mask[i + blockDim.x]; p2 += mask[i + 2 * blockDim.x]; p3 += mask[i + 3 * blockDim.x];
+  }
+  for (; i < n; i += blockDim.x) p0 += mask[i];
+  v = ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
   const double tot = block_sum_d(v, sh);
   if (threadIdx.x == 0) {
     const float tv = tv_override > 0.f ? tv_override : (float)tot;
@@ -521,16 +527,22 @@ __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartial
   const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + kl;
   if (dw) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float sa[16];                                  // 16 independent loads in flight per thread (latency-bound otherwise)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sa[u] = 0.f;
     if (k < K) {
       int i = part;
-      for (; i + 48 < nblk; i += 64) {
-        s0 += dw_partial[(long)i * K + k];         s1 += dw_partial[(long)(i + 16) * K + k];
-        s2 += dw_partial[(long)(i + 32) * K + k];  s3 += dw_partial[(long)(i + 48) * K + k];
+      for (; i + 15 * 16 < nblk; i += 256) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sa[u] += dw_partial[(long)(i + 16 * u) * K + k];
       }
-      for (; i < nblk; i += 16) s0 += dw_partial[(long)i * K + k];
+      for (; i < nblk; i += 16) sa[0] += dw_partial[(long)i * K + k];
     }
-    shw[part][kl] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sa[u] += sa[u + 8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sa[u] += sa[u + 4];
+    shw[part][kl] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     __syncthreads();
     if (part == 0 && k < K) {
       float tot = 0.f;
@@ -884,22 +896,24 @@ struct StepResults {
   float loss_mse, loss_mge, loss_adv, loss_g;                           // train.py:320 order
   float gnorm_d, gnorm_g, tv;
 };
-__global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out) {
+// zero_gnorm: the gradient norm is not known / not applicable at this point (early results, phase != "train"): report 0
+__global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int zero_gnorm) {
   if (threadIdx.x || blockIdx.x) return;
   const float T = sc->tv;
   const float lr = -((float)sc->s_real) / T, lf = -((float)sc->s_fake) / T;
   out->loss_real_d = lr; out->loss_fake_d = lf; out->loss_d = lr + lf;
   out->real_correct = (float)sc->n_real_ok; out->fake_correct = (float)sc->n_fake_ok;
-  out->gnorm_d = (float)sqrt(sc->gnorm2_d); out->tv = T;
+  out->gnorm_d = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_d); out->tv = T;
 }
-__global__ void finalize_g_kernel(const StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv) {
+__global__ void finalize_g_kernel(const StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
+                                  int zero_gnorm) {
   if (threadIdx.x || blockIdx.x) return;
   const float T = sc->tv;
   const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
   const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;
   out->loss_mse = mse; out->loss_mge = mge; out->loss_adv = adv;
   out->loss_g = (mse_w * mse + mge_w * mge) + adv_w * adv;
-  out->gnorm_g = (float)sqrt(sc->gnorm2_g); out->tv = T;
+  out->gnorm_g = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_g); out->tv = T;
 }
 
 }  // namespace gt
