@@ -36,6 +36,32 @@ D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, 
 OPT = dict(lr=0.01, weight_decay=1e-7)
 
 
+def pmc_traffic(variant):
+    """HBM bytes per launch of a GEMM variant from the committed PMC passes (profiles/<round>_pmc.json, written by
+    tools/summarize_profile.py from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same command).  Counters
+    cannot be collected inside this process; null when no profile of the build is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        key = "%d,%d" % (variant // 2, 64 if variant % 2 == 0 else 128)
+        return d["gemm_variants"][key]["hbm_bytes_per_launch"], os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) + ": " + d["source"]
+    except Exception:
+        return None, None
+
+
+def nt128_algorithmic_bytes(N):
+    """Average algorithmic bytes (operands once + result once, fp32) of the forward GEMM launches that use 128-column
+    tiles in one cfg2 step: G layers 1-3 on N rows, D layers 1-3 on 2N rows (D step) and on N rows (G step)."""
+    g, d = G_SPEC, D_SPEC
+    shapes = [(N, g["hidden_dim"], g["in_dim"])] + [(N, g["hidden_dim"], g["hidden_dim"])] * (g["num_hidden"] - 1)
+    for rows in (2 * N, N):
+        shapes += [(rows, d["hidden_dim"], d["in_dim"])] + [(rows, d["hidden_dim"], d["hidden_dim"])] * (d["num_hidden"] - 1)
+    return sum(4.0 * (m * k + n * k + m * n) for m, n, k in shapes) / len(shapes)
+
+
 def algorithmic_flops_per_frame():
     """3g - g1 + 8d - d1 MACs per frame (minimal equivalent step)."""
     def macs(spec):
@@ -212,8 +238,12 @@ def main():
                             "share_of_step_ms": ms[v] / profiled_steps})
         tot_ms, tot_fl = sum(ms), sum(fl)
         dom = max(per, key=lambda p: p["share_of_step_ms"])
+        dom_v = [v for v in range(6) if cnt[v] and "gemm_f32_kernel<%s>" % VARIANTS[v] == dom["kernel"]][0]
+        traffic, traffic_src = pmc_traffic(dom_v)
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                    "traffic_algorithmic": nt128_algorithmic_bytes(B * Tn) if dom_v == 1 else None,
                     "avg_launch_us": dom["avg_us"],
                     "gemm_family": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -9,12 +9,12 @@ OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/stats.log
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/stats.log
 BENCHP="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o k -- $BENCHP > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o k -- $BENCHP > /dev/null 2> $OUT/pmc_write.log
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o k -- $BENCHP > /dev/null 2> $OUT/pmc_mfma.log
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o k -- $BENCHP > /dev/null 2> $OUT/pmc_fetch.log
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o k -- $BENCHP > /dev/null 2> $OUT/pmc_write.log
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o k -- $BENCHP > /dev/null 2> $OUT/pmc_mfma.log
 cd $ROOT
-python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+timeout 200 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -40
 tail -c 600 $OUT/bench.json

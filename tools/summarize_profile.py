@@ -83,5 +83,25 @@ for k in sorted(mfma, key=lambda k: -mfma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) 
     if f + w < 0.5 and busy == 0:
         continue
     L.append("| `%s` | %d | %.1f | %.1f | %.2f | %.0f |" % (k, n, f, w, busy, m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n / 64))
+# machine-readable PMC aggregates per GEMM variant (kind, BN) -- bench.py reports them as roofline.traffic
+import re
+pmc = {}
+for k in mfma:
+    mm = re.match(r"gemm_f32_kernel<(\d), (\d+), (\d+)", k)
+    if not mm:
+        continue
+    key = "%s,%s" % (mm.group(1), mm.group(3))
+    d = pmc.setdefault(key, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
+    nl = max(1, nm[k])
+    d["launches"] += nl
+    d["fetch_bytes"] += fetch.get(k, {}).get("FETCH_SIZE", 0) / max(1, nf.get(k, 1)) * nl * 1024 * 2
+    d["write_bytes"] += write.get(k, {}).get("WRITE_SIZE", 0) / max(1, nw.get(k, 1)) * nl * 1024
+for d in pmc.values():
+    d["hbm_bytes_per_launch"] = (d["fetch_bytes"] + d["write_bytes"]) / d["launches"]
+    d["fetch_bytes"] /= d["launches"]
+    d["write_bytes"] /= d["launches"]
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_round.sh %s); "
+                     "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, averaged per launch" % tag,
+           "gemm_variants": pmc}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L))
