@@ -296,6 +296,7 @@ struct gt_engine {
   uint64_t seed = 0x5DEECE66DULL;
   uint64_t step_counter = 0;
   float tv_override = -1.f;
+  const double* tv_dev = nullptr;   // device-resident global normaliser (data parallel: no host round trip)
   // derived stream maps (device)
   int Dout_cfg = 0, Ds = 0, Da = 0;
   std::vector<int> h_scol, h_sstride, h_adv_cols, h_adv_inv;
@@ -306,6 +307,8 @@ struct gt_engine {
   // workspace
   std::vector<Scratch> g_act, d_act;       // hidden activations
   std::vector<Scratch> d_dz;               // panel-chain backward: dZ of every hidden layer but the last
+  // GT_OPT_PANEL_CHAIN: opt-in while the chain kernels are not faster than the per-layer GEMMs
+  bool use_chain = getenv("GT_CHAIN") != nullptr;
   Scratch dW0s;                            // panel-chain forward: aligned, zero-padded copy of W1[:, cd:cd+Da]
   Scratch dP, dadv;                        // panel-chain forward: shared first-layer part x.W1x^T + b1, adversarial columns
   bool fake_adv_valid = false; const float* fake_adv_yhs = nullptr;
@@ -568,9 +571,23 @@ extern "C" int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, 
   e->net[role].inj[pass][layer] = mask;
   return GT_OK;
 }
+extern "C" int gt_set_option(gt_engine* e, int option, int value) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  switch (option) {
+    case GT_OPT_PANEL_CHAIN: e->use_chain = value != 0; return GT_OK;
+  }
+  return fail(GT_ERR_INVALID, "unknown option %d", option);
+}
 extern "C" int gt_set_loss_normalizer(gt_engine* e, float tv) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
   e->tv_override = tv;
+  e->tv_dev = nullptr;
+  return GT_OK;
+}
+extern "C" int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_dev) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->tv_dev = tv_dev;
+  e->tv_mask = nullptr;          // re-read on the next step function
   return GT_OK;
 }
 extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B) {
@@ -769,9 +786,7 @@ static bool chain_ok(const Net& n) {
   }
   for (int l = 1; l < L; ++l)
     if (!aligned16(n.hidden[l].W, n.hidden[l].in)) return false;
-  // opt-in while the chain kernels are slower than the per-layer GEMMs ("what was tried")
-  static const bool on = getenv("GT_CHAIN") != nullptr;
-  return on;
+  return true;
 }
 
 template <int TN_, bool FWD>
@@ -876,7 +891,7 @@ static int build_adv(gt_engine* e, const float* feats, int ld_feats, long row0, 
 // tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask)
 static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
   if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
-  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->sc());
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->tv_dev, e->sc());
   LAUNCH_CHECK();
   e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
   return GT_OK;
@@ -1336,7 +1351,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const long N = (long)B * T;
   const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
   CHK(ensure_tv(e, mask, N, s));
-  const bool chain = chain_ok(D);
+  const bool chain = e->use_chain && chain_ok(D);
   const bool tr = train != 0;
   const int lda = (e->Da + 3) & ~3;
   const int passes[2] = {0, 1};
@@ -1525,7 +1540,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (!D.bound) return fail(GT_ERR_STATE, "adv_w > 0 but no discriminator bound");
     if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
     const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
-    const bool chain = chain_ok(D);
+    const bool chain = e->use_chain && chain_ok(D);
     const int lda = (e->Da + 3) & ~3;
     const int passes[1] = {2};
     const float* cat = nullptr;
@@ -1699,7 +1714,7 @@ extern "C" int gt_op_masked_mse(const float* input, const float* target, const f
   HIPCHK(hipMalloc(&ws, 1024 + 1024 * sizeof(double)));
   StepScalars* sc = (StepScalars*)ws;
   double* part = (double*)((char*)ws + 1024);
-  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, -1.f, sc);
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, -1.f, (const double*)nullptr, sc);
   const int nblk = (int)std::min<long>(1000, cdiv(N * D, RED_THREADS * 4));
   hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, input, D, target, D, mask, N, D, part, grad_input, D,
                      1.f, sc);

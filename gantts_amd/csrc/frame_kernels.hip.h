@@ -67,7 +67,8 @@ struct StepScalars {
 };
 
 // tv = sum(mask[0..n)) ; single workgroup (n = B*T is small)
-__global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, StepScalars* sc) {
+__global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
+                                StepScalars* sc) {
   __shared__ double sh[16];
   double v = 0.0;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // 0/1 values: float partial sums of <= n/4096 terms are exact
@@ -79,7 +80,7 @@ __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_
   v = ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
   const double tot = block_sum_d(v, sh);
   if (threadIdx.x == 0) {
-    const float tv = tv_override > 0.f ? tv_override : (float)tot;
+    const float tv = tv_dev ? (float)*tv_dev : (tv_override > 0.f ? tv_override : (float)tot);
     sc->tv = tv;
     sc->inv_tv = 1.0f / tv;
   }

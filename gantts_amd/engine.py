@@ -126,8 +126,24 @@ class StepEngine(object):
     def set_seed(self, seed):
         check(lib.gt_set_seed(self._h, C.c_uint64(int(seed))))
 
+    def set_option(self, name, value):
+        """Engine switches (results unchanged up to fp32 summation order): ``"panel_chain"``."""
+        opts = {"panel_chain": L.OPT_PANEL_CHAIN}
+        if name not in opts:
+            raise ValueError("unknown engine option %r" % (name,))
+        check(lib.gt_set_option(self._h, opts[name], int(bool(value))))
+
     def set_loss_normalizer(self, tv):
-        check(lib.gt_set_loss_normalizer(self._h, float(tv)))
+        """``tv``: python number, or a 1-element CUDA float64 tensor (kept alive here; read in stream order --
+        the data-parallel path hands over the all-reduced ``sum(mask)`` without a host sync)."""
+        if isinstance(tv, torch.Tensor) and tv.is_cuda:
+            if tv.dtype != torch.float64 or tv.numel() != 1:
+                raise ValueError("device loss normaliser must be a 1-element float64 tensor")
+            self._keep["tv"] = tv
+            check(lib.gt_set_loss_normalizer_device(self._h, ptr(tv)))
+        else:
+            self._keep.pop("tv", None)
+            check(lib.gt_set_loss_normalizer(self._h, float(tv)))
 
     # ---- step functions -------------------------------------------------------------------
     def set_lengths(self, lengths, B, T):
@@ -354,6 +370,11 @@ class HipStepBackend(object):
 
     def mask_of(self, batch):
         return batch["mask"]
+
+    def set_option(self, name, value):
+        self.engine.set_option(name, value)
+
+    device_normalizer = True      # set_loss_normalizer accepts a CUDA float64 tensor (no host sync)
 
     def set_loss_normalizer(self, tv):
         self.engine.set_loss_normalizer(tv)

@@ -4,10 +4,11 @@ rank), parameters / optimizer state replicated.  The reference has no multi-devi
 "gloo" in the CPU tests).
 
 Exchange steps per global step:
-  1. global valid-frame count Tv = sum over ranks of mask.sum()  -> loss normaliser on every rank
+  1. global valid-frame count Tv = sum over ranks of mask.sum()  -> loss normaliser on every rank; kept on
+     the device, its all-reduce overlaps the generator forward
      (losses divide by the GLOBAL Tv: train.py:258,269-270,286,308; seqloss.py:43);
-  2. D step: local forward+backward -> all-reduce(sum) of D's flat gradient + the 7 additive loss /
-     count sums -> identical clip-norm + optimizer step on every rank;
+  2. D step: local forward+backward -> all-reduce(sum) of D's flat gradient + the additive loss /
+     count sums (one coalesced launch) -> identical clip-norm + optimizer step on every rank;
   3. G step: same with G's flat gradient (the D->G "leak" gradient stays local: it is a
      per-frame upstream gradient, already normalised by the global Tv).
 Gradients are single flat buffers (<= 19 MB), so each exchange is ONE all-reduce per network.
@@ -25,11 +26,24 @@ class DataParallelStep(object):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always_reduce = always_reduce and dist.is_initialized()   # exercise the collectives with one rank
+        self._coalesce = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and \
+            hasattr(dist, "_coalescing_manager")
 
-    def _allreduce(self, t):
-        if self.world > 1 or self.always_reduce:
+    def _allreduce(self, *tensors):
+        """Sum over ranks, in place.  Several tensors (the flat gradient + the few loss sums of the same step)
+        go out as ONE coalesced launch where the backend supports it (RCCL: one group call, one latency)."""
+        if not (self.world > 1 or self.always_reduce):
+            return
+        if len(tensors) > 1 and self._coalesce:
+            try:
+                with dist._coalescing_manager(group=self.pg, device=tensors[0].device, async_ops=False):
+                    for t in tensors:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+                return
+            except Exception:          # backend without coalescing support (gloo): fall back for good
+                self._coalesce = False
+        for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-        return t
 
     def broadcast_parameters(self, *flat_buffers):
         """Rank 0's parameters / optimizer state become everyone's (call once after construction)."""
@@ -47,23 +61,35 @@ class DataParallelStep(object):
         """One global step on this rank's shard.  ``batch`` is the backend's opaque local batch.
         Returns (d_result or None, g_result or None), identical on all ranks."""
         be = self.backend
+        tv_work = None
         if tv_global is None:
-            tv_global = self.global_valid_frames(be.mask_of(batch))
-        be.set_loss_normalizer(tv_global)
+            if getattr(be, "device_normalizer", False) and be.mask_of(batch).is_cuda:
+                # the global valid-frame count stays on the device: its all-reduce overlaps the generator
+                # forward and nobody synchronises with the host for it
+                tv_global = be.mask_of(batch).sum().reshape(1).double()
+                if self.world > 1 or self.always_reduce:
+                    tv_work = dist.all_reduce(tv_global, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            else:
+                tv_global = self.global_valid_frames(be.mask_of(batch))
         be.zero_grad()
         be.apply_generator(batch)
+        if tv_work is not None:
+            tv_work.wait()               # stream-level dependency, not a host sync
+        be.set_loss_normalizer(tv_global)
         d_res = g_res = None
         train = phase == "train"
         if update_d:
             be.update_discriminator_begin(batch, phase)
             if train:
-                self._allreduce(be.flat_grads("D"))
-            self._allreduce(be.scalar_sums("D"))
+                self._allreduce(be.flat_grads("D"), be.scalar_sums("D"))
+            else:
+                self._allreduce(be.scalar_sums("D"))
             d_res = be.update_discriminator_end(batch, phase)
         if update_g:
             be.update_generator_begin(batch, adv_w, mse_w, mge_w, phase)
             if train:
-                self._allreduce(be.flat_grads("G"))
-            self._allreduce(be.scalar_sums("G"))
+                self._allreduce(be.flat_grads("G"), be.scalar_sums("G"))
+            else:
+                self._allreduce(be.scalar_sums("G"))
             g_res = be.update_generator_end(batch, adv_w, mse_w, mge_w, phase)
         return d_res, g_res

@@ -169,6 +169,14 @@ int gt_update_generator(gt_engine* e, const float* x, const float* y, const floa
  * gt_scalar_buffer(); the host all-reduces both (RCCL), then *_end clips, steps and finalises.
  * tv_global > 0 overrides sum(mask) as the loss normaliser (global valid-frame count). */
 int gt_set_loss_normalizer(gt_engine* e, float tv_global);
+/* same, from a device double the caller keeps alive (e.g. the all-reduced sum(mask)): no host round trip; the
+ * value is read by the next step functions in stream order.  NULL returns to the local / host normaliser. */
+int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
+/* engine switches that do not change results beyond fp32 summation order.
+ * GT_OPT_PANEL_CHAIN: run an eligible MLP discriminator (hidden 128/256, >= 2 hidden layers) through the row-panel
+ * chain kernels (activations resident in LDS across layers) instead of one GEMM per layer; default off. */
+#define GT_OPT_PANEL_CHAIN 1
+int gt_set_option(gt_engine* e, int option, int value);
 int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                   const float* mask, int B, int T, int train, float eps, void* stream);
 int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream);

@@ -28,7 +28,7 @@ def build_model(spec, seed):
     return m.cuda()
 
 
-def run_hip_case(case, return_objects=False):
+def run_hip_case(case, return_objects=False, engine_options=None):
     import gantts_amd.train as T
     from gantts_amd import optim, paramgen
     from gantts_amd.multistream import get_static_features
@@ -42,6 +42,10 @@ def run_hip_case(case, return_objects=False):
         mg.eval(), md.eval()
     og = getattr(optim, case["opt_g"][0])(mg.parameters(), **case["opt_g"][1])
     od = getattr(optim, case["opt_d"][0])(md.parameters(), **case["opt_d"][1])
+    if engine_options:
+        from gantts_amd.engine import engine_for
+        for k, v in engine_options.items():
+            engine_for(hp, mg).set_option(k, v)
     x_np, y_np, lengths = C.make_batch(case)
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
     Tn = case["T"]

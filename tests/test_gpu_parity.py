@@ -629,3 +629,22 @@ def test_inference_path_matches_reference_golden():
     _close(diff, gold["vc_diff"], rtol=1e-4, atol=1e-5, msg="vc_diff")
     with pytest.raises(NotImplementedError):
         INF.gen_parameters(gold["acoustic_predicted.mlp"], Y_mean, Y_std, mge_training=False)
+
+
+@pytest.mark.parametrize("name", ["acoustic_chain_d", "acoustic_chain_d_uncond"])
+def test_panel_chain_option_matches_reference_golden(name):
+    """The opt-in row-panel chain kernels for the discriminator (GT_OPT_PANEL_CHAIN; LDS-resident activations,
+    x-part of the first layer shared by the real and fake halves) against the same reference goldens."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_hip_case(case, engine_options={"panel_chain": True})
+    for k in gold.files:
+        if k.startswith("g_leak_norm"):
+            continue
+        if ".opt." in k:
+            _close(got[k], gold[k], rtol=5e-4, atol=1e-9, msg=k)
+        else:
+            _close(got[k], gold[k], msg=k)
+    with pytest.raises(ValueError):
+        run_hip_case(case, engine_options={"no_such_option": True})
