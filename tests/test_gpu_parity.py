@@ -648,3 +648,37 @@ def test_panel_chain_option_matches_reference_golden(name):
             _close(got[k], gold[k], msg=k)
     with pytest.raises(ValueError):
         run_hip_case(case, engine_options={"no_such_option": True})
+
+
+def test_data_parallel_step_through_rccl_world_1():
+    """DataParallelStep with a real process group (backend "nccl" == RCCL, one rank, every collective executed:
+    async all-reduce of the device-resident valid-frame count, coalesced gradient + loss-sum all-reduces) ==
+    the plain step.  The multi-rank semantics are covered by the gloo test and the two-engine emulation."""
+    import socket
+    import torch.distributed as dist
+    from gantts_amd.parallel import DataParallelStep
+    from hip_runner import run_hip_case
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        case = C.CASES["acoustic_mlp"]
+        whole = run_hip_case(case)
+        be, b = _dp_objects(case, np.arange(case["B"]))
+        dp = DataParallelStep(be, always_reduce=True)
+        assert dp._coalesce
+        for i in range(case["steps"]):
+            d, g = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"])
+            _close(d, whole["d_scalars_%d" % i], msg="rccl dp d")
+            _close(g, whole["g_scalars_%d" % i], msg="rccl dp g")
+        for tag, m in (("G", be.mg), ("D", be.md)):
+            for k, v in m.state_dict().items():
+                _close(v.cpu().numpy(), whole["%s.%s" % (tag, k)], msg=k)
+        # test phase: only the loss sums travel
+        d, g = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], phase="test")
+        assert np.isfinite(d[0]) and np.isfinite(g[3])
+    finally:
+        dist.destroy_process_group()
