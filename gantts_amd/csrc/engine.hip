@@ -1710,8 +1710,9 @@ extern "C" int gt_op_masked_mse(const float* input, const float* target, const f
   if (!mask) return fail(GT_ERR_INVALID, "Should provide either lengths or mask");  // seqloss.py:33-34
   hipStream_t s = (hipStream_t)stream;
   const long N = (long)B * T;
-  void* ws = nullptr;
-  HIPCHK(hipMalloc(&ws, 1024 + 1024 * sizeof(double)));
+  static thread_local Scratch tls_ws;     // grow-only, no per-call hipMalloc/hipFree (both synchronise the device)
+  CHK(tls_ws.ensure(1024 + 1024 * sizeof(double)));
+  void* ws = tls_ws.p;
   StepScalars* sc = (StepScalars*)ws;
   double* part = (double*)((char*)ws + 1024);
   hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, -1.f, (const double*)nullptr, sc);
@@ -1722,7 +1723,6 @@ extern "C" int gt_op_masked_mse(const float* input, const float* target, const f
   StepScalars h;
   hipError_t err = hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s);
   if (err == hipSuccess) err = hipStreamSynchronize(s);
-  (void)hipFree(ws);
   if (err != hipSuccess) return fail(GT_ERR_HIP, "masked_mse: %s", hipGetErrorString(err));
   if (loss_out) *loss_out = (float)h.s_mse / h.tv;
   return GT_OK;
@@ -1749,10 +1749,13 @@ extern "C" int gt_compute_distortions(const float* y_static, const float* y_hat_
     if (n < 0 || n > T) return fail(GT_ERR_INVALID, "length %lld outside [0, T=%d]", (long long)n, T);
     host[2 * Ds + b] = (int)n;
   }
-  void* ws = nullptr;
+  // grow-only workspace shared by all calls of this thread: the function runs once per training step
+  // (train.py:588-595) -- a hipMalloc/hipFree pair per call would synchronise the device every step
+  static thread_local Scratch tls_ws;
   const size_t off_part = ((host.size() * sizeof(int) + 255) / 256) * 256;
   const size_t off_out = off_part + (size_t)nblk * DIST_NSUM * sizeof(double);
-  HIPCHK(hipMalloc(&ws, off_out + DIST_NSUM * sizeof(double)));
+  CHK(tls_ws.ensure(off_out + DIST_NSUM * sizeof(double)));
+  void* ws = tls_ws.p;
   int* d_int = (int*)ws;
   double* part = (double*)((char*)ws + off_part);
   double* d_out = (double*)((char*)ws + off_out);
@@ -1770,7 +1773,6 @@ extern "C" int gt_compute_distortions(const float* y_static, const float* y_hat_
   double h[DIST_NSUM];
   if (err == hipSuccess) err = hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, s);
   if (err == hipSuccess) err = hipStreamSynchronize(s);   // also keeps `host` alive until the H2D is done
-  (void)hipFree(ws);
   if (err != hipSuccess) return fail(GT_ERR_HIP, "compute_distortions: %s", hipGetErrorString(err));
   out->s_mcd = h[0]; out->s_bap = h[1]; out->s_f0 = h[2]; out->n_voiced = h[3];
   out->n_vuv_err = h[4]; out->s_mse = h[5]; out->n_frames = h[6];
