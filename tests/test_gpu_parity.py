@@ -682,3 +682,58 @@ def test_data_parallel_step_through_rccl_world_1():
         assert np.isfinite(d[0]) and np.isfinite(g[3])
     finally:
         dist.destroy_process_group()
+
+
+def test_train_loop_with_generator_noise_and_two_engines_in_one_process():
+    """cfg5 plumbing: generator_add_noise=True (G in_dim += noise_dim, z ~ U[0,1) drawn on the device,
+    train.py:504-506, 542) and two independent engines (duration: R=None / Adam; acoustic) alive in one process.
+    No reference fixture can exist (torch's CPU RNG stream): checks the mechanics -- finite logs, weights move,
+    the two engines do not disturb each other, the noise stream is reproducible for a fixed seed."""
+    import types
+    import gantts_amd.train as T
+    from gantts_amd import hparams, optim
+    from hip_runner import build_model
+
+    def run(case_name, noise_dim, seed):
+        case = dict(C.TRAIN_LOOP_CASES[case_name])
+        hp = types.SimpleNamespace(**getattr(hparams, case["hp"]).values())
+        hp.stream_sizes, hp.has_dynamic_features = case["stream_sizes"], case["has_dynamic_features"]
+        hp.windows = C.WINDOWS[:case["windows"]]
+        hp.adversarial_streams, hp.mask_nth_mgc_for_adv_loss = case["adversarial_streams"], case["mask_nth_mgc"]
+        hp.discriminator_linguistic_condition = case["cond"]
+        hp.nepoch, hp.lr_decay_schedule, hp.lr_decay_epoch = 1, False, 10
+        hp.generator_add_noise, hp.generator_noise_dim, hp.generator_noise_seed = True, noise_dim, seed
+        hp.optimizer_g_params, hp.optimizer_d_params = dict(case["opt_g"][1]), dict(case["opt_d"][1])
+        T.hp, T.global_epoch = hp, 0
+        g_spec = dict(case["g"], in_dim=case["g"]["in_dim"] + noise_dim)
+        mg, md = build_model(g_spec, 11), build_model(case["d"], 22)
+        w0 = mg.flat_params().clone()
+        og = getattr(optim, case["opt_g"][0])(mg.parameters(), **case["opt_g"][1])
+        od = getattr(optim, case["opt_d"][0])(md.parameters(), **case["opt_d"][1])
+        data, mean, std = C.make_train_loop_data(case)
+
+        class Loader(list):
+            pass
+        loaders = {}
+        for phase in ("train", "test"):
+            ld = Loader((torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(l)) for x, y, l in data[phase])
+            ld.dataset = types.SimpleNamespace(Y_data_mean=mean, Y_data_std=std)
+            loaders[phase] = ld
+        logs = []
+        saved = T.log_value
+        T.log_value = lambda n, v, e: logs.append((n, float(v)))
+        try:
+            assert T.train_loop((mg, md), (og, od), loaders, w_d=1.0, mse_w=0.0, mge_w=1.0) == 0
+        finally:
+            T.log_value = saved
+        assert all(np.isfinite(v) or "f0_rmse" in n for n, v in logs), logs
+        assert not torch.equal(w0, mg.flat_params())
+        return mg.flat_params().clone(), md.flat_params().clone(), logs
+
+    a1 = run("train_loop_acoustic", 7, 123)
+    d1 = run("train_loop_d_warmup", 5, 9)           # a second (G, D, hp) set: its own engines
+    a2 = run("train_loop_acoustic", 7, 123)         # same seed after the other engines ran: identical
+    a3 = run("train_loop_acoustic", 7, 124)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+    assert not torch.equal(a1[0], a3[0])
+    assert len(d1[2]) > 0
