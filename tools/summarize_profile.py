@@ -71,8 +71,9 @@ L.append("## PMC aggregates per launch (averages over the launches of each kerne
 L.append("HBM bytes = FETCH_SIZE x 1024 x 2 (gfx950 counts a wide coalesced read at half its bytes, "
          "MI355X_MICROARCH.md \"HBM\") + WRITE_SIZE x 1024.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
          "(GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).\n")
-L.append("| kernel | launches | FETCH MB (x2 corrected) | WRITE MB | MFMA busy | MFMA instr / launch |")
-L.append("|---|---:|---:|---:|---:|---:|")
+L.append("| kernel | launches | FETCH MB (x2 corrected) | WRITE MB | HBM GB/s (bytes / avg launch time of the trace) | MFMA busy | MFMA instr / launch |")
+L.append("|---|---:|---:|---:|---:|---:|---:|")
+avg_us = {short(x["Name"]): float(x["AverageNs"]) / 1e3 for x in stats}
 for k in sorted(mfma, key=lambda k: -mfma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) - fetch.get(k, {}).get("FETCH_SIZE", 0)):
     f = fetch.get(k, {}).get("FETCH_SIZE", 0) / max(1, nf.get(k, 1)) * 1024 * 2 / 1e6
     w = write.get(k, {}).get("WRITE_SIZE", 0) / max(1, nw.get(k, 1)) * 1024 / 1e6
@@ -82,7 +83,8 @@ for k in sorted(mfma, key=lambda k: -mfma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) 
     busy = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n / (gui * 1024) if gui else 0.0
     if f + w < 0.5 and busy == 0:
         continue
-    L.append("| `%s` | %d | %.1f | %.1f | %.2f | %.0f |" % (k, n, f, w, busy, m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n / 64))
+    gbs = (f + w) * 1e6 / (avg_us[k] * 1e-6) / 1e9 if avg_us.get(k) else 0.0
+    L.append("| `%s` | %d | %.1f | %.1f | %.0f | %.2f | %.0f |" % (k, n, f, w, gbs, busy, m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n / 64))
 # machine-readable PMC aggregates per GEMM variant (kind, BN) -- bench.py reports them as roofline.traffic
 import re
 pmc = {}
