@@ -104,7 +104,28 @@ SIGNATURES = {
 }
 
 
+def _build_if_missing():
+    """The in-tree library is normally built by ``__graft_entry__.build()``.  If it is MISSING and a HIP compiler is
+    at hand, build it now (one process at a time: ranks of a multi-GPU job import concurrently) -- this is still the
+    HIP product, not a fallback.  An existing library is never rebuilt here."""
+    import fcntl
+    import shutil
+    import subprocess
+    if os.path.isfile(LIB_PATH):
+        return
+    if shutil.which("hipcc") is None and not os.path.isfile("/opt/rocm/bin/hipcc"):
+        return
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.isfile(LIB_PATH):       # another rank may have built it while we waited
+                subprocess.call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def _load():
+    _build_if_missing()
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             "gantts_amd: %s not found -- the HIP engine is the product and has no fallback. "
