@@ -178,10 +178,11 @@ def main():
         dp = DataParallelStep(backend, always_reduce=args.force_dp)
         dp.broadcast_parameters(mg.flat_params(), md.flat_params())
         batch = dict(x=x, y=y, y_static=y_static, mask=mask, R=R)
-        tv_global = float(world * B * Tn)
 
         def step():
-            return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, tv_global=tv_global)
+            # the global valid-frame count is all-reduced every step (device-resident, overlapped with the generator
+            # forward) -- it is part of a data-parallel step for real, ragged batches; no constant is passed in
+            return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0)
     else:
         def step():
             og.zero_grad()
