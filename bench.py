@@ -182,7 +182,7 @@ def main():
         def step():
             # the global valid-frame count is all-reduced every step (device-resident, overlapped with the generator
             # forward) -- it is part of a data-parallel step for real, ragged batches; no constant is passed in
-            return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0)
+            return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, lazy_g=True)
     else:
         def step():
             og.zero_grad()

@@ -87,6 +87,8 @@ SIGNATURES = {
     "gt_update_discriminator_end": (_I, [_P, _I, C.POINTER(DResult), _P]),
     "gt_update_generator_begin": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _F, _F, _P]),
     "gt_update_generator_end": (_I, [_P, _I, _F, _F, _F, C.POINTER(GResult), _P]),
+    "gt_update_discriminator_result": (_I, [_P, C.POINTER(DResult)]),
+    "gt_update_generator_result": (_I, [_P, C.POINTER(GResult)]),
     "gt_scalar_buffer": (_I, [_P, C.POINTER(_P), C.POINTER(_I)]),
     "gt_model_forward": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "gt_flush_generator_grads": (_I, [_P, _P]),

@@ -327,6 +327,8 @@ struct gt_engine {
   // as soon as THAT copy has landed, leaving the rest of the step queued on the stream.
   bool early = false, early_done = false;
   hipEvent_t ev_res = nullptr;
+  // deferred results of the split-phase calls (out == NULL): own pinned copy + event per role, fetched by gt_*_result
+  StepResults* h_def[2] = {nullptr, nullptr}; hipEvent_t ev_def[2] = {nullptr, nullptr}; bool def_pending[2] = {false, false};
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
   // recurrent generator workspace (per layer) and the lengths of the current batch
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out, l_outd;   // l_outd: inter-layer-dropped outputs
@@ -415,6 +417,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   for (int* p : ints) if (p) (void)hipFree(p);
   if (e->h_res) (void)hipHostFree(e->h_res);
   if (e->ev_res) (void)hipEventDestroy(e->ev_res);
+  for (int r = 0; r < 2; ++r) { if (e->h_def[r]) (void)hipHostFree(e->h_def[r]); if (e->ev_def[r]) (void)hipEventDestroy(e->ev_def[r]); }
   delete e;
 }
 
@@ -1328,6 +1331,14 @@ static int fetch_results(gt_engine* e, hipStream_t s) {
   HIPCHK(hipStreamSynchronize(s));
   return GT_OK;
 }
+static int post_deferred_results(gt_engine* e, int role, hipStream_t s) {
+  if (!e->h_def[role]) HIPCHK(hipHostMalloc((void**)&e->h_def[role], sizeof(StepResults)));
+  if (!e->ev_def[role]) HIPCHK(hipEventCreateWithFlags(&e->ev_def[role], hipEventDisableTiming));
+  HIPCHK(hipMemcpyAsync(e->h_def[role], e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(e->ev_def[role], s));
+  e->def_pending[role] = true;
+  return GT_OK;
+}
 static int post_early_results(gt_engine* e, hipStream_t s) {
   if (!e->ev_res) HIPCHK(hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
   HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
@@ -1414,11 +1425,28 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   return GT_OK;
 }
 
+static void fill_d_result(const StepResults* h, gt_d_result* out) {
+  out->loss_d = h->loss_d; out->loss_fake_d = h->loss_fake_d; out->loss_real_d = h->loss_real_d;
+  out->real_correct_count = h->real_correct; out->fake_correct_count = h->fake_correct;
+  out->grad_norm = h->gnorm_d;
+}
+static void fill_g_result(const StepResults* h, gt_g_result* out) {
+  out->loss_mse = h->loss_mse; out->loss_mge = h->loss_mge; out->loss_adv = h->loss_adv;
+  out->loss_g = h->loss_g; out->grad_norm = h->gnorm_g;
+}
+
 extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream) {
-  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e) return fail(GT_ERR_INVALID, "null argument");
   if (!e->d_begin_done) return fail(GT_ERR_STATE, "gt_update_discriminator_end without _begin");
   hipStream_t s = (hipStream_t)stream;
   e->d_begin_done = false;
+  if (!out) {   // deferred: enqueue everything, synchronise nothing; gt_update_discriminator_result collects
+    if (e->early_done) return fail(GT_ERR_STATE, "deferred results are a split-phase feature");
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), train ? 0 : 1);
+    LAUNCH_CHECK();
+    return post_deferred_results(e, GT_ROLE_D, s);
+  }
   if (e->early_done) {
     if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
     HIPCHK(hipEventSynchronize(e->ev_res));       // only the scalar copy; backward + step stay queued
@@ -1429,9 +1457,15 @@ extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result*
     LAUNCH_CHECK();
     CHK(fetch_results(e, s));
   }
-  out->loss_d = e->h_res->loss_d; out->loss_fake_d = e->h_res->loss_fake_d; out->loss_real_d = e->h_res->loss_real_d;
-  out->real_correct_count = e->h_res->real_correct; out->fake_correct_count = e->h_res->fake_correct;
-  out->grad_norm = e->h_res->gnorm_d;
+  fill_d_result(e->h_res, out);
+  return GT_OK;
+}
+extern "C" int gt_update_discriminator_result(gt_engine* e, gt_d_result* out) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->def_pending[GT_ROLE_D]) return fail(GT_ERR_STATE, "no deferred discriminator result pending");
+  HIPCHK(hipEventSynchronize(e->ev_def[GT_ROLE_D]));
+  e->def_pending[GT_ROLE_D] = false;
+  fill_d_result(e->h_def[GT_ROLE_D], out);
   return GT_OK;
 }
 
@@ -1608,10 +1642,18 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
 
 extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, float mse_w, float mge_w, gt_g_result* out,
                                        void* stream) {
-  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e) return fail(GT_ERR_INVALID, "null argument");
   if (!e->g_begin_done) return fail(GT_ERR_STATE, "gt_update_generator_end without _begin");
   hipStream_t s = (hipStream_t)stream;
   e->g_begin_done = false;
+  if (!out) {
+    if (e->early_done) return fail(GT_ERR_STATE, "deferred results are a split-phase feature");
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
+                       train ? 0 : 1);
+    LAUNCH_CHECK();
+    return post_deferred_results(e, GT_ROLE_G, s);
+  }
   if (e->early_done) {
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
     HIPCHK(hipEventSynchronize(e->ev_res));
@@ -1623,8 +1665,15 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
     LAUNCH_CHECK();
     CHK(fetch_results(e, s));
   }
-  out->loss_mse = e->h_res->loss_mse; out->loss_mge = e->h_res->loss_mge; out->loss_adv = e->h_res->loss_adv;
-  out->loss_g = e->h_res->loss_g; out->grad_norm = e->h_res->gnorm_g;
+  fill_g_result(e->h_res, out);
+  return GT_OK;
+}
+extern "C" int gt_update_generator_result(gt_engine* e, gt_g_result* out) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->def_pending[GT_ROLE_G]) return fail(GT_ERR_STATE, "no deferred generator result pending");
+  HIPCHK(hipEventSynchronize(e->ev_def[GT_ROLE_G]));
+  e->def_pending[GT_ROLE_G] = false;
+  fill_g_result(e->h_def[GT_ROLE_G], out);
   return GT_OK;
 }
 

@@ -253,12 +253,21 @@ class StepEngine(object):
         check(lib.gt_update_discriminator_begin(self._h, ptr(x), ptr(y_static), ptr(y_hat_static_c), ptr(mask), B, T,
                                                 int(train), float(eps), L.current_stream()))
 
-    def update_discriminator_end(self, optimizer_d, phase):
+    def update_discriminator_end(self, optimizer_d, phase, defer=False):
+        """``defer=True``: enqueue only (optimizer step, finalisation, D2H of the scalars) and return None;
+        ``update_discriminator_result()`` blocks on just that copy later."""
         train = phase == "train"
         res = L.DResult()
-        check(lib.gt_update_discriminator_end(self._h, int(train), C.byref(res), L.current_stream()))
+        check(lib.gt_update_discriminator_end(self._h, int(train), None if defer else C.byref(res), L.current_stream()))
         if train:
             optimizer_d._note_step(self, L.ROLE_D)
+        if defer:
+            return None
+        return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
+
+    def update_discriminator_result(self):
+        res = L.DResult()
+        check(lib.gt_update_discriminator_result(self._h, C.byref(res)))
         return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
 
     def update_generator_begin(self, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
@@ -282,13 +291,20 @@ class StepEngine(object):
                                             float(adv_w), ptr(mask), B, T, int(train), float(mse_w), float(mge_w),
                                             float(eps), L.current_stream()))
 
-    def update_generator_end(self, optimizer_g, adv_w, mse_w, mge_w, phase):
+    def update_generator_end(self, optimizer_g, adv_w, mse_w, mge_w, phase, defer=False):
         train = phase == "train"
         res = L.GResult()
         check(lib.gt_update_generator_end(self._h, int(train), float(adv_w), float(mse_w), float(mge_w),
-                                          C.byref(res), L.current_stream()))
+                                          None if defer else C.byref(res), L.current_stream()))
         if train:
             optimizer_g._note_step(self, L.ROLE_G)
+        if defer:
+            return None
+        return res.loss_mse, res.loss_mge, res.loss_adv, res.loss_g
+
+    def update_generator_result(self):
+        res = L.GResult()
+        check(lib.gt_update_generator_result(self._h, C.byref(res)))
         return res.loss_mse, res.loss_mge, res.loss_adv, res.loss_g
 
     def _adv_width(self):
@@ -397,12 +413,20 @@ class HipStepBackend(object):
         self.engine.update_discriminator_begin(self.md, self.od, batch["x"], batch["y_static"], self._out[1],
                                                batch["mask"], phase)
 
-    def update_discriminator_end(self, batch, phase):
-        return self.engine.update_discriminator_end(self.od, phase)
+    deferred_results = True       # *_end(defer=True) + *_result(): the host does not have to wait inside *_end
+
+    def update_discriminator_end(self, batch, phase, defer=False):
+        return self.engine.update_discriminator_end(self.od, phase, defer=defer)
+
+    def update_discriminator_result(self):
+        return self.engine.update_discriminator_result()
 
     def update_generator_begin(self, batch, adv_w, mse_w, mge_w, phase):
         self.engine.update_generator_begin(self.mg, self.md, self.og, batch["x"], batch["y"], self._out[0],
                                            batch["y_static"], self._out[1], adv_w, batch["mask"], phase, mse_w, mge_w)
 
-    def update_generator_end(self, batch, adv_w, mse_w, mge_w, phase):
-        return self.engine.update_generator_end(self.og, adv_w, mse_w, mge_w, phase)
+    def update_generator_end(self, batch, adv_w, mse_w, mge_w, phase, defer=False):
+        return self.engine.update_generator_end(self.og, adv_w, mse_w, mge_w, phase, defer=defer)
+
+    def update_generator_result(self):
+        return self.engine.update_generator_result()

@@ -26,6 +26,7 @@ class DataParallelStep(object):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always_reduce = always_reduce and dist.is_initialized()   # exercise the collectives with one rank
+        self._pending = None
         self._coalesce = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and \
             hasattr(dist, "_coalescing_manager")
 
@@ -57,9 +58,10 @@ class DataParallelStep(object):
         return float(tv.item())
 
     def step(self, batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, update_d=True, update_g=True, phase="train",
-             tv_global=None):
+             tv_global=None, lazy_g=False):
         """One global step on this rank's shard.  ``batch`` is the backend's opaque local batch.
-        Returns (d_result or None, g_result or None), identical on all ranks."""
+        Returns (d_result or None, g_result or None), identical on all ranks.  ``lazy_g=True`` returns the
+        generator scalars as a ``LazyResult`` (no host wait at the end of the step)."""
         be = self.backend
         tv_work = None
         if tv_global is None:
@@ -73,23 +75,59 @@ class DataParallelStep(object):
                 tv_global = self.global_valid_frames(be.mask_of(batch))
         be.zero_grad()
         be.apply_generator(batch)
+        if self._pending is not None:    # last step's lazy generator scalars: fetched now that this step's forward is queued
+            self._pending.get()
+            self._pending = None
         if tv_work is not None:
             tv_work.wait()               # stream-level dependency, not a host sync
         be.set_loss_normalizer(tv_global)
         d_res = g_res = None
         train = phase == "train"
+        defer = getattr(be, "deferred_results", False)
         if update_d:
             be.update_discriminator_begin(batch, phase)
             if train:
                 self._allreduce(be.flat_grads("D"), be.scalar_sums("D"))
             else:
                 self._allreduce(be.scalar_sums("D"))
-            d_res = be.update_discriminator_end(batch, phase)
+            d_res = be.update_discriminator_end(batch, phase, defer=True) if defer else be.update_discriminator_end(batch, phase)
         if update_g:
             be.update_generator_begin(batch, adv_w, mse_w, mge_w, phase)
+        if update_d and defer:
+            d_res = be.update_discriminator_result()     # the generator step is already queued behind it
+        if update_g:
             if train:
                 self._allreduce(be.flat_grads("G"), be.scalar_sums("G"))
             else:
                 self._allreduce(be.scalar_sums("G"))
-            g_res = be.update_generator_end(batch, adv_w, mse_w, mge_w, phase)
+            if defer and lazy_g:
+                be.update_generator_end(batch, adv_w, mse_w, mge_w, phase, defer=True)
+                g_res = LazyResult(be.update_generator_result)
+                self._pending = g_res
+            else:
+                g_res = be.update_generator_end(batch, adv_w, mse_w, mge_w, phase)
         return d_res, g_res
+
+
+class LazyResult(object):
+    """Generator-step scalars that are fetched (one event wait) on first use: ``tuple(r)``, ``r[i]``, ``r.get()``.
+    ``DataParallelStep.step(..., lazy_g=True)`` hands these out so that the host can enqueue the next step while the
+    GPU is still finishing this one; the next ``step`` call resolves a still-pending one before it touches the engine."""
+
+    def __init__(self, fetch):
+        self._fetch, self._value = fetch, None
+
+    def get(self):
+        if self._value is None:
+            self._value = tuple(self._fetch())
+            self._fetch = None
+        return self._value
+
+    def __iter__(self):
+        return iter(self.get())
+
+    def __getitem__(self, i):
+        return self.get()[i]
+
+    def __len__(self):
+        return len(self.get())

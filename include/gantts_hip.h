@@ -186,6 +186,11 @@ int gt_update_generator_begin(gt_engine* e, const float* x, const float* y, cons
                               void* stream);
 int gt_update_generator_end(gt_engine* e, int train, float adv_w, float mse_w, float mge_w,
                             gt_g_result* out, void* stream);
+/* Deferred results: the *_end calls accept out == NULL -- optimizer step, the scalars' finalisation and their
+ * D2H copy are enqueued, nothing is synchronised; these two block on just that copy.  A data-parallel host
+ * uses the gap to enqueue the next phase, so the GPU never waits for the host. */
+int gt_update_discriminator_result(gt_engine* e, gt_d_result* out);
+int gt_update_generator_result(gt_engine* e, gt_g_result* out);
 /* device pointer + length (in doubles) of the additive loss/count sums of the current step */
 int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n_doubles);
 

@@ -680,6 +680,12 @@ def test_data_parallel_step_through_rccl_world_1():
         # test phase: only the loss sums travel
         d, g = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], phase="test")
         assert np.isfinite(d[0]) and np.isfinite(g[3])
+        # lazy generator scalars: same numbers, fetched on first use (here: by the following step, then explicitly)
+        from gantts_amd.parallel import LazyResult
+        d1, g1 = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], phase="test", lazy_g=True)
+        d2, g2 = dp.step(b, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], phase="test", lazy_g=True)
+        assert isinstance(g1, LazyResult) and g1._value is not None and g2._value is None
+        assert tuple(g1) == tuple(g) and tuple(g2) == tuple(g) and d1 == d and d2 == d
     finally:
         dist.destroy_process_group()
 
