@@ -1375,8 +1375,14 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   }
   if (!chain || tr) {     // the [x | adv] image: A operand of the unfused path, B operand of dW_0 (train)
     CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
-    CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
-    CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
+    if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
+      hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
+                         e->d_adv_cols, e->Da, e->dcat.as<float>(), ldc, N);
+      LAUNCH_CHECK();
+    } else {
+      CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
+      CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
+    }
     e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
   }
   if (!chain) CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));

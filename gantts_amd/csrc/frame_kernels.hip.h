@@ -105,6 +105,26 @@ __global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int io
   out[(long)r * ldo + ooff + j] = in[(long)r * ldi + c];
 }
 
+// D-step input image in one pass: rows [0,N) = [x | fa[:, idx]], rows [N,2N) = [x | fb[:, idx]] (train.py:254-256 for
+// the real and the generated half).  x is read once and written twice; one launch instead of four gathers.
+__global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const float* __restrict__ fa, const float* __restrict__ fb,
+                                  int ldf, const int* __restrict__ idx, int na, float* __restrict__ out, int ldo, long N) {
+  const int w = cd + na;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * w) return;
+  const long r = e / w;
+  const int c = (int)(e - r * w);
+  if (c < cd) {
+    const float v = x[r * cd + c];
+    out[r * ldo + c] = v;
+    out[(N + r) * ldo + c] = v;
+  } else {
+    const int j = idx[c - cd];
+    out[r * ldo + c] = fa[r * ldf + j];
+    out[(N + r) * ldo + c] = fb[r * ldf + j];
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // MLPG.  The reference multiplies by a dense (T x nW*T) matrix R (nnmnkwii
 // unit_variance_mlpg, call sites gantts/multistream.py:120, models.py:66).  R is numerically
