@@ -92,6 +92,49 @@ class OracleBackend(object):
         return mse, mge, adv, (mse_w * mse + mge_w * mge) + adv_w * adv
 
 
+class DeferredOracleBackend(OracleBackend):
+    """Same compute, but with the deferred-result protocol of the HIP backend (``*_end(defer=True)`` enqueues,
+    ``*_result()`` collects): lets the CPU tests drive the non-blocking schedule of DataParallelStep."""
+    deferred_results = True
+
+    def __init__(self, case):
+        OracleBackend.__init__(self, case)
+        self._held = {}
+        self.trace = []
+
+    def update_discriminator_begin(self, batch, phase):
+        self.trace.append("d_begin")
+        OracleBackend.update_discriminator_begin(self, batch, phase)
+
+    def update_generator_begin(self, batch, adv_w, mse_w, mge_w, phase):
+        self.trace.append("g_begin")
+        OracleBackend.update_generator_begin(self, batch, adv_w, mse_w, mge_w, phase)
+
+    def apply_generator(self, batch):
+        self.trace.append("apply_g")
+        OracleBackend.apply_generator(self, batch)
+
+    def update_discriminator_end(self, batch, phase, defer=False):
+        r = OracleBackend.update_discriminator_end(self, batch, phase)
+        if not defer:
+            return r
+        self._held["D"] = r
+
+    def update_discriminator_result(self):
+        self.trace.append("d_result")
+        return self._held.pop("D")
+
+    def update_generator_end(self, batch, adv_w, mse_w, mge_w, phase, defer=False):
+        r = OracleBackend.update_generator_end(self, batch, adv_w, mse_w, mge_w, phase)
+        if not defer:
+            return r
+        self._held["G"] = r
+
+    def update_generator_result(self):
+        self.trace.append("g_result")
+        return self._held.pop("G")
+
+
 def make_batch(case, rows):
     x_np, y_np, lengths = C.make_batch(case)
     cfg = stream_config(case)
@@ -107,19 +150,21 @@ CASE = "acoustic_mlp"
 STEPS = 3
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, deferred=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gantts_amd.parallel import DataParallelStep
     case = C.CASES[CASE]
-    be = OracleBackend(case)
+    be = DeferredOracleBackend(case) if deferred else OracleBackend(case)
     dp = DataParallelStep(be)
     rows = np.arange(case["B"])[rank::world]          # deal sequences round-robin (length-sorted batch)
     batch = make_batch(case, rows)
     hist = []
     for _ in range(STEPS):
-        hist.append(dp.step(batch, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"]))
+        d, g = dp.step(batch, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], lazy_g=deferred)
+        hist.append((d, g))
+    hist = [(d, tuple(g)) for d, g in hist]
     q.put((rank, hist, [p.detach().numpy().copy() for p in be.mg.params + be.md.params]))
     dist.barrier()
     dist.destroy_process_group()
@@ -133,8 +178,32 @@ def _free_port():
     return port
 
 
+def test_deferred_schedule_and_lazy_results_single_process():
+    """The non-blocking schedule DataParallelStep uses with a deferred-result backend: the D result is collected
+    after the G step has been queued, the lazy G result after the NEXT step's forward; numbers unchanged."""
+    from gantts_amd.parallel import DataParallelStep, LazyResult
+    case = C.CASES[CASE]
+    whole = make_batch(case, np.arange(case["B"]))
+    ref = DataParallelStep(OracleBackend(case))
+    ref_hist = [ref.step(whole, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"]) for _ in range(2)]
+    be = DeferredOracleBackend(case)
+    dp = DataParallelStep(be)
+    d0, g0 = dp.step(whole, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], lazy_g=True)
+    assert isinstance(g0, LazyResult) and g0._value is None
+    assert be.trace == ["apply_g", "d_begin", "g_begin", "d_result"]
+    d1, g1 = dp.step(whole, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"], lazy_g=True)
+    assert g0._value is not None                       # resolved by the second step ...
+    assert be.trace[4:6] == ["apply_g", "g_result"]    # ... right after its forward was queued
+    assert (d0, tuple(g0)) == ref_hist[0] and (d1, tuple(g1)) == ref_hist[1]
+    assert len(g1) == 4 and g1[3] == ref_hist[1][1][3]
+    # eager mode with the same backend blocks inside the step
+    d2, g2 = dp.step(whole, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"])
+    assert isinstance(g2, tuple)
+
+
 @pytest.mark.timeout(300)
-def test_dp2_equals_single_process_on_whole_batch():
+@pytest.mark.parametrize("deferred", [False, True])
+def test_dp2_equals_single_process_on_whole_batch(deferred):
     case = C.CASES[CASE]
     # single process, whole batch, same orchestration with world = 1
     from gantts_amd.parallel import DataParallelStep
@@ -152,7 +221,7 @@ def test_dp2_equals_single_process_on_whole_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, deferred)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
