@@ -1281,7 +1281,8 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 }
 
 static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
-                    float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s) {
+                    float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
+                    StepResults* early_res = nullptr) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -1301,7 +1302,8 @@ static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, 
   LAUNCH_CHECK();
   const bool w = want_grad && want_w;
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
-                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0);
+                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
+                     early_res);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -1390,14 +1392,12 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
   CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
+  // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
+  // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
-               e->d_specs.back(), true, s));
+               e->d_specs.back(), true, s, e->early ? e->res() : nullptr));
   e->early_done = false;
-  if (e->early) {   // losses and counts are final here; gradient norm is not (reported as 0)
-    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), 1);
-    LAUNCH_CHECK();
-    CHK(post_early_results(e, s));
-  }
+  if (e->early) CHK(post_early_results(e, s));
   if (tr) {
     // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
     // (the autograd graph in the reference, train.py:265) and a generator with grads exists
@@ -1620,6 +1620,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     }
   }
   // MGE loss + gradient assembly at y_hat_static
+  const bool early_now = e->early && !(tr && direct && mse_w != 0.f);
+  int mge_blocks = 0;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
     CHK(e->partial.ensure(4096 * sizeof(double)));
@@ -1629,12 +1631,16 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     hipLaunchKernelGGL(static_grad_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
                        e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, e->partial.as<double>(), e->sc());
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
-    LAUNCH_CHECK();
+    mge_blocks = nblk;
+    if (!early_now) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
+      LAUNCH_CHECK();
+    }
   }
   e->early_done = false;
-  if (e->early && !(tr && direct && mse_w != 0.f)) {   // all four losses are final here
-    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1);
+  if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
+                       (const double*)e->partial.as<double>(), mge_blocks, (const double*)nullptr, 0);
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));
   }
@@ -1656,7 +1662,7 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
     if (e->early_done) return fail(GT_ERR_STATE, "deferred results are a split-phase feature");
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
     hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
-                       train ? 0 : 1);
+                       train ? 0 : 1, (const double*)nullptr, 0, (const double*)nullptr, 0);
     LAUNCH_CHECK();
     return post_deferred_results(e, GT_ROLE_G, s);
   }
@@ -1667,7 +1673,7 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
   } else {
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
     hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
-                       train ? 0 : 1);
+                       train ? 0 : 1, (const double*)nullptr, 0, (const double*)nullptr, 0);
     LAUNCH_CHECK();
     CHK(fetch_results(e, s));
   }

@@ -65,6 +65,12 @@ struct StepScalars {
   double s_mge, s_mse;            // sum of squared masked differences
   double gnorm2_d, gnorm2_g;      // squared grad norms (pre-clip)
 };
+// results of one update_* call, written by a single thread and copied D2H once
+struct StepResults {
+  float loss_d, loss_fake_d, loss_real_d, real_correct, fake_correct;   // train.py:278-279 order
+  float loss_mse, loss_mge, loss_adv, loss_g;                           // train.py:320 order
+  float gnorm_d, gnorm_g, tv;
+};
 
 // tv = sum(mask[0..n)) ; single workgroup (n = B*T is small)
 __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
@@ -542,7 +548,8 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 // reduces the scalar partials.
 __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
                                                                int nblk, int K, int mode, StepScalars* sc,
-                                                               float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+                                                               float* __restrict__ dw, float* __restrict__ db, int accumulate,
+                                                               StepResults* early_res /* D step: also finalize_d (gnorm 0) */) {
   __shared__ float shw[16][64];
   __shared__ double shd[16];
   const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -580,8 +587,16 @@ __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartial
     double r[5];
     for (int q = 0; q < 5; ++q) r[q] = block_sum_d(v[q], shd);
     if (threadIdx.x == 0) {
-      if (mode == HEAD_D_STEP) { sc->s_real = r[0]; sc->s_fake = r[1]; sc->n_real_ok = r[2]; sc->n_fake_ok = r[3]; }
-      else sc->s_adv = r[0];
+      if (mode == HEAD_D_STEP) {
+        sc->s_real = r[0]; sc->s_fake = r[1]; sc->n_real_ok = r[2]; sc->n_fake_ok = r[3];
+        if (early_res) {       // same arithmetic as finalize_d_kernel, one launch less on the way to the host
+          const float T = sc->tv;
+          const float lr = -((float)r[0]) / T, lf = -((float)r[1]) / T;
+          early_res->loss_real_d = lr; early_res->loss_fake_d = lf; early_res->loss_d = lr + lf;
+          early_res->real_correct = (float)r[2]; early_res->fake_correct = (float)r[3];
+          early_res->gnorm_d = 0.f; early_res->tv = T;
+        }
+      } else sc->s_adv = r[0];
       if (db) db[0] = accumulate ? db[0] + (float)r[4] : (float)r[4];
     }
   }
@@ -912,11 +927,6 @@ __global__ void highway_backward_kernel(const float* __restrict__ g, int ldgr, c
 // ---------------------------------------------------------------------------------------
 // results of one update_* call, written by a single thread and copied D2H once
 // ---------------------------------------------------------------------------------------
-struct StepResults {
-  float loss_d, loss_fake_d, loss_real_d, real_correct, fake_correct;   // train.py:278-279 order
-  float loss_mse, loss_mge, loss_adv, loss_g;                           // train.py:320 order
-  float gnorm_d, gnorm_g, tv;
-};
 // zero_gnorm: the gradient norm is not known / not applicable at this point (early results, phase != "train"): report 0
 __global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int zero_gnorm) {
   if (threadIdx.x || blockIdx.x) return;
@@ -926,9 +936,29 @@ __global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int z
   out->real_correct = (float)sc->n_real_ok; out->fake_correct = (float)sc->n_fake_ok;
   out->gnorm_d = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_d); out->tv = T;
 }
-__global__ void finalize_g_kernel(const StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
-                                  int zero_gnorm) {
-  if (threadIdx.x || blockIdx.x) return;
+// part_mge / part_mse (optional): per-block partial sums that have not been reduced into sc yet -- the fused
+// (single-GPU) call folds sum_partials_kernel into this launch; launch with 256 threads then, else 1.
+__global__ void finalize_g_kernel(StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
+                                  int zero_gnorm, const double* __restrict__ part_mge, int n_mge,
+                                  const double* __restrict__ part_mse, int n_mse) {
+  if (blockIdx.x) return;
+  if (part_mge || part_mse) {
+    __shared__ double shp[16];
+    if (part_mge) {
+      double v = 0.0;
+      for (int i = threadIdx.x; i < n_mge; i += blockDim.x) v += part_mge[i];
+      const double t = block_sum_d(v, shp);
+      if (threadIdx.x == 0) sc->s_mge = t;
+    }
+    if (part_mse) {
+      double v = 0.0;
+      for (int i = threadIdx.x; i < n_mse; i += blockDim.x) v += part_mse[i];
+      const double t = block_sum_d(v, shp);
+      if (threadIdx.x == 0) sc->s_mse = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
   const float T = sc->tv;
   const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
   const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;
