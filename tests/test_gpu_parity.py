@@ -147,7 +147,7 @@ def test_linear_backward_fused_activation_derivative():
     _close(dX.cpu().numpy(), ref, msg="dX fused")
 
 
-@pytest.mark.parametrize("B,T", [(3, 7), (2, 100), (4, 513)])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (3, 7), (2, 100), (4, 513)])
 def test_multi_stream_mlpg_forward_backward_vs_dense(B, T):
     from gantts_amd import paramgen
     from gantts_amd.engine import engine_for
@@ -743,3 +743,28 @@ def test_train_loop_with_generator_noise_and_two_engines_in_one_process():
     assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
     assert not torch.equal(a1[0], a3[0])
     assert len(d1[2]) > 0
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (2, 1), (3, 1), (1, 33)])
+def test_tiny_batches_match_oracle(B, T):
+    """Degenerate shapes (one sequence, one or two frames, one frame past a 32-row tile): one full G+D step vs the
+    oracle.  Outputs, the 9 scalars and the squared-gradient accumulators are compared tightly.  The first Adagrad
+    step is lr * sign(g): with a handful of frames a few gradient entries are pure rounding noise around zero, so
+    the updated weights are allowed a few entries that differ by (at most) 2 * lr -- measured: <= 5 of 27 200."""
+    from hip_runner import run_hip_case
+    from oracle_runner import run_oracle_case
+    case = dict(C.CASES["acoustic_mlp"], B=B, T=T, steps=1)
+    lr = case["opt_g"][1]["lr"]
+    got, ref = run_hip_case(case), run_oracle_case(case)
+    for k, r in ref.items():
+        if k.startswith("g_leak_norm"):
+            continue
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(r, dtype=np.float64)
+        if ".opt." in k:
+            _close(a, b, rtol=5e-4, atol=1e-9, msg=k)
+        elif k.startswith(("G.", "D.")):
+            bad = np.abs(a - b) > 1e-4 * max(1e-30, float(np.abs(b).max())) + 1e-6
+            assert bad.sum() <= max(1, a.size // 2000), (k, int(bad.sum()), a.size)
+            assert np.abs(a - b).max() <= 2.1 * lr, (k, float(np.abs(a - b).max()))
+        else:
+            _close(a, b, msg=k)
