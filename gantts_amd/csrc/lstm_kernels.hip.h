@@ -130,6 +130,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a
   const float* hp = a.h_prev + ((long)d * a.Bpad + b0) * H;
 
   const bool vec = (H % 4) == 0;     // rows of h / W_hh are then 16-byte aligned
+  // The gate stage's inputs (X-projection, biases, c_{t-1}, the length) do not depend on the matrix product:
+  // request them first, so that their latency is covered by the staging + MFMA phase instead of following it.
+  const int u = tid & 7, bl = tid >> 3;            // one (sequence, unit) pair per thread: u fastest
+  const int j = u0 + u, b = b0 + bl;
+  const bool mine = j < H && b < a.B;
+  const int jc = min(j, H - 1), bc = min(b, a.B - 1);
+  const long row = (long)bc * T + t;
+  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+  const long sidx = ((long)d * a.Bpad + bc) * H + jc;
+  float xin[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc] + (a.bih[d][g * H + jc] + a.bhh[d][g * H + jc]);
+  const float c_in = a.c_prev[sidx];
+  const bool active = t < a.lengths[bc];
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -154,26 +168,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a
   if (tid == 0) a.out[blockIdx.x] = red[3];
   return;
 #endif
-  // one (sequence, unit) pair per thread: u fastest (8 consecutive floats per row)
-  const int u = tid & 7, bl = tid >> 3;
-  const int j = u0 + u, b = b0 + bl;
-  if (j >= H || b >= a.B) return;
-  const long row = (long)b * T + t;
-  const bool active = t < a.lengths[b];
-  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+  if (!mine) return;
   float pre[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int c = g * 8 + u;
     float s = (red[(0 * 32 + bl) * LSTM_P + c] + red[(1 * 32 + bl) * LSTM_P + c]) +
               (red[(2 * 32 + bl) * LSTM_P + c] + red[(3 * 32 + bl) * LSTM_P + c]);
-    pre[g] = s + a.xproj[row * ld4 + d * 4 * H + g * H + j] + (a.bih[d][g * H + j] + a.bhh[d][g * H + j]);
+    pre[g] = s + xin[g];
   }
-  const long sidx = ((long)d * a.Bpad + b) * H + j;
   float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, h = 0.f;
   if (active) {
     ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
-    c = fg * a.c_prev[sidx] + ig * gg;
+    c = fg * c_in + ig * gg;
     h = og * tanhf(c);
   }
   a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
@@ -206,6 +213,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmStepArgs a
   const int K = 4 * H;
 
   const bool vec = (H % 4) == 0;
+  // inputs of the gate-derivative stage (independent of the matrix product): requested up front
+  const int pu = tid & 31, pj = min(u0 + pu, H - 1);
+  float p_dout[4], p_g[4][4], p_c[4], p_cp[4], p_dcs[4];
+  int p_len[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bc = min(b0 + (tid >> 5) + 8 * i, a.B - 1);
+    const long row = (long)bc * T + t;
+    p_len[i] = a.lengths[bc];
+    p_dout[i] = a.dout[row * ld1 + d * H + pj];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p_g[i][g] = a.gates[row * ld4 + d * 4 * H + g * H + pj];
+    p_c[i] = a.cst[row * ld1 + d * H + pj];
+    const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);     // clamped; validity checked at use
+    p_cp[i] = a.cst[rowp * ld1 + d * H + pj];
+    p_dcs[i] = a.dc_state[((long)d * a.Bpad + bc) * H + pj];
+  }
   if (a.step > 0) {
     f32x16 acc;
 #pragma unroll
@@ -280,22 +304,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmStepArgs a
     const int b = b0 + bl;
     if (b >= a.B) continue;
     const long row = (long)b * T + t;
-    const int len = a.lengths[b];
+    const int len = p_len[i];
     const bool active = t < len;
     float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
     if (active) {
-      float dh = a.dout[row * ld1 + d * H + j];
+      float dh = p_dout[i];
       if (a.step > 0)
         dh += (red[(0 * 32 + bl) * LSTM_P + u] + red[(1 * 32 + bl) * LSTM_P + u]) +
               (red[(2 * 32 + bl) * LSTM_P + u] + red[(3 * 32 + bl) * LSTM_P + u]);
-      const float ig = a.gates[row * ld4 + d * 4 * H + 0 * H + j], fg = a.gates[row * ld4 + d * 4 * H + 1 * H + j];
-      const float gg = a.gates[row * ld4 + d * 4 * H + 2 * H + j], og = a.gates[row * ld4 + d * 4 * H + 3 * H + j];
-      const float c = a.cst[row * ld1 + d * H + j];
+      const float ig = p_g[i][0], fg = p_g[i][1], gg = p_g[i][2], og = p_g[i][3];
+      const float c = p_c[i];
       float cp = 0.f;                                        // cell state entering this frame
-      if (d == 0) { if (t > 0) cp = a.cst[(row - 1) * ld1 + d * H + j]; }
-      else        { if (t + 1 < len) cp = a.cst[(row + 1) * ld1 + d * H + j]; }
+      if (d == 0) { if (t > 0) cp = p_cp[i]; }
+      else        { if (t + 1 < len) cp = p_cp[i]; }
       const float tc = tanhf(c);
-      const float dc = a.dc_state[((long)d * a.Bpad + b) * H + j] + dh * og * (1.f - tc * tc);
+      const float dc = p_dcs[i] + dh * og * (1.f - tc * tc);
       dgo = dh * tc * (og * (1.f - og));
       dgi = dc * gg * (ig * (1.f - ig));
       dgf = dc * cp * (fg * (1.f - fg));
