@@ -151,10 +151,38 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a
     // stage h_{t-1}[b][kc..] and W_hh[gate*H + u0+u][kc..], zero beyond H / unit range
     // (the state arrays are padded to 32 sequences and zero there, so every row is readable)
 #ifndef GT_ABLATE_LSTM_NO_STAGE
-    lstm_stage_kc(sA, hp, kc, H, vec, [&](int r) { return (long)r * H; }, [&](int r) { return true; });
-    lstm_stage_kc(sB, W, kc, H, vec,
-                  [&](int r) { return ((long)(r >> 3) * H + min(u0 + (r & 7), H - 1)) * H; },
-                  [&](int r) { return u0 + (r & 7) < H; });
+    auto offA = [&](int r) { return (long)r * H; };
+    auto okA = [&](int r) { return true; };
+    auto offB = [&](int r) { return ((long)(r >> 3) * H + min(u0 + (r & 7), H - 1)) * H; };
+    auto okB = [&](int r) { return u0 + (r & 7) < H; };
+    if (vec) {
+      // both panels' loads are issued before either panel's LDS stores: one memory latency per chunk, not two
+      constexpr int PER = 32 * LSTM_KC / 4 / 256;
+      f32x4 va[PER], vb[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = tid + q * 256;
+        const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+        const int kg = min(kc + k4, H - 4);
+        va[q] = *reinterpret_cast<const f32x4*>(hp + offA(r) + kg);
+        vb[q] = *reinterpret_cast<const f32x4*>(W + offB(r) + kg);
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = tid + q * 256;
+        const int k4 = (e % (LSTM_KC / 4)) * 4, r = e / (LSTM_KC / 4);
+        const bool kin = kc + k4 < H;
+        const bool bok = kin && okB(r);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          sA[(k4 + c) * LSTM_P + r] = kin ? va[q][c] : 0.f;
+          sB[(k4 + c) * LSTM_P + r] = bok ? vb[q][c] : 0.f;
+        }
+      }
+    } else {
+      lstm_stage_kc(sA, hp, kc, H, false, offA, okA);
+      lstm_stage_kc(sB, W, kc, H, false, offB, okB);
+    }
 #endif
     __syncthreads();
 #ifndef GT_ABLATE_LSTM_NO_MMA
