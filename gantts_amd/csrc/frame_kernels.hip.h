@@ -106,7 +106,9 @@ __global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int io
                                    float* __restrict__ out, int ldo, int ooff, int rows, int nj) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)rows * nj) return;
-  const int r = (int)(e / nj), j = (int)(e - (long)r * nj);
+  int r, j;
+  if ((long)rows * nj < (1L << 31)) { r = (int)((unsigned)e / (unsigned)nj); j = (int)((unsigned)e - (unsigned)r * (unsigned)nj); }
+  else { r = (int)(e / nj); j = (int)(e - (long)r * nj); }
   const int c = idx ? idx[j] : ioff + j;
   out[(long)r * ldo + ooff + j] = in[(long)r * ldi + c];
 }
@@ -118,7 +120,8 @@ __global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const flo
   const int w = cd + na;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N * w) return;
-  const long r = e / w;
+  long r;
+  if (N * w < (1L << 31)) r = (long)((unsigned)e / (unsigned)w); else r = e / w;
   const int c = (int)(e - r * w);
   if (c < cd) {
     const float v = x[r * cd + c];
@@ -399,13 +402,20 @@ __global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
   double acc = 0.0;
   const long total = rows * D;
   const float gs = g ? 2.f * gscale * sc->inv_tv : 0.f;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long r = e / D;
-    const int d = (int)(e - r * D);
+  // (row, column) advance incrementally with the grid stride: no 64-bit division per element
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long sr = stride / D;
+  const int sd = (int)(stride - sr * D);
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long r = e / D;
+  int d = (int)(e - r * D);
+  for (; e < total; e += stride) {
     const float m = mask[r];
     const float diff = a[r * lda + d] * m - b[r * ldb + d] * m;
     acc += (double)diff * (double)diff;
     if (g) g[r * ldg + d] = gs * diff * m;
+    r += sr; d += sd;
+    if (d >= D) { d -= D; ++r; }
   }
   const double tot = block_sum_d(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -619,9 +629,14 @@ __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   double acc = 0.0;
   const long total = rows * Ds;
   const float sc2 = 2.f * mge_w * sc->inv_tv;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const long r = e / Ds;
-    const int c = (int)(e - r * Ds);
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long sr = stride / Ds;
+  const int sd = (int)(stride - sr * Ds);
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long r = e / Ds;
+  int c = (int)(e - r * Ds);
+  for (; e < total; e += stride, r += sr, c += sd) {
+    if (c >= Ds) { c -= Ds; ++r; }
     const float m = mask[r];
     const float diff = yhs[r * ld1 + c] * m - ys[r * ld2 + c] * m;
     acc += (double)diff * (double)diff;
