@@ -75,7 +75,9 @@ SIGNATURES = {
     "gt_get_optimizer_step": (_I, [_P, _I, C.POINTER(_L)]),
     "gt_set_seed": (_I, [_P, C.c_uint64]),
     "gt_set_dropout_mask": (_I, [_P, _I, _I, _I, _P]),
-    "gt_set_lengths": (_I, [_P, C.POINTER(_L), _I]),
+    "gt_op_philox_mask": (_I, [_P, _I, _I, _I, _L, _F, _L, _I, _P, _P]),
+    "gt_set_lengths": (_I, [_P, C.POINTER(_L), _I, _P]),
+    "gt_invalidate_mlpg_cache": (_I, [_P]),
     "gt_zero_grad": (_I, [_P, _I]),
     "gt_apply_generator": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gt_update_discriminator": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, C.POINTER(DResult), _P]),

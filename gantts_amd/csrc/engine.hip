@@ -58,6 +58,24 @@ extern "C" const char* gt_version(void) { return "gantts_hip 0.1 (gfx950, f32 MF
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: remember the largest value set per
+// (kernel, device), so that a process driving several GPUs raises the limit on each of them.
+#include <map>
+#include <mutex>
+static int ensure_dyn_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& cur = done[std::make_pair(kernel, dev)];
+  if (bytes > cur) {
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    cur = bytes;
+  }
+  return GT_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // optional per-launch timing of the GEMM family (HIP events on the launch stream); used by
 // bench.py for the live roofline figure.  Off by default: zero overhead on the normal path.
@@ -99,13 +117,8 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
 // ------------------------------------------------------------------------------------------
 template <int KIND, int BM, int BN, bool VA, bool VB>
 static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB>, lds));
   g.n_tiles_m = cdiv(g.M, BM);
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -284,10 +297,23 @@ struct Net {
   Net() { memset(inj, 0, sizeof(inj)); }
 };
 
-struct MlpgCache {
+// Banded images of the MLPG matrices the caller has passed so far, one per (R pointer, T): batches of a corpus come in
+// many padded lengths and the caller (gantts_amd.paramgen / the reference's per-batch R) keeps one R per T, so after the
+// first sight of a T there is no extraction kernel, no D2H copy and no host synchronisation on the step path.
+// Contract (include/gantts_hip.h): R is immutable while cached; gt_invalidate_mlpg_cache() after rewriting / freeing it.
+struct MlpgBand {
   const float* R = nullptr;
   int T = 0, kb = 0;
+  uint64_t last_use = 0;
   Scratch band;
+};
+struct MlpgCache {
+  static constexpr size_t MAX_ENTRIES = 256;
+  std::vector<MlpgBand*> entries;
+  MlpgBand* cur = nullptr;
+  uint64_t tick = 0;
+  Scratch tmp;                      // per-offset maxima of a new R (persistent: no hipFree on the step path)
+  void clear() { for (auto* b : entries) { b->band.release(); delete b; } entries.clear(); cur = nullptr; }
 };
 
 struct gt_engine {
@@ -333,7 +359,15 @@ struct gt_engine {
   // recurrent generator workspace (per layer) and the lengths of the current batch
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out, l_outd;   // l_outd: inter-layer-dropped outputs
   Scratch i2o_gout;                                              // In2OutRNNHighwayNet: hidden2out output G(x)
-  Scratch l_state, l_dout, l_hshift, d_lengths;
+  Scratch l_state, l_dout, l_hshift;
+  // sequence lengths travel on the step stream through a small ring (pinned host slot -> device slot): the kernels of
+  // the previous step, still queued when the next batch's lengths arrive, keep reading THEIR slot
+  static constexpr int LEN_RING = 4;
+  int* len_host[LEN_RING] = {nullptr, nullptr, nullptr, nullptr};
+  Scratch len_dev[LEN_RING];
+  hipEvent_t len_ev[LEN_RING] = {nullptr, nullptr, nullptr, nullptr};
+  int len_cap = 0, len_slot = -1;
+  int* d_lengths() { return len_slot < 0 ? nullptr : len_dev[len_slot].as<int>(); }
   std::vector<Scratch> s_u, s_h, s_c, s_xdrop;     // SRU per-layer stashes
   Scratch s_du, s_dx, s_dbias;
   std::vector<int> h_lengths;
@@ -407,12 +441,18 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   e->dP.release(); e->dadv.release(); e->dW0s.release();
   for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
   e->i2o_gout.release();
-  e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->d_lengths.release();
+  e->l_state.release(); e->l_dout.release(); e->l_hshift.release();
+  for (int i = 0; i < gt_engine::LEN_RING; ++i) {
+    e->len_dev[i].release();
+    if (e->len_host[i]) (void)hipHostFree(e->len_host[i]);
+    if (e->len_ev[i]) (void)hipEventDestroy(e->len_ev[i]);
+  }
   for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop}) for (auto& s : *v) s.release();
   e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
-                    &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.band};
+                    &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
+  e->mlpg.clear();
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
   for (int* p : ints) if (p) (void)hipFree(p);
   if (e->h_res) (void)hipHostFree(e->h_res);
@@ -593,15 +633,32 @@ extern "C" int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_dev)
   e->tv_mask = nullptr;          // re-read on the next step function
   return GT_OK;
 }
-extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B) {
+extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, void* stream) {
   if (!e || !lengths_host || B < 1) return fail(GT_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
   e->h_lengths.resize(B);
   for (int b = 0; b < B; ++b) {
     if (lengths_host[b] < 0 || lengths_host[b] > 0x3fffffff) return fail(GT_ERR_INVALID, "length out of range");
     e->h_lengths[b] = (int)lengths_host[b];
   }
-  CHK(e->d_lengths.ensure((size_t)B * sizeof(int)));
-  HIPCHK(hipMemcpy(e->d_lengths.p, e->h_lengths.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  if (B > e->len_cap) {          // (re)allocate the pinned slots; device slots grow on demand
+    HIPCHK(hipStreamSynchronize(s));
+    const int cap = std::max(64, B + B / 2);
+    for (int i = 0; i < gt_engine::LEN_RING; ++i) {
+      if (e->len_ev[i]) HIPCHK(hipEventSynchronize(e->len_ev[i]));
+      if (e->len_host[i]) { HIPCHK(hipHostFree(e->len_host[i])); e->len_host[i] = nullptr; }
+      HIPCHK(hipHostMalloc((void**)&e->len_host[i], (size_t)cap * sizeof(int)));
+      if (!e->len_ev[i]) HIPCHK(hipEventCreateWithFlags(&e->len_ev[i], hipEventDisableTiming));
+    }
+    e->len_cap = cap;
+  }
+  const int slot = (e->len_slot + 1) % gt_engine::LEN_RING;
+  HIPCHK(hipEventSynchronize(e->len_ev[slot]));          // the copy that last used this pinned slot (4 batches ago)
+  memcpy(e->len_host[slot], e->h_lengths.data(), (size_t)B * sizeof(int));
+  CHK(e->len_dev[slot].ensure((size_t)e->len_cap * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(e->len_dev[slot].p, e->len_host[slot], (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(e->len_ev[slot], s));
+  e->len_slot = slot;
   return GT_OK;
 }
 
@@ -619,24 +676,49 @@ extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {
   return GT_OK;
 }
 
+// Philox dropout site (role, pass, layer) of engine step `step`: the keep decision of element (row, col) is
+// philox_keep(key0, key1, thresh, row, col) (gemm_f32.hip.h) -- a function of the site and the element only, not of
+// the tiling of whichever kernel applies it.  The keep probability is quantised to 16 bits (thresh = round(p * 2^16)):
+// exact for p = k / 65536 (0.5, 0.25, ...), otherwise |P(keep) - (1-p)| <= 2^-17 while the survivors are scaled by
+// the nominal 1/(1-p) like nn.Dropout does.
+static DropoutSpec philox_site_spec(gt_engine* e, int role, int pass, int layer, uint64_t step, float p) {
+  DropoutSpec d = no_drop();
+  d.p = p;
+  d.scale = 1.f / (1.f - p);
+  d.mode = DROP_PHILOX;
+  const double th = (double)p * 65536.0 + 0.5;
+  d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
+  const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
+  d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
+  d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;
+  return d;
+}
+
 // dropout spec of (role, pass, layer).  rows_off: first row of `pass` inside the stacked mask buffer.
 static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const float* stacked_mask, int ld) {
   Net& n = e->net[role];
   DropoutSpec d = no_drop();
   if (!n.training || n.d.dropout <= 0.f) return d;
-  d.p = n.d.dropout;
-  d.scale = 1.f / (1.f - n.d.dropout);
   if (stacked_mask) {
+    d.p = n.d.dropout;
+    d.scale = 1.f / (1.f - n.d.dropout);
     d.mode = DROP_BUFFER; d.mask = stacked_mask; d.ld_mask = ld;
-  } else {
-    d.mode = DROP_PHILOX;
-    const double th = (double)n.d.dropout * 65536.0 + 0.5;       // 16-bit pieces (gemm_f32.hip.h: philox_keep)
-    d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
-    const uint64_t site = e->step_counter * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
-    d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
-    d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;
+    return d;
   }
-  return d;
+  return philox_site_spec(e, role, pass, layer, e->step_counter, n.d.dropout);
+}
+
+// Parity hook: the 0/1 keep mask the engine's Philox stream assigns to dropout site (role, pass, layer) of the step
+// that starts `steps_ahead` apply_generator calls from now (1 = the next one), for a (rows, cols) activation.
+extern "C" int gt_op_philox_mask(gt_engine* e, int role, int pass, int layer, int64_t steps_ahead, float p, int64_t rows, int cols,
+                                 float* mask, void* stream) {
+  if (!e || !mask || role < 0 || role > 1 || pass < 0 || pass > 2 || layer < 0 || layer > 15 || rows < 1 || cols < 1 ||
+      steps_ahead < 0 || !(p > 0.f && p < 1.f) || rows > 0x7fffffffL)
+    return fail(GT_ERR_INVALID, "bad argument");
+  const DropoutSpec d = philox_site_spec(e, role, pass, layer, e->step_counter + (uint64_t)steps_ahead, p);
+  hipLaunchKernelGGL(philox_mask_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d, rows, cols, mask);
+  LAUNCH_CHECK();
+  return GT_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -644,17 +726,17 @@ static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const 
 // ------------------------------------------------------------------------------------------
 static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
   MlpgCache& m = e->mlpg;
-  if (m.R == R && m.T == T && m.band.p) return GT_OK;
+  ++m.tick;
+  for (auto* b : m.entries)
+    if (b->R == R && b->T == T) { b->last_use = m.tick; m.cur = b; return GT_OK; }
   const int nW = e->cfg.num_windows;
-  // per-offset maxima -> host, pick the smallest half-width whose outside is negligible
-  Scratch tmp;
-  CHK(tmp.ensure((size_t)(2 * T - 1) * sizeof(float)));
-  hipLaunchKernelGGL(mlpg_offset_max_kernel, dim3(2 * T - 1), dim3(256), 0, s, R, T, nW, tmp.as<float>());
+  // first sight of this (R, T): per-offset maxima -> host, pick the smallest half-width whose outside is negligible
+  CHK(m.tmp.ensure((size_t)(2 * T - 1) * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_offset_max_kernel, dim3(2 * T - 1), dim3(256), 0, s, R, T, nW, m.tmp.as<float>());
   LAUNCH_CHECK();
   std::vector<float> off(2 * T - 1);
-  HIPCHK(hipMemcpyAsync(off.data(), tmp.p, off.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(off.data(), m.tmp.p, off.size() * sizeof(float), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  tmp.release();
   float peak = 0.f;
   for (float v : off) peak = fmaxf(peak, v);
   if (!(peak > 0.f) || !isfinite(peak)) return fail(GT_ERR_INVALID, "MLPG matrix R is empty or not finite");
@@ -664,25 +746,39 @@ static int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
   if (kb > 63 || (kb > 48 && kb > T / 4))
     return fail(GT_ERR_INVALID, "MLPG matrix R is not banded (half-width %d of T=%d): only window sets whose "
                 "R = (W^T W)^-1 W^T decays (hparams.py:22-26) are supported", kb, T);
+  MlpgBand* b = nullptr;
+  if (m.entries.size() >= MlpgCache::MAX_ENTRIES) {      // recycle the least recently used entry
+    size_t lru = 0;
+    for (size_t i = 1; i < m.entries.size(); ++i) if (m.entries[i]->last_use < m.entries[lru]->last_use) lru = i;
+    b = m.entries[lru];
+    HIPCHK(hipStreamSynchronize(s));                      // its band may still be read by queued kernels
+  } else {
+    b = new MlpgBand();
+    m.entries.push_back(b);
+  }
   const int nb = 2 * kb + 1;
-  CHK(m.band.ensure((size_t)T * nW * nb * sizeof(float)));
-  hipLaunchKernelGGL(mlpg_extract_band_kernel, dim3(cdiv((long)T * nW * nb, 256)), dim3(256), 0, s, R, T, nW, kb, m.band.as<float>());
+  b->R = nullptr;
+  CHK(b->band.ensure((size_t)T * nW * nb * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_extract_band_kernel, dim3(cdiv((long)T * nW * nb, 256)), dim3(256), 0, s, R, T, nW, kb, b->band.as<float>());
   LAUNCH_CHECK();
-  m.R = R; m.T = T; m.kb = kb;
+  b->R = R; b->T = T; b->kb = kb; b->last_use = m.tick;
+  m.cur = b;
+  return GT_OK;
+}
+extern "C" int gt_invalidate_mlpg_cache(gt_engine* e) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  HIPCHK(hipDeviceSynchronize());
+  e->mlpg.clear();
   return GT_OK;
 }
 
 static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
                         float* ys, int ldys, int B, int T, hipStream_t s) {
-  const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
+  const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)mlpg_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
+  CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel, lds));
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds,
                      ys, ldys, B, T);
   LAUNCH_CHECK();
   return GT_OK;
@@ -690,15 +786,11 @@ static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, 
 static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, const int* sstride, int Ds,
                          float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
                          const float* mask, hipStream_t s) {
-  const int nW = e->cfg.num_windows, kb = e->mlpg.kb;
+  const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  static size_t lds_set_b = 0;
-  if (lds > lds_set_b) {
-    HIPCHK(hipFuncSetAttribute((const void*)mlpg_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set_b = lds;
-  }
+  CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel, lds));
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.band.as<float>(), kb, nW, scol, sstride, Ds,
+  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds,
                      gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc());
   LAUNCH_CHECK();
   return GT_OK;
@@ -794,13 +886,9 @@ static bool chain_ok(const Net& n) {
 
 template <int TN_, bool FWD>
 static int launch_chain_t(const ChainArgs& a, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = chain_lds_bytes(a.H, FWD ? a.K0p : 0, FWD);
   auto kern = FWD ? chain_fwd_kernel<TN_> : chain_bwd_kernel<TN_>;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    attr_set = true;
-  }
+  CHK(ensure_dyn_lds((const void*)kern, 160 * 1024 - 512));
   hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.rows, CH_ROWS)), dim3(CH_THREADS), lds, s, a);
   LAUNCH_CHECK();
   return GT_OK;
@@ -927,16 +1015,12 @@ static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T
   CHK(e->l_state.ensure(5 * st * sizeof(float)));          // h0,h1,c0,c1 (ping-pong) + dc
   float* base = e->l_state.as<float>();
   HIPCHK(hipMemsetAsync(base, 0, 5 * st * sizeof(float), s));
-  static bool attr = false;
-  if (!attr) {
-    HIPCHK(hipFuncSetAttribute((const void*)lstm_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
-    HIPCHK(hipFuncSetAttribute((const void*)lstm_bwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
-    attr = true;
-  }
+  CHK(ensure_dyn_lds((const void*)lstm_fwd_step_kernel, lstm_lds_bytes()));
+  CHK(ensure_dyn_lds((const void*)lstm_bwd_step_kernel, lstm_lds_bytes()));
   LstmStepArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.Bpad = Bpad;
-  a.lengths = e->d_lengths.as<int>();
+  a.lengths = e->d_lengths();
   for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
   a.xproj = e->l_xproj[layer].as<float>();
   a.gates = e->l_gates[layer].as<float>();
@@ -1024,7 +1108,7 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
       LAUNCH_CHECK();
       // dW_hh = dG_d^T H_shift (h that entered each frame)
       hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
-                         e->d_lengths.as<int>(), e->l_hshift.as<float>());
+                         e->d_lengths(), e->l_hshift.as<float>());
       LAUNCH_CHECK();
       CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, e->slabs,
                                  e->colp, s));

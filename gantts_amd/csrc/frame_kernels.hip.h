@@ -51,6 +51,15 @@ __device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int 
   return true;
 }
 
+// parity hook (gt_op_philox_mask): materialises the keep bits of one Philox dropout site from the layout-independent
+// definition philox_keep(row, col), one element per thread
+__global__ void philox_mask_kernel(const DropoutSpec d, long rows, int cols, float* __restrict__ mask) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int r = (int)(e / cols), c = (int)(e - (long)r * cols);
+  mask[e] = philox_keep(d.key0, d.key1, d.thresh, r, c) ? 1.f : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------
 // device scalars of one step (engine workspace).  Sums are kept in double so the 9 reported
 // scalars do not depend on the reduction tree.

@@ -44,6 +44,15 @@ def _hp_signature(hp):
             bool(getattr(hp, "discriminator_linguistic_condition", False)))
 
 
+def _same_storage(t, c, name):
+    """``t`` came from apply_generator (it carries the engine's graph bookkeeping) but is not contiguous: the copy the
+    kernels would read is a different tensor, and the engine would silently treat it as detached (no D->G gradient)."""
+    if c is not t and getattr(t, "_gt_engine", None) is not None:
+        raise RuntimeError("%s must be passed as returned by apply_generator (contiguous); a strided view would "
+                           "drop the gradient path the reference keeps (train.py:265)" % name)
+    return c
+
+
 def _check_frames(t, name, last_dim=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
@@ -77,7 +86,7 @@ class StepEngine(object):
         self._h = h
         self._finalizer = weakref.finalize(self, lib.gt_engine_destroy, h)
         self._bound = {L.ROLE_G: (None, -1, False), L.ROLE_D: (None, -1, False)}   # (model ref, version, with_grads)
-        self._bound_opt = {L.ROLE_G: (None, -1), L.ROLE_D: (None, -1)}
+        self._bound_opt = {L.ROLE_G: (None, -1, None), L.ROLE_D: (None, -1, None)}
         self._keep = {}
         nW = len(hp.windows)
         ss = [s // nW if d else s for s, d in zip(hp.stream_sizes, hp.has_dynamic_features)]
@@ -102,18 +111,27 @@ class StepEngine(object):
             check(lib.gt_set_dropout_mask(self._h, role, pass_idx, layer, ptr(m)))
         check(lib.gt_set_training(self._h, role, int(model.training)))
         self._bound[role] = (weakref.ref(model), model._version, with_grads)
-        self._bound_opt[role] = (None, -1)
+        self._bound_opt[role] = (None, -1, None)
         model._bound_engines[id(self)] = (weakref.ref(self), role)
 
     def bind_optimizer(self, role, optimizer):
-        ref, ver = self._bound_opt[role]
-        if ref is not None and ref() is optimizer and ver == optimizer._version:
-            check(lib.gt_set_lr(self._h, role, float(optimizer.param_groups[0]["lr"])))
+        """torch.optim reads ``param_groups`` on every step: any hyper-parameter edited since the last bind (weight_decay,
+        eps, betas, lr_decay, ``max_grad_norm``) re-binds; a change of ``lr`` alone (exp_lr_scheduler, train.py:323-333)
+        takes the cheap ``gt_set_lr`` path."""
+        ref, ver, hyper = self._bound_opt[role]
+        now = optimizer._hyper()
+        if ref is not None and ref() is optimizer and ver == optimizer._version and hyper[1:] == now[1:]:
+            if hyper[0] != now[0]:
+                check(lib.gt_set_lr(self._h, role, now[0]))
+                self._bound_opt[role] = (ref, ver, now)
             return
         desc = optimizer._desc()
         check(lib.gt_bind_optimizer(self._h, role, C.byref(desc)))
-        self._bound_opt[role] = (weakref.ref(optimizer), optimizer._version)
+        self._bound_opt[role] = (weakref.ref(optimizer), optimizer._version, now)
         optimizer._engines[id(self)] = (weakref.ref(self), role)
+
+    def invalidate_mlpg_cache(self):
+        check(lib.gt_invalidate_mlpg_cache(self._h))
 
     def optimizer_step_count(self, role):
         n = C.c_int64()
@@ -125,6 +143,14 @@ class StepEngine(object):
 
     def set_seed(self, seed):
         check(lib.gt_set_seed(self._h, C.c_uint64(int(seed))))
+
+    def philox_mask(self, role, pass_index, layer, p, rows, cols, steps_ahead=1):
+        """Parity hook: the (rows, cols) 0/1 keep mask of Philox dropout site (role, pass, layer) of the step that
+        starts ``steps_ahead`` apply_generator calls from now (gt_op_philox_mask)."""
+        m = torch.empty(rows, cols, device="cuda", dtype=torch.float32)
+        check(lib.gt_op_philox_mask(self._h, role, pass_index, layer, int(steps_ahead), float(p), int(rows), int(cols),
+                                    ptr(m), L.current_stream()))
+        return m
 
     def set_option(self, name, value):
         """Engine switches (results unchanged up to fp32 summation order): ``"panel_chain"``."""
@@ -157,7 +183,7 @@ class StepEngine(object):
         if len(vals) != B:
             raise RuntimeError("lengths has %d entries for a batch of %d sequences" % (len(vals), B))
         arr = (C.c_int64 * B)(*vals)
-        check(lib.gt_set_lengths(self._h, arr, B))
+        check(lib.gt_set_lengths(self._h, arr, B, L.current_stream()))
 
     def apply_generator(self, model_g, x, R, lengths=None):
         x = _check_frames(x, "x", model_g.in_dim)
@@ -185,7 +211,7 @@ class StepEngine(object):
 
     def update_discriminator(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
         y_static = _check_frames(y_static, "y_static")
-        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
@@ -208,7 +234,7 @@ class StepEngine(object):
         y = _check_frames(y, "y", model_g.out_dim)
         y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
         y_static = _check_frames(y_static, "y_static")
-        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
@@ -242,7 +268,7 @@ class StepEngine(object):
 
     def update_discriminator_begin(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
         y_static = _check_frames(y_static, "y_static")
-        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
@@ -275,7 +301,7 @@ class StepEngine(object):
         y = _check_frames(y, "y", model_g.out_dim)
         y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
         y_static = _check_frames(y_static, "y_static")
-        y_hat_static_c = _check_frames(y_hat_static, "y_hat_static", y_static.size(-1))
+        y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
@@ -386,6 +412,14 @@ class HipStepBackend(object):
 
     def mask_of(self, batch):
         return batch["mask"]
+
+    def philox_mask(self, role, pass_index, layer, p, rows, cols, steps_ahead=1):
+        """Parity hook: the (rows, cols) 0/1 keep mask of Philox dropout site (role, pass, layer) of the step that
+        starts ``steps_ahead`` apply_generator calls from now (gt_op_philox_mask)."""
+        m = torch.empty(rows, cols, device="cuda", dtype=torch.float32)
+        check(lib.gt_op_philox_mask(self._h, role, pass_index, layer, int(steps_ahead), float(p), int(rows), int(cols),
+                                    ptr(m), L.current_stream()))
+        return m
 
     def set_option(self, name, value):
         self.engine.set_option(name, value)

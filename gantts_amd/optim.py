@@ -75,6 +75,13 @@ class _FlatOptimizer(object):
         d.state1 = self._state[1].data_ptr() if len(self.STATE_KEYS) > 1 else None
         return d
 
+    def _hyper(self):
+        """(lr, everything else the fused update kernel reads) -- compared by StepEngine.bind_optimizer on every step."""
+        g = self.param_groups[0]
+        b1, b2 = g.get("betas", (0.0, 0.0))
+        return (float(g["lr"]), float(g.get("weight_decay", 0.0)), float(g["eps"]), float(g.get("lr_decay", 0.0)),
+                float(b1), float(b2), float(self.max_grad_norm))
+
     def _note_step(self, engine, role):
         self._step = engine.optimizer_step_count(role)
 

@@ -131,12 +131,25 @@ int gt_set_seed(gt_engine* e, uint64_t seed);
  * passes: G: 0 = apply_generator.  D: 0 = real rows of the D step, 1 = generated rows of the
  * D step, 2 = generated rows of the G step (the order nn.Dropout is consumed in train.py:261-307). */
 int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, const float* mask);
+/* Parity hook for the production (Philox) dropout path, nn.Dropout inside gantts/models.py:132-139: writes the 0/1 keep
+ * mask ((rows, cols) contiguous, device) that the engine's counter-based stream assigns to dropout site (role, pass,
+ * layer) of the step that starts `steps_ahead` gt_apply_generator calls from now (1 = the next step).  The D step runs
+ * its real and generated rows as ONE 2N-row pass: its site is pass 0 with rows [0,N) = real, [N,2N) = generated; pass 2
+ * is the N-row D pass of the G step.  Feeding these masks to the reference (patched nn.Dropout) reproduces the step. */
+int gt_op_philox_mask(gt_engine* e, int role, int pass, int layer, int64_t steps_ahead, float p, int64_t rows, int cols,
+                      float* mask, void* stream);
 
 /* Sequence lengths of the NEXT batch (host int64 array, as the `lengths` list the reference passes to
  * model(x, lengths=lengths), train.py:344; models.py:204-210 pack_padded_sequence).  Needed by the
  * recurrent generators only; MLP ignores lengths like the reference.  Unlike pack_padded_sequence the
- * batch need not be sorted. */
-int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B);
+ * batch need not be sorted.  The array is copied before the call returns; it reaches the device IN STREAM ORDER on
+ * `stream` (the stream of the following step functions) through a ring of pinned slots, so the still-queued kernels of
+ * the previous step keep reading their own lengths and the host never waits for the GPU here. */
+int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, void* stream);
+/* The engine keeps a banded image of every MLPG matrix R it has been given, keyed by (R pointer, T) (the reference
+ * rebuilds and uploads R every batch, train.py:511-513; callers of this library keep one device R per padded length).
+ * R must not be rewritten in place or freed-and-reused while cached: call this first (drops all cached bands). */
+int gt_invalidate_mlpg_cache(gt_engine* e);
 
 /* ---- hot path -------------------------------------------------------------------------- */
 /* optimizer.zero_grad()                                         (train.py:538-539) */

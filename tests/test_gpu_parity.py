@@ -16,12 +16,41 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RTOL = 1e-4
 
 
-def _close(a, b, rtol=RTOL, atol=1e-6, msg=""):
+def _scale_of(b, msg):
+    """Comparison scale of every element: tensors with a feature axis are judged PER COLUMN of their last dimension
+    (each stream column of a (B,T,D) frame tensor against that column's own magnitude, so the small lf0 / bap columns
+    are not hidden behind mgc), weight matrices additionally per row (output unit): scale[i,j] = min(row_i, col_j).
+    Vectors and scalars use their own max."""
+    ab = np.abs(b)
+    if b.ndim < 2 or b.shape[-1] == 1:
+        return np.full(b.shape, max(1e-30, float(ab.max()) if b.size else 1e-30))
+    col = ab.reshape(-1, b.shape[-1]).max(0)
+    scale = np.broadcast_to(col, b.shape).copy()
+    if b.ndim == 2 and "weight" in msg:
+        scale = np.minimum(scale, ab.max(1, keepdims=True))
+    return np.maximum(scale, 1e-30)
+
+
+_REPORT = os.environ.get("GT_PARITY_REPORT")     # dev aid: append "msg worst-ratio" lines instead of judging blind
+
+
+def _close(a, b, rtol=RTOL, atol=1e-6, msg="", frac_ok=0.0):
+    """|a - b| <= atol + rtol * scale element-wise, scale per column / row (see _scale_of).  frac_ok > 0 tolerates that
+    fraction of outliers (only for documented discontinuities such as the first Adagrad step, lr * sign(g))."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    scale = max(1e-30, float(np.abs(b).max()))
-    err = np.abs(a - b).max() if a.size else 0.0
     assert a.shape == b.shape, (msg, a.shape, b.shape)
-    assert err <= atol + rtol * scale, "%s: max abs err %.3e (scale %.3e, rel %.3e)" % (msg, err, scale, err / scale)
+    if not a.size:
+        return
+    err = np.abs(a - b)
+    lim = atol + rtol * _scale_of(b, msg)
+    ratio = err / lim
+    worst = float(ratio.max())
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write("%-60s worst %.3f  frac>1 %.2e  rtol %.0e atol %.0e shape %s\n" % (msg, worst, float((ratio > 1).mean()), rtol, atol, a.shape))
+    bad = float((ratio > 1).mean())
+    assert bad <= frac_ok, "%s: %.3e of the elements outside tolerance, worst error %.2fx the limit (rtol %.0e, atol %.0e)" % (
+        msg, bad, worst, rtol, atol)
 
 
 def test_library_loaded_is_the_hip_one():
@@ -407,6 +436,101 @@ def test_full_size_cfg2_step_vs_oracle_and_determinism():
         assert bad.mean() < 1e-3, "too many mismatching parameters: %g" % bad.mean()
         if bad.any():
             assert np.abs(gref[bad]).max() < 1e-3 * np.abs(gref).max(), "mismatch on a well-conditioned gradient"
+
+
+@pytest.mark.parametrize("tag,B,Tn,gh,dh,chain", [("cfg2-full-size", 32, 512, 512, 256, False),
+                                                   ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250, False),
+                                                   ("panel-chain", 4, 200, 256, 128, True)])
+def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh, chain):
+    """The path bench.py times: dropout 0.5 ON through the engine's own Philox stream (no injected masks on the HIP
+    side).  The keep masks the engine is about to use are dumped through gt_op_philox_mask -- the layout-independent
+    definition philox_keep(row, col) -- and handed to the CPU oracle as its nn.Dropout masks (the oracle is pinned to
+    the reference with masks injected the same way, tests/golden/make_golden.py); the whole step must then agree:
+    forward epilogues AND the keep bits every backward kernel regenerates (wide 16-byte and narrow epilogues, 64 / 128
+    column tiles, partial tiles, 2N-row discriminator pass, fused head, panel-chain kernels).  Two steps, Adagrad with a
+    warm accumulator (1e-4: as after some training, where the update is smooth in g) so that parameters compare tightly.
+    Reference semantics: gantts/models.py:132-139, train.py:245-320."""
+    import types
+    import gantts_amd.train as T
+    from gantts_amd import _lib as L
+    from gantts_amd import hparams, optim, paramgen
+    from gantts_amd.engine import engine_for
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model
+    N, steps, acc0, p = B * Tn, 2, 1e-4, 0.5
+    gs = dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=gh, dropout=p, last_sigmoid=False)
+    ds = dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=dh, dropout=p, last_sigmoid=True)
+    case = dict(B=B, T=Tn, din=425, dout=187, stream_sizes=[180, 3, 1, 3])
+    x_np, y_np, lengths = C.make_batch(case, seed=11)
+    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    T.hp = hp
+    R_np = np.array(paramgen.unit_variance_mlpg_matrix(hp.windows, Tn))
+    okw = dict(lr=0.01, weight_decay=1e-7)
+
+    # ---- HIP: train mode, Philox dropout; dump the masks of the coming step first ----
+    mg, md = build_model(gs, 1).train(), build_model(ds, 2).train()
+    og = optim.Adagrad(mg.parameters(), initial_accumulator_value=acc0, **okw)
+    od = optim.Adagrad(md.parameters(), initial_accumulator_value=acc0, **okw)
+    eng = engine_for(hp, mg)
+    eng.set_seed(1234)
+    eng.set_option("panel_chain", chain)
+    x, y, R = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda(), torch.from_numpy(R_np).cuda()
+    ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
+    mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
+    hip, masks = [], []
+    for st in range(steps):
+        gm = [eng.philox_mask(L.ROLE_G, 0, l, p, N, gh).cpu().view(B, Tn, gh) for l in range(3)]
+        d0 = [eng.philox_mask(L.ROLE_D, 0, l, p, 2 * N, dh).cpu() for l in range(3)]
+        d2 = [eng.philox_mask(L.ROLE_D, 2, l, p, N, dh).cpu().view(B, Tn, dh) for l in range(3)]
+        masks.append((gm, [m[:N].view(B, Tn, dh) for m in d0] + [m[N:].view(B, Tn, dh) for m in d0] + d2))
+        og.zero_grad(), od.zero_grad()
+        yh, yhs = T.apply_generator(mg, x, R, list(lengths))
+        d = T.update_discriminator(md, od, x, ys, yhs, list(lengths), mask, "train")
+        dgrad = md.flat_grads().cpu().clone()
+        g = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, list(lengths), mask, "train", mse_w=0.0, mge_w=1.0)
+        hip.append(dict(d=d, g=g, yh=yh.cpu().numpy(), yhs=yhs.cpu().numpy(), dgrad=dgrad.numpy(),
+                        ggrad=mg.flat_grads().cpu().numpy().copy()))
+    for gm, _ in masks:                       # the dumped masks are Bernoulli(0.5) and differ between sites / steps
+        assert all(abs(float(m.mean()) - 0.5) < 0.02 for m in gm)
+    assert not torch.equal(masks[0][0][0], masks[1][0][0]) and not torch.equal(masks[0][0][0], masks[0][0][1])
+
+    # ---- oracle: the same masks injected ----
+    omg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
+    omd = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
+    omg.load_state_dict(C.make_weights(gs, 1)), omd.load_state_dict(C.make_weights(ds, 2))
+    omg.training = omd.training = True
+    oog, ood = O.OracleAdagrad(omg.params, **okw), O.OracleAdagrad(omd.params, **okw)
+    for o in (oog, ood):
+        for s_ in o.sum:
+            s_.fill_(acc0)
+    cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
+    xc, yc, Rc = torch.from_numpy(x_np), torch.from_numpy(y_np), torch.from_numpy(R_np)
+    omask = O.sequence_mask(lengths, Tn).unsqueeze(-1)
+    oys = O.get_static_features(yc, 3, cfg.stream_sizes, cfg.has_dynamic_features)
+    for st in range(steps):
+        gm, dm = masks[st]
+        dd = O._DropoutSource(dm)
+        oog.zero_grad(), ood.zero_grad()
+        oyh, oyhs = O.apply_generator(cfg, omg, xc, Rc, list(lengths), drop=O._DropoutSource(gm))
+        od_ = O.update_discriminator(cfg, omd, ood, xc, oys, oyhs, list(lengths), omask, "train", drop=dd)
+        ref_dgrad = torch.cat([q.grad.reshape(-1) for q in omd.params]).numpy().copy()
+        og_ = O.update_generator(cfg, omg, omd, oog, xc, yc, oyh, oys, oyhs, 1.0, list(lengths), omask, "train",
+                                 mse_w=0.0, mge_w=1.0, drop=dd)
+        assert not dd.masks, "oracle consumed %d of 9 discriminator masks" % (9 - len(dd.masks))
+        h = hip[st]
+        t = "%s step %d " % (tag, st)
+        _close(h["yh"], oyh.detach().numpy(), msg=t + "y_hat")
+        _close(h["yhs"], oyhs.detach().numpy(), msg=t + "y_hat_static")
+        _close(h["d"], od_, msg=t + "D scalars")
+        assert h["d"][3] == od_[3] and h["d"][4] == od_[4], (h["d"], od_)
+        _close(h["g"], og_, msg=t + "G scalars")
+        # flat gradient vectors (clipped in place, like clip_grad_norm_): every element against the vector's scale
+        _close(h["dgrad"], ref_dgrad, rtol=RTOL, atol=1e-9, msg=t + "D grads")
+        _close(h["ggrad"], torch.cat([q.grad.reshape(-1) for q in omg.params]).numpy(), rtol=RTOL, atol=1e-9, msg=t + "G grads")
+    for tagm, m, om in (("G", mg, omg), ("D", md, omd)):
+        for (k, v), r in zip(m.state_dict().items(), om.params):
+            _close(v.cpu().numpy(), r.detach().numpy(), msg="%s %s.%s after 2 steps" % (tag, tagm, k))
 
 
 @pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])
