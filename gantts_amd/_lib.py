@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
-OPT_PANEL_CHAIN = 1
+OPT_PANEL_CHAIN, OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS = 1, 2, 3
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8
@@ -85,6 +85,7 @@ SIGNATURES = {
     "gt_set_loss_normalizer": (_I, [_P, _F]),
     "gt_set_loss_normalizer_device": (_I, [_P, _P]),
     "gt_set_option": (_I, [_P, _I, _I]),
+    "gt_check_faults": (_I, [_P, _P]),
     "gt_update_discriminator_begin": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "gt_update_discriminator_end": (_I, [_P, _I, C.POINTER(DResult), _P]),
     "gt_update_generator_begin": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _F, _F, _P]),

@@ -24,6 +24,7 @@
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
 #include "lstm_kernels.hip.h"
+#include "lstm_seq_kernels.hip.h"
 #include "sru_kernels.hip.h"
 #include "chain_kernels.hip.h"
 
@@ -360,6 +361,11 @@ struct gt_engine {
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out, l_outd;   // l_outd: inter-layer-dropped outputs
   Scratch i2o_gout;                                              // In2OutRNNHighwayNet: hidden2out output G(x)
   Scratch l_state, l_dout, l_hshift;
+  Scratch l_xch;                                   // persistent recurrence: exchange granules
+  unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
+  unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
+  bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
+  int lstm_fwd_upc = 0;                            // 0 = automatic
   // sequence lengths travel on the step stream through a small ring (pinned host slot -> device slot): the kernels of
   // the previous step, still queued when the next batch's lengths arrive, keep reading THEIR slot
   static constexpr int LEN_RING = 4;
@@ -428,6 +434,9 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if ((r = e->scal.ensure(1024))) { delete e; return r; }
   if (hipMemset(e->scal.p, 0, 1024) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMemset failed"); }
   if (hipHostMalloc((void**)&e->h_res, sizeof(StepResults)) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
+  if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  *e->h_fault = 0;
   *out = e;
   return GT_OK;
 }
@@ -441,7 +450,9 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   e->dP.release(); e->dadv.release(); e->dW0s.release();
   for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
   e->i2o_gout.release();
-  e->l_state.release(); e->l_dout.release(); e->l_hshift.release();
+  e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->l_xch.release();
+  if (e->d_fault) (void)hipFree(e->d_fault);
+  if (e->h_fault) (void)hipHostFree(e->h_fault);
   for (int i = 0; i < gt_engine::LEN_RING; ++i) {
     e->len_dev[i].release();
     if (e->len_host[i]) (void)hipHostFree(e->len_host[i]);
@@ -618,6 +629,8 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
   switch (option) {
     case GT_OPT_PANEL_CHAIN: e->use_chain = value != 0; return GT_OK;
+    case GT_OPT_LSTM_PERSISTENT: e->lstm_persistent = value != 0; return GT_OK;
+    case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -1043,6 +1056,107 @@ static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T
   return GT_OK;
 }
 
+// ---- persistent recurrence (lstm_seq_kernels.hip.h): one launch per layer and pass ----
+// A persistent launch that gave up (a peer workgroup never published: LSTM_FAULT_*) leaves garbage behind.  The fault
+// word is mirrored to the host behind every such launch without waiting; every later entry point looks at the mirror
+// first, gt_check_faults() synchronises and looks.
+static int fault_seen(gt_engine* e) {
+  if (e->h_fault && *e->h_fault != 0u)
+    return fail(GT_ERR_HIP, "persistent LSTM kernel fault %u: a workgroup timed out waiting for its peers (results of that "
+                "step are invalid; set GT_LSTM_STEPS=1 / GT_OPT_LSTM_PERSISTENT=0 to use the per-step kernels)", *e->h_fault);
+  return GT_OK;
+}
+extern "C" int gt_check_faults(gt_engine* e, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return fault_seen(e);
+}
+template <typename K>
+static int seq_capacity(K kern, size_t lds, int* out) {
+  // co-resident workgroups: all of them spin on each other, so the grid must fit the device at once.  The occupancy
+  // API may over-report by one block per CU (MI355X_MICROARCH.md, residency): keep that margin above one per CU.
+  int dev = 0, per_cu = 0;
+  HIPCHK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  static std::map<int, int> cus;
+  if (!cus.count(dev)) { HIPCHK(hipGetDeviceProperties(&prop, dev)); cus[dev] = prop.multiProcessorCount; }
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+  if (per_cu > 1) per_cu -= 1;
+  *out = cus[dev] * std::min(per_cu, 4);
+  return GT_OK;
+}
+template <int HP, int UPC>
+static int launch_fwd_seq(const LstmSeqArgs& a, hipStream_t s, bool* launched) {
+  const size_t lds = lstm_fwd_seq_lds<HP, UPC>();
+  CHK(ensure_dyn_lds((const void*)lstm_fwd_seq_kernel<HP, UPC>, lds));
+  int cap = 0;
+  CHK(seq_capacity(lstm_fwd_seq_kernel<HP, UPC>, lds, &cap));
+  const int grid = a.dirs * a.nbt * a.ncu;
+  if (grid > cap) { *launched = false; return GT_OK; }
+  hipLaunchKernelGGL((lstm_fwd_seq_kernel<HP, UPC>), dim3(grid), dim3(256), lds, s, a);
+  LAUNCH_CHECK();
+  *launched = true;
+  return GT_OK;
+}
+template <int HP>
+static int launch_bwd_seq(const LstmSeqArgs& a, hipStream_t s, bool* launched) {
+  const size_t lds = lstm_bwd_seq_lds<HP>();
+  CHK(ensure_dyn_lds((const void*)lstm_bwd_seq_kernel<HP>, lds));
+  int cap = 0;
+  CHK(seq_capacity(lstm_bwd_seq_kernel<HP>, lds, &cap));
+  const int grid = a.dirs * a.nbt * a.ncu;
+  if (grid > cap) { *launched = false; return GT_OK; }
+  hipLaunchKernelGGL((lstm_bwd_seq_kernel<HP>), dim3(grid), dim3(256), lds, s, a);
+  LAUNCH_CHECK();
+  *launched = true;
+  return GT_OK;
+}
+
+// Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
+// (H <= 512, grid co-resident); *launched = false leaves the work to the per-step kernels.
+static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, bool backward, const float* dout, hipStream_t s,
+                           bool* launched) {
+  *launched = false;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
+  if (!e->lstm_persistent || H > 512 || T < 2) return GT_OK;
+  const int HP = H <= 256 ? 256 : 512;
+  LstmSeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, 16);
+  a.lengths = e->d_lengths();
+  for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
+  a.xproj = e->l_xproj[layer].as<float>();
+  a.gates = e->l_gates[layer].as<float>();
+  a.cst = e->l_cst[layer].as<float>();
+  a.out = e->l_out[layer].as<float>();
+  a.dout = dout;
+  a.fault = e->d_fault;
+  a.timeout_ticks = 200000000ULL;          // 2 s at 100 MHz: far beyond any real wait, far below the watchdog
+  const int ngroups = dirs * a.nbt;
+  const size_t xch_bytes = (size_t)ngroups * 2 * 16 * (backward ? 4 : 1) * HP * sizeof(unsigned long long);
+  CHK(e->l_xch.ensure(xch_bytes));
+  HIPCHK(hipMemsetAsync(e->l_xch.p, 0, xch_bytes, s));       // tags of a previous launch must not be mistaken for this one's
+  a.xch = e->l_xch.as<unsigned long long>();
+  if (backward) {
+    a.ncu = cdiv(H, 16);
+    CHK(HP == 256 ? launch_bwd_seq<256>(a, s, launched) : launch_bwd_seq<512>(a, s, launched));
+    if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    return GT_OK;
+  }
+  // forward: as many workgroups per group as fit (4 hidden units each), else 16 per workgroup
+  int upc = e->lstm_fwd_upc;
+  if (upc != 4 && upc != 16) upc = 4;
+  for (int attempt = 0; attempt < 2 && !*launched; ++attempt) {
+    a.ncu = cdiv(H, upc);
+    if (upc == 4) CHK(HP == 256 ? (launch_fwd_seq<256, 4>(a, s, launched)) : (launch_fwd_seq<512, 4>(a, s, launched)));
+    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, s, launched)) : (launch_fwd_seq<512, 16>(a, s, launched)));
+    upc = 16;
+  }
+  if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  return GT_OK;
+}
+
 // x (N, in_dim) -> y_hat (N, out_dim); stashes X-projections / gates / cell states / layer outputs
 static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];
@@ -1060,7 +1174,9 @@ static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat
     for (int d = 0; d < dirs; ++d)   // Xp[:, d*4H:(d+1)*4H] = X W_ih^T (biases are added in the step kernel)
       CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, e->l_xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
                          4 * H, ACT_NONE, no_drop(), s));
-    CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
+    bool seq = false;
+    CHK(lstm_launch_seq(e, G, l, B, T, false, nullptr, s, &seq));
+    if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
     in = e->l_out[l].as<float>();
     ld_in = dirs * H;
     if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {
@@ -1093,7 +1209,9 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
   for (int l = Lc - 1; l >= 0; --l) {
     const LstmLayerP& L = G.lstm[l];
-    CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));     // dG overwrites l_xproj[l]
+    bool seq = false;
+    CHK(lstm_launch_seq(e, G, l, B, T, true, dout, s, &seq));  // dG overwrites l_xproj[l]
+    if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));
     const float* dG = e->l_xproj[l].as<float>();
     const bool dropped_in = l > 0 && G.training && G.d.dropout > 0.f;
     const float* Xl = l == 0 ? x : (dropped_in ? e->l_outd[l - 1].as<float>() : e->l_out[l - 1].as<float>());
@@ -1326,6 +1444,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   if (!G.bound) return fail(GT_ERR_STATE, "generator not bound");
   if (!x || !y_hat || !y_hat_static) return fail(GT_ERR_INVALID, "null tensor");
   hipStream_t s = (hipStream_t)stream;
+  CHK(fault_seen(e));
   e->step_counter++;
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
@@ -1762,7 +1881,7 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
     CHK(fetch_results(e, s));
   }
   fill_g_result(e->h_res, out);
-  return GT_OK;
+  return fault_seen(e);
 }
 extern "C" int gt_update_generator_result(gt_engine* e, gt_g_result* out) {
   if (!e || !out) return fail(GT_ERR_INVALID, "null argument");

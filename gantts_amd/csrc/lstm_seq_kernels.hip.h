@@ -1,0 +1,343 @@
+// Persistent recurrence kernels of LSTMRNN / GRURNN / In2OutRNNHighwayNet (reference gantts/models.py:170-213:
+// pack_padded_sequence -> nn.LSTM -> pad_packed_sequence) for gfx950: ONE launch walks all T time steps of one
+// layer (both directions, every batch tile) instead of one launch per step (lstm_kernels.hip.h, kept as the
+// fallback for shapes that do not fit and as the A/B reference).
+//
+// Decomposition.  A *group* is one (direction, 16-sequence batch tile): an independent recurrence.  Its gate
+// columns are split over `ncu` workgroups (one per CU).  Every workgroup keeps ITS slice of W_hh in registers for
+// the whole launch (MFMA B operand, v_mfma_f32_16x16x4_f32: M = 16 sequences), keeps the cell state / running
+// dL/dc of its hidden units in registers, and per time step
+//   forward : gathers h_{t-1} of the whole group (16 x H) -> LDS, multiplies by its W_hh slice, applies the gate
+//             non-linearities for its UPC hidden units, stashes gates / c / h, publishes its slice of h_t;
+//   backward: gathers dG_{t+1} (16 x 4H) -> LDS, dh_t = dOut_t + dG_{t+1} . W_hh for its 16 hidden units,
+//             gate derivatives, writes dG_t (over the X-projection storage) and publishes it.
+// The exchange between workgroups uses the placement-independent granule protocol of the CDNA4 guide (G16, R2):
+// the data IS the flag -- 8-byte {value, tag = step + 1} granules written by ONE relaxed agent-scope (sc1,
+// write-through) store and swept with relaxed agent-scope loads until every tag matches; two buffers alternate by
+// step parity (a producer can only be one step ahead of the slowest consumer, because publishing step s+1 needs all
+// of step s).  No assumption on dispatch order or XCD placement; all workgroups must be co-resident (the launcher
+// checks the grid against the device's capacity), every wait is bounded by a wall-clock timeout that raises a
+// fault word instead of hanging the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_f32.hip.h"
+#include "lstm_kernels.hip.h"
+
+namespace gt {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+enum { LSTM_FAULT_TIMEOUT_FWD = 1, LSTM_FAULT_TIMEOUT_BWD = 2 };
+
+struct LstmSeqArgs {
+  int B, T, H, dirs;
+  int nbt;                        // batch tiles of 16 sequences
+  int ncu;                        // workgroups per group
+  const int* lengths;             // [B] device
+  const float* Whh[2];            // (4H, H) row-major, per direction
+  const float* bih[2];
+  const float* bhh[2];
+  float* xproj;                   // [N][dirs*4H]  forward: X W_ih^T (in); backward: dG (out), same storage
+  float* gates;                   // [N][dirs*4H]  post-activation i,f,g,o
+  float* cst;                     // [N][dirs*H]
+  float* out;                     // [N][dirs*H]   h_t (zero beyond the length)
+  const float* dout;              // [N][dirs*H]   upstream gradient (backward)
+  unsigned long long* xch;        // granules: [group][2][16 * KX]  (KX = HP forward, 4*HP backward), zeroed per launch
+  unsigned int* fault;            // device fault word (0 = ok)
+  unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz) a single wait may take
+};
+
+__device__ __forceinline__ unsigned long long xch_load(const unsigned long long* p) {
+  return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xch_store(unsigned long long* p, float v, unsigned tag) {
+  __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned fault_load(const unsigned int* p) {
+  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS image of the MFMA A operand (16 rows x K): element (k, m) lives where ONE ds_read_b128 of lane
+// (m = lane & 15, kq = lane >> 4) returns the operands of four consecutive 16x16x4 MFMAs (k = 16*kb + 4*j + kq).
+__device__ __forceinline__ int a_img_idx(int k, int m) { return (((k >> 4) * 64 + (k & 3) * 16 + m) << 2) + ((k >> 2) & 3); }
+
+// Sweep NG granules per thread (granule g = tid + 256*j <-> k = g / 16, m = g % 16) of `src` until every valid one
+// carries `epoch`; values go to the LDS A image.  kvalid: columns that have a producer.  Returns false on timeout / fault.
+template <int NG>
+__device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int kvalid, float* sA,
+                                             const LstmSeqArgs& a, unsigned fault_code) {
+  const int tid = threadIdx.x;
+  const int m = tid & 15, k0 = tid >> 4;
+  unsigned long long v[NG];
+  unsigned spins = 0;
+  unsigned long long t_start = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int k = k0 + 16 * j;
+      v[j] = xch_load(src + (size_t)(k < kvalid ? k : 0) * 16 + m);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int k = k0 + 16 * j;
+      ok &= (k >= kvalid) || ((unsigned)(v[j] >> 32) == epoch);
+    }
+    if (__all(ok)) break;
+    ++spins;
+    if ((spins & 63u) == 0u) {            // wave-uniform bookkeeping, off the fast path
+      const unsigned long long now = wall_clock64();
+      if (t_start == 0) t_start = now;
+      if (fault_load(a.fault) != 0u) return false;
+      if (now - t_start > a.timeout_ticks) {
+        if ((tid & 63) == 0) atomicCAS(a.fault, 0u, fault_code);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int k = k0 + 16 * j;
+    if (k < kvalid) sA[a_img_idx(k, m)] = __uint_as_float((unsigned)v[j]);
+  }
+  return true;
+}
+
+template <int HP, int UPC> constexpr size_t lstm_fwd_seq_lds() {
+  return (size_t)(HP * 16 + (16 / UPC) * 16 * 4 * UPC) * sizeof(float);     // A image + KS x 16 x NC partials
+}
+template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16) * sizeof(float); }
+
+// ------------------------------------------------------------------------------------------
+// forward.  grid = dirs * nbt * ncu workgroups of 256; workgroup -> (group = bid % ngroups, cu = bid / ngroups);
+// it owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
+// wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
+// ------------------------------------------------------------------------------------------
+template <int HP, int UPC>
+__global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
+  constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP / 16;
+  static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;                       // [HP x 16] permuted
+  float* red = sm + HP * 16;            // [KS][16][NC]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ngroups = a.dirs * a.nbt;
+  const int group = blockIdx.x % ngroups, cu = blockIdx.x / ngroups;
+  const int d = group % a.dirs, bt = group / a.dirs;
+  const int H = a.H, T = a.T, B = a.B;
+  const int u0 = cu * UPC;
+  const int kvalid = a.ncu * UPC;       // hidden units that have a producer (>= H)
+  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+
+  // ---- this wave's W_hh slice -> registers (B operand: lane holds W[k = .. + kq][n = lane & 15])
+  const int tile = wave % NT, kpart = wave / NT;
+  const int n = lane & 15, kq = lane >> 4;
+  float wreg[WR];
+  {
+    const int c = tile * 16 + n, gate = c / UPC, uu = c % UPC;
+    const bool wok = u0 + uu < H;
+    const float* Wrow = a.Whh[d] + (long)(gate * H + min(u0 + uu, H - 1)) * H;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const int k = kpart * KW + 16 * (i >> 2) + 4 * (i & 3) + kq;
+      wreg[i] = (wok && k < H) ? Wrow[min(k, H - 1)] : 0.f;
+    }
+  }
+  // ---- gate stage: thread (sequence gb, unit gu) for tid < 16*UPC
+  const bool gthread = tid < 16 * UPC;
+  const int gb = tid & 15, gu = (tid >> 4) % UPC;
+  const int bg = bt * 16 + gb, bgc = min(bg, B - 1);
+  const int j = u0 + gu, jc = min(j, H - 1);
+  const bool store_ok = gthread && bg < B && j < H;
+  const int len = (gthread && bg < B) ? a.lengths[bgc] : 0;
+  float bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bias[g] = a.bih[d][g * H + jc] + a.bhh[d][g * H + jc];
+  float c_state = 0.f;
+  unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * HP);
+
+  for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // columns without a producer stay zero for good
+  __syncthreads();
+
+  auto row_of = [&](int s) { return (long)bgc * T + (d == 0 ? s : T - 1 - s); };
+  float xin[4];
+  {
+    const long row = row_of(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+  }
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+    if (s > 0) {
+      if (!sweep_to_lds<NG>(xb + (size_t)((s - 1) & 1) * (16 * HP), (unsigned)s, kvalid, sA, a, LSTM_FAULT_TIMEOUT_FWD)) return;
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = sA + (((kpart * (KW / 16)) * 64 + kq * 16 + n) << 2);
+#pragma unroll
+      for (int kb = 0; kb < KW / 16; ++kb) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(kpart * 16 + kq * 4 + r) * NC + tile * 16 + n] = acc[r];   // C: row = kq*4 + r, col = n
+      __syncthreads();
+    }
+    if (gthread) {
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float sum = 0.f;
+        if (s > 0) {
+#pragma unroll
+          for (int kp = 0; kp < KS; ++kp) sum += red[(kp * 16 + gb) * NC + g * UPC + gu];
+        }
+        pre[g] = sum + (xin[g] + bias[g]);
+      }
+      const bool active = t < len && j < H;         // padding units of the last workgroup publish exact zeros
+      float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, h = 0.f;
+      if (active) {
+        ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+        c = fg * c_state + ig * gg;
+        h = og * tanhf(c);
+      }
+      c_state = c;                       // state is held at zero while inactive
+      if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (16 * HP) + (size_t)j * 16 + gb, h, (unsigned)(s + 1));
+      if (store_ok) {
+        const long row = (long)bg * T + t;
+        a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
+        a.gates[row * ld4 + d * 4 * H + 1 * H + j] = fg;
+        a.gates[row * ld4 + d * 4 * H + 2 * H + j] = gg;
+        a.gates[row * ld4 + d * 4 * H + 3 * H + j] = og;
+        a.cst[row * ld1 + d * H + j] = c;
+        a.out[row * ld1 + d * H + j] = h;
+      }
+      if (s + 1 < T) {                   // next step's X-projection: in flight while the group exchanges h_t
+        const long row = row_of(s + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  grid = dirs * nbt * ncu, ncu = ceil(H/16): the workgroup owns 16 hidden units (one MFMA N tile) of
+// dh; K = 4*HP gate columns (k = gate*HP + unit), wave w multiplies gate w's block.  Direction 0 walks
+// t = T-1..0, direction 1 walks t = 0..T-1.  Thread (sequence tid & 15, unit tid >> 4) owns one (b, u) pair.
+// ------------------------------------------------------------------------------------------
+template <int HP>
+__global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
+  constexpr int WR = HP / 4, NGQ = HP / 16;       // per wave: HP rows of K; per gate: HP/16 granules per thread
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;                       // [4*HP x 16] permuted
+  float* red = sm + 4 * HP * 16;        // [4][16][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ngroups = a.dirs * a.nbt;
+  const int group = blockIdx.x % ngroups, cu = blockIdx.x / ngroups;
+  const int d = group % a.dirs, bt = group / a.dirs;
+  const int H = a.H, T = a.T, B = a.B;
+  const int u0 = cu * 16;
+  const int uvalid = a.ncu * 16;        // units that have a producer
+  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
+  const int n = lane & 15, kq = lane >> 4;
+
+  // B operand: W_hh[(gate = wave)*H + k][u0 + n], k = 16*(i>>2) + 4*(i&3) + kq
+  float wreg[WR];
+  {
+    const bool wok = u0 + n < H;
+    const float* Wc = a.Whh[d] + (long)wave * H * H + min(u0 + n, H - 1);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const int k = 16 * (i >> 2) + 4 * (i & 3) + kq;
+      wreg[i] = (wok && k < H) ? Wc[(long)min(k, H - 1) * H] : 0.f;
+    }
+  }
+  const int gb = tid & 15, gu = tid >> 4;
+  const int bg = bt * 16 + gb, bgc = min(bg, B - 1);
+  const int j = u0 + gu, jc = min(j, H - 1);
+  const bool store_ok = bg < B && j < H;
+  const int len = bg < B ? a.lengths[bgc] : 0;
+  float dcs = 0.f;
+  unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * 4 * HP);
+
+  for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
+  __syncthreads();
+
+  // stash of one (b, u, t): requested one step ahead of its use
+  struct Stash { float dout, ig, fg, gg, og, c, cp; };
+  auto load_stash = [&](int s) {
+    Stash z;
+    const int t = d == 0 ? T - 1 - s : s;
+    const long row = (long)bgc * T + t;
+    z.dout = a.dout[row * ld1 + d * H + jc];
+    z.ig = a.gates[row * ld4 + d * 4 * H + 0 * H + jc];
+    z.fg = a.gates[row * ld4 + d * 4 * H + 1 * H + jc];
+    z.gg = a.gates[row * ld4 + d * 4 * H + 2 * H + jc];
+    z.og = a.gates[row * ld4 + d * 4 * H + 3 * H + jc];
+    z.c = a.cst[row * ld1 + d * H + jc];
+    const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);   // clamped; validity checked at use
+    z.cp = a.cst[rowp * ld1 + d * H + jc];
+    return z;
+  };
+  Stash st = load_stash(0);
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    if (s > 0) {
+      const unsigned long long* src = xb + (size_t)((s - 1) & 1) * (16 * 4 * HP);
+#pragma unroll 1
+      for (int g = 0; g < 4; ++g)
+        if (!sweep_to_lds<NGQ>(src + (size_t)g * HP * 16, (unsigned)s, uvalid, sA + g * HP * 16, a, LSTM_FAULT_TIMEOUT_BWD)) return;
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = sA + wave * HP * 16 + ((kq * 16 + n) << 2);
+#pragma unroll
+      for (int kb = 0; kb < HP / 16; ++kb) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + n] = acc[r];
+      __syncthreads();
+    }
+    const bool active = t < len && j < H;
+    float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
+    if (active) {
+      float dh = st.dout;
+      if (s > 0) dh += (red[(0 * 16 + gb) * 16 + gu] + red[(1 * 16 + gb) * 16 + gu]) + (red[(2 * 16 + gb) * 16 + gu] + red[(3 * 16 + gb) * 16 + gu]);
+      float cp = 0.f;                                        // cell state entering this frame
+      if (d == 0) { if (t > 0) cp = st.cp; }
+      else        { if (t + 1 < len) cp = st.cp; }
+      const float tc = tanhf(st.c);
+      const float dc = dcs + dh * st.og * (1.f - tc * tc);
+      dgo = dh * tc * (st.og * (1.f - st.og));
+      dgi = dc * st.gg * (st.ig * (1.f - st.ig));
+      dgf = dc * cp * (st.fg * (1.f - st.fg));
+      dgg = dc * st.ig * (1.f - st.gg * st.gg);
+      dcn = dc * st.fg;
+    }
+    dcs = dcn;
+    if (s + 1 < T && j < HP) {
+      unsigned long long* dst = xb + (size_t)(s & 1) * (16 * 4 * HP) + (size_t)j * 16 + gb;
+      xch_store(dst + (size_t)0 * HP * 16, dgi, (unsigned)(s + 1));
+      xch_store(dst + (size_t)1 * HP * 16, dgf, (unsigned)(s + 1));
+      xch_store(dst + (size_t)2 * HP * 16, dgg, (unsigned)(s + 1));
+      xch_store(dst + (size_t)3 * HP * 16, dgo, (unsigned)(s + 1));
+    }
+    if (store_ok) {
+      const long row = (long)bg * T + t;
+      a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
+      a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
+      a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
+      a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
+    }
+    if (s + 1 < T) st = load_stash(s + 1);
+  }
+}
+
+}  // namespace gt

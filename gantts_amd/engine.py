@@ -130,6 +130,10 @@ class StepEngine(object):
         self._bound_opt[role] = (weakref.ref(optimizer), optimizer._version, now)
         optimizer._engines[id(self)] = (weakref.ref(self), role)
 
+    def check_faults(self):
+        """Synchronises the current stream and raises if a persistent kernel gave up waiting for a peer."""
+        check(lib.gt_check_faults(self._h, L.current_stream()))
+
     def invalidate_mlpg_cache(self):
         check(lib.gt_invalidate_mlpg_cache(self._h))
 
@@ -153,11 +157,13 @@ class StepEngine(object):
         return m
 
     def set_option(self, name, value):
-        """Engine switches (results unchanged up to fp32 summation order): ``"panel_chain"``."""
-        opts = {"panel_chain": L.OPT_PANEL_CHAIN}
+        """Engine switches (results unchanged up to fp32 summation order): ``"panel_chain"``, ``"lstm_persistent"``,
+        ``"lstm_fwd_units"``."""
+        opts = {"panel_chain": L.OPT_PANEL_CHAIN, "lstm_persistent": L.OPT_LSTM_PERSISTENT,
+                "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
-        check(lib.gt_set_option(self._h, opts[name], int(bool(value))))
+        check(lib.gt_set_option(self._h, opts[name], int(value)))
 
     def set_loss_normalizer(self, tv):
         """``tv``: python number, or a 1-element CUDA float64 tensor (kept alive here; read in stream order --

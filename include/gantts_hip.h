@@ -189,7 +189,17 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * GT_OPT_PANEL_CHAIN: run an eligible MLP discriminator (hidden 128/256, >= 2 hidden layers) through the row-panel
  * chain kernels (activations resident in LDS across layers) instead of one GEMM per layer; default off. */
 #define GT_OPT_PANEL_CHAIN 1
+/* GT_OPT_LSTM_PERSISTENT (default 1): recurrent generators (models.py:170-213) run each layer's time loop as ONE
+ * persistent launch (W_hh slices resident in registers, h exchanged between workgroups through tagged granules);
+ * 0 = one launch per time step.  GT_OPT_LSTM_FWD_UNITS: hidden units per workgroup of the forward persistent kernel
+ * (4 or 16; 0 = automatic). */
+#define GT_OPT_LSTM_PERSISTENT 2
+#define GT_OPT_LSTM_FWD_UNITS 3
 int gt_set_option(gt_engine* e, int option, int value);
+/* The persistent recurrence kernels bound every inter-workgroup wait by a wall-clock timeout and raise a device fault
+ * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;
+ * this call synchronises `stream` and reports the current state. */
+int gt_check_faults(gt_engine* e, void* stream);
 int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                   const float* mask, int B, int T, int train, float eps, void* stream);
 int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream);

@@ -193,6 +193,22 @@ ORACLE_ONLY_CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
         update_d=True, update_g=True),
+    # cfg3 (BASELINE.json configs[2]) at its real widths -- BiLSTM 3 x 256 generator, 425 -> 187, conditioned MLP D
+    # 483 -> 256 x 3 -> 1, B = 32 (two 16-sequence batch tiles), variable lengths -- with T cut to what the CPU oracle's
+    # python time loop finishes in seconds: every code path of the persistent recurrence kernels that depends on the
+    # widths (64 workgroups per group, K split over the waves, the 4H-wide backward exchange) is the full-size one
+    "acoustic_lstm_at_size": dict(
+        hp="tts_acoustic", B=32, T=96, din=425, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="LSTMRNN", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256,
+               bidirectional=True, dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     "vc_in2out_rnn_dropout": dict(
         hp="vc", B=3, T=33, din=75, dout=75,
         stream_sizes=[75], has_dynamic_features=[True],
