@@ -26,7 +26,6 @@
 #include "lstm_kernels.hip.h"
 #include "lstm_seq_kernels.hip.h"
 #include "sru_kernels.hip.h"
-#include "chain_kernels.hip.h"
 
 using namespace gt;
 
@@ -333,12 +332,6 @@ struct gt_engine {
   MlpgCache mlpg;
   // workspace
   std::vector<Scratch> g_act, d_act;       // hidden activations
-  std::vector<Scratch> d_dz;               // panel-chain backward: dZ of every hidden layer but the last
-  // GT_OPT_PANEL_CHAIN: opt-in while the chain kernels are not faster than the per-layer GEMMs
-  bool use_chain = getenv("GT_CHAIN") != nullptr;
-  Scratch dW0s;                            // panel-chain forward: aligned, zero-padded copy of W1[:, cd:cd+Da]
-  Scratch dP, dadv;                        // panel-chain forward: shared first-layer part x.W1x^T + b1, adversarial columns
-  bool fake_adv_valid = false; const float* fake_adv_yhs = nullptr;
   Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, dmask, tx, gx, dgx, dtz, dout;
   Scratch scal;                            // StepScalars + StepResults
   StepResults* h_res = nullptr;            // pinned
@@ -366,6 +359,7 @@ struct gt_engine {
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
   bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
   int lstm_fwd_upc = 0;                            // 0 = automatic
+  bool lstm_xcd_local = getenv("GT_LSTM_NO_XCD_LOCAL") == nullptr;   // GT_OPT_LSTM_XCD_LOCAL
   // sequence lengths travel on the step stream through a small ring (pinned host slot -> device slot): the kernels of
   // the previous step, still queued when the next batch's lengths arrive, keep reading THEIR slot
   static constexpr int LEN_RING = 4;
@@ -446,8 +440,6 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& s : e->g_act) s.release();
   for (auto& s : e->d_act) s.release();
-  for (auto& s : e->d_dz) s.release();
-  e->dP.release(); e->dadv.release(); e->dW0s.release();
   for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
   e->i2o_gout.release();
   e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->l_xch.release();
@@ -628,9 +620,9 @@ extern "C" int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, 
 extern "C" int gt_set_option(gt_engine* e, int option, int value) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
   switch (option) {
-    case GT_OPT_PANEL_CHAIN: e->use_chain = value != 0; return GT_OK;
     case GT_OPT_LSTM_PERSISTENT: e->lstm_persistent = value != 0; return GT_OK;
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
+    case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -877,120 +869,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
   return GT_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// discriminator through the row-panel chain kernels (chain_kernels.hip.h)
-// ------------------------------------------------------------------------------------------
 static int cond_dim(gt_engine* e);
-static inline int aligned16(const void* p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
-static bool chain_ok(const Net& n) {
-  if (n.d.arch != GT_ARCH_MLP) return false;
-  const int L = (int)n.hidden.size();
-  if (L < 2 || L > CH_MAXS) return false;
-  const int H = n.hidden[0].out;
-  if (H != 128 && H != 256) return false;
-  for (int l = 0; l < L; ++l) {
-    if (n.hidden[l].out != H) return false;
-    if (l > 0 && n.hidden[l].in != H) return false;
-  }
-  for (int l = 1; l < L; ++l)
-    if (!aligned16(n.hidden[l].W, n.hidden[l].in)) return false;
-  return true;
-}
-
-template <int TN_, bool FWD>
-static int launch_chain_t(const ChainArgs& a, hipStream_t s) {
-  const size_t lds = chain_lds_bytes(a.H, FWD ? a.K0p : 0, FWD);
-  auto kern = FWD ? chain_fwd_kernel<TN_> : chain_bwd_kernel<TN_>;
-  CHK(ensure_dyn_lds((const void*)kern, 160 * 1024 - 512));
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.rows, CH_ROWS)), dim3(CH_THREADS), lds, s, a);
-  LAUNCH_CHECK();
-  return GT_OK;
-}
-static int launch_chain(bool fwd, const ChainArgs& a, hipStream_t s) {
-  if (a.rows <= 0) return GT_OK;
-  if (chain_lds_bytes(a.H, fwd ? a.K0p : 0, fwd) > 160 * 1024 - 512) return fail(GT_ERR_DIM, "panel chain: first-layer depth %d too large", a.K0);
-  switch (a.H) {
-    case 128: return fwd ? launch_chain_t<1, true>(a, s) : launch_chain_t<1, false>(a, s);
-    case 256: return fwd ? launch_chain_t<2, true>(a, s) : launch_chain_t<2, false>(a, s);
-  }
-  return fail(GT_ERR_DIM, "panel chain: unsupported hidden width %d", a.H);
-}
-// D forward: hidden stack over `rows` rows whose adversarial columns are adv (rows x Da, pitch lda); the
-// conditioning part of layer 0 (x . W1[:, :cd]^T + b1, n_x rows) is computed once and shared by all
-// rows r with the same r % n_x (the real and the fake half of the D step see the same x, train.py:254-256).
-static int d_forward_chain(gt_engine* e, const float* x, long n_x, const float* adv, int lda, long rows, const int* passes,
-                           int npass, long rows_each, hipStream_t s) {
-  Net& D = e->net[GT_ROLE_D];
-  const int L = (int)D.hidden.size(), H = D.hidden[0].out, cd = cond_dim(e);
-  e->d_specs.resize(L);
-  for (int l = 0; l < L; ++l) {
-    CHK(e->d_act[l].ensure((size_t)rows * H * sizeof(float)));
-    const float* inj = nullptr;
-    CHK(stage_injected(e, GT_ROLE_D, l, passes, npass, rows_each, H, &inj, s));
-    e->d_specs[l] = drop_spec(e, GT_ROLE_D, passes[0], l, inj, H);
-  }
-  ChainArgs a;
-  memset(&a, 0, sizeof(a));
-  a.rows = rows; a.H = H; a.K0 = e->Da; a.A0 = adv; a.lda0 = lda; a.n_stages = L;
-  if (cd > 0) {
-    if (!x) return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
-    CHK(e->dP.ensure((size_t)n_x * H * sizeof(float)));
-    CHK(linear_forward(x, cd, D.hidden[0].W, D.hidden[0].in, D.hidden[0].b, e->dP.as<float>(), H, n_x, cd, H, ACT_NONE, no_drop(), s));
-    a.P = e->dP.as<float>(); a.ldp = H; a.p_mod = n_x;
-  }
-  // stage-0 weights: the adversarial slice W1[:, cd:cd+Da] (row pitch in_dim, unaligned in general) as an
-  // aligned H x K0p image, zero beyond Da (the padding is written once, the slice every call: W changes)
-  const int K0p = chain_k0p(e->Da);
-  a.K0p = K0p;
-  {
-    const void* before = e->dW0s.p;
-    CHK(e->dW0s.ensure((size_t)H * K0p * sizeof(float)));
-    if (e->dW0s.p != before) HIPCHK(hipMemsetAsync(e->dW0s.p, 0, (size_t)H * K0p * sizeof(float), s));
-    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv((long)H * e->Da, 256)), dim3(256), 0, s, D.hidden[0].W, D.hidden[0].in, cd,
-                       (const int*)nullptr, e->dW0s.as<float>(), K0p, 0, H, e->Da);
-    LAUNCH_CHECK();
-  }
-  if ((long)n_x * H >= (1L << 31)) return fail(GT_ERR_DIM, "panel chain: conditioning batch too large");
-  for (int l = 0; l < L; ++l) {
-    ChainStage& S = a.st[l];
-    const Lin& Ld = D.hidden[l];
-    S.W = l == 0 ? e->dW0s.as<float>() : Ld.W; S.ldw = l == 0 ? K0p : Ld.in; S.bias = Ld.b;
-    S.out = e->d_act[l].as<float>(); S.ldo = H;
-    S.act = ACT_LEAKY_DROPOUT; S.drop = e->d_specs[l];
-  }
-  return launch_chain(true, a, s);
-}
-
-// D backward-data: dz_in = dZ of the last hidden layer (rows x H) -> dZ of layers L-2 .. 0 into e->d_dz[l];
-// store_all = false keeps only dZ_0 (the G step computes no weight gradients).
-static int d_backward_chain(gt_engine* e, const float* dz_in, long rows, bool store_all, hipStream_t s) {
-  Net& D = e->net[GT_ROLE_D];
-  const int L = (int)D.hidden.size(), H = D.hidden[0].out;
-  e->d_dz.resize(L - 1);
-  ChainArgs a;
-  memset(&a, 0, sizeof(a));
-  a.rows = rows; a.H = H; a.A0 = dz_in; a.lda0 = H; a.n_stages = L - 1;
-  for (int st = 0; st < L - 1; ++st) {
-    const int l = L - 1 - st;                       // consumes dZ_l, produces dZ_{l-1}
-    ChainStage& S = a.st[st];
-    S.W = D.hidden[l].W; S.ldw = D.hidden[l].in;
-    S.Hact = e->d_act[l - 1].as<float>(); S.ldh = H;
-    S.act = ACT_LEAKY_DROPOUT; S.drop = e->d_specs[l - 1];
-    if (store_all || l - 1 == 0) {
-      CHK(e->d_dz[l - 1].ensure((size_t)rows * H * sizeof(float)));
-      S.out = e->d_dz[l - 1].as<float>(); S.ldo = H;
-    }
-  }
-  return launch_chain(false, a, s);
-}
-
-// adversarial columns of `feats` -> rows [row0, row0 + N) of e->dadv (pitch lda)
-static int build_adv(gt_engine* e, const float* feats, int ld_feats, long row0, long N, int lda, hipStream_t s) {
-  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * e->Da, 256)), dim3(256), 0, s, feats, ld_feats, 0, e->d_adv_cols,
-                     e->dadv.as<float>() + row0 * lda, lda, 0, (int)N, e->Da);
-  LAUNCH_CHECK();
-  return GT_OK;
-}
 
 // tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask)
 static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
@@ -1072,45 +951,42 @@ extern "C" int gt_check_faults(gt_engine* e, void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return fault_seen(e);
 }
-template <typename K>
-static int seq_capacity(K kern, size_t lds, int* out) {
-  // co-resident workgroups: all of them spin on each other, so the grid must fit the device at once.  The occupancy
-  // API may over-report by one block per CU (MI355X_MICROARCH.md, residency): keep that margin above one per CU.
-  int dev = 0, per_cu = 0;
+// Co-resident workgroups per XCD: all workgroups of a launch spin on each other, so the whole grid must be resident
+// at once.  The occupancy API may over-report by one block per CU (MI355X_MICROARCH.md, residency): keep that margin
+// above one per CU.  The grid is laid out per XCD (seq_group_of), so the bound is per XCD as well.
+static int seq_xcds(int* nxcd, int* cus_per_xcd) {
+  int dev = 0;
   HIPCHK(hipGetDevice(&dev));
-  hipDeviceProp_t prop;
   static std::map<int, int> cus;
-  if (!cus.count(dev)) { HIPCHK(hipGetDeviceProperties(&prop, dev)); cus[dev] = prop.multiProcessorCount; }
+  if (!cus.count(dev)) { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, dev)); cus[dev] = prop.multiProcessorCount; }
+  *nxcd = cus[dev] % 8 == 0 && cus[dev] >= 64 ? 8 : 1;      // MI355X: 8 XCDs x 32 CUs
+  *cus_per_xcd = cus[dev] / *nxcd;
+  return GT_OK;
+}
+template <typename K>
+static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* launched) {
+  CHK(ensure_dyn_lds((const void*)kern, lds));
+  int per_cu = 0, nxcd = 1, cpx = 1;
+  CHK(seq_xcds(&nxcd, &cpx));
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
   if (per_cu > 1) per_cu -= 1;
-  *out = cus[dev] * std::min(per_cu, 4);
+  per_cu = std::min(per_cu, 4);
+  const int ngroups = a.dirs * a.nbt;
+  const int rounds = cdiv(ngroups, nxcd);                   // groups that share one XCD
+  if ((long)a.ncu * rounds > (long)cpx * per_cu) { *launched = false; return GT_OK; }
+  a.nxcd = nxcd;
+  hipLaunchKernelGGL(kern, dim3(nxcd * a.ncu * rounds), dim3(256), lds, s, a);
+  LAUNCH_CHECK();
+  *launched = true;
   return GT_OK;
 }
 template <int HP, int UPC>
-static int launch_fwd_seq(const LstmSeqArgs& a, hipStream_t s, bool* launched) {
-  const size_t lds = lstm_fwd_seq_lds<HP, UPC>();
-  CHK(ensure_dyn_lds((const void*)lstm_fwd_seq_kernel<HP, UPC>, lds));
-  int cap = 0;
-  CHK(seq_capacity(lstm_fwd_seq_kernel<HP, UPC>, lds, &cap));
-  const int grid = a.dirs * a.nbt * a.ncu;
-  if (grid > cap) { *launched = false; return GT_OK; }
-  hipLaunchKernelGGL((lstm_fwd_seq_kernel<HP, UPC>), dim3(grid), dim3(256), lds, s, a);
-  LAUNCH_CHECK();
-  *launched = true;
-  return GT_OK;
+static int launch_fwd_seq(LstmSeqArgs& a, hipStream_t s, bool* launched) {
+  return launch_seq(lstm_fwd_seq_kernel<HP, UPC>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
 }
 template <int HP>
-static int launch_bwd_seq(const LstmSeqArgs& a, hipStream_t s, bool* launched) {
-  const size_t lds = lstm_bwd_seq_lds<HP>();
-  CHK(ensure_dyn_lds((const void*)lstm_bwd_seq_kernel<HP>, lds));
-  int cap = 0;
-  CHK(seq_capacity(lstm_bwd_seq_kernel<HP>, lds, &cap));
-  const int grid = a.dirs * a.nbt * a.ncu;
-  if (grid > cap) { *launched = false; return GT_OK; }
-  hipLaunchKernelGGL((lstm_bwd_seq_kernel<HP>), dim3(grid), dim3(256), lds, s, a);
-  LAUNCH_CHECK();
-  *launched = true;
-  return GT_OK;
+static int launch_bwd_seq(LstmSeqArgs& a, hipStream_t s, bool* launched) {
+  return launch_seq(lstm_bwd_seq_kernel<HP>, lstm_bwd_seq_lds<HP>(), a, s, launched);
 }
 
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
@@ -1134,10 +1010,12 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.fault = e->d_fault;
   a.timeout_ticks = 200000000ULL;          // 2 s at 100 MHz: far beyond any real wait, far below the watchdog
   const int ngroups = dirs * a.nbt;
-  const size_t xch_bytes = (size_t)ngroups * 2 * 16 * (backward ? 4 : 1) * HP * sizeof(unsigned long long);
-  CHK(e->l_xch.ensure(xch_bytes));
-  HIPCHK(hipMemsetAsync(e->l_xch.p, 0, xch_bytes, s));       // tags of a previous launch must not be mistaken for this one's
+  const size_t xch_n = (size_t)ngroups * 2 * 16 * (backward ? 4 : 1) * HP, chk_n = (size_t)ngroups * 256;
+  CHK(e->l_xch.ensure((xch_n + chk_n) * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(e->l_xch.p, 0, (xch_n + chk_n) * sizeof(unsigned long long), s));   // no tag of an earlier launch survives
   a.xch = e->l_xch.as<unsigned long long>();
+  a.xcc_chk = a.xch + xch_n;              // [group][ncu <= 256]  (the kernels index it with ncu as the pitch)
+  a.allow_xcd_local = e->lstm_xcd_local ? 1 : 0;
   if (backward) {
     a.ncu = cdiv(H, 16);
     CHK(HP == 256 ? launch_bwd_seq<256>(a, s, launched) : launch_bwd_seq<512>(a, s, launched));
@@ -1146,12 +1024,12 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   }
   // forward: as many workgroups per group as fit (4 hidden units each), else 16 per workgroup
   int upc = e->lstm_fwd_upc;
-  if (upc != 4 && upc != 16) upc = 4;
-  for (int attempt = 0; attempt < 2 && !*launched; ++attempt) {
+  if (upc != 4 && upc != 8 && upc != 16) upc = 8;
+  for (; upc <= 16 && !*launched; upc *= 2) {
     a.ncu = cdiv(H, upc);
-    if (upc == 4) CHK(HP == 256 ? (launch_fwd_seq<256, 4>(a, s, launched)) : (launch_fwd_seq<512, 4>(a, s, launched)));
-    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, s, launched)) : (launch_fwd_seq<512, 16>(a, s, launched)));
-    upc = 16;
+    if (upc == 4)      CHK(HP == 256 ? (launch_fwd_seq<256, 4>(a, s, launched)) : (launch_fwd_seq<512, 4>(a, s, launched)));
+    else if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, s, launched)) : (launch_fwd_seq<512, 8>(a, s, launched)));
+    else               CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, s, launched)) : (launch_fwd_seq<512, 16>(a, s, launched)));
   }
   if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   return GT_OK;
@@ -1567,30 +1445,20 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const long N = (long)B * T;
   const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
   CHK(ensure_tv(e, mask, N, s));
-  const bool chain = e->use_chain && chain_ok(D);
   const bool tr = train != 0;
-  const int lda = (e->Da + 3) & ~3;
   const int passes[2] = {0, 1};
-  if (chain) {
-    CHK(e->dadv.ensure((size_t)2 * N * lda * sizeof(float)));
-    CHK(build_adv(e, y_static, e->Ds, 0, N, lda, s));
-    CHK(build_adv(e, y_hat_static, e->Ds, N, N, lda, s));
-    e->fake_adv_valid = true; e->fake_adv_yhs = y_hat_static;
-    CHK(d_forward_chain(e, x, N, e->dadv.as<float>(), lda, 2 * N, passes, 2, N, s));
+  // the [x | adv] image of both halves: real rows, then generated rows
+  CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+  if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
+    hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
+                       e->d_adv_cols, e->Da, e->dcat.as<float>(), ldc, N);
+    LAUNCH_CHECK();
+  } else {
+    CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
+    CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
-  if (!chain || tr) {     // the [x | adv] image: A operand of the unfused path, B operand of dW_0 (train)
-    CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
-    if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
-      hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
-                         e->d_adv_cols, e->Da, e->dcat.as<float>(), ldc, N);
-      LAUNCH_CHECK();
-    } else {
-      CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
-      CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
-    }
-    e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-  }
-  if (!chain) CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+  CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
   const int H = D.d.hidden_dim;
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
@@ -1611,22 +1479,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     float* leak = nullptr;
     if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
     const int col0 = cond_dim(e);
-    if (chain) {
-      const int L = (int)D.hidden.size();
-      CHK(d_backward_chain(e, e->dzA.as<float>(), 2 * N, true, s));
-      for (int l = L - 1; l >= 0; --l) {
-        const Lin& Ld = D.hidden[l];
-        const float* dZ = l == L - 1 ? e->dzA.as<float>() : e->d_dz[l].as<float>();
-        const float* Xin = l > 0 ? e->d_act[l - 1].as<float>() : e->dcat.as<float>();
-        CHK(linear_backward_weight(dZ, H, Xin, l > 0 ? H : ldc, 2 * N, Ld.out, Ld.in, Ld.dW, Ld.db, D.grads_dirty, e->slabs, e->colp, s));
-      }
-      if (leak)
-        CHK(linear_backward_data(e->d_dz[0].as<float>() + N * H, H, D.hidden[0].W, D.hidden[0].in, col0, leak, e->Da, N, H, e->Da,
-                                 ACT_NONE, nullptr, 0, no_drop(), s));
-    } else {
-      CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
-                         e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
-    }
+    CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
+                       e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
     D.grads_dirty = true;
     if (want_leak) e->leak_pending = true;
   }
@@ -1783,26 +1637,14 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (!D.bound) return fail(GT_ERR_STATE, "adv_w > 0 but no discriminator bound");
     if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
     const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
-    const bool chain = e->use_chain && chain_ok(D);
-    const int lda = (e->Da + 3) & ~3;
     const int passes[1] = {2};
-    const float* cat = nullptr;
-    if (chain) {
-      CHK(e->dadv.ensure((size_t)2 * N * lda * sizeof(float)));
-      if (!(e->fake_adv_valid && e->fake_adv_yhs == y_hat_static)) {
-        CHK(build_adv(e, y_hat_static, Ds, N, N, lda, s));
-        e->fake_adv_valid = true; e->fake_adv_yhs = y_hat_static;
-      }
-      CHK(d_forward_chain(e, x, N, e->dadv.as<float>() + N * lda, lda, N, passes, 1, N, s));
-    } else {
-      CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
-      if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
-        CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
-        e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-      }
-      cat = e->dcat.as<float>() + N * ldc;
-      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+    if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
+      CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
+      e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
     }
+    const float* cat = e->dcat.as<float>() + N * ldc;
+    CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
@@ -1812,14 +1654,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
       const int col0 = cond_dim(e);
-      if (chain) {
-        CHK(d_backward_chain(e, e->dzA.as<float>(), N, false, s));
-        CHK(linear_backward_data(e->d_dz[0].as<float>(), H, D.hidden[0].W, D.hidden[0].in, col0, gadv, e->Da, N, H, e->Da, ACT_NONE,
-                                 nullptr, 0, no_drop(), s));
-      } else {
-        CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
-                           e->Da, col0, e->Da, 0, N, s));
-      }
+      CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
+                         e->Da, col0, e->Da, 0, N, s));
     }
   }
   // MGE loss + gradient assembly at y_hat_static

@@ -105,7 +105,39 @@ struct GemmArgs {
   long slab_stride;
   float* colsum_slab;        // TN: per-slab column sums of A (bias gradient), [nslab][M], or null
   int n_tiles_m, n_tiles_n;
+  // Start stagger (launcher-set; 0 = off).  The two workgroups that share a CU share its matrix pipes: started together
+  // they also reach their load prologues and their store epilogues together, and the pipes idle through both.  One
+  // of the two ("late") waits `stagger_cycles` before it starts -- the other one has the pipes to itself meanwhile,
+  // so no matrix time is lost -- and from then on one workgroup's prologue / epilogue runs under the other's K loop.
+  int stagger_cycles;
+  int stagger_mode;          // who is late: 1 = upper half of the grid, 2 = odd wave slot (HW_ID), 3 = second ticket of its CU
+  unsigned int* stagger_ticket;   // mode 3: zeroed [2048] counters, key = (XCC_ID, SE_ID, SH_ID, CU_ID)
 };
+
+// HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), all 32 bits: s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id
+__device__ __forceinline__ unsigned hw_id_reg() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }
+__device__ __forceinline__ unsigned xcc_id_reg() { return __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+__device__ __forceinline__ unsigned cu_key() {   // CU_ID [11:8], SH_ID [12], SE_ID [15:13] of HW_ID + XCC_ID [3:0]
+  const unsigned h = hw_id_reg();
+  return ((xcc_id_reg() & 0xfu) << 7) | (((h >> 13) & 0x7u) << 5) | (((h >> 12) & 0x1u) << 4) | ((h >> 8) & 0xfu);
+}
+__device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* smem) {
+  if (g.stagger_cycles <= 0) return;
+  bool late = false;
+  if (g.stagger_mode == 1) late = blockIdx.x >= (gridDim.x + 1) / 2;
+  else if (g.stagger_mode == 2) late = (hw_id_reg() & 1u) != 0u;
+  else if (g.stagger_mode == 3) {
+    unsigned* sh = reinterpret_cast<unsigned*>(smem);
+    if (threadIdx.x == 0) sh[0] = atomicAdd(g.stagger_ticket + cu_key(), 1u);
+    __syncthreads();
+    late = (sh[0] & 1u) != 0u;
+    __syncthreads();
+  }
+  if (late) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < (long long)g.stagger_cycles) __builtin_amdgcn_s_sleep(16);
+  }
+}
 
 // LDS pitches per orientation (floats)
 template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
@@ -127,6 +159,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BK][LDM]
   float* Bs = smem + 2 * GEMM_BK * LDM;      // [2][BK][LDN]
+  gemm_start_stagger(g, smem);
 
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
   // XCD a contiguous run of tiles (neighbouring tiles share the weight panel in that XCD's L2).

@@ -13,11 +13,18 @@
 //             gate derivatives, writes dG_t (over the X-projection storage) and publishes it.
 // The exchange between workgroups uses the placement-independent granule protocol of the CDNA4 guide (G16, R2):
 // the data IS the flag -- 8-byte {value, tag = step + 1} granules written by ONE relaxed agent-scope (sc1,
-// write-through) store and swept with relaxed agent-scope loads until every tag matches; two buffers alternate by
-// step parity (a producer can only be one step ahead of the slowest consumer, because publishing step s+1 needs all
-// of step s).  No assumption on dispatch order or XCD placement; all workgroups must be co-resident (the launcher
-// checks the grid against the device's capacity), every wait is bounded by a wall-clock timeout that raises a
-// fault word instead of hanging the GPU.
+// write-through) store and swept with relaxed agent-scope loads (L1 bypass) until every tag matches; two buffers
+// alternate by step parity (a producer can only be one step ahead of the slowest consumer, because publishing step
+// s+1 needs all of step s).  All workgroups must be co-resident (the launcher checks the grid against the device's
+// capacity); every wait is bounded by a wall-clock timeout that raises a fault word instead of hanging the GPU.
+//
+// XCD-local fast path.  The write-through hand-off costs ~3 us per step (store to the fabric, reload from it).  The
+// workgroup -> group map therefore puts the workgroups of one group on ONE XCD under the observed dispatch rule
+// (workgroup b runs on XCD b % 8), and at kernel start every group CHECKS it: each workgroup publishes its XCC_ID
+// through the placement-independent protocol, all members read all ids.  Only if they agree does the group switch
+// its stores to workgroup-scope ones (sc0: the line stays in that XCD's L2, which is the coherence point of all its
+// CUs; the sweeps keep bypassing L1), a hand-off at L2-hit latency.  A group that is NOT co-located keeps the
+// agent-scope protocol: placement changes speed, never results.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,6 +52,10 @@ struct LstmSeqArgs {
   float* out;                     // [N][dirs*H]   h_t (zero beyond the length)
   const float* dout;              // [N][dirs*H]   upstream gradient (backward)
   unsigned long long* xch;        // granules: [group][2][16 * KX]  (KX = HP forward, 4*HP backward), zeroed per launch
+  unsigned long long* xcc_chk;    // co-location check: [group][256] granules {XCC_ID, tag 1}, zeroed per launch (ncu <= 256)
+  int nxcd;                       // XCDs the launcher spread the groups over (grid = nxcd * ncu * ceil(ngroups / nxcd))
+  int allow_xcd_local;            // 0: always the agent-scope protocol
+  unsigned int* dbg_protocol;     // optional [ngroups]: 1 = the group ran XCD-local, 2 = agent scope
   unsigned int* fault;            // device fault word (0 = ok)
   unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz) a single wait may take
 };
@@ -52,10 +63,12 @@ struct LstmSeqArgs {
 __device__ __forceinline__ unsigned long long xch_load(const unsigned long long* p) {
   return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void xch_store(unsigned long long* p, float v, unsigned tag) {
-  __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void xch_store(unsigned long long* p, float v, unsigned tag, bool xcd_local) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if (xcd_local) __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else           __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned xcc_id_of_wave() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu; }   // HW_REG_XCC_ID
 __device__ __forceinline__ unsigned fault_load(const unsigned int* p) {
   return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -107,14 +120,57 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
   return true;
 }
 
+// workgroup -> (group, cu): the workgroups of one group share bid % nxcd (one XCD under the observed dispatch rule)
+__device__ __forceinline__ bool seq_group_of(const LstmSeqArgs& a, int* group, int* cu) {
+  const int xs = blockIdx.x % a.nxcd, idx = blockIdx.x / a.nxcd;
+  *group = xs + a.nxcd * (idx / a.ncu);
+  *cu = idx % a.ncu;
+  return *group < a.dirs * a.nbt;
+}
+// true iff every workgroup of this group runs on the same XCD (decided identically by all of them)
+__device__ __forceinline__ bool seq_colocated(const LstmSeqArgs& a, int group, int cu, float* scratch, unsigned fault_code, bool* ok) {
+  *ok = true;
+  if (!a.allow_xcd_local) return false;
+  unsigned long long* chk = a.xcc_chk + (size_t)group * 256;
+  const unsigned mine = xcc_id_of_wave();
+  if (threadIdx.x == 0) xch_store(chk + cu, __uint_as_float(mine), 1u, false);
+  int* flag = reinterpret_cast<int*>(scratch);
+  if (threadIdx.x < 64) {
+    bool same = true;
+    unsigned spins = 0;
+    unsigned long long t_start = 0;
+    for (int i = threadIdx.x; i < a.ncu; i += 64) {
+      unsigned long long v;
+      for (;;) {
+        v = xch_load(chk + i);
+        if ((unsigned)(v >> 32) == 1u) break;
+        if ((++spins & 63u) == 0u) {
+          const unsigned long long now = wall_clock64();
+          if (t_start == 0) t_start = now;
+          if (fault_load(a.fault) != 0u || now - t_start > a.timeout_ticks) { atomicCAS(a.fault, 0u, fault_code); *ok = false; break; }
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!*ok) break;
+      same &= (unsigned)v == mine;
+    }
+    const bool all_same = __all(same && *ok);
+    if (threadIdx.x == 0) flag[0] = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  const bool r = flag[0] != 0;
+  __syncthreads();
+  return r;
+}
+
 template <int HP, int UPC> constexpr size_t lstm_fwd_seq_lds() {
   return (size_t)(HP * 16 + (16 / UPC) * 16 * 4 * UPC) * sizeof(float);     // A image + KS x 16 x NC partials
 }
 template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16) * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------
-// forward.  grid = dirs * nbt * ncu workgroups of 256; workgroup -> (group = bid % ngroups, cu = bid / ngroups);
-// it owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
+// forward.  grid = nxcd * ncu * ceil(ngroups / nxcd) workgroups of 256 (seq_group_of); the workgroup
+// owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
 // wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
 // ------------------------------------------------------------------------------------------
 template <int HP, int UPC>
@@ -125,8 +181,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   float* sA = sm;                       // [HP x 16] permuted
   float* red = sm + HP * 16;            // [KS][16][NC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ngroups = a.dirs * a.nbt;
-  const int group = blockIdx.x % ngroups, cu = blockIdx.x / ngroups;
+  int group, cu;
+  if (!seq_group_of(a, &group, &cu)) return;
   const int d = group % a.dirs, bt = group / a.dirs;
   const int H = a.H, T = a.T, B = a.B;
   const int u0 = cu * UPC;
@@ -160,6 +216,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   float c_state = 0.f;
   unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * HP);
 
+  bool chk_ok;
+  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_FWD, &chk_ok);
+  if (fault_load(a.fault) != 0u) return;
+  if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
   for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // columns without a producer stay zero for good
   __syncthreads();
 
@@ -206,7 +266,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
         h = og * tanhf(c);
       }
       c_state = c;                       // state is held at zero while inactive
-      if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (16 * HP) + (size_t)j * 16 + gb, h, (unsigned)(s + 1));
+      if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (16 * HP) + (size_t)j * 16 + gb, h, (unsigned)(s + 1), xcd_local);
       if (store_ok) {
         const long row = (long)bg * T + t;
         a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
@@ -237,8 +297,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   float* sA = sm;                       // [4*HP x 16] permuted
   float* red = sm + 4 * HP * 16;        // [4][16][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ngroups = a.dirs * a.nbt;
-  const int group = blockIdx.x % ngroups, cu = blockIdx.x / ngroups;
+  int group, cu;
+  if (!seq_group_of(a, &group, &cu)) return;
   const int d = group % a.dirs, bt = group / a.dirs;
   const int H = a.H, T = a.T, B = a.B;
   const int u0 = cu * 16;
@@ -265,6 +325,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   float dcs = 0.f;
   unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * 4 * HP);
 
+  bool chk_ok;
+  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_BWD, &chk_ok);
+  if (fault_load(a.fault) != 0u) return;
+  if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
   for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
   __syncthreads();
 
@@ -324,10 +388,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
     dcs = dcn;
     if (s + 1 < T && j < HP) {
       unsigned long long* dst = xb + (size_t)(s & 1) * (16 * 4 * HP) + (size_t)j * 16 + gb;
-      xch_store(dst + (size_t)0 * HP * 16, dgi, (unsigned)(s + 1));
-      xch_store(dst + (size_t)1 * HP * 16, dgf, (unsigned)(s + 1));
-      xch_store(dst + (size_t)2 * HP * 16, dgg, (unsigned)(s + 1));
-      xch_store(dst + (size_t)3 * HP * 16, dgo, (unsigned)(s + 1));
+      xch_store(dst + (size_t)0 * HP * 16, dgi, (unsigned)(s + 1), xcd_local);
+      xch_store(dst + (size_t)1 * HP * 16, dgf, (unsigned)(s + 1), xcd_local);
+      xch_store(dst + (size_t)2 * HP * 16, dgg, (unsigned)(s + 1), xcd_local);
+      xch_store(dst + (size_t)3 * HP * 16, dgo, (unsigned)(s + 1), xcd_local);
     }
     if (store_ok) {
       const long row = (long)bg * T + t;

@@ -157,10 +157,10 @@ class StepEngine(object):
         return m
 
     def set_option(self, name, value):
-        """Engine switches (results unchanged up to fp32 summation order): ``"panel_chain"``, ``"lstm_persistent"``,
-        ``"lstm_fwd_units"``."""
-        opts = {"panel_chain": L.OPT_PANEL_CHAIN, "lstm_persistent": L.OPT_LSTM_PERSISTENT,
-                "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS}
+        """Engine switches (results unchanged up to fp32 summation order): ``"lstm_persistent"``,
+        ``"lstm_fwd_units"``, ``"lstm_xcd_local"``."""
+        opts = {"lstm_persistent": L.OPT_LSTM_PERSISTENT,
+                "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

@@ -185,16 +185,16 @@ int gt_set_loss_normalizer(gt_engine* e, float tv_global);
 /* same, from a device double the caller keeps alive (e.g. the all-reduced sum(mask)): no host round trip; the
  * value is read by the next step functions in stream order.  NULL returns to the local / host normaliser. */
 int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
-/* engine switches that do not change results beyond fp32 summation order.
- * GT_OPT_PANEL_CHAIN: run an eligible MLP discriminator (hidden 128/256, >= 2 hidden layers) through the row-panel
- * chain kernels (activations resident in LDS across layers) instead of one GEMM per layer; default off. */
-#define GT_OPT_PANEL_CHAIN 1
+/* engine switches that do not change results beyond fp32 summation order. */
 /* GT_OPT_LSTM_PERSISTENT (default 1): recurrent generators (models.py:170-213) run each layer's time loop as ONE
  * persistent launch (W_hh slices resident in registers, h exchanged between workgroups through tagged granules);
  * 0 = one launch per time step.  GT_OPT_LSTM_FWD_UNITS: hidden units per workgroup of the forward persistent kernel
- * (4 or 16; 0 = automatic). */
+ * (4, 8 or 16; 0 = automatic). */
 #define GT_OPT_LSTM_PERSISTENT 2
 #define GT_OPT_LSTM_FWD_UNITS 3
+/* GT_OPT_LSTM_XCD_LOCAL (default 1): a group of workgroups that verifies at kernel start that it runs on ONE XCD
+ * exchanges through that XCD's L2 (workgroup-scope stores) instead of write-through stores; 0 = always write-through. */
+#define GT_OPT_LSTM_XCD_LOCAL 4
 int gt_set_option(gt_engine* e, int option, int value);
 /* The persistent recurrence kernels bound every inter-workgroup wait by a wall-clock timeout and raise a device fault
  * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;

@@ -483,10 +483,10 @@ def clip_grad_norm_(params, max_norm=1.0):
 
 
 class OracleAdagrad(object):
-    def __init__(self, params, lr=0.01, lr_decay=0.0, weight_decay=0.0, eps=1e-10):
+    def __init__(self, params, lr=0.01, lr_decay=0.0, weight_decay=0.0, eps=1e-10, initial_accumulator_value=0.0):
         self.params = list(params)
         self.lr, self.lr_decay, self.wd, self.eps = lr, lr_decay, weight_decay, eps
-        self.sum = [torch.zeros_like(p) for p in self.params]
+        self.sum = [torch.full_like(p, float(initial_accumulator_value)) for p in self.params]     # torch.optim.Adagrad
         self.step_count = 0
 
     def zero_grad(self):

@@ -82,7 +82,7 @@ CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=0)),
         windows=3, steps=3, adv_w=1.0, mse_w=1.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
-    # discriminator wide enough (hidden 128, 3 layers) for the row-panel chain kernels: injected dropout masks,
+    # wider discriminator (hidden 128, 3 layers; fixture name kept from round 1): injected dropout masks,
     # conditioned D, ragged panel tail (2*B*T = 138 rows), real/fake halves sharing the x part of layer 0
     "acoustic_chain_d": dict(
         hp="tts_acoustic", B=3, T=23, din=30, dout=187,
@@ -205,9 +205,11 @@ ORACLE_ONLY_CASES = {
                bidirectional=True, dropout=0.0, last_sigmoid=False),
         d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256,
                dropout=0.0, last_sigmoid=True),
-        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
-        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
-        windows=3, steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        # warm accumulators (as after some training): the first step of a COLD Adagrad is lr * g / (|g| + 1e-10), which
+        # turns the relative rounding error of every near-zero gradient entry into an absolute parameter error
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
     "vc_in2out_rnn_dropout": dict(
         hp="vc", B=3, T=33, din=75, dout=75,

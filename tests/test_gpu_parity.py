@@ -439,16 +439,16 @@ def test_full_size_cfg2_step_vs_oracle_and_determinism():
             assert np.abs(gref[bad]).max() < 1e-3 * np.abs(gref).max(), "mismatch on a well-conditioned gradient"
 
 
-@pytest.mark.parametrize("tag,B,Tn,gh,dh,chain", [("cfg2-full-size", 32, 512, 512, 256, False),
-                                                   ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250, False),
-                                                   ("panel-chain", 4, 200, 256, 128, True)])
-def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh, chain):
+@pytest.mark.parametrize("tag,B,Tn,gh,dh", [("cfg2-full-size", 32, 512, 512, 256),
+                                             ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250),
+                                             ("64-row-tiles", 4, 200, 256, 128)])
+def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh):
     """The path bench.py times: dropout 0.5 ON through the engine's own Philox stream (no injected masks on the HIP
     side).  The keep masks the engine is about to use are dumped through gt_op_philox_mask -- the layout-independent
     definition philox_keep(row, col) -- and handed to the CPU oracle as its nn.Dropout masks (the oracle is pinned to
     the reference with masks injected the same way, tests/golden/make_golden.py); the whole step must then agree:
     forward epilogues AND the keep bits every backward kernel regenerates (wide 16-byte and narrow epilogues, 64 / 128
-    column tiles, partial tiles, 2N-row discriminator pass, fused head, panel-chain kernels).  Two steps, Adagrad with a
+    row and column tiles, partial tiles, 2N-row discriminator pass, fused head).  Two steps, Adagrad with a
     warm accumulator (1e-4: as after some training, where the update is smooth in g) so that parameters compare tightly.
     Reference semantics: gantts/models.py:132-139, train.py:245-320."""
     import types
@@ -475,7 +475,6 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
     od = optim.Adagrad(md.parameters(), initial_accumulator_value=acc0, **okw)
     eng = engine_for(hp, mg)
     eng.set_seed(1234)
-    eng.set_option("panel_chain", chain)
     x, y, R = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda(), torch.from_numpy(R_np).cuda()
     ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
     mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
@@ -806,25 +805,6 @@ def test_inference_path_matches_reference_golden():
     _close(diff, gold["vc_diff"], rtol=1e-4, atol=1e-5, msg="vc_diff")
     with pytest.raises(NotImplementedError):
         INF.gen_parameters(gold["acoustic_predicted.mlp"], Y_mean, Y_std, mge_training=False)
-
-
-@pytest.mark.parametrize("name", ["acoustic_chain_d", "acoustic_chain_d_uncond"])
-def test_panel_chain_option_matches_reference_golden(name):
-    """The opt-in row-panel chain kernels for the discriminator (GT_OPT_PANEL_CHAIN; LDS-resident activations,
-    x-part of the first layer shared by the real and fake halves) against the same reference goldens."""
-    from hip_runner import run_hip_case
-    case = C.CASES[name]
-    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
-    got = run_hip_case(case, engine_options={"panel_chain": True})
-    for k in gold.files:
-        if k.startswith("g_leak_norm"):
-            continue
-        if ".opt." in k:
-            _close(got[k], gold[k], rtol=5e-4, atol=1e-9, msg=k)
-        else:
-            _close(got[k], gold[k], msg=k)
-    with pytest.raises(ValueError):
-        run_hip_case(case, engine_options={"no_such_option": True})
 
 
 def test_data_parallel_step_through_rccl_world_1():

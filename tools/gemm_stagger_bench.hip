@@ -1,0 +1,95 @@
+// A/B harness (no torch): f32 MFMA GEMM launches of the cfg2 step with the start stagger of gemm_f32.hip.h
+// (who-is-late modes x delays) on random operands.   usage: gemm_stagger_bench [reps]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../gantts_amd/csrc/gemm_f32.hip.h"
+using namespace gt;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+static float* dfill(size_t n, float scale, unsigned s) {
+  std::vector<float> h(n);
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.f * 2.f - 1.f) * scale; }
+  float* p; CK(hipMalloc((void**)&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
+}
+__global__ void census_kernel(unsigned* keys, unsigned* hw) { if (threadIdx.x == 0) { keys[blockIdx.x] = cu_key(); hw[blockIdx.x] = hw_id_reg(); } }
+
+template <int KIND, int BM, int BN>
+static double run(GemmArgs g, int nslab, int reps, unsigned* ticket) {
+  const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
+  auto kern = gemm_f32_kernel<KIND, BM, BN, true, true>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) { if (g.stagger_mode == 3) CK(hipMemsetAsync(ticket, 0, 2048 * 4, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g); }
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) { if (g.stagger_mode == 3) CK(hipMemsetAsync(ticket, 0, 2048 * 4, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g); }
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms * 1e3 / reps;
+}
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 30;
+  // census: what does a 512-workgroup launch look like to cu_key()?
+  {
+    unsigned *dk, *dh; CK(hipMalloc((void**)&dk, 1024 * 4)); CK(hipMalloc((void**)&dh, 1024 * 4));
+    hipLaunchKernelGGL(census_kernel, dim3(512), dim3(256), 60000, 0, dk, dh);
+    std::vector<unsigned> k(512), h(512);
+    CK(hipMemcpy(k.data(), dk, 512 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h.data(), dh, 512 * 4, hipMemcpyDeviceToHost));
+    std::vector<int> cnt(2048, 0);
+    for (auto v : k) cnt[v & 2047]++;
+    int distinct = 0, twos = 0; for (int c : cnt) { if (c) ++distinct; if (c == 2) ++twos; }
+    printf("census: 512 workgroups (60 KB LDS each) -> %d distinct CU keys, %d keys with exactly 2\n", distinct, twos);
+    printf("  first blocks: "); for (int b = 0; b < 12; ++b) printf("[b%d key %03x hw %08x] ", b, k[b], h[b]); printf("\n");
+    printf("  blocks 256..: "); for (int b = 256; b < 262; ++b) printf("[b%d key %03x hw %08x] ", b, k[b], h[b]); printf("\n");
+    int same = 0; for (int b = 0; b < 256; ++b) if (k[b] == k[b + 256]) ++same;
+    printf("  blocks b and b+256 on the same CU: %d of 256;  wave-slot parity of b<256: ", same);
+    int odd = 0; for (int b = 0; b < 256; ++b) odd += h[b] & 1; printf("%d odd, of b>=256: ", odd);
+    odd = 0; for (int b = 256; b < 512; ++b) odd += h[b] & 1; printf("%d odd\n", odd);
+  }
+  unsigned* ticket; CK(hipMalloc((void**)&ticket, 2048 * 4));
+  struct Shape { const char* name; int kind, M, N, K, bm; };
+  const Shape shapes[] = {
+    {"fwd  G  16384x512x512  (128x128)", GEMM_NT, 16384, 512, 512, 128},
+    {"fwd  D  32768x256x256  (128x128)", GEMM_NT, 32768, 256, 256, 128},
+    {"fwd  D  16384x256x256  ( 64x128)", GEMM_NT, 16384, 256, 256, 64},
+    {"bwdX G  16384x512x512  (128x128)", GEMM_NN, 16384, 512, 512, 128},
+    {"bwdW G  512x512x16384  (128x128, 32 slabs)", GEMM_TN, 512, 512, 16384, 128},
+  };
+  for (const Shape& sh : shapes) {
+    const bool tn = sh.kind == GEMM_TN;
+    float* A = dfill((size_t)(tn ? sh.K * sh.M : sh.M * sh.K), 1.f, 1);
+    float* B = dfill((size_t)sh.N * sh.K, 0.05f, 2);
+    float* Cc; CK(hipMalloc((void**)&Cc, (size_t)(tn ? 32 : 1) * sh.M * sh.N * 4 + 64));
+    float* Hh = dfill((size_t)sh.M * sh.N, 1.f, 3);
+    float* bias = dfill(sh.N, 0.1f, 4);
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.M = sh.M; g.N = sh.N; g.K = sh.K; g.C = Cc; g.ldc = sh.N; g.wide_store = 1;
+    g.drop.mode = DROP_PHILOX; g.drop.p = 0.5f; g.drop.scale = 2.f; g.drop.thresh = 32768; g.drop.key0 = 123; g.drop.key1 = 456;
+    int nslab = 1;
+    if (sh.kind == GEMM_NT) { g.A = A; g.lda = sh.K; g.B = B; g.ldb = sh.K; g.bias = bias; g.act = ACT_LEAKY_DROPOUT; }
+    else if (sh.kind == GEMM_NN) { g.A = A; g.lda = sh.K; g.B = B; g.ldb = sh.N; g.act = ACT_LEAKY_DROPOUT; g.H = Hh; g.ldh = sh.N; }
+    else { g.A = A; g.lda = sh.M; g.B = B; g.ldb = sh.N; nslab = 32; g.k_chunk = sh.K / 32; g.slab_stride = (long)sh.M * sh.N; g.drop.mode = DROP_NONE; g.act = ACT_NONE; }
+    const double flops = 2.0 * sh.M * sh.N * sh.K;
+    printf("%s   ideal %.1f us\n", sh.name, flops / 157.3e12 * 1e6);
+    const double ideal_cycles = flops / 157.3e12 * 2.4e9;
+    for (int mode = 0; mode <= 3; ++mode) {
+      for (int pct : {25, 50, 75}) {
+        if (mode == 0 && pct != 25) continue;
+        g.stagger_mode = mode; g.stagger_ticket = ticket;
+        g.stagger_cycles = mode == 0 ? 0 : (int)(ideal_cycles * pct / 100.0 * (100.0 / 2400.0));   // clock64 = 100 MHz constant clock?  see note
+        double us;
+        if (sh.kind == GEMM_NT) us = sh.bm == 128 ? run<GEMM_NT, 128, 128>(g, 1, reps, ticket) : run<GEMM_NT, 64, 128>(g, 1, reps, ticket);
+        else if (sh.kind == GEMM_NN) us = run<GEMM_NN, 128, 128>(g, 1, reps, ticket);
+        else us = run<GEMM_TN, 128, 128>(g, nslab, reps, ticket);
+        printf("   mode %d delay %3d%% (%6d ticks): %7.1f us  %6.1f TFLOP/s\n", mode, mode ? pct : 0, g.stagger_cycles, us, flops / (us * 1e-6) / 1e12);
+      }
+    }
+    hipFree(A); hipFree(B); hipFree(Cc); hipFree(Hh); hipFree(bias);
+  }
+  return 0;
+}

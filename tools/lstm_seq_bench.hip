@@ -70,7 +70,9 @@ int main(int argc, char** argv) {
   unsigned int* fault = dalloc<unsigned int>(16);
   const int HP = H <= 256 ? 256 : 512;
   const size_t xch_n = (size_t)dirs * cdiv(B, 16) * 2 * 16 * 4 * HP;
-  unsigned long long* xch = dalloc<unsigned long long>(xch_n);
+  const size_t chk_n = (size_t)dirs * cdiv(B, 16) * 256;
+  unsigned long long* xch = dalloc<unsigned long long>(xch_n + chk_n);
+  int xcd_local = 1;
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipFuncSetAttribute((const void*)lstm_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
@@ -101,13 +103,15 @@ int main(int argc, char** argv) {
     for (int d = 0; d < dirs; ++d) { a.Whh[d] = Whh[d]; a.bih[d] = bih[d]; a.bhh[d] = bhh[d]; }
     a.xproj = q.xproj; a.gates = q.gates; a.cst = q.cst; a.out = q.out; a.dout = dout;
     a.xch = xch; a.fault = fault; a.timeout_ticks = 100000000ULL;     // 1 s
-    CK(hipMemsetAsync(xch, 0, xch_n * sizeof(unsigned long long), s));
+    CK(hipMemsetAsync(xch, 0, (xch_n + chk_n) * sizeof(unsigned long long), s));
+    a.xcc_chk = xch + xch_n; a.nxcd = 8; a.allow_xcd_local = xcd_local; a.dbg_protocol = fault + 4;
     a.ncu = backward ? cdiv(H, 16) : cdiv(H, upc);
-    const int grid = dirs * a.nbt * a.ncu;
+    const int rounds = cdiv(dirs * a.nbt, a.nxcd);
+    const int grid = a.nxcd * a.ncu * rounds;
     size_t lds; const void* kern;
 #define PICK(KERN, LDS) { kern = (const void*)KERN; lds = LDS; CK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       int per = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, KERN, 256, lds)); \
-      if (grid > per * prop.multiProcessorCount) { printf("  grid %d exceeds residency %d x %d\n", grid, per, prop.multiProcessorCount); return false; } \
+      if (a.ncu * rounds > per * (prop.multiProcessorCount / 8)) { printf("  %d workgroups per XCD exceed residency %d x %d\n", a.ncu * rounds, per, prop.multiProcessorCount / 8); return false; } \
       hipLaunchKernelGGL(KERN, dim3(grid), dim3(256), lds, s, a); }
     if (backward) { if (HP == 256) PICK((lstm_bwd_seq_kernel<256>), (lstm_bwd_seq_lds<256>())) else PICK((lstm_bwd_seq_kernel<512>), (lstm_bwd_seq_lds<512>())) }
     else if (upc == 4) { if (HP == 256) PICK((lstm_fwd_seq_kernel<256, 4>), (lstm_fwd_seq_lds<256, 4>())) else PICK((lstm_fwd_seq_kernel<512, 4>), (lstm_fwd_seq_lds<512, 4>())) }
@@ -136,7 +140,8 @@ int main(int argc, char** argv) {
     double dg = maxdiff(P.gates, R.gates, (size_t)N * dirs * 4 * H, &sc); printf("    %s gates  max|d| %.3e (scale %.2e)\n", what, dg, sc);
     double dc = maxdiff(P.cst, R.cst, (size_t)N * dirs * H, &sc); printf("    %s c      max|d| %.3e (scale %.2e)\n", what, dc, sc);
     double dh = maxdiff(P.out, R.out, (size_t)N * dirs * H, &sc); printf("    %s h      max|d| %.3e (scale %.2e)\n", what, dh, sc);
-    unsigned f; CK(hipMemcpy(&f, fault, 4, hipMemcpyDeviceToHost));
+    unsigned f, pr[8]; CK(hipMemcpy(&f, fault, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(pr, fault + 4, 32, hipMemcpyDeviceToHost));
+    printf("    protocol per group (1 xcd-local, 2 agent): %u %u %u %u\n", pr[0], pr[1], pr[2], pr[3]);
     printf("    fault word %u  %s\n", f, (dg < 2e-4 && dc < 2e-3 && dh < 2e-4 && f == 0) ? "OK" : "MISMATCH");
   };
 
@@ -144,10 +149,12 @@ int main(int argc, char** argv) {
   printf("forward\n");
   reset_xp(R);
   timed("per-step launches", [&] { steps(R, false); });
+  for (int proto = 0; proto < 2; ++proto)
   for (int upc : {4, 8, 16}) {
+    xcd_local = proto;
     reset_xp(P);
     CK(hipMemsetAsync(P.gates, 0xff, (size_t)N * dirs * 4 * H * sizeof(float), s));
-    char nm[64]; snprintf(nm, sizeof(nm), "persistent, %d units/workgroup", upc);
+    char nm[64]; snprintf(nm, sizeof(nm), "persistent %s, %d units/wg", proto ? "xcd-local" : "agent", upc);
     bool ok = true;
     timed(nm, [&] { ok = seq(P, false, upc); });
     if (ok) report("fwd");
@@ -158,13 +165,16 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(P.cst, R.cst, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
   CK(hipMemcpy(P.out, R.out, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
   timed("per-step launches", [&] { steps(R, true); });
+  for (int proto = 0; proto < 2; ++proto) {
+  xcd_local = proto;
   bool okb = true;
-  timed("persistent", [&] { okb = seq(P, true, 0); });
+  timed(proto ? "persistent xcd-local" : "persistent agent", [&] { okb = seq(P, true, 0); });
   if (okb) {
     double sc;
     double dd = maxdiff(P.xproj, R.xproj, (size_t)N * dirs * 4 * H, &sc);
     unsigned f; CK(hipMemcpy(&f, fault, 4, hipMemcpyDeviceToHost));
     printf("    bwd dG     max|d| %.3e (scale %.2e)  fault word %u  %s\n", dd, sc, f, (dd < 1e-4 * std::max(1.0, sc) && f == 0) ? "OK" : "MISMATCH");
+  }
   }
   return 0;
 }
