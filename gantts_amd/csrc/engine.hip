@@ -541,6 +541,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden); e->l_outd.resize(desc->num_hidden);
   } else if (desc->arch == GT_ARCH_SRU) {
     if (desc->rnn_dropout < 0.f || desc->rnn_dropout >= 1.f) return fail(GT_ERR_INVALID, "rnn_dropout must be in [0,1)");
+    if (desc->num_hidden > 8) return fail(GT_ERR_INVALID, "SRURNN: at most 8 layers (two dropout sites per layer)");
     const int ncols = desc->hidden_dim * (desc->bidirectional ? 2 : 1);
     n.sru.clear();
     for (int l = 0; l < desc->num_hidden; ++l) {
@@ -1155,6 +1156,7 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
   if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {   // the last layer has dropout 0 (SRU.__init__)
     a.use_mask = 1; a.keep_scale = 1.f / (1.f - G.d.dropout); a.thresh = drop_thresh(G.d.dropout);
     sru_keys(e, l, 1, &a.key0, &a.key1);
+    a.mask_buf = G.inj[0][2 * l + 1];                                // gt_set_dropout_mask(G, 0, 2*l + 1): [B][ncols]
   }
   return a;
 }
@@ -1178,7 +1180,7 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       sru_keys(e, l, 0, &k0, &k1);
       hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, in, ld_in, e->s_xdrop[l].as<float>(),
                          L.in, B, T, L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, 0,
-                         (const float*)nullptr, 0);
+                         (const float*)nullptr, 0, G.inj[0][2 * l]);           // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
       LAUNCH_CHECK();
       xin = e->s_xdrop[l].as<float>();
       ld_xin = L.in;
@@ -1250,7 +1252,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
         sru_keys(e, l, 0, &k0, &k1);
         hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, dh_other, L.in, dh_other, L.in, B, T,
                            L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, L.k == 3 ? 1 : 0,
-                           (const float*)e->s_dx.as<float>(), ncols);
+                           (const float*)e->s_dx.as<float>(), ncols, G.inj[0][2 * l]);
         LAUNCH_CHECK();
       }
       std::swap(dh, dh_other);

@@ -107,11 +107,13 @@ struct GemmArgs {
   int n_tiles_m, n_tiles_n;
   // Start stagger (launcher-set; 0 = off).  The two workgroups that share a CU share its matrix pipes: started together
   // they also reach their load prologues and their store epilogues together, and the pipes idle through both.  One
-  // of the two ("late") waits `stagger_cycles` before it starts -- the other one has the pipes to itself meanwhile,
-  // so no matrix time is lost -- and from then on one workgroup's prologue / epilogue runs under the other's K loop.
-  int stagger_cycles;
-  int stagger_mode;          // who is late: 1 = upper half of the grid, 2 = odd wave slot (HW_ID), 3 = second ticket of its CU
-  unsigned int* stagger_ticket;   // mode 3: zeroed [2048] counters, key = (XCC_ID, SE_ID, SH_ID, CU_ID)
+  // of the two ("late") waits `stagger_ticks` (100 MHz wall-clock ticks) before it starts -- the other one has the
+  // pipes to itself meanwhile, so no matrix time is lost -- and from then on one workgroup's prologue / epilogue runs
+  // under the other's K loop.
+  int stagger_ticks;
+  int stagger_mode;          // who is late: 1 = upper half of the grid, 2 = odd wave slot (HW_ID), 3 = odd ticket of its CU
+  unsigned int* stagger_ticket;   // mode 3: [2048] counters keyed by (XCC_ID, SE_ID, SH_ID, CU_ID); never reset (parity alternates)
+  unsigned int* stagger_dbg;      // optional [grid]: cu_key | late << 16
 };
 
 // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), all 32 bits: s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id
@@ -122,7 +124,7 @@ __device__ __forceinline__ unsigned cu_key() {   // CU_ID [11:8], SH_ID [12], SE
   return ((xcc_id_reg() & 0xfu) << 7) | (((h >> 13) & 0x7u) << 5) | (((h >> 12) & 0x1u) << 4) | ((h >> 8) & 0xfu);
 }
 __device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* smem) {
-  if (g.stagger_cycles <= 0) return;
+  if (g.stagger_ticks <= 0) return;
   bool late = false;
   if (g.stagger_mode == 1) late = blockIdx.x >= (gridDim.x + 1) / 2;
   else if (g.stagger_mode == 2) late = (hw_id_reg() & 1u) != 0u;
@@ -133,9 +135,10 @@ __device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* sme
     late = (sh[0] & 1u) != 0u;
     __syncthreads();
   }
+  if (g.stagger_dbg && threadIdx.x == 0) g.stagger_dbg[blockIdx.x] = cu_key() | (late ? 0x10000u : 0u);
   if (late) {
-    const long long t0 = clock64();
-    while (clock64() - t0 < (long long)g.stagger_cycles) __builtin_amdgcn_s_sleep(16);
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(2);
   }
 }
 

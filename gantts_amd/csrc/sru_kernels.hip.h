@@ -35,6 +35,7 @@ struct SruArgs {
   float* dbias_part;              // [B][2*ncols]
   // variational output dropout (one mask per (sequence, column), shared over time)
   int use_mask; float keep_scale; uint32_t thresh, key0, key1;
+  const float* mask_buf;          // parity hook: injected 0/1 keep mask [B][ncols] instead of the Philox stream
 };
 
 __device__ __forceinline__ float sru_act(float c, int act) { return act == SRU_RELU ? fmaxf(c, 0.f) : (act == SRU_TANH ? tanhf(c) : c); }
@@ -43,6 +44,7 @@ __device__ __forceinline__ float sru_dact(float c, float val, int act) {
 }
 __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
   if (!a.use_mask) return 1.f;
+  if (a.mask_buf) return a.mask_buf[(long)b * (a.H * a.dirs) + col] != 0.f ? a.keep_scale : 0.f;
   uint32_t r[4];
   philox4x32_10((uint32_t)b, (uint32_t)col, a.key0, a.key1, r);
   return r[0] >= a.thresh ? a.keep_scale : 0.f;
@@ -149,15 +151,20 @@ __global__ __launch_bounds__(256) void sru_bwd_kernel(const SruArgs a) {
 // variational input dropout: y[row][i] = x[row][i] * mask(b, i)    (mask shared over time)
 __global__ void sru_input_dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int T, int n,
                                          float keep_scale, uint32_t thresh, uint32_t key0, uint32_t key1, int accumulate_from,
-                                         const float* __restrict__ add, int ldadd) {
+                                         const float* __restrict__ add, int ldadd, const float* __restrict__ mask_buf) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)B * T * n) return;
   const int i = (int)(e % n);
   const long row = e / n;
   const int b = (int)(row / T);
-  uint32_t r[4];
-  philox4x32_10((uint32_t)b, (uint32_t)i, key0, key1, r);
-  float v = x[row * ldx + i] * (r[0] >= thresh ? keep_scale : 0.f);
+  bool keep;
+  if (mask_buf) keep = mask_buf[(long)b * n + i] != 0.f;      // injected [B][n] keep mask (parity hook)
+  else {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)b, (uint32_t)i, key0, key1, r);
+    keep = r[0] >= thresh;
+  }
+  float v = x[row * ldx + i] * (keep ? keep_scale : 0.f);
   if (accumulate_from) v += add[row * ldadd + i];
   y[row * ldy + i] = v;
 }

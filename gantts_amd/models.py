@@ -323,7 +323,27 @@ class SRURNN(_FlatNetwork):
         self._finish_init()
 
     def set_dropout_masks(self, pass_index, masks):
-        raise NotImplementedError("dropout mask injection is not available for recurrent generators")
+        """Parity hook for the SRU cell's variational dropout: ``masks`` in the order a forward pass draws them --
+        per layer the input mask (B, n_in) if ``rnn_dropout > 0``, then the output mask (B, H*dirs) if ``dropout > 0``
+        and the layer is not the last -- as 0/1 keep tensors; ``None`` restores the Philox stream."""
+        if pass_index != 0:
+            raise ValueError("recurrent generators have a single forward pass (index 0)")
+        masks = list(masks) if masks is not None else None
+        ncols = self.hidden_dim * self.num_direction
+        for layer in range(self.num_hidden):
+            n_in = self.in_dim if layer == 0 else ncols
+            for which, on, width in ((0, self.rnn_dropout > 0, n_in), (1, self.dropout_p > 0 and layer + 1 < self.num_hidden, ncols)):
+                m = None
+                if masks is not None and on:
+                    if not masks:
+                        raise ValueError("too few dropout masks for this SRURNN")
+                    m = masks.pop(0).to(self._flat.device, torch.float32).contiguous()
+                    if m.dim() != 2 or m.size(1) != width:
+                        raise ValueError("SRU layer %d %s mask must be (B, %d), got %s" % (layer, "input" if which == 0 else "output", width, tuple(m.shape)))
+                self._masks[(0, 2 * layer + which)] = m
+        if masks:
+            raise ValueError("too many dropout masks for this SRURNN")
+        self._version += 1
 
     def forward(self, sequence, lengths=None):
         return self._own_engine().model_forward(self, sequence)

@@ -129,7 +129,9 @@ int gt_set_seed(gt_engine* e, uint64_t seed);
 /* Parity hook: use the caller's 0/1 float mask ((rows, hidden) contiguous, device) instead of the
  * Philox stream for dropout site `layer` of forward pass `pass` of `role`; NULL restores Philox.
  * passes: G: 0 = apply_generator.  D: 0 = real rows of the D step, 1 = generated rows of the
- * D step, 2 = generated rows of the G step (the order nn.Dropout is consumed in train.py:261-307). */
+ * D step, 2 = generated rows of the G step (the order nn.Dropout is consumed in train.py:261-307).
+ * SRURNN (models.py:152-154: rnn_dropout / dropout of the SRU cell are VARIATIONAL masks, one per sequence and shared
+ * over time): `layer` = 2*l selects the input mask of SRU layer l, shape (B, n_in_l); 2*l + 1 its output mask, (B, H*dirs). */
 int gt_set_dropout_mask(gt_engine* e, int role, int pass, int layer, const float* mask);
 /* Parity hook for the production (Philox) dropout path, nn.Dropout inside gantts/models.py:132-139: writes the 0/1 keep
  * mask ((rows, cols) contiguous, device) that the engine's counter-based stream assigns to dropout site (role, pass,

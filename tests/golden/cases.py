@@ -236,6 +236,34 @@ ORACLE_ONLY_CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # the hparams-default generator family (hparams.py:111-124, 211-222) with BOTH variational dropouts on, masks
+    # injected: bidirectional, first layer k = 4 (n_in != ncols), upper layers k = 3 (highway gradient by-passes the
+    # input dropout), relu
+    "acoustic_sru_dropout": dict(
+        hp="tts_acoustic", B=5, T=26, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="SRURNN", in_dim=30, out_dim=187, num_hidden=3, hidden_dim=20,
+               bidirectional=True, dropout=0.2, last_sigmoid=False, use_relu=1, rnn_dropout=0.2),
+        d=dict(kind="MLP", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.3, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
+    # unidirectional tanh SRU with both dropouts, k = 3 in every layer (n_in == ncols from the start)
+    "acoustic_sru_uni_k3_dropout": dict(
+        hp="tts_acoustic", B=3, T=19, din=16, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="SRURNN", in_dim=16, out_dim=187, num_hidden=3, hidden_dim=16,
+               bidirectional=False, dropout=0.3, last_sigmoid=False, use_relu=0, rnn_dropout=0.25),
+        d=dict(kind="MLP", in_dim=74, out_dim=1, num_hidden=2, hidden_dim=16,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
     # unidirectional tanh SRU whose first layer already has n_in == ncols (k = 3 everywhere)
     "acoustic_sru_uni_k3": dict(
         hp="tts_acoustic", B=2, T=23, din=16, dout=187,
@@ -353,6 +381,16 @@ def make_dropout_masks(case, step, seed=99):
     B, T = case["B"], case["T"]
 
     def draw(spec):
+        if spec["kind"] == "SRURNN":      # variational masks, one per sequence, in the order the cell draws them
+            ncols = spec["hidden_dim"] * (2 if spec["bidirectional"] else 1)
+            out = []
+            for l in range(spec["num_hidden"]):
+                n_in = spec["in_dim"] if l == 0 else ncols
+                if spec["rnn_dropout"] > 0:
+                    out.append((rs.rand(B, n_in) >= spec["rnn_dropout"]).astype(np.float32))
+                if spec["dropout"] > 0 and l + 1 < spec["num_hidden"]:
+                    out.append((rs.rand(B, ncols) >= spec["dropout"]).astype(np.float32))
+            return out
         if spec["dropout"] <= 0:
             return []
         return [(rs.rand(B, T, h) >= spec["dropout"]).astype(np.float32) for h in hidden_sites(spec)]

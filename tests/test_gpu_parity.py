@@ -439,6 +439,33 @@ def test_full_size_cfg2_step_vs_oracle_and_determinism():
             assert np.abs(gref[bad]).max() < 1e-3 * np.abs(gref).max(), "mismatch on a well-conditioned gradient"
 
 
+def _rms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt((a * a).mean())) if a.size else 0.0
+
+
+def _close_within_conditioning(got, ref, ref_perturbed, msg, denom=None, floor=1e-4, factor=6.0, cap=5e-3):
+    """rms(got - ref) / rms(denom or ref) of ONE tensor must not exceed what the reference itself does when its weights move
+    by one float32 ulp: ``floor + factor * rms(ref_perturbed - ref) / rms(..)``, never more than ``cap``.
+
+    Why: LeakyReLU has a kink and the reference differentiates it by the SIGN of the stored output (in-place
+    LeakyReLU, gantts/models.py:132).  With N = 16384 frames x 512 units, a handful of pre-activations per layer land
+    within rounding of 0; there two correct float32 evaluations (CPU vs GPU summation order -- or the reference with its
+    weights nudged by 1 ulp) pick different slopes (1 vs 0.01), and each such flip moves one element of dZ by its whole
+    size and, through the layers below, a rank-one piece of every lower weight gradient.  Measured on MI355X at full
+    size (tools/diag_grads.py, dropout off / Philox / injected alike): relative rms error 1e-4..4e-4 on hidden-layer
+    gradients, 1e-6 on the layers above the last activation; at N = 256 everything is at 5e-7.  A wrong keep bit or a
+    wrong tile, in contrast, shows up at 1e-2..1 (the limit stays 5e-3)."""
+    den = max(_rms(ref if denom is None else denom), 1e-30)
+    err, cond = _rms(np.asarray(got, np.float64) - ref) / den, _rms(np.asarray(ref_perturbed, np.float64) - ref) / den
+    lim = min(cap, floor + factor * cond)
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write("%-60s rel-rms err %.3e  ref conditioning %.3e  limit %.3e\n" % (msg, err, cond, lim))
+        return
+    assert err <= lim, "%s: relative rms error %.3e > %.3e (the reference's own float32 conditioning: %.3e)" % (msg, err, lim, cond)
+
+
 @pytest.mark.parametrize("tag,B,Tn,gh,dh", [("cfg2-full-size", 32, 512, 512, 256),
                                              ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250),
                                              ("64-row-tiles", 4, 200, 256, 128)])
@@ -448,8 +475,11 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
     definition philox_keep(row, col) -- and handed to the CPU oracle as its nn.Dropout masks (the oracle is pinned to
     the reference with masks injected the same way, tests/golden/make_golden.py); the whole step must then agree:
     forward epilogues AND the keep bits every backward kernel regenerates (wide 16-byte and narrow epilogues, 64 / 128
-    row and column tiles, partial tiles, 2N-row discriminator pass, fused head).  Two steps, Adagrad with a
-    warm accumulator (1e-4: as after some training, where the update is smooth in g) so that parameters compare tightly.
+    row and column tiles, partial tiles, 2N-row discriminator pass, fused head).  Two steps, Adagrad with a warm
+    accumulator (1e-4: as after some training, where the update is smooth in g).
+    Forward quantities of the first step and all scalars: 1e-4 per column.  Gradients and what follows from them
+    (parameters, the second step's forward): per tensor, within the reference's own float32 conditioning, measured in
+    the test by running the oracle a second time with its weights moved by one ulp (_close_within_conditioning).
     Reference semantics: gantts/models.py:132-139, train.py:245-320."""
     import types
     import gantts_amd.train as T
@@ -495,42 +525,68 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
         assert all(abs(float(m.mean()) - 0.5) < 0.02 for m in gm)
     assert not torch.equal(masks[0][0][0], masks[1][0][0]) and not torch.equal(masks[0][0][0], masks[0][0][1])
 
-    # ---- oracle: the same masks injected ----
-    omg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
-    omd = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
-    omg.load_state_dict(C.make_weights(gs, 1)), omd.load_state_dict(C.make_weights(ds, 2))
-    omg.training = omd.training = True
-    oog, ood = O.OracleAdagrad(omg.params, **okw), O.OracleAdagrad(omd.params, **okw)
-    for o in (oog, ood):
-        for s_ in o.sum:
-            s_.fill_(acc0)
+    # ---- oracle: the same masks injected; run twice -- as is, and with every weight moved by ~1 ulp ----
     cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
     xc, yc, Rc = torch.from_numpy(x_np), torch.from_numpy(y_np), torch.from_numpy(R_np)
     omask = O.sequence_mask(lengths, Tn).unsqueeze(-1)
     oys = O.get_static_features(yc, 3, cfg.stream_sizes, cfg.has_dynamic_features)
+    wg0, wd0 = C.make_weights(gs, 1), C.make_weights(ds, 2)
+
+    def oracle_run(nudge):
+        omg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
+        omd = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
+        rs = np.random.RandomState(5)
+        jig = (lambda w: (w * (1.0 + nudge * rs.randn(*w.shape))).astype(np.float32)) if nudge else (lambda w: w)
+        omg.load_state_dict({k: jig(v) for k, v in wg0.items()}), omd.load_state_dict({k: jig(v) for k, v in wd0.items()})
+        omg.training = omd.training = True
+        init_g, init_d = [q.detach().numpy().copy() for q in omg.params], [q.detach().numpy().copy() for q in omd.params]
+        oog, ood = O.OracleAdagrad(omg.params, initial_accumulator_value=acc0, **okw), O.OracleAdagrad(omd.params, initial_accumulator_value=acc0, **okw)
+        rec = []
+        for st in range(steps):
+            gm, dm = masks[st]
+            dd = O._DropoutSource(dm)
+            oog.zero_grad(), ood.zero_grad()
+            oyh, oyhs = O.apply_generator(cfg, omg, xc, Rc, list(lengths), drop=O._DropoutSource(gm))
+            od_ = O.update_discriminator(cfg, omd, ood, xc, oys, oyhs, list(lengths), omask, "train", drop=dd)
+            dgr = [q.grad.numpy().copy() for q in omd.params]
+            og_ = O.update_generator(cfg, omg, omd, oog, xc, yc, oyh, oys, oyhs, 1.0, list(lengths), omask, "train",
+                                     mse_w=0.0, mge_w=1.0, drop=dd)
+            assert not dd.masks, "oracle consumed %d of 9 discriminator masks" % (9 - len(dd.masks))
+            rec.append(dict(d=od_, g=og_, yh=oyh.detach().numpy().copy(), yhs=oyhs.detach().numpy().copy(), dgrad=dgr,
+                            ggrad=[q.grad.numpy().copy() for q in omg.params]))
+        return rec, [q.detach().numpy() - i for q, i in zip(omg.params, init_g)], [q.detach().numpy() - i for q, i in zip(omd.params, init_d)], omg.names, omd.names
+
+    ref, ref_gu, ref_du, gnames, dnames = oracle_run(0.0)         # records of both steps, total parameter updates
+    alt, alt_gu, alt_du, _, _ = oracle_run(1.2e-7)                # the same with every weight moved by one float32 ulp
+
+    def split(flat, like):
+        out, off = [], 0
+        for r in like:
+            out.append(flat[off:off + r.size].reshape(r.shape))
+            off += r.size
+        return out
+
     for st in range(steps):
-        gm, dm = masks[st]
-        dd = O._DropoutSource(dm)
-        oog.zero_grad(), ood.zero_grad()
-        oyh, oyhs = O.apply_generator(cfg, omg, xc, Rc, list(lengths), drop=O._DropoutSource(gm))
-        od_ = O.update_discriminator(cfg, omd, ood, xc, oys, oyhs, list(lengths), omask, "train", drop=dd)
-        ref_dgrad = torch.cat([q.grad.reshape(-1) for q in omd.params]).numpy().copy()
-        og_ = O.update_generator(cfg, omg, omd, oog, xc, yc, oyh, oys, oyhs, 1.0, list(lengths), omask, "train",
-                                 mse_w=0.0, mge_w=1.0, drop=dd)
-        assert not dd.masks, "oracle consumed %d of 9 discriminator masks" % (9 - len(dd.masks))
-        h = hip[st]
+        h, r, a = hip[st], ref[st], alt[st]
         t = "%s step %d " % (tag, st)
-        _close(h["yh"], oyh.detach().numpy(), msg=t + "y_hat")
-        _close(h["yhs"], oyhs.detach().numpy(), msg=t + "y_hat_static")
-        _close(h["d"], od_, msg=t + "D scalars")
-        assert h["d"][3] == od_[3] and h["d"][4] == od_[4], (h["d"], od_)
-        _close(h["g"], og_, msg=t + "G scalars")
-        # flat gradient vectors (clipped in place, like clip_grad_norm_): every element against the vector's scale
-        _close(h["dgrad"], ref_dgrad, rtol=RTOL, atol=1e-9, msg=t + "D grads")
-        _close(h["ggrad"], torch.cat([q.grad.reshape(-1) for q in omg.params]).numpy(), rtol=RTOL, atol=1e-9, msg=t + "G grads")
-    for tagm, m, om in (("G", mg, omg), ("D", md, omd)):
-        for (k, v), r in zip(m.state_dict().items(), om.params):
-            _close(v.cpu().numpy(), r.detach().numpy(), msg="%s %s.%s after 2 steps" % (tag, tagm, k))
+        _close(h["d"], r["d"], msg=t + "D scalars")
+        assert h["d"][3] == r["d"][3] and h["d"][4] == r["d"][4], (h["d"], r["d"])
+        _close(h["g"], r["g"], msg=t + "G scalars")
+        if st == 0:
+            _close(h["yh"], r["yh"], msg=t + "y_hat")
+            _close(h["yhs"], r["yhs"], msg=t + "y_hat_static")
+        else:       # inherits the parameter differences of the step before
+            _close_within_conditioning(h["yh"], r["yh"], a["yh"], t + "y_hat")
+            _close_within_conditioning(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static")
+        for nm, got, rr, aa in zip(dnames, split(h["dgrad"], r["dgrad"]), r["dgrad"], a["dgrad"]):
+            _close_within_conditioning(got, rr, aa, t + "D.grad " + nm)
+        for nm, got, rr, aa in zip(gnames, split(h["ggrad"], r["ggrad"]), r["ggrad"], a["ggrad"]):
+            _close_within_conditioning(got, rr, aa, t + "G.grad " + nm)
+    # parameters after both steps: the UPDATE each tensor received, judged against its own size
+    for tagm, m, ru, au, w0 in (("G", mg, ref_gu, alt_gu, wg0), ("D", md, ref_du, alt_du, wd0)):
+        for (k, v), r_, a_ in zip(m.state_dict().items(), ru, au):
+            _close_within_conditioning(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k),
+                                       floor=1e-3, cap=2e-2)
 
 
 @pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])

@@ -23,9 +23,9 @@ static double run(GemmArgs g, int nslab, int reps, unsigned* ticket) {
   g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) { if (g.stagger_mode == 3) CK(hipMemsetAsync(ticket, 0, 2048 * 4, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g); }
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g);
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) { if (g.stagger_mode == 3) CK(hipMemsetAsync(ticket, 0, 2048 * 4, 0)); hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g); }
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   CK(hipGetLastError());
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     int odd = 0; for (int b = 0; b < 256; ++b) odd += h[b] & 1; printf("%d odd, of b>=256: ", odd);
     odd = 0; for (int b = 256; b < 512; ++b) odd += h[b] & 1; printf("%d odd\n", odd);
   }
-  unsigned* ticket; CK(hipMalloc((void**)&ticket, 2048 * 4));
+  unsigned* ticket; CK(hipMalloc((void**)&ticket, 2048 * 4)); CK(hipMemset(ticket, 0, 2048 * 4));
   struct Shape { const char* name; int kind, M, N, K, bm; };
   const Shape shapes[] = {
     {"fwd  G  16384x512x512  (128x128)", GEMM_NT, 16384, 512, 512, 128},
@@ -76,19 +76,27 @@ int main(int argc, char** argv) {
     else { g.A = A; g.lda = sh.M; g.B = B; g.ldb = sh.N; nslab = 32; g.k_chunk = sh.K / 32; g.slab_stride = (long)sh.M * sh.N; g.drop.mode = DROP_NONE; g.act = ACT_NONE; }
     const double flops = 2.0 * sh.M * sh.N * sh.K;
     printf("%s   ideal %.1f us\n", sh.name, flops / 157.3e12 * 1e6);
-    const double ideal_cycles = flops / 157.3e12 * 2.4e9;
+    unsigned* dbg; CK(hipMalloc((void**)&dbg, 4096 * 4));
     for (int mode = 0; mode <= 3; ++mode) {
-      for (int pct : {25, 50, 75}) {
-        if (mode == 0 && pct != 25) continue;
-        g.stagger_mode = mode; g.stagger_ticket = ticket;
-        g.stagger_cycles = mode == 0 ? 0 : (int)(ideal_cycles * pct / 100.0 * (100.0 / 2400.0));   // clock64 = 100 MHz constant clock?  see note
+      for (int us10 : {5, 10, 20, 40, 80, 160, 320}) {           // delay in units of 0.1 us
+        if (mode == 0 && us10 != 5) continue;
+        g.stagger_mode = mode; g.stagger_ticket = ticket; g.stagger_dbg = dbg;
+        g.stagger_ticks = mode == 0 ? 0 : us10 * 10;             // 100 MHz ticks
         double us;
         if (sh.kind == GEMM_NT) us = sh.bm == 128 ? run<GEMM_NT, 128, 128>(g, 1, reps, ticket) : run<GEMM_NT, 64, 128>(g, 1, reps, ticket);
         else if (sh.kind == GEMM_NN) us = run<GEMM_NN, 128, 128>(g, 1, reps, ticket);
         else us = run<GEMM_TN, 128, 128>(g, nslab, reps, ticket);
-        printf("   mode %d delay %3d%% (%6d ticks): %7.1f us  %6.1f TFLOP/s\n", mode, mode ? pct : 0, g.stagger_cycles, us, flops / (us * 1e-6) / 1e12);
+        // who was late in the LAST launch: CUs with exactly one late workgroup of their two
+        std::vector<unsigned> hd(4096); CK(hipMemcpy(hd.data(), dbg, 4096 * 4, hipMemcpyDeviceToHost));
+        const int grid = ((sh.M + sh.bm - 1) / sh.bm) * ((sh.N + 127) / 128) * nslab;
+        std::vector<int> tot(2048, 0), lat(2048, 0);
+        for (int b = 0; b < grid && b < 4096; ++b) { tot[hd[b] & 2047]++; lat[hd[b] & 2047] += (hd[b] >> 16) & 1; }
+        int cus = 0, one = 0; for (int k = 0; k < 2048; ++k) if (tot[k]) { ++cus; if (tot[k] == 2 && lat[k] == 1) ++one; }
+        printf("   mode %d delay %5.1f us: %7.1f us  %6.1f TFLOP/s   (%d CUs, %d with one early + one late)\n", mode, mode ? us10 / 10.0 : 0.0, us,
+               flops / (us * 1e-6) / 1e12, cus, mode ? one : 0);
       }
     }
+    hipFree(dbg);
     hipFree(A); hipFree(B); hipFree(Cc); hipFree(Hh); hipFree(bias);
   }
   return 0;
