@@ -115,6 +115,17 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
 // ------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------
+static int gemm_cu_count() {
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  hipDeviceProp_t prop;
+  const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  cus[dev] = n;
+  return n;
+}
 template <int KIND, int BM, int BN, bool VA, bool VB>
 static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
@@ -123,6 +134,11 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
+  // Start stagger (gemm_f32.hip.h): with two or more workgroups per CU, the one in an odd wave slot starts 0.5 us late.
+  // Measured on MI355X (tools/gemm_stagger_bench.hip, random operands): 16384x512x512 forward 90.7 -> 80.4 us,
+  // weight gradient 85.9 -> 72.7 us, 32768x256x256 53.3 -> 48.2 us; delays of 0.5 .. 2 us are equivalent, >= 16 us lose.
+  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 50;
+  if (stagger_ticks > 0 && grid > gemm_cu_count()) { g.stagger_ticks = stagger_ticks; g.stagger_mode = 2; }
   GemmProfiler::Rec rec;
   if (g_prof.on) {
     rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
@@ -982,12 +998,14 @@ static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* l
   return GT_OK;
 }
 template <int HP, int UPC>
-static int launch_fwd_seq(LstmSeqArgs& a, hipStream_t s, bool* launched) {
-  return launch_seq(lstm_fwd_seq_kernel<HP, UPC>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+static int launch_fwd_seq(LstmSeqArgs& a, int bt, hipStream_t s, bool* launched) {
+  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
+                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
 }
 template <int HP>
-static int launch_bwd_seq(LstmSeqArgs& a, hipStream_t s, bool* launched) {
-  return launch_seq(lstm_bwd_seq_kernel<HP>, lstm_bwd_seq_lds<HP>(), a, s, launched);
+static int launch_bwd_seq(LstmSeqArgs& a, int bt, hipStream_t s, bool* launched) {
+  return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8>, lstm_bwd_seq_lds<HP>(), a, s, launched)
+                 : launch_seq(lstm_bwd_seq_kernel<HP, 16>, lstm_bwd_seq_lds<HP>(), a, s, launched);
 }
 
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
@@ -998,9 +1016,14 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   if (!e->lstm_persistent || H > 512 || T < 2) return GT_OK;
   const int HP = H <= 256 ? 256 : 512;
+  int nxcd = 1, cpx = 1;
+  CHK(seq_xcds(&nxcd, &cpx));
+  // batch tile: 16 sequences per group (full MFMA rows) once that already gives every XCD a group; else 8, which
+  // halves the exchange volume of a group and spreads the recurrences over more XCDs (their L2s bound the exchange)
+  const int bt = dirs * cdiv(B, 16) >= nxcd ? 16 : 8;
   LstmSeqArgs a;
   memset(&a, 0, sizeof(a));
-  a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, 16);
+  a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, bt);
   a.lengths = e->d_lengths();
   for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
   a.xproj = e->l_xproj[layer].as<float>();
@@ -1011,26 +1034,25 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.fault = e->d_fault;
   a.timeout_ticks = 200000000ULL;          // 2 s at 100 MHz: far beyond any real wait, far below the watchdog
   const int ngroups = dirs * a.nbt;
-  const size_t xch_n = (size_t)ngroups * 2 * 16 * (backward ? 4 : 1) * HP, chk_n = (size_t)ngroups * 256;
+  const size_t xch_n = (size_t)ngroups * (backward ? lstm_bwd_xch_u64(HP) : lstm_fwd_xch_u64(HP)), chk_n = (size_t)ngroups * 256;
   CHK(e->l_xch.ensure((xch_n + chk_n) * sizeof(unsigned long long)));
-  HIPCHK(hipMemsetAsync(e->l_xch.p, 0, (xch_n + chk_n) * sizeof(unsigned long long), s));   // no tag of an earlier launch survives
+  HIPCHK(hipMemsetAsync(e->l_xch.p, 0, (xch_n + chk_n) * sizeof(unsigned long long), s));   // no tag / flag of an earlier launch survives
   a.xch = e->l_xch.as<unsigned long long>();
-  a.xcc_chk = a.xch + xch_n;              // [group][ncu <= 256]  (the kernels index it with ncu as the pitch)
+  a.xcc_chk = a.xch + xch_n;              // [group][256]
   a.allow_xcd_local = e->lstm_xcd_local ? 1 : 0;
   if (backward) {
     a.ncu = cdiv(H, 16);
-    CHK(HP == 256 ? launch_bwd_seq<256>(a, s, launched) : launch_bwd_seq<512>(a, s, launched));
+    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, s, launched) : launch_bwd_seq<512>(a, bt, s, launched));
     if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     return GT_OK;
   }
-  // forward: as many workgroups per group as fit (4 hidden units each), else 16 per workgroup
+  // forward: 8 hidden units per workgroup (32 workgroups per group at H = 256: one XCD's worth), else 16
   int upc = e->lstm_fwd_upc;
-  if (upc != 4 && upc != 8 && upc != 16) upc = 8;
+  if (upc != 8 && upc != 16) upc = 8;
   for (; upc <= 16 && !*launched; upc *= 2) {
     a.ncu = cdiv(H, upc);
-    if (upc == 4)      CHK(HP == 256 ? (launch_fwd_seq<256, 4>(a, s, launched)) : (launch_fwd_seq<512, 4>(a, s, launched)));
-    else if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, s, launched)) : (launch_fwd_seq<512, 8>(a, s, launched)));
-    else               CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, s, launched)) : (launch_fwd_seq<512, 16>(a, s, launched)));
+    if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, bt, s, launched)) : (launch_fwd_seq<512, 8>(a, bt, s, launched)));
+    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, bt, s, launched)) : (launch_fwd_seq<512, 16>(a, bt, s, launched)));
   }
   if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   return GT_OK;

@@ -3,14 +3,18 @@
 // layer (both directions, every batch tile) instead of one launch per step (lstm_kernels.hip.h, kept as the
 // fallback for shapes that do not fit and as the A/B reference).
 //
-// Decomposition.  A *group* is one (direction, 16-sequence batch tile): an independent recurrence.  Its gate
+// Decomposition.  A *group* is one (direction, batch tile of BT = 16 or 8 sequences): an independent recurrence
+// (the launcher picks BT = 8 when that gives every XCD a group of its own: the exchange is bound by the L2 of the
+// XCD a group lives on, and 8-sequence tiles halve its volume at the price of half-empty MFMA rows).  Its gate
 // columns are split over `ncu` workgroups (one per CU).  Every workgroup keeps ITS slice of W_hh in registers for
 // the whole launch (MFMA B operand, v_mfma_f32_16x16x4_f32: M = 16 sequences), keeps the cell state / running
 // dL/dc of its hidden units in registers, and per time step
 //   forward : gathers h_{t-1} of the whole group (16 x H) -> LDS, multiplies by its W_hh slice, applies the gate
 //             non-linearities for its UPC hidden units, stashes gates / c / h, publishes its slice of h_t;
 //   backward: gathers dG_{t+1} (16 x 4H) -> LDS, dh_t = dOut_t + dG_{t+1} . W_hh for its 16 hidden units,
-//             gate derivatives, writes dG_t (over the X-projection storage) and publishes it.
+//             gate derivatives, writes dG_t (over the X-projection storage) and publishes it.  The 4x wider payload
+//             goes out untagged (16-byte {dgi, dgf, dgg, dgo} per (unit, sequence)) behind one flag per producing
+//             wave (G16, R1: payload stores, drain, flag; consumer: flag, then L1-bypassing 16-byte loads).
 // The exchange between workgroups uses the placement-independent granule protocol of the CDNA4 guide (G16, R2):
 // the data IS the flag -- 8-byte {value, tag = step + 1} granules written by ONE relaxed agent-scope (sc1,
 // write-through) store and swept with relaxed agent-scope loads (L1 bypass) until every tag matches; two buffers
@@ -77,46 +81,61 @@ __device__ __forceinline__ unsigned fault_load(const unsigned int* p) {
 // (m = lane & 15, kq = lane >> 4) returns the operands of four consecutive 16x16x4 MFMAs (k = 16*kb + 4*j + kq).
 __device__ __forceinline__ int a_img_idx(int k, int m) { return (((k >> 4) * 64 + (k & 3) * 16 + m) << 2) + ((k >> 2) & 3); }
 
-// Sweep NG granules per thread (granule g = tid + 256*j <-> k = g / 16, m = g % 16) of `src` until every valid one
-// carries `epoch`; values go to the LDS A image.  kvalid: columns that have a producer.  Returns false on timeout / fault.
-template <int NG>
+// wave-uniform bookkeeping of a spin loop: true = give up (a peer raised the fault word, or this wait timed out)
+__device__ __forceinline__ bool spin_expired(const LstmSeqArgs& a, unsigned& spins, unsigned long long& t_start, unsigned fault_code) {
+  if ((++spins & 63u) != 0u) return false;
+  const unsigned long long now = wall_clock64();
+  if (t_start == 0) t_start = now;
+  if (fault_load(a.fault) != 0u) return true;
+  if (now - t_start > a.timeout_ticks) {
+    if ((threadIdx.x & 63) == 0) atomicCAS(a.fault, 0u, fault_code);
+    return true;
+  }
+  return false;
+}
+
+// Forward exchange, consumer side.  Granule (k, m) of `src` lives at k*BT + m; thread -> m = tid % BT and the NG
+// columns k = tid / BT + (256 / BT) * j.  First ONE granule per thread is polled (a different one per workgroup) until
+// it carries `epoch` -- the producers publish within a fraction of a microsecond of each other, and polling the whole
+// image from every workgroup is what saturates the XCD's L2 -- then whole sweeps, started at a workgroup-dependent
+// column so that the workgroups of a group do not walk the L2 channels in lock step.  Values go to the LDS A image.
+template <int NG, int BT>
 __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int kvalid, float* sA,
-                                             const LstmSeqArgs& a, unsigned fault_code) {
+                                             const LstmSeqArgs& a, int rot, unsigned fault_code) {
+  constexpr int KS_ = 256 / BT;        // column stride between a thread's granules
   const int tid = threadIdx.x;
-  const int m = tid & 15, k0 = tid >> 4;
-  unsigned long long v[NG];
+  const int m = tid % BT, k0 = tid / BT;
   unsigned spins = 0;
   unsigned long long t_start = 0;
+  {
+    const int ks = k0 + KS_ * (rot % NG);
+    if (ks < kvalid) {
+      const unsigned long long* sp = src + (size_t)ks * BT + m;
+      for (;;) {
+        const bool ok = (unsigned)(xch_load(sp) >> 32) == epoch;
+        if (__all(ok)) break;
+        if (spin_expired(a, spins, t_start, fault_code)) return false;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  unsigned long long v[NG];
+  int kk[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) { const int jr = j + rot; kk[j] = k0 + KS_ * (jr % NG); }
   for (;;) {
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int k = k0 + 16 * j;
-      v[j] = xch_load(src + (size_t)(k < kvalid ? k : 0) * 16 + m);
-    }
+    for (int j = 0; j < NG; ++j) v[j] = xch_load(src + (size_t)(kk[j] < kvalid ? kk[j] : 0) * BT + m);
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      const int k = k0 + 16 * j;
-      ok &= (k >= kvalid) || ((unsigned)(v[j] >> 32) == epoch);
-    }
+    for (int j = 0; j < NG; ++j) ok &= (kk[j] >= kvalid) || ((unsigned)(v[j] >> 32) == epoch);
     if (__all(ok)) break;
-    ++spins;
-    if ((spins & 63u) == 0u) {            // wave-uniform bookkeeping, off the fast path
-      const unsigned long long now = wall_clock64();
-      if (t_start == 0) t_start = now;
-      if (fault_load(a.fault) != 0u) return false;
-      if (now - t_start > a.timeout_ticks) {
-        if ((tid & 63) == 0) atomicCAS(a.fault, 0u, fault_code);
-        return false;
-      }
-    }
+    if (spin_expired(a, spins, t_start, fault_code)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
-  for (int j = 0; j < NG; ++j) {
-    const int k = k0 + 16 * j;
-    if (k < kvalid) sA[a_img_idx(k, m)] = __uint_as_float((unsigned)v[j]);
-  }
+  for (int j = 0; j < NG; ++j)
+    if (kk[j] < kvalid) sA[a_img_idx(kk[j], m)] = __uint_as_float((unsigned)v[j]);
   return true;
 }
 
@@ -128,18 +147,17 @@ __device__ __forceinline__ bool seq_group_of(const LstmSeqArgs& a, int* group, i
   return *group < a.dirs * a.nbt;
 }
 // true iff every workgroup of this group runs on the same XCD (decided identically by all of them)
-__device__ __forceinline__ bool seq_colocated(const LstmSeqArgs& a, int group, int cu, float* scratch, unsigned fault_code, bool* ok) {
-  *ok = true;
+__device__ __forceinline__ bool seq_colocated(const LstmSeqArgs& a, int group, int cu, float* scratch, unsigned fault_code) {
   if (!a.allow_xcd_local) return false;
   unsigned long long* chk = a.xcc_chk + (size_t)group * 256;
   const unsigned mine = xcc_id_of_wave();
   if (threadIdx.x == 0) xch_store(chk + cu, __uint_as_float(mine), 1u, false);
   int* flag = reinterpret_cast<int*>(scratch);
   if (threadIdx.x < 64) {
-    bool same = true;
+    bool same = true, alive = true;
     unsigned spins = 0;
     unsigned long long t_start = 0;
-    for (int i = threadIdx.x; i < a.ncu; i += 64) {
+    for (int i = threadIdx.x; i < a.ncu && alive; i += 64) {
       unsigned long long v;
       for (;;) {
         v = xch_load(chk + i);
@@ -147,14 +165,13 @@ __device__ __forceinline__ bool seq_colocated(const LstmSeqArgs& a, int group, i
         if ((++spins & 63u) == 0u) {
           const unsigned long long now = wall_clock64();
           if (t_start == 0) t_start = now;
-          if (fault_load(a.fault) != 0u || now - t_start > a.timeout_ticks) { atomicCAS(a.fault, 0u, fault_code); *ok = false; break; }
+          if (fault_load(a.fault) != 0u || now - t_start > a.timeout_ticks) { atomicCAS(a.fault, 0u, fault_code); alive = false; break; }
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      if (!*ok) break;
-      same &= (unsigned)v == mine;
+      same &= alive && (unsigned)v == mine;
     }
-    const bool all_same = __all(same && *ok);
+    const bool all_same = __all(same && alive);
     if (threadIdx.x == 0) flag[0] = all_same ? 1 : 0;
   }
   __syncthreads();
@@ -167,16 +184,21 @@ template <int HP, int UPC> constexpr size_t lstm_fwd_seq_lds() {
   return (size_t)(HP * 16 + (16 / UPC) * 16 * 4 * UPC) * sizeof(float);     // A image + KS x 16 x NC partials
 }
 template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16) * sizeof(float); }
+// exchange area of one group, in 8-byte units (the launcher sizes and zeroes it): forward 2 granule images;
+// backward 2 images of 16-byte chunks + 128 flag words
+constexpr size_t lstm_fwd_xch_u64(int HP) { return (size_t)2 * 16 * HP; }
+constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64; }
 
 // ------------------------------------------------------------------------------------------
 // forward.  grid = nxcd * ncu * ceil(ngroups / nxcd) workgroups of 256 (seq_group_of); the workgroup
 // owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
 // wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
 // ------------------------------------------------------------------------------------------
-template <int HP, int UPC>
+template <int HP, int UPC, int BT>
 __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
-  constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP / 16;
+  constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP * BT / 256;
   static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
+  static_assert(BT == 8 || BT == 16, "BT");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sA = sm;                       // [HP x 16] permuted
   float* red = sm + HP * 16;            // [KS][16][NC]
@@ -203,10 +225,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       wreg[i] = (wok && k < H) ? Wrow[min(k, H - 1)] : 0.f;
     }
   }
-  // ---- gate stage: thread (sequence gb, unit gu) for tid < 16*UPC
-  const bool gthread = tid < 16 * UPC;
-  const int gb = tid & 15, gu = (tid >> 4) % UPC;
-  const int bg = bt * 16 + gb, bgc = min(bg, B - 1);
+  // ---- gate stage: thread (sequence gb, unit gu) for tid < BT*UPC
+  const bool gthread = tid < BT * UPC;
+  const int gb = tid % BT, gu = (tid / BT) % UPC;
+  const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
   const bool store_ok = gthread && bg < B && j < H;
   const int len = (gthread && bg < B) ? a.lengths[bgc] : 0;
@@ -214,13 +236,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
 #pragma unroll
   for (int g = 0; g < 4; ++g) bias[g] = a.bih[d][g * H + jc] + a.bhh[d][g * H + jc];
   float c_state = 0.f;
-  unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * HP);
+  unsigned long long* xb = a.xch + (size_t)group * lstm_fwd_xch_u64(HP);
 
-  bool chk_ok;
-  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_FWD, &chk_ok);
+  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_FWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // columns without a producer stay zero for good
+  for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // rows >= BT and columns without a producer stay zero for good
   __syncthreads();
 
   auto row_of = [&](int s) { return (long)bgc * T + (d == 0 ? s : T - 1 - s); };
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     if (s > 0) {
-      if (!sweep_to_lds<NG>(xb + (size_t)((s - 1) & 1) * (16 * HP), (unsigned)s, kvalid, sA, a, LSTM_FAULT_TIMEOUT_FWD)) return;
+      if (!sweep_to_lds<NG, BT>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* ap = sA + (((kpart * (KW / 16)) * 64 + kq * 16 + n) << 2);
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
         h = og * tanhf(c);
       }
       c_state = c;                       // state is held at zero while inactive
-      if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (16 * HP) + (size_t)j * 16 + gb, h, (unsigned)(s + 1), xcd_local);
+      if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (BT * HP) + (size_t)j * BT + gb, h, (unsigned)(s + 1), xcd_local);
       if (store_ok) {
         const long row = (long)bg * T + t;
         a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
@@ -285,14 +306,45 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   }
 }
 
+// 16-byte loads that bypass L1 (sc1), N at a time, completed inside the statement (hipcc does not count asm loads)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load8_sc1(const u32x4* const (&p)[8], u32x4 (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+__device__ __forceinline__ void flag_store(unsigned int* p, unsigned v, bool xcd_local) {
+  if (xcd_local) __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else           __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local) {
+  flag_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), xcd_local);
+}
+
 // ------------------------------------------------------------------------------------------
-// backward.  grid = dirs * nbt * ncu, ncu = ceil(H/16): the workgroup owns 16 hidden units (one MFMA N tile) of
-// dh; K = 4*HP gate columns (k = gate*HP + unit), wave w multiplies gate w's block.  Direction 0 walks
-// t = T-1..0, direction 1 walks t = 0..T-1.  Thread (sequence tid & 15, unit tid >> 4) owns one (b, u) pair.
+// backward.  grid as forward with ncu = ceil(H/16): the workgroup owns 16 hidden units (one MFMA N tile) of dh;
+// K = 4*HP gate columns (k = gate*HP + unit), wave w multiplies gate w's block.  Direction 0 walks t = T-1..0,
+// direction 1 walks t = 0..T-1.  Thread (sequence tid % BT, unit tid / BT < 16) owns one (b, u) pair.
+// Exchange image of one step: 16-byte chunk (u, b) = {dgi, dgf, dgg, dgo} at u*BT + b; flag word of producing wave
+// w of workgroup c at c*NW + w, monotonic (= steps published).
 // ------------------------------------------------------------------------------------------
-template <int HP>
+template <int HP, int BT>
 __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
-  constexpr int WR = HP / 4, NGQ = HP / 16;       // per wave: HP rows of K; per gate: HP/16 granules per thread
+  constexpr int WR = HP / 4;
+  constexpr int NW = 16 * BT / 64;                // producing waves per workgroup
+  constexpr int NCH = HP * BT / 256;              // 16-byte chunks per thread and step
+  static_assert(BT == 8 || BT == 16, "BT");
+  static_assert(NCH % 8 == 0, "chunks are loaded 8 at a time");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sA = sm;                       // [4*HP x 16] permuted
   float* red = sm + 4 * HP * 16;        // [4][16][16]
@@ -317,16 +369,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
       wreg[i] = (wok && k < H) ? Wc[(long)min(k, H - 1) * H] : 0.f;
     }
   }
-  const int gb = tid & 15, gu = tid >> 4;
-  const int bg = bt * 16 + gb, bgc = min(bg, B - 1);
+  const bool gthread = tid < 16 * BT;
+  const int gb = tid % BT, gu = (tid / BT) & 15;
+  const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
-  const bool store_ok = bg < B && j < H;
-  const int len = bg < B ? a.lengths[bgc] : 0;
+  const bool store_ok = gthread && bg < B && j < H;
+  const int len = (gthread && bg < B) ? a.lengths[bgc] : 0;
   float dcs = 0.f;
-  unsigned long long* xb = a.xch + (size_t)group * 2 * (16 * 4 * HP);
+  unsigned long long* xb = a.xch + (size_t)group * lstm_bwd_xch_u64(HP);
+  u32x4* xdata = reinterpret_cast<u32x4*>(xb);                                   // [2][HP*BT] chunks
+  unsigned int* xflag = reinterpret_cast<unsigned int*>(xb + (size_t)2 * 16 * HP * 2);   // [ncu * NW] <= 128
+  const int nflags = a.ncu * NW;
 
-  bool chk_ok;
-  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_BWD, &chk_ok);
+  const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_BWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
   for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
@@ -352,10 +407,41 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
     if (s > 0) {
-      const unsigned long long* src = xb + (size_t)((s - 1) & 1) * (16 * 4 * HP);
-#pragma unroll 1
-      for (int g = 0; g < 4; ++g)
-        if (!sweep_to_lds<NGQ>(src + (size_t)g * HP * 16, (unsigned)s, uvalid, sA + g * HP * 16, a, LSTM_FAULT_TIMEOUT_BWD)) return;
+      {   // every wave waits for every producing wave of the group to have published step s-1
+        unsigned spins = 0;
+        unsigned long long t_start = 0;
+        for (;;) {
+          bool ok = true;
+          for (int i = lane; i < nflags; i += 64) ok &= fault_load(xflag + i) >= (unsigned)s;
+          if (__all(ok)) break;
+          if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) return;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const u32x4* src = xdata + (size_t)((s - 1) & 1) * (HP * BT);
+#pragma unroll
+      for (int c0 = 0; c0 < NCH; c0 += 8) {
+        const u32x4* p[8];
+        u32x4 v[8];
+        int cc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int jr = c0 + q + cu;                      // workgroup-dependent start: spread the L2 channels
+          cc[q] = tid + 256 * (jr % NCH);
+          const int u = cc[q] / BT;
+          p[q] = src + (u < uvalid ? cc[q] : 0);
+        }
+        load8_sc1(p, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int u = cc[q] / BT, b = cc[q] % BT;
+          if (u < uvalid) {
+            const int ai = a_img_idx(u, b);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sA[g * HP * 16 + ai] = __uint_as_float(v[q][g]);
+          }
+        }
+      }
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* ap = sA + wave * HP * 16 + ((kq * 16 + n) << 2);
@@ -369,38 +455,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
       for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + n] = acc[r];
       __syncthreads();
     }
-    const bool active = t < len && j < H;
-    float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
-    if (active) {
-      float dh = st.dout;
-      if (s > 0) dh += (red[(0 * 16 + gb) * 16 + gu] + red[(1 * 16 + gb) * 16 + gu]) + (red[(2 * 16 + gb) * 16 + gu] + red[(3 * 16 + gb) * 16 + gu]);
-      float cp = 0.f;                                        // cell state entering this frame
-      if (d == 0) { if (t > 0) cp = st.cp; }
-      else        { if (t + 1 < len) cp = st.cp; }
-      const float tc = tanhf(st.c);
-      const float dc = dcs + dh * st.og * (1.f - tc * tc);
-      dgo = dh * tc * (st.og * (1.f - st.og));
-      dgi = dc * st.gg * (st.ig * (1.f - st.ig));
-      dgf = dc * cp * (st.fg * (1.f - st.fg));
-      dgg = dc * st.ig * (1.f - st.gg * st.gg);
-      dcn = dc * st.fg;
+    if (gthread) {
+      const bool active = t < len && j < H;
+      float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
+      if (active) {
+        float dh = st.dout;
+        if (s > 0) dh += (red[(0 * 16 + gb) * 16 + gu] + red[(1 * 16 + gb) * 16 + gu]) + (red[(2 * 16 + gb) * 16 + gu] + red[(3 * 16 + gb) * 16 + gu]);
+        float cp = 0.f;                                        // cell state entering this frame
+        if (d == 0) { if (t > 0) cp = st.cp; }
+        else        { if (t + 1 < len) cp = st.cp; }
+        const float tc = tanhf(st.c);
+        const float dc = dcs + dh * st.og * (1.f - tc * tc);
+        dgo = dh * tc * (st.og * (1.f - st.og));
+        dgi = dc * st.gg * (st.ig * (1.f - st.ig));
+        dgf = dc * cp * (st.fg * (1.f - st.fg));
+        dgg = dc * st.ig * (1.f - st.gg * st.gg);
+        dcn = dc * st.fg;
+      }
+      dcs = dcn;
+      if (s + 1 < T) {
+        float* dst = reinterpret_cast<float*>(xdata + (size_t)(s & 1) * (HP * BT) + (size_t)j * BT + gb);
+        payload_store(dst + 0, dgi, xcd_local);
+        payload_store(dst + 1, dgf, xcd_local);
+        payload_store(dst + 2, dgg, xcd_local);
+        payload_store(dst + 3, dgo, xcd_local);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's payload is in L2 (or written through) ...
+        if (lane == 0) flag_store(xflag + cu * NW + wave, (unsigned)(s + 1), xcd_local);   // ... before its flag says so
+      }
+      if (store_ok) {
+        const long row = (long)bg * T + t;
+        a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
+        a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
+        a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
+        a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
+      }
+      if (s + 1 < T) st = load_stash(s + 1);
     }
-    dcs = dcn;
-    if (s + 1 < T && j < HP) {
-      unsigned long long* dst = xb + (size_t)(s & 1) * (16 * 4 * HP) + (size_t)j * 16 + gb;
-      xch_store(dst + (size_t)0 * HP * 16, dgi, (unsigned)(s + 1), xcd_local);
-      xch_store(dst + (size_t)1 * HP * 16, dgf, (unsigned)(s + 1), xcd_local);
-      xch_store(dst + (size_t)2 * HP * 16, dgg, (unsigned)(s + 1), xcd_local);
-      xch_store(dst + (size_t)3 * HP * 16, dgo, (unsigned)(s + 1), xcd_local);
-    }
-    if (store_ok) {
-      const long row = (long)bg * T + t;
-      a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
-      a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
-      a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
-      a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
-    }
-    if (s + 1 < T) st = load_stash(s + 1);
   }
 }
 

@@ -191,7 +191,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 /* GT_OPT_LSTM_PERSISTENT (default 1): recurrent generators (models.py:170-213) run each layer's time loop as ONE
  * persistent launch (W_hh slices resident in registers, h exchanged between workgroups through tagged granules);
  * 0 = one launch per time step.  GT_OPT_LSTM_FWD_UNITS: hidden units per workgroup of the forward persistent kernel
- * (4, 8 or 16; 0 = automatic). */
+ * (8 or 16; 0 = automatic). */
 #define GT_OPT_LSTM_PERSISTENT 2
 #define GT_OPT_LSTM_FWD_UNITS 3
 /* GT_OPT_LSTM_XCD_LOCAL (default 1): a group of workgroups that verifies at kernel start that it runs on ONE XCD

@@ -69,10 +69,10 @@ int main(int argc, char** argv) {
   float* state = dalloc<float>(5 * st);
   unsigned int* fault = dalloc<unsigned int>(16);
   const int HP = H <= 256 ? 256 : 512;
-  const size_t xch_n = (size_t)dirs * cdiv(B, 16) * 2 * 16 * 4 * HP;
-  const size_t chk_n = (size_t)dirs * cdiv(B, 16) * 256;
+  const size_t xch_n = (size_t)dirs * cdiv(B, 8) * lstm_bwd_xch_u64(HP);       // the larger of the two layouts, 8-sequence tiles
+  const size_t chk_n = (size_t)dirs * cdiv(B, 8) * 256;
   unsigned long long* xch = dalloc<unsigned long long>(xch_n + chk_n);
-  int xcd_local = 1;
+  int xcd_local = 1, bt = 16;
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipFuncSetAttribute((const void*)lstm_fwd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm_lds_bytes()));
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
   };
   auto seq = [&](Bufs& q, bool backward, int upc) -> bool {
     LstmSeqArgs a; memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, 16); a.lengths = lengths;
+    a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, bt); a.lengths = lengths;
     for (int d = 0; d < dirs; ++d) { a.Whh[d] = Whh[d]; a.bih[d] = bih[d]; a.bhh[d] = bhh[d]; }
     a.xproj = q.xproj; a.gates = q.gates; a.cst = q.cst; a.out = q.out; a.dout = dout;
     a.xch = xch; a.fault = fault; a.timeout_ticks = 100000000ULL;     // 1 s
@@ -113,10 +113,12 @@ int main(int argc, char** argv) {
       int per = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, KERN, 256, lds)); \
       if (a.ncu * rounds > per * (prop.multiProcessorCount / 8)) { printf("  %d workgroups per XCD exceed residency %d x %d\n", a.ncu * rounds, per, prop.multiProcessorCount / 8); return false; } \
       hipLaunchKernelGGL(KERN, dim3(grid), dim3(256), lds, s, a); }
-    if (backward) { if (HP == 256) PICK((lstm_bwd_seq_kernel<256>), (lstm_bwd_seq_lds<256>())) else PICK((lstm_bwd_seq_kernel<512>), (lstm_bwd_seq_lds<512>())) }
-    else if (upc == 4) { if (HP == 256) PICK((lstm_fwd_seq_kernel<256, 4>), (lstm_fwd_seq_lds<256, 4>())) else PICK((lstm_fwd_seq_kernel<512, 4>), (lstm_fwd_seq_lds<512, 4>())) }
-    else if (upc == 8) { if (HP == 256) PICK((lstm_fwd_seq_kernel<256, 8>), (lstm_fwd_seq_lds<256, 8>())) else PICK((lstm_fwd_seq_kernel<512, 8>), (lstm_fwd_seq_lds<512, 8>())) }
-    else { if (HP == 256) PICK((lstm_fwd_seq_kernel<256, 16>), (lstm_fwd_seq_lds<256, 16>())) else PICK((lstm_fwd_seq_kernel<512, 16>), (lstm_fwd_seq_lds<512, 16>())) }
+#define PICK_BT(K8, K16, LDS) { if (bt == 8) PICK(K8, LDS) else PICK(K16, LDS) }
+    if (backward) { if (HP == 256) PICK_BT((lstm_bwd_seq_kernel<256, 8>), (lstm_bwd_seq_kernel<256, 16>), (lstm_bwd_seq_lds<256>())) else PICK_BT((lstm_bwd_seq_kernel<512, 8>), (lstm_bwd_seq_kernel<512, 16>), (lstm_bwd_seq_lds<512>())) }
+    else if (upc == 4) { if (HP == 256) PICK_BT((lstm_fwd_seq_kernel<256, 4, 8>), (lstm_fwd_seq_kernel<256, 4, 16>), (lstm_fwd_seq_lds<256, 4>())) else PICK_BT((lstm_fwd_seq_kernel<512, 4, 8>), (lstm_fwd_seq_kernel<512, 4, 16>), (lstm_fwd_seq_lds<512, 4>())) }
+    else if (upc == 8) { if (HP == 256) PICK_BT((lstm_fwd_seq_kernel<256, 8, 8>), (lstm_fwd_seq_kernel<256, 8, 16>), (lstm_fwd_seq_lds<256, 8>())) else PICK_BT((lstm_fwd_seq_kernel<512, 8, 8>), (lstm_fwd_seq_kernel<512, 8, 16>), (lstm_fwd_seq_lds<512, 8>())) }
+    else { if (HP == 256) PICK_BT((lstm_fwd_seq_kernel<256, 16, 8>), (lstm_fwd_seq_kernel<256, 16, 16>), (lstm_fwd_seq_lds<256, 16>())) else PICK_BT((lstm_fwd_seq_kernel<512, 16, 8>), (lstm_fwd_seq_kernel<512, 16, 16>), (lstm_fwd_seq_lds<512, 16>())) }
+#undef PICK_BT
 #undef PICK
     CK(hipGetLastError());
     return true;
@@ -150,11 +152,13 @@ int main(int argc, char** argv) {
   reset_xp(R);
   timed("per-step launches", [&] { steps(R, false); });
   for (int proto = 0; proto < 2; ++proto)
+  for (int btv : {16, 8})
   for (int upc : {4, 8, 16}) {
-    xcd_local = proto;
+    xcd_local = proto; bt = btv;
+    if (proto == 0 && btv == 8) continue;
     reset_xp(P);
     CK(hipMemsetAsync(P.gates, 0xff, (size_t)N * dirs * 4 * H * sizeof(float), s));
-    char nm[64]; snprintf(nm, sizeof(nm), "persistent %s, %d units/wg", proto ? "xcd-local" : "agent", upc);
+    char nm[64]; snprintf(nm, sizeof(nm), "persist. %s bt%d %d units/wg", proto ? "xcd-local" : "agent", bt, upc);
     bool ok = true;
     timed(nm, [&] { ok = seq(P, false, upc); });
     if (ok) report("fwd");
@@ -165,10 +169,12 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(P.cst, R.cst, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
   CK(hipMemcpy(P.out, R.out, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
   timed("per-step launches", [&] { steps(R, true); });
-  for (int proto = 0; proto < 2; ++proto) {
-  xcd_local = proto;
+  for (int proto = 0; proto < 2; ++proto)
+  for (int btv : {16, 8}) {
+  xcd_local = proto; bt = btv;
   bool okb = true;
-  timed(proto ? "persistent xcd-local" : "persistent agent", [&] { okb = seq(P, true, 0); });
+  char nmb[64]; snprintf(nmb, sizeof(nmb), "persistent %s bt%d", proto ? "xcd-local" : "agent", bt);
+  timed(nmb, [&] { okb = seq(P, true, 0); });
   if (okb) {
     double sc;
     double dd = maxdiff(P.xproj, R.xproj, (size_t)N * dirs * 4 * H, &sc);
