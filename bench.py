@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
+    ap.add_argument("--dp-python", action="store_true", help="data parallelism orchestrated from Python (torch.distributed "
+                    "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -186,7 +188,7 @@ def main():
     y_static = get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features)
     mask = sequence_mask(lengths).unsqueeze(-1)
 
-    if world > 1 or args.force_dp:
+    if (world > 1 or args.force_dp) and args.dp_python:
         backend = HipStepBackend(hp, mg, md, og, od)
         dp = DataParallelStep(backend, always_reduce=args.force_dp)
         dp.broadcast_parameters(mg.flat_params(), md.flat_params())
@@ -197,6 +199,21 @@ def main():
             # forward) -- it is part of a data-parallel step for real, ragged batches; no constant is passed in
             return dp.step(batch, adv_w=1.0, mse_w=0.0, mge_w=1.0, lazy_g=True)
     else:
+        if world > 1 or args.force_dp:
+            # the engine's own communicator (include/gantts_hip.h gt_comm_*): rank 0's id travels over the bootstrap
+            # process group once; from then on every collective of a step is issued by the engine itself -- gradient
+            # buckets per layer on its communicator stream, overlapped with the backward pass
+            from gantts_amd.engine import engine_for
+            eng = engine_for(hp, mg)
+            idt = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            dist.broadcast(mg.flat_params(), src=0)
+            dist.broadcast(md.flat_params(), src=0)
+            eng.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+
+
         def step():
             og.zero_grad()
             od.zero_grad()

@@ -16,6 +16,7 @@ OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL = 2, 3, 4
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8
+COMM_ID_BYTES = 128
 
 
 class StreamConfig(C.Structure):
@@ -86,6 +87,10 @@ SIGNATURES = {
     "gt_set_loss_normalizer_device": (_I, [_P, _P]),
     "gt_set_option": (_I, [_P, _I, _I]),
     "gt_check_faults": (_I, [_P, _P]),
+    "gt_comm_unique_id": (_I, [_P]),
+    "gt_comm_init": (_I, [_P, _I, _I, _P]),
+    "gt_comm_destroy": (_I, [_P]),
+    "gt_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "gt_update_discriminator_begin": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "gt_update_discriminator_end": (_I, [_P, _I, C.POINTER(DResult), _P]),
     "gt_update_generator_begin": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _F, _F, _P]),

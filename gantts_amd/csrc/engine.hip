@@ -126,6 +126,18 @@ static int gemm_cu_count() {
   cus[dev] = n;
   return n;
 }
+// per-device ticket counters of the start stagger (mode 3): the two workgroups of a CU draw consecutive tickets
+static unsigned int* gemm_stagger_tickets() {
+  static std::map<int, unsigned int*> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = bufs.find(dev);
+  if (it != bufs.end()) return it->second;
+  unsigned int* p = nullptr;
+  if (hipMalloc((void**)&p, 2048 * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, 2048 * sizeof(unsigned int)) != hipSuccess) p = nullptr;
+  bufs[dev] = p;
+  return p;
+}
 template <int KIND, int BM, int BN, bool VA, bool VB>
 static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
@@ -137,8 +149,12 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   // Start stagger (gemm_f32.hip.h): with two or more workgroups per CU, the one in an odd wave slot starts 0.5 us late.
   // Measured on MI355X (tools/gemm_stagger_bench.hip, random operands): 16384x512x512 forward 90.7 -> 80.4 us,
   // weight gradient 85.9 -> 72.7 us, 32768x256x256 53.3 -> 48.2 us; delays of 0.5 .. 2 us are equivalent, >= 16 us lose.
-  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 50;
-  if (stagger_ticks > 0 && grid > gemm_cu_count()) { g.stagger_ticks = stagger_ticks; g.stagger_mode = 2; }
+  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 100;
+  static const int stagger_mode = getenv("GT_GEMM_STAGGER_MODE") ? atoi(getenv("GT_GEMM_STAGGER_MODE")) : 3;
+  if (stagger_ticks > 0 && grid > gemm_cu_count()) {
+    g.stagger_ticks = stagger_ticks; g.stagger_mode = stagger_mode;
+    if (stagger_mode == 3 && !(g.stagger_ticket = gemm_stagger_tickets())) g.stagger_ticks = 0;
+  }
   GemmProfiler::Rec rec;
   if (g_prof.on) {
     rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
@@ -371,6 +387,9 @@ struct gt_engine {
   Scratch i2o_gout;                                              // In2OutRNNHighwayNet: hidden2out output G(x)
   Scratch l_state, l_dout, l_hshift;
   Scratch l_xch;                                   // persistent recurrence: exchange granules
+  struct GtComm* comm = nullptr;                   // gt_comm_init: RCCL communicator + comm stream (data parallel)
+  std::vector<std::pair<long, long>> comm_done[2]; // per role: gradient ranges (offset, count) already handed to RCCL this step
+  Scratch comm_tv;                                 // device double: global valid-frame count
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
   bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
@@ -458,6 +477,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   for (auto& s : e->d_act) s.release();
   for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
   e->i2o_gout.release();
+  (void)gt_comm_destroy(e);
+  e->comm_tv.release();
   e->l_state.release(); e->l_dout.release(); e->l_hshift.release(); e->l_xch.release();
   if (e->d_fault) (void)hipFree(e->d_fault);
   if (e->h_fault) (void)hipHostFree(e->h_fault);
@@ -862,6 +883,8 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
   return GT_OK;
 }
 
+static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
+
 // hidden stack backward.  dz_top: gradient w.r.t. the pre-activation of the TOP hidden layer
 // (already multiplied by f'), in buffer `cur` (rows x hidden).  Produces dW/db (if want_w) and,
 // optionally, dX[:, col0:col0+ncols] of the stack input for rows [row0, row0+nrows).
@@ -873,7 +896,10 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
     const Lin& L = n.hidden[l];
     const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
     const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
-    if (want_w) CHK(linear_backward_weight(cur, L.out, Xin, ldx, rows, L.out, L.in, L.dW, L.db, n.grads_dirty, e->slabs, e->colp, s));
+    if (want_w) {
+      CHK(linear_backward_weight(cur, L.out, Xin, ldx, rows, L.out, L.in, L.dW, L.db, n.grads_dirty, e->slabs, e->colp, s));
+      CHK(comm_grads_ready(e, role, L.dW, (long)L.out * L.in + L.out, s));     // this layer's bucket goes out under the layers below
+    }
     if (l > 0) {
       CHK(linear_backward_data(cur, L.out, L.W, L.in, 0, other, L.in, rows, L.out, L.in, ACT_LEAKY_DROPOUT,
                                acts[l - 1].as<float>(), L.in, specs[l - 1], s));
@@ -888,10 +914,183 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
 
 static int cond_dim(gt_engine* e);
 
-// tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask)
+// ------------------------------------------------------------------------------------------
+// data-parallel communicator (gt_comm_init / gt_comm_destroy).
+// One process per GPU; every rank holds the full G / D and a shard of the minibatch (whole sequences).  With a
+// communicator attached, the fused step functions are data-parallel by themselves: the valid-frame count, every
+// network's gradient and the additive loss sums are summed over the ranks with RCCL (the ROCm build of NCCL, xGMI
+// between the GPUs of a node) on a separate HIP stream, each gradient bucket (one layer) as soon as its weight-gradient
+// reduction has finished -- i.e. UNDER the rest of the backward pass -- and clip-norm + optimizer run on the reduced
+// gradient, so all replicas take bit-identical steps.  RCCL is bound at run time (dlopen), the library has no link
+// dependency on it; a host in any language drives this through the C ABI.
+// ------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+struct GtNcclId { char internal[GT_COMM_ID_BYTES]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(GtNcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, GtNcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  // prefer the copy that is already in the process (PyTorch ships its own librccl), then the ROCm one
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) return nullptr;
+#define GT_SYM(field, name) *(void**)(&api.field) = dlsym(h, name)
+  GT_SYM(GetUniqueId, "ncclGetUniqueId"); GT_SYM(CommInitRank, "ncclCommInitRank"); GT_SYM(CommDestroy, "ncclCommDestroy");
+  GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GroupStart, "ncclGroupStart"); GT_SYM(GroupEnd, "ncclGroupEnd");
+  GT_SYM(GetErrorString, "ncclGetErrorString");
+#undef GT_SYM
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GroupStart || !api.GroupEnd) return nullptr;
+  api.lib = h;
+  return &api;
+}
+#define NCCLCHK(expr)                                                                                      \
+  do {                                                                                                     \
+    int _r = (expr);                                                                                       \
+    if (_r != 0) return fail(GT_ERR_HIP, "%s failed: %s", #expr, rccl_api()->GetErrorString ? rccl_api()->GetErrorString(_r) : "?"); \
+  } while (0)
+enum { GT_NCCL_SUM = 0, GT_NCCL_FLOAT = 7, GT_NCCL_DOUBLE = 8 };
+
+struct GtComm {
+  void* comm = nullptr;
+  int rank = 0, world = 1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int next_ev = 0;
+  hipEvent_t ev_done = nullptr;
+};
+
+extern "C" int gt_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(GT_ERR_INVALID, "null argument");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(GT_ERR_HIP, "RCCL (librccl.so) could not be loaded");
+  NCCLCHK(api->GetUniqueId((GtNcclId*)id_out));
+  return GT_OK;
+}
+extern "C" int gt_comm_destroy(gt_engine* e) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  if (!e->comm) return GT_OK;
+  (void)hipDeviceSynchronize();
+  GtComm* c = e->comm;
+  if (c->comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  e->comm = nullptr;
+  return GT_OK;
+}
+extern "C" int gt_comm_init(gt_engine* e, int rank, int world, const void* id) {
+  if (!e || !id || world < 1 || rank < 0 || rank >= world) return fail(GT_ERR_INVALID, "bad argument");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(GT_ERR_HIP, "RCCL (librccl.so) could not be loaded");
+  CHK(gt_comm_destroy(e));
+  GtComm* c = new GtComm();
+  c->rank = rank; c->world = world;
+  e->comm = c;
+  GtNcclId nid;
+  memcpy(&nid, id, sizeof(nid));
+  int r = api->CommInitRank(&c->comm, world, nid, rank);
+  if (r != 0) { c->comm = nullptr; (void)gt_comm_destroy(e); return fail(GT_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(r) : "?"); }
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& ev : c->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  CHK(e->comm_tv.ensure(64));
+  return GT_OK;
+}
+extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
+  if (!e || !rank || !world) return fail(GT_ERR_INVALID, "null argument");
+  *rank = e->comm ? e->comm->rank : 0;
+  *world = e->comm ? e->comm->world : 1;
+  return GT_OK;
+}
+
+// all-reduce(sum) of buf[0..count) in place on the communicator's stream, ordered after everything queued on `compute`
+static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute) {
+  GtComm* c = e->comm;
+  hipEvent_t ev = c->ev[c->next_ev];
+  c->next_ev = (c->next_ev + 1) % 8;
+  HIPCHK(hipEventRecord(ev, compute));
+  HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, c->stream));
+  return GT_OK;
+}
+// `compute` continues only after everything handed to the communicator so far has finished
+static int comm_join(gt_engine* e, hipStream_t compute) {
+  GtComm* c = e->comm;
+  HIPCHK(hipEventRecord(c->ev_done, c->stream));
+  HIPCHK(hipStreamWaitEvent(compute, c->ev_done, 0));
+  return GT_OK;
+}
+// the gradient of [lo, lo + count) of `role` is final on `compute`: sum it over the ranks, under the rest of the backward
+static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute) {
+  if (!e->comm || !lo || count <= 0) return GT_OK;
+  Net& n = e->net[role];
+  const long off = lo - n.d.grads;
+  if (off < 0 || off + count > n.d.n_params) return fail(GT_ERR_STATE, "gradient bucket outside the bound buffer");
+  CHK(comm_allreduce_after(e, n.d.grads + off, (size_t)count, GT_NCCL_FLOAT, compute));
+  e->comm_done[role].push_back(std::make_pair(off, count));
+  return GT_OK;
+}
+// end of a backward pass: whatever part of the flat gradient no bucket covered, plus the step's additive loss sums
+// (`n_sums` doubles at `sums`), then `compute` waits for the communicator
+static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute) {
+  if (!e->comm) return GT_OK;
+  Net& n = e->net[role];
+  if (grads) {
+    auto& done = e->comm_done[role];
+    std::sort(done.begin(), done.end());
+    long pos = 0;
+    for (size_t i = 0; i <= done.size(); ++i) {
+      const long next = i < done.size() ? done[i].first : (long)n.d.n_params;
+      if (next > pos) CHK(comm_allreduce_after(e, n.d.grads + pos, (size_t)(next - pos), GT_NCCL_FLOAT, compute));
+      if (i < done.size()) pos = std::max(pos, done[i].first + done[i].second);
+    }
+  }
+  e->comm_done[role].clear();
+  if (sums && n_sums > 0) CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
+  return comm_join(e, compute);
+}
+
+// Data-parallel early results: the step's loss sums are final on `compute` here, long before its backward pass is.
+// They are summed over the ranks, finalised and copied to the host ON THE COMMUNICATOR'S STREAM, so the fused call can
+// return as soon as that copy lands while the backward pass, its gradient buckets and the optimizer keep going.
+static int post_early_results(gt_engine* e, hipStream_t s);
+static int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float adv_w, float mse_w, float mge_w, hipStream_t compute) {
+  GtComm* c = e->comm;
+  CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
+  if (role == GT_ROLE_D) hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), e->res(), 1);
+  else hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
+                          (const double*)nullptr, 0, (const double*)nullptr, 0);
+  LAUNCH_CHECK();
+  return post_early_results(e, c->stream);
+}
+
+// tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask).  With a communicator the
+// count is the GLOBAL one: losses are normalised by the valid frames of the whole minibatch (train.py:258, seqloss.py:43).
 static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
   if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
-  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, e->tv_dev, e->sc());
+  const double* tv_dev = e->tv_dev;
+  if (e->comm && !tv_dev && !(e->tv_override > 0.f)) {
+    hipLaunchKernelGGL(mask_total_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->comm_tv.as<double>());
+    LAUNCH_CHECK();
+    CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
+    CHK(comm_join(e, s));
+    tv_dev = e->comm_tv.as<double>();
+  }
+  hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, tv_dev, e->sc());
   LAUNCH_CHECK();
   e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
   return GT_OK;
@@ -1107,6 +1306,7 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
   // hidden2out: dW = gy^T out_top, db, d out_top = gy W
   CHK(linear_backward_weight(gy, Do, e->l_out[Lc - 1].as<float>(), dirs * H, N, Do, dirs * H, G.last.dW, G.last.db, acc, e->slabs,
                              e->colp, s));
+  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * dirs * H + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
   for (int l = Lc - 1; l >= 0; --l) {
     const LstmLayerP& L = G.lstm[l];
@@ -1132,6 +1332,8 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
       CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, e->slabs,
                                  e->colp, s));
     }
+    // this layer's parameters (both directions: W_ih, W_hh, b_ih, b_hh each) are one contiguous bucket
+    CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), s));
     if (l > 0) {   // gradient w.r.t. the layer below's output: sum over directions of dG_d W_ih_d
       for (int d = 0; d < dirs; ++d) {
         GemmArgs g;
@@ -1238,6 +1440,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
   float* dh = e->l_dout.as<float>();
   float* dh_other = dh + (size_t)N * std::max(ncols, inmax);
   CHK(linear_backward_weight(gy, Do, e->s_h[Lc - 1].as<float>(), ncols, N, Do, ncols, G.last.dW, G.last.db, acc, e->slabs, e->colp, s));
+  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * ncols + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dh, ncols, N, Do, ncols, ACT_NONE, nullptr, 0, no_drop(), s));
   for (int l = Lc - 1; l >= 0; --l) {
     const SruLayerP& L = G.sru[l];
@@ -1261,6 +1464,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     // dW = xin^T dU   (TN: A = xin is m-contiguous over n_in, B = dU)
     CHK(linear_backward_weight(xin, ld_xin, e->s_du.as<float>(), ncols * L.k, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs,
                                e->colp, s));
+    CHK(comm_grads_ready(e, GT_ROLE_G, L.dW, (long)L.in * ncols * L.k + 2L * ncols, s));
     if (l > 0) {
       // d in = (dU W^T) (.) mask_in + highway term     (NT: B[n = i][k = c] = W[i*ldw + c])
       GemmArgs g;
@@ -1468,8 +1672,10 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   hipStream_t s = (hipStream_t)stream;
   const long N = (long)B * T;
   const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
-  CHK(ensure_tv(e, mask, N, s));
   const bool tr = train != 0;
+  if (e->comm && tr && D.grads_dirty)
+    return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
+  CHK(ensure_tv(e, mask, N, s));
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
   CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
@@ -1489,11 +1695,14 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
   // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
+  const bool plain_early = e->early && !e->comm, comm_early = e->early && e->comm;
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
-               e->d_specs.back(), true, s, e->early ? e->res() : nullptr));
+               e->d_specs.back(), true, s, plain_early ? e->res() : nullptr));
   e->early_done = false;
-  if (e->early) CHK(post_early_results(e, s));
+  if (plain_early) CHK(post_early_results(e, s));
+  if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
   if (tr) {
+    CHK(comm_grads_ready(e, GT_ROLE_D, D.last.dW, (long)D.last.in * D.last.out + D.last.out, s));
     // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
     // (the autograd graph in the reference, train.py:265) and a generator with grads exists
     Net& G = e->net[GT_ROLE_G];
@@ -1508,6 +1717,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     D.grads_dirty = true;
     if (want_leak) e->leak_pending = true;
   }
+  // data parallel: the rest of D's gradient + the four loss / count sums, then the step stream waits for the communicator
+  CHK(comm_finish_step(e, GT_ROLE_D, tr, &e->sc()->s_real, comm_early ? 0 : 4, s));
   e->d_begin_done = true;
   return GT_OK;
 }
@@ -1600,6 +1811,7 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     LAUNCH_CHECK();
     CHK(linear_backward_weight(e->dtz.as<float>(), sd, x, G.d.in_dim, N, sd, sd, G.gate.dW, G.gate.db, G.grads_dirty, e->slabs,
                                e->colp, s));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.gate.dW, (long)sd * sd + sd, s));
     CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
   } else if (e->g_used_mlpg) {
     CHK(mlpg_backward(e, gs, e->Ds, e->d_scol, e->d_sstride, e->Ds, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
@@ -1619,6 +1831,7 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   const Lin& Lt = G.hidden.back();
   CHK(linear_backward_weight(gy, Do, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
                              e->slabs, e->colp, s));
+  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
   const int H = G.d.hidden_dim;
   CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
   CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
@@ -1649,6 +1862,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   const int Do = G.d.out_dim;
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
+  if (e->comm && tr && G.grads_dirty)
+    return fail(GT_ERR_STATE, "data-parallel step: optimizer_g.zero_grad() must precede update_generator");
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
   const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
@@ -1683,7 +1898,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     }
   }
   // MGE loss + gradient assembly at y_hat_static
-  const bool early_now = e->early && !(tr && direct && mse_w != 0.f);
+  const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
+  const bool early_now = early_ok && !e->comm, comm_early = early_ok && e->comm;
   int mge_blocks = 0;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
@@ -1707,10 +1923,12 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));
   }
+  if (comm_early) CHK(comm_early_results(e, GT_ROLE_G, &e->sc()->s_adv, 3, adv_w, mse_w, mge_w, s));
   if (tr) {
     CHK(generator_backward(e, e->last_x, y, y_hat, mask, mse_w, s));  // G's own input (cat(x, z), train.py:542)
     e->leak_pending = false;
   }
+  CHK(comm_finish_step(e, GT_ROLE_G, tr, &e->sc()->s_adv, comm_early ? 0 : 3, s));
   e->g_begin_done = true;
   return GT_OK;
 }

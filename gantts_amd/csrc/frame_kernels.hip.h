@@ -101,6 +101,15 @@ __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_
   }
 }
 
+// out[0] = sum(mask[0..n)) as a double (data parallel: the local term of the global valid-frame count)
+__global__ void mask_total_kernel(const float* __restrict__ mask, int n, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)mask[i];
+  const double tot = block_sum_d(v, sh);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
 // mask[b][t] = t < len[b]   (reference gantts/seqloss.py:9-20)
 __global__ void sequence_mask_kernel(const long* __restrict__ lengths, int B, int T, float* __restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

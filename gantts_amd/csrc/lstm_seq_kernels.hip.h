@@ -107,6 +107,7 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
   const int m = tid % BT, k0 = tid / BT;
   unsigned spins = 0;
   unsigned long long t_start = 0;
+#ifndef GT_SEQ_NO_SENTINEL
   {
     const int ks = k0 + KS_ * (rot % NG);
     if (ks < kvalid) {
@@ -119,6 +120,7 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
       }
     }
   }
+#endif
   unsigned long long v[NG];
   int kk[NG];
 #pragma unroll

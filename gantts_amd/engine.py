@@ -130,6 +130,31 @@ class StepEngine(object):
         self._bound_opt[role] = (weakref.ref(optimizer), optimizer._version, now)
         optimizer._engines[id(self)] = (weakref.ref(self), role)
 
+    # ---- data-parallel communicator (RCCL inside the engine; include/gantts_hip.h gt_comm_*) -------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes identifying a new communicator: rank 0 creates them, every rank passes them to ``comm_init``."""
+        buf = (C.c_char * L.COMM_ID_BYTES)()
+        check(lib.gt_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, world, unique_id):
+        """Collective over all ranks.  From here on the fused step functions of this engine are data-parallel: gradients
+        (bucketed per layer, overlapped with backward), loss sums and the valid-frame count are summed over the ranks
+        inside ``update_discriminator`` / ``update_generator``, which return the GLOBAL scalars on every rank."""
+        if len(unique_id) != L.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % L.COMM_ID_BYTES)
+        buf = (C.c_char * L.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib.gt_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_destroy(self):
+        check(lib.gt_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        check(lib.gt_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def check_faults(self):
         """Synchronises the current stream and raises if a persistent kernel gave up waiting for a peer."""
         check(lib.gt_check_faults(self._h, L.current_stream()))

@@ -21,9 +21,10 @@ import torch.distributed as dist
 
 
 class DataParallelStep(object):
-    def __init__(self, backend, process_group=None, always_reduce=False):
+    def __init__(self, backend, process_group=None, always_reduce=False, reduce_via_host=False):
         self.backend = backend
         self.pg = process_group
+        self.via_host = reduce_via_host    # device tensors through a CPU-only process group (gloo): tests on one GPU
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always_reduce = always_reduce and dist.is_initialized()   # exercise the collectives with one rank
         self._pending = None
@@ -34,6 +35,12 @@ class DataParallelStep(object):
         """Sum over ranks, in place.  Several tensors (the flat gradient + the few loss sums of the same step)
         go out as ONE coalesced launch where the backend supports it (RCCL: one group call, one latency)."""
         if not (self.world > 1 or self.always_reduce):
+            return
+        if self.via_host:
+            for t in tensors:
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+                t.copy_(h)
             return
         if len(tensors) > 1 and self._coalesce:
             try:
@@ -69,7 +76,9 @@ class DataParallelStep(object):
                 # the global valid-frame count stays on the device: its all-reduce overlaps the generator
                 # forward and nobody synchronises with the host for it
                 tv_global = be.mask_of(batch).sum().reshape(1).double()
-                if self.world > 1 or self.always_reduce:
+                if self.via_host:
+                    self._allreduce(tv_global)
+                elif self.world > 1 or self.always_reduce:
                     tv_work = dist.all_reduce(tv_global, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             else:
                 tv_global = self.global_valid_frames(be.mask_of(batch))

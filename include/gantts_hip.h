@@ -202,6 +202,21 @@ int gt_set_option(gt_engine* e, int option, int value);
  * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;
  * this call synchronises `stream` and reports the current state. */
 int gt_check_faults(gt_engine* e, void* stream);
+/* ---- data-parallel communicator (one process per GPU; RCCL == NCCL on ROCm, bound at run time) ----
+ * The reference has no multi-device code; the step being sharded is train.py:538-585.  Every rank holds the
+ * full G / D and whole sequences of the minibatch.  With a communicator attached the FUSED step functions above are
+ * data-parallel by themselves: the valid-frame count, each network's gradient (one bucket per layer, handed to RCCL as
+ * soon as that layer's weight gradient is final, i.e. overlapped with the rest of the backward pass) and the additive
+ * loss / count sums are summed over the ranks; clip-norm + optimizer then run on the reduced gradient, so all replicas
+ * take bit-identical steps and every rank returns the GLOBAL scalars.  zero_grad must precede each update_* call.
+ * gt_comm_unique_id: rank 0 fills `id_out` (GT_COMM_ID_BYTES) and ships it to the other ranks by any means;
+ * gt_comm_init: collective over all ranks (ncclCommInitRank); gt_comm_destroy detaches (also done by gt_engine_destroy). */
+#define GT_COMM_ID_BYTES 128
+int gt_comm_unique_id(void* id_out);
+int gt_comm_init(gt_engine* e, int rank, int world, const void* id);
+int gt_comm_destroy(gt_engine* e);
+int gt_comm_info(gt_engine* e, int* rank, int* world);
+
 int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                   const float* mask, int B, int T, int train, float eps, void* stream);
 int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream);

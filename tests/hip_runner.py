@@ -28,7 +28,7 @@ def build_model(spec, seed):
     return m.cuda()
 
 
-def run_hip_case(case, return_objects=False, engine_options=None):
+def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False):
     import gantts_amd.train as T
     from gantts_amd import optim, paramgen
     from gantts_amd.multistream import get_static_features
@@ -46,6 +46,10 @@ def run_hip_case(case, return_objects=False, engine_options=None):
         from gantts_amd.engine import engine_for
         for k, v in engine_options.items():
             engine_for(hp, mg).set_option(k, v)
+    if comm_world_1:      # the engine's own data-parallel path (RCCL communicator, bucketed all-reduce) with a single rank
+        from gantts_amd.engine import engine_for
+        eng = engine_for(hp, mg)
+        eng.comm_init(0, 1, eng.comm_unique_id())
     x_np, y_np, lengths = C.make_batch(case)
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
     Tn = case["T"]

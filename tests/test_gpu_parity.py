@@ -870,6 +870,100 @@ def test_inference_path_matches_reference_golden():
         INF.gen_parameters(gold["acoustic_predicted.mlp"], Y_mean, Y_std, mge_training=False)
 
 
+@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out"])
+def test_engine_communicator_world_1_matches_reference_golden(name):
+    """gt_comm_init with one rank: the step goes through the engine's data-parallel path (global valid-frame count,
+    per-layer gradient buckets handed to RCCL on the communicator's stream under the backward pass, loss sums, join,
+    clip + optimizer on the reduced gradient) and must reproduce the reference-generated fixture exactly like the
+    plain path does."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = run_hip_case(case, comm_world_1=True)
+    for k in gold.files:
+        if k.startswith("g_leak_norm"):
+            continue
+        if "scalars" in k:
+            _close(got[k], gold[k], msg=k)
+            if k.startswith("d_scalars"):
+                assert got[k][3] == gold[k][3] and got[k][4] == gold[k][4]
+        elif ".opt." in k:
+            _close(got[k], gold[k], rtol=5e-4, atol=1e-9, msg=k)
+        else:
+            _close(got[k], gold[k], msg=k)
+
+
+def _dp2_hip_worker(rank, world, port, q):
+    """One of two processes sharing cuda:0: HipStepBackend on its shard, DataParallelStep over a gloo group (device
+    tensors staged through the host -- two RCCL ranks cannot share one GPU)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gantts_amd.train as T
+    from gantts_amd import optim, paramgen
+    from gantts_amd.engine import HipStepBackend
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.parallel import DataParallelStep
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model, make_hp
+    case = C.CASES["acoustic_mlp"]
+    hp = make_hp(case)
+    T.hp = hp
+    mg, md = build_model(case["g"], 11).eval(), build_model(case["d"], 22).eval()
+    og = getattr(optim, case["opt_g"][0])(mg.parameters(), **case["opt_g"][1])
+    od = getattr(optim, case["opt_d"][0])(md.parameters(), **case["opt_d"][1])
+    x_np, y_np, lengths = C.make_batch(case)
+    rows = np.arange(case["B"])[rank::world]
+    x, y = torch.from_numpy(x_np[rows]).cuda(), torch.from_numpy(y_np[rows]).cuda()
+    lens = lengths[rows]
+    batch = dict(x=x, y=y, R=paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, case["T"]), lengths=list(lens),
+                 y_static=get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features),
+                 mask=sequence_mask(torch.from_numpy(lens).cuda(), max_len=case["T"]).unsqueeze(-1))
+    dp = DataParallelStep(HipStepBackend(hp, mg, md, og, od), reduce_via_host=True)
+    hist = []
+    for _ in range(case["steps"]):
+        d, g = dp.step(batch, adv_w=case["adv_w"], mse_w=case["mse_w"], mge_w=case["mge_w"])
+        hist.append((tuple(d), tuple(g)))
+    torch.cuda.synchronize()
+    params = {"G." + k: v.cpu().numpy() for k, v in mg.state_dict().items()}
+    params.update({"D." + k: v.cpu().numpy() for k, v in md.state_dict().items()})
+    q.put((rank, hist, params))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_hip_backend_two_processes_equal_whole_batch_golden():
+    """world_size 2 through a REAL process group with the HIP split-phase backend on both ranks (one GPU, two
+    processes, two engines): sharded batch == the reference's result on the whole batch, replicas bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    case = C.CASES["acoustic_mlp"]
+    gold = np.load(os.path.join(GOLDEN, "acoustic_mlp.npz"))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp2_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, hist, params in results:
+        for i, (d, g) in enumerate(hist):
+            _close(d, gold["d_scalars_%d" % i], msg="dp2 rank %d step %d D" % (rank, i))
+            assert d[3] == gold["d_scalars_%d" % i][3] and d[4] == gold["d_scalars_%d" % i][4]
+            _close(g, gold["g_scalars_%d" % i], msg="dp2 rank %d step %d G" % (rank, i))
+    for k in results[0][2]:
+        _close(results[0][2][k], gold[k], msg="dp2 " + k)
+    for k in results[0][2]:
+        assert np.array_equal(results[0][2][k], results[1][2][k]), k       # replicas bit-identical
+
+
 def test_data_parallel_step_through_rccl_world_1():
     """DataParallelStep with a real process group (backend "nccl" == RCCL, one rank, every collective executed:
     async all-reduce of the device-resident valid-frame count, coalesced gradient + loss-sum all-reduces) ==

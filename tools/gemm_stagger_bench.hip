@@ -99,5 +99,46 @@ int main(int argc, char** argv) {
     hipFree(dbg);
     hipFree(A); hipFree(B); hipFree(Cc); hipFree(Hh); hipFree(bias);
   }
+  // ---- mixed sequence: the five launches one after the other (as inside a training step), repeated
+  {
+    struct Buf { float *A, *B, *C, *H, *bias; };
+    std::vector<Buf> bufs; std::vector<GemmArgs> gs; std::vector<int> slabs;
+    for (const Shape& sh : shapes) {
+      const bool tn = sh.kind == GEMM_TN;
+      Buf b; b.A = dfill((size_t)(tn ? sh.K * sh.M : sh.M * sh.K), 1.f, 1); b.B = dfill((size_t)sh.N * sh.K, 0.05f, 2);
+      CK(hipMalloc((void**)&b.C, (size_t)(tn ? 32 : 1) * sh.M * sh.N * 4 + 64)); b.H = dfill((size_t)sh.M * sh.N, 1.f, 3); b.bias = dfill(sh.N, 0.1f, 4);
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.M = sh.M; g.N = sh.N; g.K = sh.K; g.C = b.C; g.ldc = sh.N; g.wide_store = 1;
+      g.drop.mode = DROP_PHILOX; g.drop.p = 0.5f; g.drop.scale = 2.f; g.drop.thresh = 32768; g.drop.key0 = 123; g.drop.key1 = 456;
+      int nslab = 1;
+      if (sh.kind == GEMM_NT) { g.A = b.A; g.lda = sh.K; g.B = b.B; g.ldb = sh.K; g.bias = b.bias; g.act = ACT_LEAKY_DROPOUT; }
+      else if (sh.kind == GEMM_NN) { g.A = b.A; g.lda = sh.K; g.B = b.B; g.ldb = sh.N; g.act = ACT_LEAKY_DROPOUT; g.H = b.H; g.ldh = sh.N; }
+      else { g.A = b.A; g.lda = sh.M; g.B = b.B; g.ldb = sh.N; nslab = 32; g.k_chunk = sh.K / 32; g.slab_stride = (long)sh.M * sh.N; g.drop.mode = DROP_NONE; g.act = ACT_NONE; }
+      bufs.push_back(b); gs.push_back(g); slabs.push_back(nslab);
+    }
+    auto launch_one = [&](int i, int mode, int ticks) {
+      GemmArgs g = gs[i]; g.stagger_mode = mode; g.stagger_ticks = ticks; g.stagger_ticket = ticket;
+      const Shape& sh = shapes[i];
+#define L1(KIND, BM) { const size_t lds = gemm_lds_bytes<KIND, BM, 128>(); auto kern = gemm_f32_kernel<KIND, BM, 128, true, true>; \
+        g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + 127) / 128; \
+        hipLaunchKernelGGL(kern, dim3(g.n_tiles_m * g.n_tiles_n * slabs[i]), dim3(256), lds, 0, g); }
+      if (sh.kind == GEMM_NT) { if (sh.bm == 128) L1(GEMM_NT, 128) else L1(GEMM_NT, 64) }
+      else if (sh.kind == GEMM_NN) L1(GEMM_NN, 128)
+      else L1(GEMM_TN, 128)
+#undef L1
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double fl = 0; for (const Shape& sh : shapes) fl += 2.0 * sh.M * sh.N * sh.K;
+    for (int mode : {0, 2, 3}) for (int ticks : {50, 100, 200}) {
+      if (mode == 0 && ticks != 50) continue;
+      for (int it = 0; it < 3; ++it) for (int i = 0; i < 5; ++i) launch_one(i, mode, mode ? ticks : 0);
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < reps; ++it) for (int i = 0; i < 5; ++i) launch_one(i, mode, mode ? ticks : 0);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("mixed sequence of the 5 launches: mode %d delay %.1f us: %.1f us per sequence  %.1f TFLOP/s\n", mode, mode ? ticks / 100.0 : 0.0,
+             ms * 1e3 / reps, fl / (ms * 1e-3 / reps) / 1e12);
+    }
+  }
   return 0;
 }
