@@ -146,10 +146,11 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
-  // Start stagger (gemm_f32.hip.h): with two or more workgroups per CU, the one in an odd wave slot starts 0.5 us late.
-  // Measured on MI355X (tools/gemm_stagger_bench.hip, random operands): 16384x512x512 forward 90.7 -> 80.4 us,
-  // weight gradient 85.9 -> 72.7 us, 32768x256x256 53.3 -> 48.2 us; delays of 0.5 .. 2 us are equivalent, >= 16 us lose.
-  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 100;
+  // Start stagger (gemm_f32.hip.h), OFF by default: in isolation (tools/gemm_stagger_bench.hip, dense random operands,
+  // the five big launches of a step back to back) letting one of the two workgroups of a CU start 0.5 .. 2 us late is
+  // worth 10-15 % (372 -> 325 us per sequence); inside the training step it measured 0.0 % in every mode,
+  // so it stays a measurement switch: GT_GEMM_STAGGER_TICKS (10 ns units), GT_GEMM_STAGGER_MODE.
+  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 0;
   static const int stagger_mode = getenv("GT_GEMM_STAGGER_MODE") ? atoi(getenv("GT_GEMM_STAGGER_MODE")) : 3;
   if (stagger_ticks > 0 && grid > gemm_cu_count()) {
     g.stagger_ticks = stagger_ticks; g.stagger_mode = stagger_mode;
@@ -389,7 +390,9 @@ struct gt_engine {
   Scratch l_xch;                                   // persistent recurrence: exchange granules
   struct GtComm* comm = nullptr;                   // gt_comm_init: RCCL communicator + comm stream (data parallel)
   std::vector<std::pair<long, long>> comm_done[2]; // per role: gradient ranges (offset, count) already handed to RCCL this step
+  std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
+  bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
   bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
@@ -673,7 +676,7 @@ extern "C" int gt_set_loss_normalizer(gt_engine* e, float tv) {
 extern "C" int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_dev) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
   e->tv_dev = tv_dev;
-  e->tv_mask = nullptr;          // re-read on the next step function
+  e->tv_mask = nullptr; e->tv_inflight = false;          // re-read on the next step function
   return GT_OK;
 }
 extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, void* stream) {
@@ -708,7 +711,7 @@ extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, 
 extern "C" int gt_zero_grad(gt_engine* e, int role) {
   if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
   e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
-  e->tv_mask = nullptr;
+  e->tv_mask = nullptr; e->tv_inflight = false;
   if (role == GT_ROLE_G) e->leak_pending = false;
   return GT_OK;
 }
@@ -884,6 +887,7 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
 }
 
 static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
+static int comm_flush(gt_engine* e, int role, hipStream_t compute);
 
 // hidden stack backward.  dz_top: gradient w.r.t. the pre-activation of the TOP hidden layer
 // (already multiplied by f'), in buffer `cur` (rows x hidden).  Produces dW/db (if want_w) and,
@@ -898,7 +902,8 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
     const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
     if (want_w) {
       CHK(linear_backward_weight(cur, L.out, Xin, ldx, rows, L.out, L.in, L.dW, L.db, n.grads_dirty, e->slabs, e->colp, s));
-      CHK(comm_grads_ready(e, role, L.dW, (long)L.out * L.in + L.out, s));     // this layer's bucket goes out under the layers below
+      CHK(comm_grads_ready(e, role, L.dW, (long)L.out * L.in + L.out, s));
+      if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
     }
     if (l > 0) {
       CHK(linear_backward_data(cur, L.out, L.W, L.in, 0, other, L.in, rows, L.out, L.in, ACT_LEAKY_DROPOUT,
@@ -1034,14 +1039,33 @@ static int comm_join(gt_engine* e, hipStream_t compute) {
   HIPCHK(hipStreamWaitEvent(compute, c->ev_done, 0));
   return GT_OK;
 }
-// the gradient of [lo, lo + count) of `role` is final on `compute`: sum it over the ranks, under the rest of the backward
+// the gradient of [lo, lo + count) of `role` is final on `compute`.  Ranges are collected and handed to RCCL by
+// comm_flush in as few messages as their adjacency allows (a small all-reduce is pure latency: the layers above the
+// first one leave together, under the first layer's backward; only the first layer's message is exposed).
 static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute) {
   if (!e->comm || !lo || count <= 0) return GT_OK;
   Net& n = e->net[role];
   const long off = lo - n.d.grads;
   if (off < 0 || off + count > n.d.n_params) return fail(GT_ERR_STATE, "gradient bucket outside the bound buffer");
-  CHK(comm_allreduce_after(e, n.d.grads + off, (size_t)count, GT_NCCL_FLOAT, compute));
-  e->comm_done[role].push_back(std::make_pair(off, count));
+  e->comm_pending[role].push_back(std::make_pair(off, count));
+  return GT_OK;
+}
+static int comm_flush(gt_engine* e, int role, hipStream_t compute) {
+  if (!e->comm) return GT_OK;
+  auto& pend = e->comm_pending[role];
+  if (pend.empty()) return GT_OK;
+  Net& n = e->net[role];
+  std::sort(pend.begin(), pend.end());
+  size_t i = 0;
+  while (i < pend.size()) {
+    long lo = pend[i].first, hi = lo + pend[i].second;
+    size_t j = i + 1;
+    while (j < pend.size() && pend[j].first <= hi) { hi = std::max(hi, pend[j].first + pend[j].second); ++j; }
+    CHK(comm_allreduce_after(e, n.d.grads + lo, (size_t)(hi - lo), GT_NCCL_FLOAT, compute));
+    e->comm_done[role].push_back(std::make_pair(lo, hi - lo));
+    i = j;
+  }
+  pend.clear();
   return GT_OK;
 }
 // end of a backward pass: whatever part of the flat gradient no bucket covered, plus the step's additive loss sums
@@ -1050,6 +1074,7 @@ static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, in
   if (!e->comm) return GT_OK;
   Net& n = e->net[role];
   if (grads) {
+    CHK(comm_flush(e, role, compute));
     auto& done = e->comm_done[role];
     std::sort(done.begin(), done.end());
     long pos = 0;
@@ -1060,6 +1085,7 @@ static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, in
     }
   }
   e->comm_done[role].clear();
+  e->comm_pending[role].clear();
   if (sums && n_sums > 0) CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
   return comm_join(e, compute);
 }
@@ -1080,14 +1106,25 @@ static int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, 
 
 // tv = sum(mask) (or the data-parallel override) -> device scalars; once per (step, mask).  With a communicator the
 // count is the GLOBAL one: losses are normalised by the valid frames of the whole minibatch (train.py:258, seqloss.py:43).
+// Two halves so that the all-reduce of the count runs under the forward pass that precedes its first use:
+// ensure_tv_begin where the mask is first seen, ensure_tv right before the first kernel that reads the normaliser.
+static int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t s) {
+  if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
+  if (e->comm && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight) {
+    hipLaunchKernelGGL(mask_total_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->comm_tv.as<double>());
+    LAUNCH_CHECK();
+    CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
+    e->tv_inflight = true;
+  }
+  return GT_OK;
+}
 static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
   if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
   const double* tv_dev = e->tv_dev;
   if (e->comm && !tv_dev && !(e->tv_override > 0.f)) {
-    hipLaunchKernelGGL(mask_total_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->comm_tv.as<double>());
-    LAUNCH_CHECK();
-    CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
+    CHK(ensure_tv_begin(e, mask, N, s));
     CHK(comm_join(e, s));
+    e->tv_inflight = false;
     tv_dev = e->comm_tv.as<double>();
   }
   hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->tv_override, tv_dev, e->sc());
@@ -1334,6 +1371,7 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
     }
     // this layer's parameters (both directions: W_ih, W_hh, b_ih, b_hh each) are one contiguous bucket
     CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), s));
+    CHK(comm_flush(e, GT_ROLE_G, s));               // with hidden2out above it: under the recurrence of the layer below
     if (l > 0) {   // gradient w.r.t. the layer below's output: sum over directions of dG_d W_ih_d
       for (int d = 0; d < dirs; ++d) {
         GemmArgs g;
@@ -1465,6 +1503,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     CHK(linear_backward_weight(xin, ld_xin, e->s_du.as<float>(), ncols * L.k, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs,
                                e->colp, s));
     CHK(comm_grads_ready(e, GT_ROLE_G, L.dW, (long)L.in * ncols * L.k + 2L * ncols, s));
+    if (l > 0) CHK(comm_flush(e, GT_ROLE_G, s));
     if (l > 0) {
       // d in = (dU W^T) (.) mask_in + highway term     (NT: B[n = i][k = c] = W[i*ldw + c])
       GemmArgs g;
@@ -1555,7 +1594,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
   e->fake_cat_valid = false;
-  e->tv_mask = nullptr;             // a new batch: the mask contents may have changed
+  e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
   e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
   e->g_pass_valid = true;
@@ -1675,7 +1714,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const bool tr = train != 0;
   if (e->comm && tr && D.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
-  CHK(ensure_tv(e, mask, N, s));
+  CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
   CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
@@ -1696,6 +1735,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   const bool plain_early = e->early && !e->comm, comm_early = e->early && e->comm;
+  CHK(ensure_tv(e, mask, N, s));
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
                e->d_specs.back(), true, s, plain_early ? e->res() : nullptr));
   e->early_done = false;

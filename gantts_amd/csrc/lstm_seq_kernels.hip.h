@@ -95,10 +95,11 @@ __device__ __forceinline__ bool spin_expired(const LstmSeqArgs& a, unsigned& spi
 }
 
 // Forward exchange, consumer side.  Granule (k, m) of `src` lives at k*BT + m; thread -> m = tid % BT and the NG
-// columns k = tid / BT + (256 / BT) * j.  First ONE granule per thread is polled (a different one per workgroup) until
-// it carries `epoch` -- the producers publish within a fraction of a microsecond of each other, and polling the whole
-// image from every workgroup is what saturates the XCD's L2 -- then whole sweeps, started at a workgroup-dependent
-// column so that the workgroups of a group do not walk the L2 channels in lock step.  Values go to the LDS A image.
+// columns k = tid / BT + (256 / BT) * j.  With 16 granules per thread, first ONE of them is polled (a different one per
+// workgroup) until it carries `epoch` -- the producers publish within a fraction of a microsecond of each other, and
+// polling the whole image from every workgroup is what saturates the XCD's L2 -- then whole sweeps, started at a
+// workgroup-dependent column so that the workgroups of a group do not walk the L2 channels in lock step.  Values go
+// to the LDS A image.
 template <int NG, int BT>
 __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int kvalid, float* sA,
                                              const LstmSeqArgs& a, int rot, unsigned fault_code) {
@@ -107,8 +108,7 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
   const int m = tid % BT, k0 = tid / BT;
   unsigned spins = 0;
   unsigned long long t_start = 0;
-#ifndef GT_SEQ_NO_SENTINEL
-  {
+  if (NG > 8) {      // measured (tools/lstm_seq_bench): the extra round trip pays only for the 16-granule sweeps
     const int ks = k0 + KS_ * (rot % NG);
     if (ks < kvalid) {
       const unsigned long long* sp = src + (size_t)ks * BT + m;
@@ -120,7 +120,6 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
       }
     }
   }
-#endif
   unsigned long long v[NG];
   int kk[NG];
 #pragma unroll

@@ -10,7 +10,8 @@ using namespace gt;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 static float* dfill(size_t n, float scale, unsigned s) {
   std::vector<float> h(n);
-  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.f * 2.f - 1.f) * scale; }
+  const bool half_zero = getenv("GT_SB_HALF_ZERO") != nullptr;     // like post-dropout activations: every other value exactly 0
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.f * 2.f - 1.f) * scale; if (half_zero && (s & 0x10000u)) v = 0.f; }
   float* p; CK(hipMalloc((void**)&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
 }
 __global__ void census_kernel(unsigned* keys, unsigned* hw) { if (threadIdx.x == 0) { keys[blockIdx.x] = cu_key(); hw[blockIdx.x] = hw_id_reg(); } }
