@@ -137,6 +137,8 @@ def main():
                     "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
     args = ap.parse_args()
 
+    if args.force_dp:      # a one-rank communicator would otherwise take the plain path (a sum over one rank is the identity)
+        os.environ["GT_COMM_FORCE_COLLECTIVES"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, rendezvous on 127.0.0.1
         # (rank 0 prints the one JSON line; this process is replaced, so its exit status is the job's)

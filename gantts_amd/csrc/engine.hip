@@ -138,10 +138,14 @@ static unsigned int* gemm_stagger_tickets() {
   bufs[dev] = p;
   return p;
 }
-template <int KIND, int BM, int BN, bool VA, bool VB>
+// products of the GEMM family: f32 MFMA (default) or bf16 MFMA with f32 accumulation (GT_OPT_MATMUL_BF16; set per engine
+// entry point for the launches it issues on this thread)
+static thread_local int tl_gemm_prec = PREC_F32;
+
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>
 static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
-  const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
-  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB>, lds));
+  const size_t lds = gemm_lds_bytes<KIND, BM, BN, PREC>();
+  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC>, lds));
   g.n_tiles_m = cdiv(g.M, BM);
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -162,7 +166,7 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
@@ -177,10 +181,16 @@ static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
                  (KIND != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
   const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
   const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
-  if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true>(g, nslab, s);
-  if (va) return launch_gemm_t<KIND, BM, BN, true, false>(g, nslab, s);
-  if (vb) return launch_gemm_t<KIND, BM, BN, false, true>(g, nslab, s);
-  return launch_gemm_t<KIND, BM, BN, false, false>(g, nslab, s);
+  if (tl_gemm_prec == PREC_BF16) {
+    if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true, PREC_BF16>(g, nslab, s);
+    if (va) return launch_gemm_t<KIND, BM, BN, true, false, PREC_BF16>(g, nslab, s);
+    if (vb) return launch_gemm_t<KIND, BM, BN, false, true, PREC_BF16>(g, nslab, s);
+    return launch_gemm_t<KIND, BM, BN, false, false, PREC_BF16>(g, nslab, s);
+  }
+  if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true, PREC_F32>(g, nslab, s);
+  if (va) return launch_gemm_t<KIND, BM, BN, true, false, PREC_F32>(g, nslab, s);
+  if (vb) return launch_gemm_t<KIND, BM, BN, false, true, PREC_F32>(g, nslab, s);
+  return launch_gemm_t<KIND, BM, BN, false, false, PREC_F32>(g, nslab, s);
 }
 
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
@@ -398,6 +408,7 @@ struct gt_engine {
   bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
   int lstm_fwd_upc = 0;                            // 0 = automatic
   bool lstm_xcd_local = getenv("GT_LSTM_NO_XCD_LOCAL") == nullptr;   // GT_OPT_LSTM_XCD_LOCAL
+  bool matmul_bf16 = false;                                          // GT_OPT_MATMUL_BF16
   // sequence lengths travel on the step stream through a small ring (pinned host slot -> device slot): the kernels of
   // the previous step, still queued when the next batch's lengths arrive, keep reading THEIR slot
   static constexpr int LEN_RING = 4;
@@ -664,6 +675,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_LSTM_PERSISTENT: e->lstm_persistent = value != 0; return GT_OK;
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
     case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
+    case GT_OPT_MATMUL_BF16: e->matmul_bf16 = value != 0; return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -977,6 +989,11 @@ struct GtComm {
   hipEvent_t ev_done = nullptr;
 };
 
+// A sum over ONE rank is the identity: a single-rank communicator takes the plain path (no collective, no second
+// stream).  GT_COMM_FORCE_COLLECTIVES=1 issues every call anyway -- the launch / cross-stream cost of the schedule can
+// then be measured on one GPU (bench.py --force-dp).
+static inline bool comm_on(const gt_engine* e);
+
 extern "C" int gt_comm_unique_id(void* id_out) {
   if (!id_out) return fail(GT_ERR_INVALID, "null argument");
   RcclApi* api = rccl_api();
@@ -1022,6 +1039,10 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
   return GT_OK;
 }
 
+static inline bool comm_on(const gt_engine* e) {
+  static const bool force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
+  return e->comm != nullptr && (e->comm->world > 1 || force);
+}
 // all-reduce(sum) of buf[0..count) in place on the communicator's stream, ordered after everything queued on `compute`
 static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute) {
   GtComm* c = e->comm;
@@ -1043,7 +1064,7 @@ static int comm_join(gt_engine* e, hipStream_t compute) {
 // comm_flush in as few messages as their adjacency allows (a small all-reduce is pure latency: the layers above the
 // first one leave together, under the first layer's backward; only the first layer's message is exposed).
 static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute) {
-  if (!e->comm || !lo || count <= 0) return GT_OK;
+  if (!comm_on(e) || !lo || count <= 0) return GT_OK;
   Net& n = e->net[role];
   const long off = lo - n.d.grads;
   if (off < 0 || off + count > n.d.n_params) return fail(GT_ERR_STATE, "gradient bucket outside the bound buffer");
@@ -1051,7 +1072,7 @@ static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count,
   return GT_OK;
 }
 static int comm_flush(gt_engine* e, int role, hipStream_t compute) {
-  if (!e->comm) return GT_OK;
+  if (!comm_on(e)) return GT_OK;
   auto& pend = e->comm_pending[role];
   if (pend.empty()) return GT_OK;
   Net& n = e->net[role];
@@ -1071,7 +1092,7 @@ static int comm_flush(gt_engine* e, int role, hipStream_t compute) {
 // end of a backward pass: whatever part of the flat gradient no bucket covered, plus the step's additive loss sums
 // (`n_sums` doubles at `sums`), then `compute` waits for the communicator
 static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute) {
-  if (!e->comm) return GT_OK;
+  if (!comm_on(e)) return GT_OK;
   Net& n = e->net[role];
   if (grads) {
     CHK(comm_flush(e, role, compute));
@@ -1110,7 +1131,7 @@ static int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, 
 // ensure_tv_begin where the mask is first seen, ensure_tv right before the first kernel that reads the normaliser.
 static int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t s) {
   if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
-  if (e->comm && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight) {
+  if (comm_on(e) && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight) {
     hipLaunchKernelGGL(mask_total_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, e->comm_tv.as<double>());
     LAUNCH_CHECK();
     CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
@@ -1121,7 +1142,7 @@ static int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t 
 static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
   if (e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override) return GT_OK;
   const double* tv_dev = e->tv_dev;
-  if (e->comm && !tv_dev && !(e->tv_override > 0.f)) {
+  if (comm_on(e) && !tv_dev && !(e->tv_override > 0.f)) {
     CHK(ensure_tv_begin(e, mask, N, s));
     CHK(comm_join(e, s));
     e->tv_inflight = false;
@@ -1135,6 +1156,7 @@ static int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {
 
 static int check_common(gt_engine* e, int B, int T) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
+  tl_gemm_prec = e->matmul_bf16 ? PREC_BF16 : PREC_F32;       // every step / forward entry point passes through here
   if (B < 1 || T < 1) return fail(GT_ERR_INVALID, "B and T must be positive");
   if ((long)B * T > 0x3fffffffL) return fail(GT_ERR_INVALID, "B*T too large");
   return GT_OK;
@@ -1712,7 +1734,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const long N = (long)B * T;
   const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
   const bool tr = train != 0;
-  if (e->comm && tr && D.grads_dirty)
+  if (comm_on(e) && tr && D.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
   CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
   const int passes[2] = {0, 1};
@@ -1734,7 +1756,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
   // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
-  const bool plain_early = e->early && !e->comm, comm_early = e->early && e->comm;
+  const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
   CHK(ensure_tv(e, mask, N, s));
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
                e->d_specs.back(), true, s, plain_early ? e->res() : nullptr));
@@ -1902,7 +1924,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   const int Do = G.d.out_dim;
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
-  if (e->comm && tr && G.grads_dirty)
+  if (comm_on(e) && tr && G.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_g.zero_grad() must precede update_generator");
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
@@ -1939,7 +1961,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   // MGE loss + gradient assembly at y_hat_static
   const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
-  const bool early_now = early_ok && !e->comm, comm_early = early_ok && e->comm;
+  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e);
   int mge_blocks = 0;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
@@ -2196,6 +2218,7 @@ extern "C" int gt_op_linear_forward(const float* X, int ldx, const float* W, con
                                     int in_dim, int out_dim, int act, const float* keep_mask, float p, void* stream) {
   if (!X || !W || !Y || rows < 1 || in_dim < 1 || out_dim < 1) return fail(GT_ERR_INVALID, "bad argument");
   if (act < 0 || act > 2) return fail(GT_ERR_INVALID, "unknown activation");
+  tl_gemm_prec = PREC_F32;
   return linear_forward(X, ldx, W, in_dim, bias, Y, ldy, rows, in_dim, out_dim, act, buffer_spec(keep_mask, p, out_dim), (hipStream_t)stream);
 }
 
@@ -2204,6 +2227,7 @@ extern "C" int gt_op_linear_backward(const float* dY, int lddy, const float* X, 
                                      const float* keep_mask_prev, float p_prev, float* dW, float* db, void* stream) {
   if (!dY || rows < 1 || in_dim < 1 || out_dim < 1) return fail(GT_ERR_INVALID, "bad argument");
   hipStream_t s = (hipStream_t)stream;
+  tl_gemm_prec = PREC_F32;
   if (dX) {
     if (!W) return fail(GT_ERR_INVALID, "dX requested without W");
     if (act_prev != ACT_NONE && !H_prev) return fail(GT_ERR_INVALID, "activation derivative requested without H_prev");

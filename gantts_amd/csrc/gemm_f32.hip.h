@@ -32,6 +32,16 @@ namespace gt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// PREC: arithmetic of the products.  PREC_F32: v_mfma_f32_32x32x2_f32 on f32 operands (exact f32, the default).
+// PREC_BF16 (mixed precision, BASELINE.json configs[2]): operands are rounded to bf16 (RNE) on their way into LDS and
+// multiplied by v_mfma_f32_32x32x16_bf16 with f32 accumulation -- 16x the matrix rate; memory layout, epilogues and
+// the f32 master copies of weights / activations / gradients are unchanged.
+enum GemmPrec { PREC_F32 = 0, PREC_BF16 = 1 };
+constexpr int GEMM_KP = 40;     // PREC_BF16: LDS row pitch in bf16 (BK + 8 = 80 bytes: the 16 rows of a ds_read_b128 lane group
+                                // start in 16 different 16-byte slots of the 256-byte bank row)
 
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_THREADS = 256;
@@ -145,11 +155,17 @@ __device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* sme
 // LDS pitches per orientation (floats)
 template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
 template <int KIND, int BN> constexpr int gemm_ldn() { return KIND == GEMM_NT ? BN + 1 : BN + 4; }
-template <int KIND, int BM, int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * GEMM_BK * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float); }
+template <int KIND, int BM, int BN, int PREC = PREC_F32>
+constexpr size_t gemm_lds_bytes() {
+  if (PREC == PREC_F32) return (size_t)2 * GEMM_BK * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float);
+  // bf16 image [2][BM + BN rows][GEMM_KP], but never less than what the epilogue staging (4 waves x 32 x (BN/2 + 4) floats)
+  // and the column-sum scratch (256 x 4 floats) reuse it for
+  size_t img = (size_t)2 * (BM + BN) * GEMM_KP * 2, stg = (size_t)4 * 32 * (BN / 2 + 4) * 4, cs = (size_t)GEMM_THREADS * 4 * 4;
+  return img > stg ? (img > cs ? img : cs) : (stg > cs ? stg : cs);
+}
 
 // VA / VB: operand is loaded 16 B per lane (requires 16-byte aligned base and pitch % 4 == 0)
-template <int KIND, int BM, int BN, bool VA, bool VB>
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int LDM = gemm_ldm<KIND, BM>(), LDN = gemm_ldn<KIND, BN>();
   constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
@@ -162,6 +178,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BK][LDM]
   float* Bs = smem + 2 * GEMM_BK * LDM;      // [2][BK][LDN]
+  // PREC_BF16: row-major bf16 images, k contiguous: Ah[2][BM][GEMM_KP], Bh[2][BN][GEMM_KP]
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+  __bf16* Bh = Ah + 2 * BM * GEMM_KP;
   gemm_start_stagger(g, smem);
 
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
@@ -285,6 +304,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   // registers -> LDS
   auto store_a = [&](int u, float* as) {
     int kk, mm; a_pos(u, kk, mm);
+    if (PREC == PREC_BF16) {
+      __bf16* ah = reinterpret_cast<__bf16*>(as);      // the caller passes the buffer base reinterpreted
+      if (A_KC && VA) {
+        bf16x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (__bf16)ra[u * 4 + c];
+        *reinterpret_cast<bf16x4*>(ah + mm * GEMM_KP + kk) = v;
+      } else if (A_KC) {
+        ah[mm * GEMM_KP + kk] = (__bf16)ra[u];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VWA; ++c) ah[(mm + c) * GEMM_KP + kk] = (__bf16)ra[u * VWA + c];
+      }
+      if (KIND == GEMM_TN && want_csum) {
+#pragma unroll
+        for (int c = 0; c < VWA; ++c) csum[c] += ra[u * VWA + c];
+      }
+      return;
+    }
     if (A_KC) {
 #pragma unroll
       for (int c = 0; c < VWA; ++c) as[(kk + c) * LDM + mm] = ra[u * VWA + c];
@@ -303,6 +341,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   };
   auto store_b = [&](int u, float* bs) {
     int kk, nn; b_pos(u, kk, nn);
+    if (PREC == PREC_BF16) {
+      __bf16* bh = reinterpret_cast<__bf16*>(bs);
+      if (B_KC && VB) {
+        bf16x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (__bf16)rb[u * 4 + c];
+        *reinterpret_cast<bf16x4*>(bh + nn * GEMM_KP + kk) = v;
+      } else if (B_KC) {
+        bh[nn * GEMM_KP + kk] = (__bf16)rb[u];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VWB; ++c) bh[(nn + c) * GEMM_KP + kk] = (__bf16)rb[u * VWB + c];
+      }
+      return;
+    }
     if (B_KC) {
 #pragma unroll
       for (int c = 0; c < VWB; ++c) bs[(kk + c) * LDN + nn] = rb[u * VWB + c];
@@ -335,9 +388,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     for (int u = 0; u < UB; ++u) load_b(u, tail0, krem0);
     pA += stepA; pB += stepB;
 #pragma unroll
-    for (int u = 0; u < UA; ++u) store_a(u, As);
+    for (int u = 0; u < UA; ++u) store_a(u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Ah) : As);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) store_b(u, Bs);
+    for (int u = 0; u < UB; ++u) store_b(u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Bh) : Bs);
   }
   __syncthreads();
 
@@ -356,6 +409,43 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
     const int krem = k_end - (k_begin + (kt + 1) * GEMM_BK);
+    if (PREC == PREC_BF16) {
+      // 8 MFMAs of 32 cycles per K-tile: the loader, not the matrix pipe, sets the pace (the launch is bound by the
+      // f32 operands it streams).  Next tile: global -> registers first, products of this tile, then registers -> the
+      // other LDS buffer; latency is covered by the 3 workgroups a CU holds.
+      if (prefetch) {
+#pragma unroll
+        for (int u = 0; u < UA; ++u) load_a(u, tail, krem);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) load_b(u, tail, krem);
+      }
+      const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * GEMM_KP + 8 * half;
+      const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * GEMM_KP + 8 * half;
+#pragma unroll
+      for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
+        bf16x8 fa[TM], fb[TN_];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * GEMM_KP + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * GEMM_KP + kk * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN_; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (prefetch) {
+        __bf16* aw = Ah + (buf ^ 1) * BM * GEMM_KP;
+        __bf16* bw = Bh + (buf ^ 1) * BN * GEMM_KP;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) store_a(u, reinterpret_cast<float*>(aw));
+#pragma unroll
+        for (int u = 0; u < UB; ++u) store_b(u, reinterpret_cast<float*>(bw));
+        pA += stepA; pB += stepB;
+      }
+      __syncthreads();
+      return;
+    }
     const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31 + half * LDM;
     const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31 + half * LDN;
     float* as_w = As + (buf ^ 1) * GEMM_BK * LDM;
@@ -467,7 +557,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     // LDS region, and the strip leaves row-wise: 16 B per lane, WN*4-byte contiguous row segments
     // (4x fewer store instructions, full-line writes).  H (NN: f' of the producer) is read the same way.
     constexpr int EP = WN + 4;                    // pitch (floats), keeps 16 B alignment
-    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN>(), "epilogue staging exceeds the LDS image");
+    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN, PREC>(), "epilogue staging exceeds the LDS image");
     constexpr int LPR = WN / 4;                   // lanes per row
     constexpr int RPI = 64 / LPR;                 // rows per store instruction
     __syncthreads();                              // the K loop's LDS image is dead from here on

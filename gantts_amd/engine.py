@@ -183,9 +183,10 @@ class StepEngine(object):
 
     def set_option(self, name, value):
         """Engine switches (results unchanged up to fp32 summation order): ``"lstm_persistent"``,
-        ``"lstm_fwd_units"``, ``"lstm_xcd_local"``."""
+        ``"lstm_fwd_units"``, ``"lstm_xcd_local"``; ``"matmul_bf16"`` switches the GEMMs to bf16 products with float32 accumulation."""
         opts = {"lstm_persistent": L.OPT_LSTM_PERSISTENT,
-                "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL}
+                "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL,
+                "matmul_bf16": L.OPT_MATMUL_BF16}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

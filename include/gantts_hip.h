@@ -197,6 +197,11 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 /* GT_OPT_LSTM_XCD_LOCAL (default 1): a group of workgroups that verifies at kernel start that it runs on ONE XCD
  * exchanges through that XCD's L2 (workgroup-scope stores) instead of write-through stores; 0 = always write-through. */
 #define GT_OPT_LSTM_XCD_LOCAL 4
+/* GT_OPT_MATMUL_BF16 (default 0): mixed precision for the frame x weight products of BOTH networks (BASELINE.json
+ * configs[2]): operands are rounded to bfloat16 inside the GEMM and multiplied on the bf16 matrix cores with float32
+ * accumulation; parameters ("master weights"), optimizer state, activations in memory, the recurrent state and every
+ * reduction stay float32.  Results differ from the float32 path at the 1e-2 relative level (tests/test_gpu_parity.py). */
+#define GT_OPT_MATMUL_BF16 5
 int gt_set_option(gt_engine* e, int option, int value);
 /* The persistent recurrence kernels bound every inter-workgroup wait by a wall-clock timeout and raise a device fault
  * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;

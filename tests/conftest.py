@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the communicator tests attach a ONE-rank communicator: make it issue its collectives (a sum over one rank is the
+# identity and would otherwise be skipped), so that the data-parallel schedule itself is what gets tested
+os.environ.setdefault("GT_COMM_FORCE_COLLECTIVES", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:

@@ -646,6 +646,44 @@ def test_oracle_only_step_matches_oracle(name):
             _close(got[k], r, msg=k)
 
 
+def test_matmul_bf16_step_tracks_the_float32_oracle():
+    """GT_OPT_MATMUL_BF16 (BASELINE.json configs[2]: bf16 products, float32 accumulation, float32 master weights and
+    state) on cfg3 at its real widths (BiLSTM 3 x 256, 425 -> 187, conditioned MLP D, B = 32, T = 96): one G+D step against
+    the FLOAT32 CPU oracle.  Tolerances are the measured bf16 rounding level (operands carry 8 mantissa bits: 4e-3
+    relative per value, averaged down by the K ~ 256..512 long sums), an order of magnitude above the float32 path's and
+    two below what a wrong operand layout produces: forward outputs and losses 2e-2 of their scale, gradients 5e-2
+    relative rms per tensor."""
+    from hip_runner import run_hip_case
+    from oracle_runner import run_oracle_case
+    case = dict(C.ORACLE_ONLY_CASES["acoustic_lstm_at_size"])
+    case["steps"] = 1
+    got, objs = run_hip_case(case, return_objects=True, engine_options={"matmul_bf16": 1})
+    ref = run_oracle_case(case)
+    for k in ("y_hat", "y_hat_static"):
+        err = _rms(got[k] - ref[k]) / _rms(ref[k])
+        if _REPORT:
+            open(_REPORT, "a").write("bf16 %-20s rel-rms %.3e\n" % (k, err))
+        assert err < 2e-2, (k, err)
+    for k in ("d_scalars_0", "g_scalars_0"):
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+        if _REPORT:
+            open(_REPORT, "a").write("bf16 %-20s %s vs %s\n" % (k, a, b))
+        assert (rel[:3] < 2e-2).all(), (k, a, b)
+    # parameters after one warm-accumulator Adagrad step: the update is ~ the gradient; compare updates per tensor
+    w0g, w0d = C.make_weights(case["g"], 11), C.make_weights(case["d"], 22)
+    worst = 0.0
+    for tag, w0 in (("G.", w0g), ("D.", w0d)):
+        for name, init in w0.items():
+            ug, ur = got[tag + name] - init, ref[tag + name] - init
+            err = _rms(ug - ur) / max(_rms(ur), 1e-30)
+            worst = max(worst, err)
+            if _REPORT:
+                open(_REPORT, "a").write("bf16 update %-40s rel-rms %.3e\n" % (tag + name, err))
+            assert err < 8e-2, (tag + name, err)
+    assert worst > 1e-4, "suspiciously exact: the bf16 path did not run"
+
+
 def test_lstm_full_size_persistent_equals_per_step_kernels():
     """cfg3 at full size (B=32, T=1024, BiLSTM 3x256, variable lengths): the persistent recurrence kernels (one launch
     per layer, W_hh resident on chip, h / dG exchanged between workgroups) against the per-step kernels the small

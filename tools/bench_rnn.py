@@ -19,12 +19,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--gen", default="lstm", choices=["lstm", "sru"])
+ap.add_argument("--gen", default="lstm", choices=["lstm", "sru", "mlp"])
+ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                help="bf16: GEMM operands rounded to bfloat16, f32 accumulation, f32 master weights / state (GT_OPT_MATMUL_BF16)")
 args = ap.parse_args()
 B, Tn = args.batch, args.frames
 hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
 T.hp = hp
-if args.gen == "lstm":
+if args.gen == "mlp":
+    mg = models.MLP(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False).cuda().train()
+elif args.gen == "lstm":
     mg = models.LSTMRNN(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True, dropout=0.0).cuda().train()
 else:   # hparams.tts_acoustic default generator (hparams.py:211-222)
     mg = models.SRURNN(in_dim=425, out_dim=187, num_hidden=6, hidden_dim=512, bidirectional=True, dropout=0.2,
@@ -40,6 +44,9 @@ R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn)
 ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
 mask = sequence_mask(lengths.cuda()).unsqueeze(-1)
 cl = [int(v) for v in lengths]
+if args.dtype == "bf16":
+    from gantts_amd.engine import engine_for  # noqa: E402
+    engine_for(hp, mg).set_option("matmul_bf16", 1)
 
 
 def step():
@@ -57,4 +64,5 @@ for _ in range(args.steps):
     out = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print("%s fp32 B=%d T=%d: %.1f ms/step, %.0f padded frames/s, scalars %s" % ("cfg3 BiLSTM 3x256" if args.gen == "lstm" else "SRU 6x512 bi (hparams default G)", B, Tn, dt * 1e3, B * Tn / dt, out))
+name = {"lstm": "cfg3 BiLSTM 3x256", "sru": "SRU 6x512 bi (hparams default G)", "mlp": "cfg2 MLP 3x512"}[args.gen]
+print("%s %s B=%d T=%d: %.2f ms/step, %.0f padded frames/s, scalars %s" % (name, args.dtype, B, Tn, dt * 1e3, B * Tn / dt, out))
