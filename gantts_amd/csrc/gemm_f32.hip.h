@@ -249,7 +249,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   float ra[UA * VWA], rb[UB * VWB];
 
   // One unit of the next K-tile: global -> registers.  krem = number of valid k in that tile.
-  auto load_a = [&](int u, bool tail, int krem) {
+  auto load_a = [&](auto& ra, int u, bool tail, int krem) {
     int kk, mm; a_pos(u, kk, mm);
     uint32_t off = offA[u];
     if (tail) {  // keep the address inside the matrix: step back to the last valid k (vector start)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
       }
     }
   };
-  auto load_b = [&](int u, bool tail, int krem) {
+  auto load_b = [&](auto& rb, int u, bool tail, int krem) {
     int kk, nn; b_pos(u, kk, nn);
     uint32_t off = offB[u];
     if (tail) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   for (int c = 0; c < VWA; ++c) csum[c] = 0.f;
   const bool want_csum = KIND == GEMM_TN && g.colsum_slab != nullptr && tile_n == 0;
   // registers -> LDS
-  auto store_a = [&](int u, float* as) {
+  auto store_a = [&](auto& ra, int u, float* as) {
     int kk, mm; a_pos(u, kk, mm);
     if (PREC == PREC_BF16) {
       __bf16* ah = reinterpret_cast<__bf16*>(as);      // the caller passes the buffer base reinterpreted
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
       for (int c = 0; c < VWA; ++c) csum[c] += ra[u * VWA + c];
     }
   };
-  auto store_b = [&](int u, float* bs) {
+  auto store_b = [&](auto& rb, int u, float* bs) {
     int kk, nn; b_pos(u, kk, nn);
     if (PREC == PREC_BF16) {
       __bf16* bh = reinterpret_cast<__bf16*>(bs);
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     const bool tail0 = has_tail && nk == 1;
     const int krem0 = k_end - k_begin;
 #pragma unroll
-    for (int u = 0; u < UA; ++u) load_a(u, tail0, krem0);
+    for (int u = 0; u < UA; ++u) load_a(ra, u, tail0, krem0);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) load_b(u, tail0, krem0);
+    for (int u = 0; u < UB; ++u) load_b(rb, u, tail0, krem0);
     pA += stepA; pB += stepB;
 #pragma unroll
-    for (int u = 0; u < UA; ++u) store_a(u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Ah) : As);
+    for (int u = 0; u < UA; ++u) store_a(ra, u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Ah) : As);
 #pragma unroll
-    for (int u = 0; u < UB; ++u) store_b(u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Bh) : Bs);
+    for (int u = 0; u < UB; ++u) store_b(rb, u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Bh) : Bs);
   }
   __syncthreads();
 
@@ -409,43 +409,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
     const int krem = k_end - (k_begin + (kt + 1) * GEMM_BK);
-    if (PREC == PREC_BF16) {
-      // 8 MFMAs of 32 cycles per K-tile: the loader, not the matrix pipe, sets the pace (the launch is bound by the
-      // f32 operands it streams).  Next tile: global -> registers first, products of this tile, then registers -> the
-      // other LDS buffer; latency is covered by the 3 workgroups a CU holds.
-      if (prefetch) {
-#pragma unroll
-        for (int u = 0; u < UA; ++u) load_a(u, tail, krem);
-#pragma unroll
-        for (int u = 0; u < UB; ++u) load_b(u, tail, krem);
-      }
-      const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * GEMM_KP + 8 * half;
-      const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * GEMM_KP + 8 * half;
-#pragma unroll
-      for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
-        bf16x8 fa[TM], fb[TN_];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * GEMM_KP + kk * 16);
-#pragma unroll
-        for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * GEMM_KP + kk * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN_; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-      if (prefetch) {
-        __bf16* aw = Ah + (buf ^ 1) * BM * GEMM_KP;
-        __bf16* bw = Bh + (buf ^ 1) * BN * GEMM_KP;
-#pragma unroll
-        for (int u = 0; u < UA; ++u) store_a(u, reinterpret_cast<float*>(aw));
-#pragma unroll
-        for (int u = 0; u < UB; ++u) store_b(u, reinterpret_cast<float*>(bw));
-        pA += stepA; pB += stepB;
-      }
-      __syncthreads();
-      return;
-    }
     const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31 + half * LDM;
     const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31 + half * LDN;
     float* as_w = As + (buf ^ 1) * GEMM_BK * LDM;
@@ -480,13 +443,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
         // unit u is loaded in group (u*NH)/U and stored in group NH + (u*NH)/U
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
-          if ((u * NH) / UA == gi) load_a(u, tail, krem);
-          if (NH + (u * NH) / UA == gi) store_a(u, as_w);
+          if ((u * NH) / UA == gi) load_a(ra, u, tail, krem);
+          if (NH + (u * NH) / UA == gi) store_a(ra, u, as_w);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-          if ((u * NH) / UB + (UB < NH ? 1 : 0) == gi) load_b(u, tail, krem);
-          if (NH + (u * NH) / UB + (UB < NH ? 1 : 0) == gi) store_b(u, bs_w);
+          if ((u * NH) / UB + (UB < NH ? 1 : 0) == gi) load_b(rb, u, tail, krem);
+          if (NH + (u * NH) / UB + (UB < NH ? 1 : 0) == gi) store_b(rb, u, bs_w);
         }
       }
 #pragma unroll
@@ -509,6 +472,60 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
+  if (PREC == PREC_BF16) {
+    // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace, and what it has to hide is
+    // the latency of the f32 operand loads.  Two register sets: while tile t is multiplied, tile t+1 sits in one set
+    // (requested a whole tile earlier) and the loads of tile t+2 are issued into the other; tile t+1 goes to the other
+    // LDS buffer after the products, one barrier per tile.
+    float ra2[UA * VWA], rb2[UB * VWB];
+    auto mma_tile = [&](int buf) {
+      const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * GEMM_KP + 8 * half;
+      const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * GEMM_KP + 8 * half;
+#pragma unroll
+      for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
+        bf16x8 fa[TM], fb[TN_];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * GEMM_KP + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * GEMM_KP + kk * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN_; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    auto request = [&](auto& Ra, auto& Rb, int t) {        // global loads of tile t (pA / pB point at it)
+      const bool tl = has_tail && t == nk - 1;
+      const int krem = k_end - (k_begin + t * GEMM_BK);
+#pragma unroll
+      for (int u = 0; u < UA; ++u) load_a(Ra, u, tl, krem);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) load_b(Rb, u, tl, krem);
+      pA += stepA; pB += stepB;
+    };
+    auto deposit = [&](auto& Ra, auto& Rb, int buf) {      // registers -> LDS buffer `buf`
+#pragma unroll
+      for (int u = 0; u < UA; ++u) store_a(Ra, u, reinterpret_cast<float*>(Ah + buf * BM * GEMM_KP));
+#pragma unroll
+      for (int u = 0; u < UB; ++u) store_b(Rb, u, reinterpret_cast<float*>(Bh + buf * BN * GEMM_KP));
+    };
+    // tile 0 is in LDS buffer 0 (prologue above); tile 1 -> set (ra, rb)
+    if (nk > 1) request(ra, rb, 1);
+    for (int t = 0; t < nk; t += 2) {
+      // even tile t: set (ra, rb) holds t+1; request t+2 into (ra2, rb2)
+      if (t + 2 < nk) request(ra2, rb2, t + 2);
+      mma_tile(0);
+      if (t + 1 < nk) deposit(ra, rb, 1);
+      __syncthreads();
+      if (t + 1 >= nk) break;
+      // odd tile t+1: set (ra2, rb2) holds t+2; request t+3 into (ra, rb)
+      if (t + 3 < nk) request(ra, rb, t + 3);
+      mma_tile(1);
+      if (t + 2 < nk) deposit(ra2, rb2, 0);
+      __syncthreads();
+    }
+  } else {
   int kt = 0;
   for (; kt + 2 < nk; ++kt) k_tile(kt, T_{}, F_{});                 // next tile is a full one
   if (kt + 2 == nk) {                                               // next tile is the last one
@@ -516,6 +533,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     ++kt;
   }
   if (kt + 1 == nk) k_tile(kt, F_{}, F_{});                         // last tile: nothing to prefetch
+  }
 
   if (KIND == GEMM_TN && want_csum) {
     // all waves are past the last barrier of the K loop; reuse the LDS as scratch.

@@ -251,6 +251,21 @@ ORACLE_ONLY_CASES = {
         opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.3, mge_w=1.0, dropout_on=True,
         update_d=True, update_g=True),
+    # cfg4 / hparams-default generator at its real widths (hparams.py:211-222: SRU 6 x 512 bidirectional, relu,
+    # dropout 0.2, rnn_dropout 0.2; 425 -> 187) with the conditioned 3 x 256 discriminator, B = 16; T cut to what
+    # the oracle's python time loop finishes in seconds.  Parity unpinned (un-vendored SRU), masks injected.
+    "acoustic_sru_at_size": dict(
+        hp="tts_acoustic", B=16, T=64, din=425, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="SRURNN", in_dim=425, out_dim=187, num_hidden=6, hidden_dim=512,
+               bidirectional=True, dropout=0.2, last_sigmoid=False, use_relu=1, rnn_dropout=0.2),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256,
+               dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        windows=3, steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
     # unidirectional tanh SRU with both dropouts, k = 3 in every layer (n_in == ncols from the start)
     "acoustic_sru_uni_k3_dropout": dict(
         hp="tts_acoustic", B=3, T=19, din=16, dout=187,

@@ -736,6 +736,51 @@ def test_lstm_full_size_persistent_equals_per_step_kernels():
     np.testing.assert_allclose(a[2][bshort, 1:], np.broadcast_to(bias, a[2][bshort, 1:].shape), rtol=0, atol=1e-7)
 
 
+def test_sru_full_size_cfg4_step_is_finite_and_reproducible():
+    """BASELINE.json configs[3] at full size (hparams-default SRU 6 x 512 bidirectional with both dropouts, B = 16,
+    T = 2048): the oracle's python time loop is out of reach there (its parity case runs at T = 64, same widths), so the
+    full-size run is checked through properties: finite outputs and losses, loss_mge / loss_mse of a fresh network near the
+    per-frame dimension counts (y ~ N(0,1): 63 and 187), frames beyond a length DO change the output (the reference's SRU
+    ignores lengths, models.py:161-164), run-to-run bit-reproducibility."""
+    import types
+    import gantts_amd.train as T
+    from gantts_amd import hparams, models, optim, paramgen
+    from gantts_amd.engine import engine_for
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    B, Tn = 16, 2048
+    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    T.hp = hp
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, Tn, 425, generator=g).cuda()
+    y = torch.randn(B, Tn, 187, generator=g).cuda()
+    lengths = [Tn] + [int(v) for v in torch.randint(Tn // 2, Tn, (B - 1,), generator=g)]
+    R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn)
+    ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
+    mask = sequence_mask(torch.tensor(lengths).cuda(), max_len=Tn).unsqueeze(-1)
+
+    def once():
+        torch.manual_seed(3)
+        mg = models.SRURNN(in_dim=425, out_dim=187, num_hidden=6, hidden_dim=512, bidirectional=True, dropout=0.2,
+                           use_relu=1, rnn_dropout=0.2).cuda().train()
+        md = models.MLP(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True).cuda().train()
+        og, od = optim.Adagrad(mg.parameters(), lr=0.01), optim.Adagrad(md.parameters(), lr=0.01)
+        engine_for(hp, mg).set_seed(99)
+        og.zero_grad(), od.zero_grad()
+        yh, yhs = T.apply_generator(mg, x, R, lengths)
+        d = T.update_discriminator(md, od, x, ys, yhs, lengths, mask, "train")
+        gg = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, lengths, mask, "train", mse_w=0.0, mge_w=1.0)
+        return d, gg, yh.cpu(), mg.flat_params().cpu().clone()
+
+    a, b = once(), once()
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert all(np.isfinite(v) for v in a[0] + a[1]) and torch.isfinite(a[2]).all() and torch.isfinite(a[3]).all()
+    assert 0.5 * 63 < a[1][1] < 6 * 63 and 0.5 * 187 < a[1][0] < 6 * 187, a[1]
+    assert 0 <= a[0][3] <= sum(lengths) and 0 <= a[0][4] <= sum(lengths)
+    short = int(np.argmin(lengths))
+    assert a[2][short, lengths[short]:].abs().max() > 0          # padded frames run through the recurrence like real ones
+
+
 def _dist_hp(case):
     import types
     from gantts_amd import hparams
@@ -1040,6 +1085,65 @@ def test_data_parallel_step_through_rccl_world_1():
         assert tuple(g1) == tuple(g) and tuple(g2) == tuple(g) and d1 == d and d2 == d
     finally:
         dist.destroy_process_group()
+
+
+def test_generator_noise_step_matches_oracle_values():
+    """cfg5's data path by VALUE: generator_add_noise feeds G with cat(x, z) (train.py:504-506, 542) while the
+    conditioned discriminator still sees x alone (train.py:254-256) -- G's first layer is in_dim + noise_dim wide, D's
+    conditioning width differs from G's input width, and G's weight gradient must be taken against cat(x, z).  Same z
+    on both sides, dropout masks injected, two steps, against the CPU oracle."""
+    import types
+    import gantts_amd.train as T
+    from gantts_amd import hparams, optim, paramgen
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model
+    B, Tn, din, nz = 4, 30, 40, 9
+    gs = dict(kind="MLP", in_dim=din + nz, out_dim=187, num_hidden=2, hidden_dim=48, dropout=0.5, last_sigmoid=False)
+    ds = dict(kind="MLP", in_dim=58 + din, out_dim=1, num_hidden=2, hidden_dim=24, dropout=0.5, last_sigmoid=True)
+    case = dict(B=B, T=Tn, din=din, dout=187, stream_sizes=[180, 3, 1, 3], g=gs, d=ds)
+    x_np, y_np, lengths = C.make_batch(case, seed=21)
+    rs = np.random.RandomState(77)
+    z_np = rs.rand(B, Tn, nz).astype(np.float32)
+    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
+    hp.generator_add_noise, hp.generator_noise_dim = True, nz
+    T.hp = hp
+    R_np = np.array(paramgen.unit_variance_mlpg_matrix(hp.windows, Tn))
+    okw = dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)
+    mg, md = build_model(gs, 3).train(), build_model(ds, 4).train()
+    og, od = optim.Adagrad(mg.parameters(), **okw), optim.Adagrad(md.parameters(), **okw)
+    omg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
+    omd = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
+    omg.load_state_dict(C.make_weights(gs, 3)), omd.load_state_dict(C.make_weights(ds, 4))
+    oog, ood = O.OracleAdagrad(omg.params, **okw), O.OracleAdagrad(omd.params, **okw)
+    cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
+    x, y, z, R = (torch.from_numpy(a).cuda() for a in (x_np, y_np, z_np, R_np))
+    ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
+    mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
+    xc, yc, zc, Rc = (torch.from_numpy(a) for a in (x_np, y_np, z_np, R_np))
+    omask = O.sequence_mask(lengths, Tn).unsqueeze(-1)
+    oys = O.get_static_features(yc, 3, cfg.stream_sizes, cfg.has_dynamic_features)
+    for st in range(2):
+        gm = [(rs.rand(B, Tn, 48) >= 0.5).astype(np.float32) for _ in range(2)]
+        dm = [(rs.rand(B, Tn, 24) >= 0.5).astype(np.float32) for _ in range(6)]
+        mg.set_dropout_masks(0, [torch.from_numpy(m) for m in gm])
+        for p_ in range(3):
+            md.set_dropout_masks(p_, [torch.from_numpy(m) for m in dm[2 * p_:2 * p_ + 2]])
+        og.zero_grad(), od.zero_grad()
+        yh, yhs = T.apply_generator(mg, torch.cat((x, z), -1), R, list(lengths))
+        d = T.update_discriminator(md, od, x, ys, yhs, list(lengths), mask, "train")
+        g = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, list(lengths), mask, "train", mse_w=0.2, mge_w=1.0)
+        dd = O._DropoutSource([torch.from_numpy(m) for m in dm])
+        oog.zero_grad(), ood.zero_grad()
+        oyh, oyhs = O.apply_generator(cfg, omg, torch.cat((xc, zc), -1), Rc, list(lengths), drop=O._DropoutSource([torch.from_numpy(m) for m in gm]))
+        od_ = O.update_discriminator(cfg, omd, ood, xc, oys, oyhs, list(lengths), omask, "train", drop=dd)
+        og_ = O.update_generator(cfg, omg, omd, oog, xc, yc, oyh, oys, oyhs, 1.0, list(lengths), omask, "train",
+                                 mse_w=0.2, mge_w=1.0, drop=dd)
+        _close(yh.cpu().numpy(), oyh.detach().numpy(), msg="noise step %d y_hat" % st)
+        _close(d, od_, msg="noise step %d D scalars" % st)
+        _close(g, og_, msg="noise step %d G scalars" % st)
+    for (k, v), r in list(zip(mg.state_dict().items(), omg.params)) + list(zip(md.state_dict().items(), omd.params)):
+        _close(v.cpu().numpy(), r.detach().numpy(), msg="noise " + k)
 
 
 def test_train_loop_with_generator_noise_and_two_engines_in_one_process():

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r01      -> gpurun_out/profile_r01/{stats,pmc_*}/...
 # --kernel-trace --stats in one run; PMC counters in their own runs (never combined with sys/hip tracing).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
@@ -16,5 +16,13 @@ timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -o k -- $BENCHP > /dev/null 2> $OUT/pmc_mfma.log
 cd $ROOT
 timeout 200 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
+# recurrent generators (cfg3 BiLSTM fp32 / bf16 products, hparams-default SRU): kernel trace + the un-profiled line
+cd /tmp
+for v in "lstm fp32" "lstm bf16" "sru fp32"; do
+  set -- $v
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rnn_$1_$2 -o k -- python $ROOT/tools/bench_rnn.py --gen $1 --dtype $2 --steps 3 > /dev/null 2> $OUT/rnn_$1_$2.err
+  timeout 200 python $ROOT/tools/bench_rnn.py --gen $1 --dtype $2 > $OUT/rnn_$1_$2.log 2>&1
+done
+cd $ROOT
 ls -R $OUT | head -40
 tail -c 600 $OUT/bench.json
