@@ -1256,14 +1256,20 @@ static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* l
   return GT_OK;
 }
 template <int HP, int UPC>
-static int launch_fwd_seq(LstmSeqArgs& a, int bt, hipStream_t s, bool* launched) {
-  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
-                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+static int launch_fwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
+  if (bf16)
+    return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_BF16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
+                   : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_BF16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_F32>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
+                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_F32>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
 }
 template <int HP>
-static int launch_bwd_seq(LstmSeqArgs& a, int bt, hipStream_t s, bool* launched) {
-  return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8>, lstm_bwd_seq_lds<HP>(), a, s, launched)
-                 : launch_seq(lstm_bwd_seq_kernel<HP, 16>, lstm_bwd_seq_lds<HP>(), a, s, launched);
+static int launch_bwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
+  if (bf16)
+    return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_BF16>, lstm_bwd_seq_lds<HP>(), a, s, launched)
+                   : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_BF16>, lstm_bwd_seq_lds<HP>(), a, s, launched);
+  return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_F32>, lstm_bwd_seq_lds<HP>(), a, s, launched)
+                 : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_F32>, lstm_bwd_seq_lds<HP>(), a, s, launched);
 }
 
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
@@ -1300,7 +1306,7 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.allow_xcd_local = e->lstm_xcd_local ? 1 : 0;
   if (backward) {
     a.ncu = cdiv(H, 16);
-    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, s, launched) : launch_bwd_seq<512>(a, bt, s, launched));
+    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, e->matmul_bf16, s, launched) : launch_bwd_seq<512>(a, bt, e->matmul_bf16, s, launched));
     if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     return GT_OK;
   }
@@ -1309,8 +1315,8 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   if (upc != 8 && upc != 16) upc = 8;
   for (; upc <= 16 && !*launched; upc *= 2) {
     a.ncu = cdiv(H, upc);
-    if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, bt, s, launched)) : (launch_fwd_seq<512, 8>(a, bt, s, launched)));
-    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, bt, s, launched)) : (launch_fwd_seq<512, 16>(a, bt, s, launched)));
+    if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, bt, e->matmul_bf16, s, launched)) : (launch_fwd_seq<512, 8>(a, bt, e->matmul_bf16, s, launched)));
+    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, bt, e->matmul_bf16, s, launched)) : (launch_fwd_seq<512, 16>(a, bt, e->matmul_bf16, s, launched)));
   }
   if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   return GT_OK;

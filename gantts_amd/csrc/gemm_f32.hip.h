@@ -473,11 +473,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   using T_ = std::true_type;
   using F_ = std::false_type;
   if (PREC == PREC_BF16) {
-    // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace, and what it has to hide is
-    // the latency of the f32 operand loads.  Two register sets: while tile t is multiplied, tile t+1 sits in one set
-    // (requested a whole tile earlier) and the loads of tile t+2 are issued into the other; tile t+1 goes to the other
-    // LDS buffer after the products, one barrier per tile.
-    float ra2[UA * VWA], rb2[UB * VWB];
+    // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace (the launch is bound by the
+    // f32 operands it streams and converts).  Per tile: request tile t+1 (global -> registers), multiply tile t, deposit
+    // tile t+1 into the other LDS buffer, one barrier; the load latency is covered by the three workgroups a CU holds.
+    // (A second register set requesting tile t+2 was measured SLOWER -- 246 VGPRs, one workgroup less per CU:
+    // cfg2 step 1.30 -> 1.54 ms.)
     auto mma_tile = [&](int buf) {
       const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * GEMM_KP + 8 * half;
       const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * GEMM_KP + 8 * half;
@@ -510,19 +510,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 #pragma unroll
       for (int u = 0; u < UB; ++u) store_b(Rb, u, reinterpret_cast<float*>(Bh + buf * BN * GEMM_KP));
     };
-    // tile 0 is in LDS buffer 0 (prologue above); tile 1 -> set (ra, rb)
-    if (nk > 1) request(ra, rb, 1);
-    for (int t = 0; t < nk; t += 2) {
-      // even tile t: set (ra, rb) holds t+1; request t+2 into (ra2, rb2)
-      if (t + 2 < nk) request(ra2, rb2, t + 2);
-      mma_tile(0);
-      if (t + 1 < nk) deposit(ra, rb, 1);
-      __syncthreads();
-      if (t + 1 >= nk) break;
-      // odd tile t+1: set (ra2, rb2) holds t+2; request t+3 into (ra, rb)
-      if (t + 3 < nk) request(ra, rb, t + 3);
-      mma_tile(1);
-      if (t + 2 < nk) deposit(ra2, rb2, 0);
+    for (int t = 0; t < nk; ++t) {          // tile 0 is in LDS buffer 0 (prologue above)
+      if (t + 1 < nk) request(ra, rb, t + 1);
+      mma_tile(t & 1);
+      if (t + 1 < nk) deposit(ra, rb, (t + 1) & 1);
       __syncthreads();
     }
   } else {

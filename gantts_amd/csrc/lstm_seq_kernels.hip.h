@@ -100,7 +100,12 @@ __device__ __forceinline__ bool spin_expired(const LstmSeqArgs& a, unsigned& spi
 // polling the whole image from every workgroup is what saturates the XCD's L2 -- then whole sweeps, started at a
 // workgroup-dependent column so that the workgroups of a group do not walk the L2 channels in lock step.  Values go
 // to the LDS A image.
-template <int NG, int BT>
+// bf16 variant of the A image (PREC_BF16: the recurrent products run on v_mfma_f32_16x16x32_bf16, 8 consecutive k per
+// lane): row-major [m][kp] bf16 with kp = K + 8 -- the 16 rows of a ds_read_b128 lane group start in 16 different
+// 16-byte slots of the 256-byte bank row (row pitch = 16 bytes mod 256 for K a multiple of 128).
+__device__ __forceinline__ int a_imgh_idx(int k, int m, int kp) { return m * kp + k; }
+
+template <int NG, int BT, int PREC, int KPH>
 __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int kvalid, float* sA,
                                              const LstmSeqArgs& a, int rot, unsigned fault_code) {
   constexpr int KS_ = 256 / BT;        // column stride between a thread's granules
@@ -136,7 +141,11 @@ __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restric
   }
 #pragma unroll
   for (int j = 0; j < NG; ++j)
-    if (kk[j] < kvalid) sA[a_img_idx(kk[j], m)] = __uint_as_float((unsigned)v[j]);
+    if (kk[j] < kvalid) {
+      const float val = __uint_as_float((unsigned)v[j]);
+      if (PREC == PREC_BF16) reinterpret_cast<__bf16*>(sA)[a_imgh_idx(kk[j], m, KPH)] = (__bf16)val;
+      else sA[a_img_idx(kk[j], m)] = val;
+    }
   return true;
 }
 
@@ -195,9 +204,10 @@ constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64;
 // owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
 // wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
 // ------------------------------------------------------------------------------------------
-template <int HP, int UPC, int BT>
+template <int HP, int UPC, int BT, int PREC = PREC_F32>
 __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
   constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP * BT / 256;
+  constexpr int KPH = HP + 8, WRH = KW / 32;     // PREC_BF16: image pitch, MFMAs (= 8-bf16 weight fragments) per wave
   static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
   static_assert(BT == 8 || BT == 16, "BT");
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -215,15 +225,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   // ---- this wave's W_hh slice -> registers (B operand: lane holds W[k = .. + kq][n = lane & 15])
   const int tile = wave % NT, kpart = wave / NT;
   const int n = lane & 15, kq = lane >> 4;
-  float wreg[WR];
+  float wreg[PREC == PREC_BF16 ? 1 : WR];
+  bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
   {
     const int c = tile * 16 + n, gate = c / UPC, uu = c % UPC;
     const bool wok = u0 + uu < H;
     const float* Wrow = a.Whh[d] + (long)(gate * H + min(u0 + uu, H - 1)) * H;
+    if (PREC == PREC_BF16) {       // lane: column n, k = kpart*KW + 32*i + 8*kq + 0..7
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      const int k = kpart * KW + 16 * (i >> 2) + 4 * (i & 3) + kq;
-      wreg[i] = (wok && k < H) ? Wrow[min(k, H - 1)] : 0.f;
+      for (int i = 0; i < WRH; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = kpart * KW + 32 * i + 8 * kq + q;
+          wregh[i][q] = (__bf16)((wok && k < H) ? Wrow[min(k, H - 1)] : 0.f);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const int k = kpart * KW + 16 * (i >> 2) + 4 * (i & 3) + kq;
+        wreg[i] = (wok && k < H) ? Wrow[min(k, H - 1)] : 0.f;
+      }
     }
   }
   // ---- gate stage: thread (sequence gb, unit gu) for tid < BT*UPC
@@ -255,15 +276,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     if (s > 0) {
-      if (!sweep_to_lds<NG, BT>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
+      if (!sweep_to_lds<NG, BT, PREC, KPH>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = sA + (((kpart * (KW / 16)) * 64 + kq * 16 + n) << 2);
+      if (PREC == PREC_BF16) {
+        const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + kpart * KW + 8 * kq;     // row m = lane & 15
 #pragma unroll
-      for (int kb = 0; kb < KW / 16; ++kb) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+        for (int i = 0; i < WRH; ++i)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ah + 32 * i), wregh[i], acc, 0, 0, 0);
+      } else {
+        const float* ap = sA + (((kpart * (KW / 16)) * 64 + kq * 16 + n) << 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+        for (int kb = 0; kb < KW / 16; ++kb) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(kpart * 16 + kq * 4 + r) * NC + tile * 16 + n] = acc[r];   // C: row = kq*4 + r, col = n
@@ -339,9 +367,10 @@ __device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local)
 // Exchange image of one step: 16-byte chunk (u, b) = {dgi, dgf, dgg, dgo} at u*BT + b; flag word of producing wave
 // w of workgroup c at c*NW + w, monotonic (= steps published).
 // ------------------------------------------------------------------------------------------
-template <int HP, int BT>
+template <int HP, int BT, int PREC = PREC_F32>
 __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
   constexpr int WR = HP / 4;
+  constexpr int KPH = 4 * HP + 8, WRH = HP / 32;  // PREC_BF16: pitch of the [16][4*HP] bf16 image, MFMAs per wave
   constexpr int NW = 16 * BT / 64;                // producing waves per workgroup
   constexpr int NCH = HP * BT / 256;              // 16-byte chunks per thread and step
   static_assert(BT == 8 || BT == 16, "BT");
@@ -360,14 +389,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   const int n = lane & 15, kq = lane >> 4;
 
   // B operand: W_hh[(gate = wave)*H + k][u0 + n], k = 16*(i>>2) + 4*(i&3) + kq
-  float wreg[WR];
+  float wreg[PREC == PREC_BF16 ? 1 : WR];
+  bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
   {
     const bool wok = u0 + n < H;
     const float* Wc = a.Whh[d] + (long)wave * H * H + min(u0 + n, H - 1);
+    if (PREC == PREC_BF16) {       // lane: output unit n, k = 32*i + 8*kq + 0..7 (rows of gate `wave`'s block of W_hh)
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      const int k = 16 * (i >> 2) + 4 * (i & 3) + kq;
-      wreg[i] = (wok && k < H) ? Wc[(long)min(k, H - 1) * H] : 0.f;
+      for (int i = 0; i < WRH; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = 32 * i + 8 * kq + q;
+          wregh[i][q] = (__bf16)((wok && k < H) ? Wc[(long)min(k, H - 1) * H] : 0.f);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const int k = 16 * (i >> 2) + 4 * (i & 3) + kq;
+        wreg[i] = (wok && k < H) ? Wc[(long)min(k, H - 1) * H] : 0.f;
+      }
     }
   }
   const bool gthread = tid < 16 * BT;
@@ -437,20 +477,33 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         for (int q = 0; q < 8; ++q) {
           const int u = cc[q] / BT, b = cc[q] % BT;
           if (u < uvalid) {
-            const int ai = a_img_idx(u, b);
+            if (PREC == PREC_BF16) {
+              __bf16* ah = reinterpret_cast<__bf16*>(sA) + b * KPH + u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sA[g * HP * 16 + ai] = __uint_as_float(v[q][g]);
+              for (int g = 0; g < 4; ++g) ah[g * HP] = (__bf16)__uint_as_float(v[q][g]);
+            } else {
+              const int ai = a_img_idx(u, b);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) sA[g * HP * 16 + ai] = __uint_as_float(v[q][g]);
+            }
           }
         }
       }
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = sA + wave * HP * 16 + ((kq * 16 + n) << 2);
+      if (PREC == PREC_BF16) {
+        const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + wave * HP + 8 * kq;
 #pragma unroll
-      for (int kb = 0; kb < HP / 16; ++kb) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+        for (int i = 0; i < WRH; ++i)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ah + 32 * i), wregh[i], acc, 0, 0, 0);
+      } else {
+        const float* ap = sA + wave * HP * 16 + ((kq * 16 + n) << 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+        for (int kb = 0; kb < HP / 16; ++kb) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[kb * 4 + q], acc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + n] = acc[r];
