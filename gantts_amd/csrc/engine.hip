@@ -193,10 +193,24 @@ static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
   return launch_gemm_t<KIND, BM, BN, false, false, PREC_F32>(g, nslab, s);
 }
 
+// Tile choice (measured with tools/gemm_tile_sweep.hip on the cfg2 shapes, 16-byte-loadable operands): 64x64 tiles beat
+// 128x128 / 64x128 / 128x64 on every forward / backward-data shape of the step (16384x512x512: 77 vs 80 us; 32768x256x256:
+// 44.7 vs 47.9; 16384x256x256: 25.1 vs 27.4 / 31.5) -- four tiles per CU drain their epilogues under each other's K loops,
+// and the 2x operand re-reads come out of the XCD's L2.  Operands that need the 4-byte loader keep the larger tiles
+// (their loader is the bottleneck, and a tile re-read costs 4x the instructions).
+static int gemm_tile_mode() {   // measurement switch: GT_GEMM_TILES=big restores the residency model for every launch
+  static const int m = [] { const char* v = getenv("GT_GEMM_TILES"); return v && !strcmp(v, "big") ? 1 : 0; }();
+  return m;
+}
+static bool gemm_vec_ok(const float* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
+
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   const int bn = pick_bn(g.N);
-  // Tile height by a residency model: 128-row tiles keep 2 workgroups per CU resident (512 at once),
+  const bool vec = gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb);
+  if (kind != GEMM_TN && vec && g.M > 64 && tl_gemm_prec == PREC_F32 && gemm_tile_mode() == 0)
+    return kind == GEMM_NT ? launch_gemm_v<GEMM_NT, 64, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 64, 64>(g, 1, s);
+  // Otherwise tile height by a residency model: 128-row tiles keep 2 workgroups per CU resident (512 at once),
   // 64-row tiles 3-4 (LDS-limited: 768 with 128 columns, 1024 with 64) at ~0.55x the work each.
   // Cost = resident rounds x work per tile; e.g. 384 tiles (187-wide output) or 1024 tiles (2N x 483)
   // finish sooner as 64-row tiles, exactly 512 tiles do not.
@@ -213,7 +227,9 @@ static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
     case GEMM_NN:
       if (small) return bn == 64 ? launch_gemm_v<GEMM_NN, 64, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 64, 128>(g, 1, s);
       return bn == 64 ? launch_gemm_v<GEMM_NN, 128, 64>(g, 1, s) : launch_gemm_v<GEMM_NN, 128, 128>(g, 1, s);
-    default: return bn == 64 ? launch_gemm_v<GEMM_TN, 128, 64>(g, nslab, s) : launch_gemm_v<GEMM_TN, 128, 128>(g, nslab, s);
+    default:
+      if (g.n_tiles_m == 64) return launch_gemm_v<GEMM_TN, 64, 64>(g, nslab, s);     // linear_backward_weight's choice (tile height in n_tiles_m)
+      return bn == 64 ? launch_gemm_v<GEMM_TN, 128, 64>(g, nslab, s) : launch_gemm_v<GEMM_TN, 128, 128>(g, nslab, s);
   }
 }
 
@@ -265,8 +281,11 @@ struct Scratch {  // growable device buffer
 static int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
                                   float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s) {
   if (dW) {
-    const int bn = pick_bn(in);
-    const int tiles = cdiv(out, 128) * cdiv(in, bn);
+    // 64x64 tiles when both operands take 16-byte loads: the same workgroup count with 4x fewer partial slabs (less slab
+    // traffic in the product's epilogue and in the combine: 512x512 over 16384 frames 8 slabs instead of 32)
+    const bool t64 = gemm_vec_ok(dZ, lddz) && gemm_vec_ok(X, ldx) && tl_gemm_prec == PREC_F32 && gemm_tile_mode() == 0;
+    const int bn = t64 ? 64 : pick_bn(in);
+    const int tiles = cdiv(out, t64 ? 64 : 128) * cdiv(in, bn);
     int nslab = std::max(1, 512 / tiles);   // <= 2 workgroups per CU x 256 CUs: one resident round
     const int max_slab = (int)((rows + 255) / 256);
     if (nslab > max_slab) nslab = max_slab;
@@ -282,6 +301,7 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     g.M = out; g.N = in; g.K = (int)rows; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
     g.colsum_slab = db ? bias_slabs : nullptr;
     g.drop = no_drop();
+    g.n_tiles_m = t64 ? 64 : 128;        // tile height request (launch_gemm_t overwrites the field with the tile count)
     CHK(launch_gemm(GEMM_TN, g, nslab, s));
     if (slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0) {
       const int main_blocks = cdiv(slab_stride / 4, 256);

@@ -444,12 +444,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
           if ((u * NH) / UA == gi) load_a(ra, u, tail, krem);
+#ifdef GT_ABLATE_NO_LDSWRITE
+          if (NH + (u * NH) / UA == gi) { for (int c = 0; c < VWA; ++c) asm volatile("" ::"v"(ra[u * VWA + c])); }
+#else
           if (NH + (u * NH) / UA == gi) store_a(ra, u, as_w);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           if ((u * NH) / UB + (UB < NH ? 1 : 0) == gi) load_b(rb, u, tail, krem);
+#ifdef GT_ABLATE_NO_LDSWRITE
+          if (NH + (u * NH) / UB + (UB < NH ? 1 : 0) == gi) { for (int c = 0; c < VWB; ++c) asm volatile("" ::"v"(rb[u * VWB + c])); }
+#else
           if (NH + (u * NH) / UB + (UB < NH ? 1 : 0) == gi) store_b(rb, u, bs_w);
+#endif
         }
       }
 #pragma unroll
@@ -472,6 +480,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
+#ifdef GT_GEMM_CLK_DBG   // harness only: shader cycles / wall ticks of this workgroup's K loop -> stagger_dbg[4*block ..]
+  const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
   if (PREC == PREC_BF16) {
     // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace (the launch is bound by the
     // f32 operands it streams and converts).  Per tile: request tile t+1 (global -> registers), multiply tile t, deposit
@@ -526,6 +537,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   if (kt + 1 == nk) k_tile(kt, F_{}, F_{});                         // last tile: nothing to prefetch
   }
 
+#ifdef GT_GEMM_CLK_DBG
+  if (g.stagger_dbg && tid == 0) {
+    const unsigned long long dc = clock64() - dbg_c0, dw = wall_clock64() - dbg_w0;
+    g.stagger_dbg[4 * blockIdx.x] = (unsigned)dc; g.stagger_dbg[4 * blockIdx.x + 1] = (unsigned)dw;
+    g.stagger_dbg[4 * blockIdx.x + 2] = (unsigned)(dbg_w0 & 0xffffffffu); g.stagger_dbg[4 * blockIdx.x + 3] = (unsigned)((dbg_w0 + dw) & 0xffffffffu);
+  }
+#endif
   if (KIND == GEMM_TN && want_csum) {
     // all waves are past the last barrier of the K loop; reuse the LDS as scratch.
     // threads tid, tid + BM/VWA, ... own the same VWA columns starting at (tid % (BM/VWA)) * VWA
