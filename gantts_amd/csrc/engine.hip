@@ -398,6 +398,8 @@ struct gt_engine {
   Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, dmask, tx, gx, dgx, dtz, dout;
   Scratch scal;                            // StepScalars + StepResults
   StepResults* h_res = nullptr;            // pinned
+  StepResults* h_res_dev = nullptr;        // the same page as the kernels see it: the fused calls' finalisation writes the
+                                           // scalars straight into host memory (no device -> host copy launch behind it)
   // per-step state
   int B = 0, T = 0; long N = 0;
   const float* last_x = nullptr; const float* last_yhat = nullptr; const float* last_yhs = nullptr;
@@ -497,6 +499,7 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if ((r = e->scal.ensure(1024))) { delete e; return r; }
   if (hipMemset(e->scal.p, 0, 1024) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMemset failed"); }
   if (hipHostMalloc((void**)&e->h_res, sizeof(StepResults)) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  if (hipHostGetDevicePointer((void**)&e->h_res_dev, e->h_res, 0) != hipSuccess) { (void)hipGetLastError(); e->h_res_dev = nullptr; }
   if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
   if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
   *e->h_fault = 0;
@@ -1138,8 +1141,9 @@ static int post_early_results(gt_engine* e, hipStream_t s);
 static int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float adv_w, float mse_w, float mge_w, hipStream_t compute) {
   GtComm* c = e->comm;
   CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
-  if (role == GT_ROLE_D) hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), e->res(), 1);
-  else hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
+  StepResults* target = e->h_res_dev ? e->h_res_dev : e->res();     // see post_early_results
+  if (role == GT_ROLE_D) hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), target, 1);
+  else hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), target, adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
                           (const double*)nullptr, 0, (const double*)nullptr, 0);
   LAUNCH_CHECK();
   return post_early_results(e, c->stream);
@@ -1737,9 +1741,10 @@ static int post_deferred_results(gt_engine* e, int role, hipStream_t s) {
   e->def_pending[role] = true;
   return GT_OK;
 }
+static StepResults* early_res_target(gt_engine* e) { return e->h_res_dev ? e->h_res_dev : e->res(); }
 static int post_early_results(gt_engine* e, hipStream_t s) {
   if (!e->ev_res) HIPCHK(hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
-  HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  if (!e->h_res_dev) HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(e->ev_res, s));
   e->early_done = true;
   return GT_OK;
@@ -1785,7 +1790,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
   CHK(ensure_tv(e, mask, N, s));
   CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
-               e->d_specs.back(), true, s, plain_early ? e->res() : nullptr));
+               e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr));
   e->early_done = false;
   if (plain_early) CHK(post_early_results(e, s));
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
@@ -2006,7 +2011,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   e->early_done = false;
   if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
-    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), early_res_target(e), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
                        (const double*)e->partial.as<double>(), mge_blocks, (const double*)nullptr, 0);
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));

@@ -218,46 +218,53 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
   const int rows = MLPG_TT + 2 * kb;
   float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nbp]
   const float* yb = y + (long)b * T * ldy;
-  {  // stage the data tile: this thread always loads column c = tid % CC (blockDim % CC == 0)
-    const int c_own = threadIdx.x % MLPG_CC;
-    const bool c_ok = c_own < nc;
-    const int my_col = c_ok ? scol[c0 + c_own] : 0, my_st = c_ok ? sstride[c0 + c_own] : 0;
-    const int total = rows * nW * MLPG_CC;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+  // Staging is one wave per LDS row (64 lanes = the 64 columns of a data row / the taps of a band row), rows strided over
+  // the 16 waves, (row, window) advanced incrementally: no integer division per element, 8 independent loads in flight.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
+  {  // data tile: LDS row rw = r * nW + w holds frame t0 - kb + r, window w
+    const bool c_ok = lane < nc;
+    const int my_col = c_ok ? scol[c0 + lane] : 0, my_st = c_ok ? sstride[c0 + lane] : 0;
+    const int nrw = rows * nW;
+    const int dr = nwv / nW, dw = nwv % nW;
+    int r = wv / nW, w = wv % nW;
+    for (int rw0 = wv; rw0 < nrw; rw0 += 8 * nwv) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int e = min(e0 + q * (int)blockDim.x, total - 1);
-        const int w = (e / MLPG_CC) % nW, r = e / (MLPG_CC * nW);
         const int t = t0 - kb + r;
         const int tc = min(max(t, 0), T - 1);
         const float x = yb[(long)tc * ldy + my_col + (my_st > 0 ? w * my_st : 0)];
         v[q] = (c_ok && t >= 0 && t < T && (my_st > 0 || w == 0)) ? x : 0.f;
+        r += dr; w += dw;
+        if (w >= nW) { w -= nW; ++r; }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int e = e0 + q * (int)blockDim.x;
-        if (e < total) sm[e] = v[q];
+        const int rw = rw0 + q * nwv;
+        if (rw < nrw) sm[rw * MLPG_CC + lane] = v[q];
       }
     }
   }
-  {  // band rows: 8 independent loads in flight per thread (a load->store loop would pay the latency per element)
-    const int total = MLPG_TT * nW * nbp;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
-      float v[8];
+  {  // band rows: LDS row tw = tl * nW + w  <-  band row t0 * nW + tw (the band is [t][w][nb], so rows are consecutive)
+    const int nrow = MLPG_TT * nW;
+    const long src_rows = (long)T * nW;
+    for (int jp = lane; jp < nbp; jp += 64) {      // one pass for half-widths up to 28 (nbp <= 64 taps)
+      const int j = jp - MLPG_PAD;
+      const bool j_ok = j >= 0 && j < nb;
+      const int jc = min(max(j, 0), nb - 1);
+      for (int tw0 = wv; tw0 < nrow; tw0 += 8 * nwv) {
+        float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = min(e0 + q * (int)blockDim.x, total - 1);
-        const int jp = e % nbp, tw = e / nbp;                    // tw = tl*nW + w
-        const int t = t0 + tw / nW, j = jp - MLPG_PAD;
-        const bool ok = t < T && j >= 0 && j < nb;
-        const float x = band[((long)min(t, T - 1) * nW + tw % nW) * nb + min(max(j, 0), nb - 1)];
-        v[q] = ok ? x : 0.f;
-      }
+        for (int q = 0; q < 8; ++q) {
+          const long row = (long)t0 * nW + tw0 + q * nwv;
+          const float x = band[min(row, src_rows - 1) * nb + jc];
+          v[q] = (j_ok && row < src_rows) ? x : 0.f;
+        }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = e0 + q * (int)blockDim.x;
-        if (e < total) sb[e] = v[q];
+        for (int q = 0; q < 8; ++q) {
+          const int tw = tw0 + q * nwv;
+          if (tw < nrow) sb[tw * nbp + jp] = v[q];
+        }
       }
     }
   }
@@ -317,45 +324,46 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
   const int rows = MLPG_TT + 2 * kb;
   float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nbp]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
-  {
-    const int total = rows * MLPG_CC;
-    const int cb = threadIdx.x % MLPG_CC;
-    const bool cb_ok = cb < nc;
-    const int ccl = cb_ok ? c0 + cb : c0;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
+  {  // gradient tile: one wave per frame row (see the forward kernel's staging)
+    const bool c_ok = lane < nc;
+    const int ccl = c_ok ? c0 + lane : c0;
+    for (int r0 = wv; r0 < rows; r0 += 8 * nwv) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int e = min(e0 + q * (int)blockDim.x, total - 1);
-        const int t = t0 - kb + e / MLPG_CC;
+        const int t = t0 - kb + r0 + q * nwv;
         const int tc = min(max(t, 0), T - 1);
         const float x = gb[(long)tc * ldgs + ccl];
-        v[q] = (cb_ok && t >= 0 && t < T) ? x : 0.f;
+        v[q] = (c_ok && t >= 0 && t < T) ? x : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int e = e0 + q * (int)blockDim.x;
-        if (e < total) sm[e] = v[q];
+        const int r = r0 + q * nwv;
+        if (r < rows) sm[r * MLPG_CC + lane] = v[q];
       }
     }
   }
-  {
-    const int total = rows * nW * nbp;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * blockDim.x) {
-      float v[8];
+  {  // band rows of the staged frames: LDS row rw = r * nW + w  <-  band row (t0 - kb) * nW + rw; frames outside [0,T) are zero
+    const int nrow = rows * nW;
+    const long src_rows = (long)T * nW, base = (long)(t0 - kb) * nW;
+    for (int jp = lane; jp < nbp; jp += 64) {
+      const int j = jp - MLPG_PAD;
+      const bool j_ok = j >= 0 && j < nb;
+      const int jc = min(max(j, 0), nb - 1);
+      for (int rw0 = wv; rw0 < nrow; rw0 += 8 * nwv) {
+        float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = min(e0 + q * (int)blockDim.x, total - 1);
-        const int jp = e % nbp, rw = e / nbp;                    // rw = r*nW + w
-        const int t = t0 - kb + rw / nW, j = jp - MLPG_PAD;
-        const bool ok = t >= 0 && t < T && j >= 0 && j < nb;
-        const float x = band[((long)min(max(t, 0), T - 1) * nW + rw % nW) * nb + min(max(j, 0), nb - 1)];
-        v[q] = ok ? x : 0.f;
-      }
+        for (int q = 0; q < 8; ++q) {
+          const long row = base + rw0 + q * nwv;
+          const float x = band[min(max(row, 0L), src_rows - 1) * nb + jc];
+          v[q] = (j_ok && row >= 0 && row < src_rows) ? x : 0.f;
+        }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = e0 + q * (int)blockDim.x;
-        if (e < total) sb[e] = v[q];
+        for (int q = 0; q < 8; ++q) {
+          const int rw = rw0 + q * nwv;
+          if (rw < nrow) sb[rw * nbp + jp] = v[q];
+        }
       }
     }
   }
