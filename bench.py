@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 VARIANTS = ["fwd X.W^T BN64", "fwd X.W^T BN128", "bwd-data dZ.W BN64", "bwd-data dZ.W BN128",
-            "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128"]
+            "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128", "layer chain fwd X.W^T BN64", "layer chain bwd-data dZ.W BN64"]
 
 G_SPEC = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
 D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
@@ -46,20 +46,10 @@ def pmc_traffic(variant):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        key = "%d,%d" % (variant // 2, 64 if variant % 2 == 0 else 128)
+        key = "chain,%d" % (variant - 6) if variant >= 6 else "%d,%d" % (variant // 2, 64 if variant % 2 == 0 else 128)
         return d["gemm_variants"][key]["hbm_bytes_per_launch"], os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) + ": " + d["source"]
     except Exception:
         return None, None
-
-
-def nt128_algorithmic_bytes(N):
-    """Average algorithmic bytes (operands once + result once, fp32) of the forward GEMM launches that use 128-column
-    tiles in one cfg2 step: G layers 1-3 on N rows, D layers 1-3 on 2N rows (D step) and on N rows (G step)."""
-    g, d = G_SPEC, D_SPEC
-    shapes = [(N, g["hidden_dim"], g["in_dim"])] + [(N, g["hidden_dim"], g["hidden_dim"])] * (g["num_hidden"] - 1)
-    for rows in (2 * N, N):
-        shapes += [(rows, d["hidden_dim"], d["in_dim"])] + [(rows, d["hidden_dim"], d["hidden_dim"])] * (d["num_hidden"] - 1)
-    return sum(4.0 * (m * k + n * k + m * n) for m, n, k in shapes) / len(shapes)
 
 
 def algorithmic_flops_per_frame():
@@ -261,22 +251,25 @@ def main():
     roofline = None
     if profile:
         import ctypes as C
-        ms, fl, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+        NS = L.PROFILE_SLOTS
+        ms, fl, cnt = (C.c_double * NS)(), (C.c_double * NS)(), (C.c_int64 * NS)()
         L.check(L.lib.gt_profile_read(ms, fl, cnt))
+        alg = (C.c_double * NS)()
+        L.check(L.lib.gt_profile_bytes(alg))
         per = []
-        for v in range(6):
+        for v in range(NS):
             if cnt[v]:
                 per.append({"kernel": "gemm_f32_kernel<%s>" % VARIANTS[v], "launches_per_step": cnt[v] / profiled_steps,
                             "avg_us": 1e3 * ms[v] / cnt[v], "tflops": fl[v] / (ms[v] * 1e-3) / 1e12,
                             "share_of_step_ms": ms[v] / profiled_steps})
         tot_ms, tot_fl = sum(ms), sum(fl)
         dom = max(per, key=lambda p: p["share_of_step_ms"])
-        dom_v = [v for v in range(6) if cnt[v] and "gemm_f32_kernel<%s>" % VARIANTS[v] == dom["kernel"]][0]
+        dom_v = [v for v in range(NS) if cnt[v] and "gemm_f32_kernel<%s>" % VARIANTS[v] == dom["kernel"]][0]
         traffic, traffic_src = pmc_traffic(dom_v)
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                    "traffic_algorithmic": nt128_algorithmic_bytes(B * Tn) if dom_v == 1 else None,
+                    "traffic_algorithmic": alg[dom_v] / cnt[dom_v],
                     "avg_launch_us": dom["avg_us"],
                     "gemm_family": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
-OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16 = 2, 3, 4, 5
+OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_GEMM_CHAIN = 2, 3, 4, 5, 6
+PROFILE_SLOTS = 8
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8
@@ -110,6 +111,7 @@ SIGNATURES = {
     "gt_op_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P]),
     "gt_profile_enable": (_I, [_I]),
     "gt_profile_read": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "gt_profile_bytes": (_I, [C.POINTER(C.c_double)]),
     "gt_op_linear_backward": (_I, [_P, _I, _P, _I, _P, _L, _I, _I, _P, _I, _P, _I, _P, _F, _P, _P, _P]),
 }
 

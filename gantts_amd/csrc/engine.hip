@@ -23,6 +23,7 @@
 #include "../../include/gantts_hip.h"
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
+#include "gemm_chain.hip.h"
 #include "lstm_kernels.hip.h"
 #include "lstm_seq_kernels.hip.h"
 #include "sru_kernels.hip.h"
@@ -82,7 +83,8 @@ static int ensure_dyn_lds(const void* kernel, size_t bytes) {
 // ------------------------------------------------------------------------------------------
 struct GemmProfiler {
   bool on = false;
-  struct Rec { int kind, bn; double flops; hipEvent_t e0, e1; };
+  struct Rec { int kind, bn; double flops, bytes; hipEvent_t e0, e1; };
+  double last_bytes[GT_PROFILE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic bytes per slot of the last gt_profile_read
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
@@ -96,20 +98,31 @@ extern "C" int gt_profile_enable(int on) {
   g_prof.on = on != 0;
   return GT_OK;
 }
-// Drains the recorded launches into per-variant totals.  variant = kind*2 + (bn==128): 6 slots.
+// Drains the recorded launches into per-variant totals.  variant = kind*2 + (bn==128): 6 slots, then slot 6 = layer-chain
+// launches of forward products, slot 7 = layer-chain launches of backward-data products (gemm_chain.hip.h).
 // out_ms[v] = summed kernel time, out_flops[v] = summed algorithmic 2*M*N*K, out_count[v] = launches.
 extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_count) {
-  for (int v = 0; v < 6; ++v) { out_ms[v] = 0; out_flops[v] = 0; out_count[v] = 0; }
+  for (int v = 0; v < GT_PROFILE_SLOTS; ++v) { out_ms[v] = 0; out_flops[v] = 0; out_count[v] = 0; g_prof.last_bytes[v] = 0; }
   for (auto& r : g_prof.recs) {
     if (hipEventSynchronize(r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventSynchronize failed");
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventElapsedTime failed");
-    const int v = r.kind * 2 + (r.bn == 128 ? 1 : 0);
-    out_ms[v] += ms; out_flops[v] += r.flops; out_count[v] += 1;
+    const int v = r.kind >= 3 ? 3 + r.kind : r.kind * 2 + (r.bn == 128 ? 1 : 0);     // kind 3 / 4: chain of NT / NN products
+    out_ms[v] += ms; out_flops[v] += r.flops; out_count[v] += 1; g_prof.last_bytes[v] += r.bytes;
     g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1);
   }
   g_prof.recs.clear();
   return GT_OK;
+}
+// Algorithmic HBM bytes (every operand once, the result once, fp32) of the launches the last gt_profile_read drained.
+extern "C" int gt_profile_bytes(double* out_bytes) {
+  for (int v = 0; v < GT_PROFILE_SLOTS; ++v) out_bytes[v] = g_prof.last_bytes[v];
+  return GT_OK;
+}
+static double gemm_algorithmic_bytes(int kind, const GemmArgs& g) {
+  double b = 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N);
+  if (kind == GEMM_NN && g.act != ACT_NONE && g.H) b += 4.0 * (double)g.M * g.N;     // the producer's stored activation
+  return b;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -162,7 +175,7 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
   }
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
@@ -176,7 +189,6 @@ static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 
 template <int KIND, int BM, int BN>
 static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
   GemmArgs g = g_in;
-  // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
   g.wide_store = KIND != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
                  (KIND != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
   const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
@@ -204,8 +216,130 @@ static int gemm_tile_mode() {   // measurement switch: GT_GEMM_TILES=big restore
 }
 static bool gemm_vec_ok(const float* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
+struct Scratch {  // growable device buffer
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return GT_OK;
+    if (p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(p)); p = nullptr; bytes = 0; }
+    const size_t cap = need + need / 8;
+    HIPCHK(hipMalloc(&p, cap));
+    bytes = cap;
+    return GT_OK;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+// ---- layer chains (gemm_chain.hip.h).  While a chain is open on this thread, products that qualify (forward / backward
+// -data, both operands 16-byte loadable, f32) are collected instead of launched; a product whose A operand is the previous
+// one's output becomes dependent on it panel by panel.  chain_flush() launches what was collected: one persistent
+// launch for two or more products, the ordinary launch for a single one.
+struct ChainBuild {
+  bool open = false;
+  int n = 0, nxcd = 8;
+  ChainArgs a;
+  Scratch* ctl = nullptr;          // engine-owned control block (queue heads, exit counter, per-panel counters)
+  unsigned int* fault = nullptr;
+  double flops = 0;
+};
+static thread_local ChainBuild tl_chain;
+static bool gemm_chain_enabled() { return true; }   // per engine: GT_OPT_GEMM_CHAIN / GT_GEMM_CHAIN=1
+static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s);
+static void gemm_set_wide_store(int kind, GemmArgs& g) {
+  // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
+  g.wide_store = kind != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
+                 (kind != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
+}
+static int chain_flush(hipStream_t s) {
+  ChainBuild& cb = tl_chain;
+  const int n = cb.n;
+  cb.n = 0;
+  if (n == 0) return GT_OK;
+  if (n == 1) {
+    const bool was_open = cb.open;
+    cb.open = false;                                   // the single product takes the ordinary path
+    const int r = launch_gemm(cb.a.op[0].kind, cb.a.op[0].g, 1, s);
+    cb.open = was_open;
+    return r;
+  }
+  int words = cb.nxcd + 1, items = 0;
+  for (int i = 0; i < n; ++i) { cb.a.op[i].done_base = words - (cb.nxcd + 1); words += cb.a.op[i].g.n_tiles_m; items += cb.a.op[i].g.n_tiles_m * cb.a.op[i].g.n_tiles_n; }
+  const size_t bytes = (size_t)words * sizeof(unsigned int);
+  if (bytes > cb.ctl->bytes) {                         // a fresh (larger) block starts zeroed; afterwards the last
+    CHK(cb.ctl->ensure(bytes * 2));                    // workgroup of every launch leaves it zeroed for the next one
+    HIPCHK(hipMemsetAsync(cb.ctl->p, 0, cb.ctl->bytes, s));
+  }
+  cb.a.n_ops = n; cb.a.nxcd = cb.nxcd; cb.a.ctl = cb.ctl->as<unsigned int>(); cb.a.fault = cb.fault;
+  cb.a.ctl_words = words;
+  cb.a.timeout_ticks = 300000000ull;                   // 3 s of the 100 MHz wall clock
+  const size_t lds = std::max(gemm_lds_bytes<GEMM_NT, CHAIN_BM, CHAIN_BN>(), gemm_lds_bytes<GEMM_NN, CHAIN_BM, CHAIN_BN>());
+  CHK(ensure_dyn_lds((const void*)gemm_chain_kernel, lds));
+  const int grid = std::max(cb.nxcd, std::min(4 * gemm_cu_count(), cdiv(items, cb.nxcd) * cb.nxcd));
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = cb.a.op[0].kind == GEMM_NT ? 3 : 4; rec.bn = 64; rec.flops = cb.flops; rec.bytes = 0;
+    for (int i = 0; i < n; ++i) rec.bytes += gemm_algorithmic_bytes(cb.a.op[i].kind, cb.a.op[i].g);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  static const bool chain_dbg = getenv("GT_CHAIN_DBG") != nullptr;     // diagnosis: per-workgroup phase times of every chain launch
+  static unsigned long long* dbg_buf = nullptr;
+  cb.a.dbg = nullptr;
+  if (chain_dbg) {
+    if (!dbg_buf) HIPCHK(hipMalloc((void**)&dbg_buf, 2048 * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dbg_buf, 0, 2048 * 8 * sizeof(unsigned long long), s));
+    cb.a.dbg = dbg_buf;
+  }
+  hipLaunchKernelGGL(gemm_chain_kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, cb.a);
+  LAUNCH_CHECK();
+  if (chain_dbg) {
+    std::vector<unsigned long long> h(2048 * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double t[6] = {0, 0, 0, 0, 0, 0}, tmax = 0; int per_x[16] = {0};
+    for (int b = 0; b < grid; ++b) { for (int k = 0; k < 6; ++k) t[k] += (double)h[8 * b + k]; tmax = std::max(tmax, (double)h[8 * b + 5]); per_x[h[8 * b + 6] & 15]++; }
+    fprintf(stderr, "[chain] ops %d kind %d grid %d items %d: per workgroup avg: %.1f tiles, dequeue %.2f us, dep wait %.2f us, tile %.2f us, publish %.2f us per tile; "
+            "workgroup lifetime avg %.1f us max %.1f us; workgroups per XCD %d %d %d %d %d %d %d %d\n", n, cb.a.op[0].kind, grid, items, t[0] / grid,
+            t[1] / t[0] / 100, t[2] / t[0] / 100, t[3] / t[0] / 100, t[4] / t[0] / 100, t[5] / grid / 100, tmax / 100,
+            per_x[0], per_x[1], per_x[2], per_x[3], per_x[4], per_x[5], per_x[6], per_x[7]);
+  }
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
+}
+// true: the product was taken into the open chain
+static int chain_offer(int kind, const GemmArgs& g, hipStream_t s, bool* taken) {
+  ChainBuild& cb = tl_chain;
+  *taken = false;
+  const bool ok = (kind == GEMM_NT || kind == GEMM_NN) && tl_gemm_prec == PREC_F32 && gemm_tile_mode() == 0 &&
+                  gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb) && !g.accumulate;
+  if (!ok) return chain_flush(s);                      // keep the stream order: what was collected goes first
+  int dep = -1;
+  if (cb.n > 0) {
+    const GemmArgs& p = cb.a.op[cb.n - 1].g;
+    const bool follows = g.A == p.C && g.lda == p.ldc && g.M == p.M && g.K == p.N && kind == cb.a.op[0].kind;
+    if (!follows || cb.n == CHAIN_MAX_OPS) CHK(chain_flush(s));
+    else dep = cb.n - 1;
+  }
+  ChainOp& op = cb.a.op[cb.n];
+  op.g = g; op.kind = kind; op.dep = dep; op.done_base = 0; op.pad_ = 0;
+  op.g.n_tiles_m = cdiv(g.M, CHAIN_BM); op.g.n_tiles_n = cdiv(g.N, CHAIN_BN);
+  op.g.stagger_ticks = 0; op.g.stagger_dbg = nullptr;
+  gemm_set_wide_store(kind, op.g);
+  if (cb.n == 0) cb.flops = 0;
+  cb.flops += 2.0 * g.M * g.N * g.K;
+  cb.n += 1;
+  *taken = true;
+  return GT_OK;
+}
+
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
+  if (tl_chain.open) {
+    bool taken = false;
+    CHK(chain_offer(kind, g, s, &taken));
+    if (taken) return GT_OK;
+  }
   const int bn = pick_bn(g.N);
   const bool vec = gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb);
   if (kind != GEMM_TN && vec && g.M > 64 && tl_gemm_prec == PREC_F32 && gemm_tile_mode() == 0)
@@ -261,20 +395,6 @@ static int linear_backward_data(const float* dZ, int lddz, const float* W, int l
   return launch_gemm(GEMM_NN, g, 1, s);
 }
 
-struct Scratch {  // growable device buffer
-  void* p = nullptr;
-  size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return GT_OK;
-    if (p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(p)); p = nullptr; bytes = 0; }
-    const size_t cap = need + need / 8;
-    HIPCHK(hipMalloc(&p, cap));
-    bytes = cap;
-    return GT_OK;
-  }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
-  template <typename T> T* as() { return (T*)p; }
-};
 
 // dW (+)= dZ^T X ; db (+)= colsum(dZ)   -- split over the frame dimension, fixed-order combine.
 // The bias gradient rides along in the weight-gradient kernel (column sums of its A operand).
@@ -425,6 +545,10 @@ struct gt_engine {
   std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
   bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
+  Scratch chain_ctl;                               // layer-chain launches: queue heads + per-panel counters (gemm_chain.hip.h)
+  std::vector<Scratch> dz_extra;                   // backward-data chains keep every layer's dZ until its weight gradient ran
+  bool gemm_chain = getenv("GT_GEMM_CHAIN") && getenv("GT_GEMM_CHAIN")[0] == '1';   // GT_OPT_GEMM_CHAIN (default off)
+  unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
   bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
@@ -502,7 +626,9 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if (hipHostGetDevicePointer((void**)&e->h_res_dev, e->h_res, 0) != hipSuccess) { (void)hipGetLastError(); e->h_res_dev = nullptr; }
   if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
   if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
-  *e->h_fault = 0;
+  e->h_fault[0] = 0; e->h_fault[1] = 0;
+  if (hipHostGetDevicePointer((void**)&e->h_fault_dev, e->h_fault, 0) != hipSuccess) { (void)hipGetLastError(); e->h_fault_dev = nullptr; }
+  else e->h_fault_dev += 1;
   *out = e;
   return GT_OK;
 }
@@ -699,6 +825,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
     case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16: e->matmul_bf16 = value != 0; return GT_OK;
+    case GT_OPT_GEMM_CHAIN: e->gemm_chain = value != 0; return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -901,6 +1028,50 @@ static int stage_injected(gt_engine* e, int role, int layer, const int* passes, 
   return GT_OK;
 }
 
+// Layer chains are used on parts whose workgroups report the XCC ids 0 .. 7 (MI355X in its default partition mode):
+// checked once per device with a census launch.
+static int seq_xcds(int* nxcd, int* cus_per_xcd);
+static bool chain_topology_ok() {
+  static std::mutex mu;
+  static std::map<int, bool> ok;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = ok.find(dev);
+  if (it != ok.end()) return it->second;
+  bool good = false;
+  int nxcd = 1, cpx = 0;
+  if (seq_xcds(&nxcd, &cpx) == GT_OK && nxcd == 8) {
+    unsigned int* d = nullptr;
+    unsigned int h[512];
+    if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
+      hipLaunchKernelGGL(chain_census_kernel, dim3(512), dim3(64), 0, 0, d);
+      if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned seen = 0; bool in_range = true;
+        for (unsigned v : h) { if (v >= 8) in_range = false; else seen |= 1u << v; }
+        good = in_range && seen == 0xffu;
+      }
+      (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+  }
+  ok[dev] = good;
+  return good;
+}
+static bool chain_wanted(gt_engine* e) { return e->gemm_chain && gemm_chain_enabled() && chain_topology_ok(); }
+static void chain_begin(gt_engine* e) {
+  ChainBuild& cb = tl_chain;
+  cb.n = 0;
+  cb.open = chain_wanted(e);
+  cb.ctl = &e->chain_ctl; cb.fault = e->d_fault; cb.nxcd = 8;
+}
+static int chain_end(hipStream_t s) {
+  const int r = tl_chain.open ? chain_flush(s) : GT_OK;
+  tl_chain.open = false; tl_chain.n = 0;
+  return r;
+}
+#define CHAINED(e, s, call) do { chain_begin(e); const int r1_ = (call); const int r2_ = chain_end(s); if (r1_ != GT_OK) return r1_; if (r2_ != GT_OK) return r2_; } while (0)
+
 // hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
 static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
                          const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s) {
@@ -931,22 +1102,59 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
                           const std::vector<DropoutSpec>& specs, float* cur, float* other, bool want_w,
                           float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s) {
   Net& n = e->net[role];
-  for (int l = (int)n.hidden.size() - 1; l >= 0; --l) {
-    const Lin& L = n.hidden[l];
-    const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
-    const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
-    if (want_w) {
-      CHK(linear_backward_weight(cur, L.out, Xin, ldx, rows, L.out, L.in, L.dW, L.db, n.grads_dirty, e->slabs, e->colp, s));
-      CHK(comm_grads_ready(e, role, L.dW, (long)L.out * L.in + L.out, s));
-      if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
+  const int L = (int)n.hidden.size();
+  if (!chain_wanted(e)) {
+    // per-layer launches: each layer's weight gradient right behind the product that made its dZ (still warm in L2 / MALL)
+    for (int l = L - 1; l >= 0; --l) {
+      const Lin& Lr = n.hidden[l];
+      const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
+      const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
+      if (want_w) {
+        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s));
+        CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+        if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
+      }
+      if (l > 0) {
+        CHK(linear_backward_data(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
+                                 acts[l - 1].as<float>(), Lr.in, specs[l - 1], s));
+        std::swap(cur, other);
+      } else if (dX) {
+        CHK(linear_backward_data(cur + row0 * Lr.out, Lr.out, Lr.W, Lr.in, col0, dX, lddx, nrows, Lr.out, ncols, ACT_NONE, nullptr, 0,
+                                 no_drop(), s));
+      }
     }
-    if (l > 0) {
-      CHK(linear_backward_data(cur, L.out, L.W, L.in, 0, other, L.in, rows, L.out, L.in, ACT_LEAKY_DROPOUT,
-                               acts[l - 1].as<float>(), L.in, specs[l - 1], s));
-      std::swap(cur, other);
-    } else if (dX) {
-      CHK(linear_backward_data(cur + row0 * L.out, L.out, L.W, L.in, col0, dX, lddx, nrows, L.out, ncols, ACT_NONE, nullptr, 0,
-                               no_drop(), s));
+    return GT_OK;
+  }
+  // Layer chains: dz[l] = gradient w.r.t. the pre-activation of hidden layer l, one buffer per layer; the backward-data
+  // products of all layers go first as ONE launch, the weight gradients after them.
+  std::vector<float*> dz(L, nullptr);
+  if ((int)e->dz_extra.size() < L) e->dz_extra.resize(L);
+  for (int l = L - 1; l >= 0; --l) {
+    if (l == L - 1) dz[l] = cur;
+    else if (l == L - 2) dz[l] = other;
+    else { CHK(e->dz_extra[l].ensure((size_t)rows * n.hidden[l].out * sizeof(float))); dz[l] = e->dz_extra[l].as<float>(); }
+  }
+  chain_begin(e);
+  for (int l = L - 1; l > 0; --l) {
+    const Lin& Lr = n.hidden[l];
+    const int r = linear_backward_data(dz[l], Lr.out, Lr.W, Lr.in, 0, dz[l - 1], Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
+                                       acts[l - 1].as<float>(), Lr.in, specs[l - 1], s);
+    if (r != GT_OK) { (void)chain_end(s); return r; }
+  }
+  CHK(chain_end(s));
+  if (dX && L > 0) {
+    const Lin& L0 = n.hidden[0];
+    CHK(linear_backward_data(dz[0] + row0 * L0.out, L0.out, L0.W, L0.in, col0, dX, lddx, nrows, L0.out, ncols, ACT_NONE, nullptr, 0,
+                             no_drop(), s));
+  }
+  if (want_w) {
+    for (int l = L - 1; l >= 0; --l) {
+      const Lin& Lr = n.hidden[l];
+      const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
+      const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
+      CHK(linear_backward_weight(dz[l], Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s));
+      CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+      if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's weight gradient
     }
   }
   return GT_OK;
@@ -1239,9 +1447,14 @@ static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T
 // word is mirrored to the host behind every such launch without waiting; every later entry point looks at the mirror
 // first, gt_check_faults() synchronises and looks.
 static int fault_seen(gt_engine* e) {
-  if (e->h_fault && *e->h_fault != 0u)
+  const unsigned int f = e->h_fault ? (e->h_fault[0] | e->h_fault[1]) : 0u;
+  if (f & 0xffu)
     return fail(GT_ERR_HIP, "persistent LSTM kernel fault %u: a workgroup timed out waiting for its peers (results of that "
-                "step are invalid; set GT_LSTM_STEPS=1 / GT_OPT_LSTM_PERSISTENT=0 to use the per-step kernels)", *e->h_fault);
+                "step are invalid; set GT_LSTM_STEPS=1 / GT_OPT_LSTM_PERSISTENT=0 to use the per-step kernels)", f);
+  if (f)
+    return fail(GT_ERR_HIP, "layer-chain launch fault 0x%x (%s): results of that step are invalid; GT_GEMM_CHAIN=0 / "
+                "GT_OPT_GEMM_CHAIN=0 selects the per-layer launches", f,
+                (f & CHAIN_FAULT_TIMEOUT) ? "a tile timed out waiting for its input panel" : "an XCD received no workgroup");
   return GT_OK;
 }
 extern "C" int gt_check_faults(gt_engine* e, void* stream) {
@@ -1597,10 +1810,17 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
   } else if (G.d.arch == GT_ARCH_SRU) {
     CHK(sru_forward(e, x, B, T, y_hat, s));
   } else {
-    CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
-    const Lin& Lh = G.hidden.back();
-    CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
-                       G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+    // hidden stack + last_linear: the layers whose operands take 16-byte loads run as one layer-chain launch
+    chain_begin(e);
+    int r = stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s);
+    if (r == GT_OK) {
+      const Lin& Lh = G.hidden.back();
+      r = linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                         G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+    }
+    const int r2 = chain_end(s);
+    if (r != GT_OK) return r;
+    CHK(r2);
   }
   if (is_i2o(G.d.arch)) {
     if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
@@ -1723,7 +1943,7 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step; o.max_norm = n.od.max_grad_norm;
   const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
   hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
-                     part, nblk, norm2_out, o);
+                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -1780,7 +2000,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
   e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-  CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  CHAINED(e, s, stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
   const int H = D.d.hidden_dim;
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
@@ -1976,7 +2196,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
     }
     const float* cat = e->dcat.as<float>() + N * ldc;
-    CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    CHAINED(e, s, stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));

@@ -155,18 +155,27 @@ __device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* sme
 // LDS pitches per orientation (floats)
 template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
 template <int KIND, int BN> constexpr int gemm_ldn() { return KIND == GEMM_NT ? BN + 1 : BN + 4; }
-template <int KIND, int BM, int BN, int PREC = PREC_F32>
+template <int KIND, int BM, int BN, int PREC = PREC_F32, int BKT = GEMM_BK>
 constexpr size_t gemm_lds_bytes() {
-  if (PREC == PREC_F32) return (size_t)2 * GEMM_BK * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float);
+  if (PREC == PREC_F32) {     // the operand image, but never less than the epilogue staging (4 waves x 32 x (BN/2 + 4) floats)
+    size_t img = (size_t)2 * BKT * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float), stg = (size_t)4 * 32 * (BN / 2 + 4) * 4;
+    return img > stg ? img : stg;
+  }
   // bf16 image [2][BM + BN rows][GEMM_KP], but never less than what the epilogue staging (4 waves x 32 x (BN/2 + 4) floats)
   // and the column-sum scratch (256 x 4 floats) reuse it for
   size_t img = (size_t)2 * (BM + BN) * GEMM_KP * 2, stg = (size_t)4 * 32 * (BN / 2 + 4) * 4, cs = (size_t)GEMM_THREADS * 4 * 4;
   return img > stg ? (img > cs ? img : cs) : (stg > cs ? stg : cs);
 }
 
+// One BM x BN output tile (slab `slab` of the frame split for TN) of the product described by g, by the 256 threads of a
+// workgroup; `smem` = gemm_lds_bytes<KIND, BM, BN, PREC>() bytes of LDS, free on entry (callers that run several tiles in
+// one workgroup put a barrier between them).
 // VA / VB: operand is loaded 16 B per lane (requires 16-byte aligned base and pitch % 4 == 0)
-template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+// BKT: K depth of one LDS stage (f32 only: 32, or 16 = half the LDS image, twice the workgroups per CU)
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, const int tile_m, const int tile_n, float* smem) {
+  static_assert(BKT == 32 || (BKT == 16 && PREC == PREC_F32), "K depth of an LDS stage");
+  constexpr int GEMM_BK = BKT;                  // shadows the namespace constant inside this function
   constexpr int LDM = gemm_ldm<KIND, BM>(), LDN = gemm_ldn<KIND, BN>();
   constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
   constexpr int TM = WM / 32, TN_ = WN / 32;    // MFMA tiles per wave
@@ -175,27 +184,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   constexpr int VWA = VA ? 4 : 1, VWB = VB ? 4 : 1;
   constexpr int UA = BM * GEMM_BK / GEMM_THREADS / VWA;   // load units (instructions) per thread per K-tile
   constexpr int UB = BN * GEMM_BK / GEMM_THREADS / VWB;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BK][LDM]
   float* Bs = smem + 2 * GEMM_BK * LDM;      // [2][BK][LDN]
   // PREC_BF16: row-major bf16 images, k contiguous: Ah[2][BM][GEMM_KP], Bh[2][BN][GEMM_KP]
   __bf16* Ah = reinterpret_cast<__bf16*>(smem);
   __bf16* Bh = Ah + 2 * BM * GEMM_KP;
-  gemm_start_stagger(g, smem);
-
-  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
-  // XCD a contiguous run of tiles (neighbouring tiles share the weight panel in that XCD's L2).
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
-  const int slab = bid / tiles_mn;
-  const int t = bid - slab * tiles_mn;
-  // n fastest: workgroups sharing an M panel (the big frame matrix) run back to back
-  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int k_begin = 0, k_end = g.K;
@@ -584,7 +577,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
     // LDS region, and the strip leaves row-wise: 16 B per lane, WN*4-byte contiguous row segments
     // (4x fewer store instructions, full-line writes).  H (NN: f' of the producer) is read the same way.
     constexpr int EP = WN + 4;                    // pitch (floats), keeps 16 B alignment
-    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN, PREC>(), "epilogue staging exceeds the LDS image");
+    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN, PREC, BKT>(), "epilogue staging exceeds the LDS image");
     constexpr int LPR = WN / 4;                   // lanes per row
     constexpr int RPI = 64 / LPR;                 // rows per store instruction
     __syncthreads();                              // the K loop's LDS image is dead from here on
@@ -704,6 +697,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
       }
     }
   }
+}
+
+// One launch = one product: workgroup -> (slab, tile_m, tile_n).
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm_start_stagger(g, smem);
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of tiles (neighbouring tiles share the weight panel in that XCD's L2).
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
+  const int slab = bid / tiles_mn;
+  const int t = bid - slab * tiles_mn;
+  // n fastest: workgroups sharing an M panel (the big frame matrix) run back to back
+  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
+  gemm_tile<KIND, BM, BN, VA, VB, PREC, BKT>(g, slab, tile_m, tile_n, smem);
 }
 
 }  // namespace gt

@@ -186,7 +186,7 @@ class StepEngine(object):
         ``"lstm_fwd_units"``, ``"lstm_xcd_local"``; ``"matmul_bf16"`` switches the GEMMs to bf16 products with float32 accumulation."""
         opts = {"lstm_persistent": L.OPT_LSTM_PERSISTENT,
                 "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL,
-                "matmul_bf16": L.OPT_MATMUL_BF16}
+                "matmul_bf16": L.OPT_MATMUL_BF16, "gemm_chain": L.OPT_GEMM_CHAIN}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

@@ -16,10 +16,10 @@ static float* dfill(size_t n, float scale, unsigned s) {
   float* p; CK(hipMalloc((void**)&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
 }
 static int g_reps = 30, g_target = 512, g_bm = 128;
-template <int KIND, int BM, int BN>
+template <int KIND, int BM, int BN, int BKT = 32>
 static double run(GemmArgs g, int nslab) {
-  const size_t lds = gemm_lds_bytes<KIND, BM, BN>();
-  auto kern = gemm_f32_kernel<KIND, BM, BN, true, true>;
+  const size_t lds = gemm_lds_bytes<KIND, BM, BN, PREC_F32, BKT>();
+  auto kern = gemm_f32_kernel<KIND, BM, BN, true, true, PREC_F32, BKT>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -71,11 +71,17 @@ int main(int argc, char** argv) {
       if (sh.kind == GEMM_NT) {
         REP(128, 128, (run<GEMM_NT, 128, 128>(g, 1))) REP(64, 128, (run<GEMM_NT, 64, 128>(g, 1)))
         REP(128, 64, (run<GEMM_NT, 128, 64>(g, 1))) REP(64, 64, (run<GEMM_NT, 64, 64>(g, 1)))
+        printf("   K depth 16:\n");
+        REP(128, 128, (run<GEMM_NT, 128, 128, 16>(g, 1))) REP(64, 128, (run<GEMM_NT, 64, 128, 16>(g, 1))) REP(64, 64, (run<GEMM_NT, 64, 64, 16>(g, 1)))
       } else if (sh.kind == GEMM_NN) {
         REP(128, 128, (run<GEMM_NN, 128, 128>(g, 1))) REP(64, 128, (run<GEMM_NN, 64, 128>(g, 1)))
         REP(128, 64, (run<GEMM_NN, 128, 64>(g, 1))) REP(64, 64, (run<GEMM_NN, 64, 64>(g, 1)))
+        printf("   K depth 16:\n");
+        REP(128, 128, (run<GEMM_NN, 128, 128, 16>(g, 1))) REP(64, 128, (run<GEMM_NN, 64, 128, 16>(g, 1))) REP(64, 64, (run<GEMM_NN, 64, 64, 16>(g, 1)))
       } else {
         REP(128, 128, (run<GEMM_TN, 128, 128>(g, ns))) REP(128, 64, (run<GEMM_TN, 128, 64>(g, ns)))
+        printf("   K depth 16:\n");
+        REP(64, 64, (run<GEMM_TN, 64, 64, 16>(g, ns))) REP(128, 128, (run<GEMM_TN, 128, 128, 16>(g, ns)))
         for (int target : {512, 1024, 2048}) {     // workgroups in the launch: 64-row tiles need 4x fewer slabs for the same count
           g_target = target;
           REP(64, 64, (run<GEMM_TN, 64, 64>(g, ns))) REP(64, 128, (run<GEMM_TN, 64, 128>(g, ns))) REP(128, 128, (run<GEMM_TN, 128, 128>(g, ns)))
