@@ -545,6 +545,7 @@ struct gt_engine {
   std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
   bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
+  Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   Scratch chain_ctl;                               // layer-chain launches: queue heads + per-panel counters (gemm_chain.hip.h)
   std::vector<Scratch> dz_extra;                   // backward-data chains keep every layer's dZ until its weight gradient ran
   bool gemm_chain = getenv("GT_GEMM_CHAIN") && getenv("GT_GEMM_CHAIN")[0] == '1';   // GT_OPT_GEMM_CHAIN (default off)
@@ -655,6 +656,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
+  e->w0pad[0].release(); e->w0pad[1].release(); e->chain_ctl.release();
+  for (auto& z : e->dz_extra) z.release();
   e->mlpg.clear();
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
   for (int* p : ints) if (p) (void)hipFree(p);
@@ -1085,7 +1088,19 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
     specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out);
-    CHK(linear_forward(cur, ld, L.W, L.in, L.b, acts[l].as<float>(), L.out, rows, L.in, L.out, ACT_LEAKY_DROPOUT, specs[l], s));
+    const float* W = L.W;
+    int ldw = L.in;
+    if (l == 0 && (L.in & 3) && gemm_vec_ok(cur, ld) && tl_gemm_prec == PREC_F32) {
+      // The input image takes 16-byte loads (the discriminator's [x | adv] image, pitch 484) but the weight rows (483
+      // floats) do not: multiply by a copy of W with its row pitch rounded up to 4 floats, re-made from the caller's
+      // parameter buffer before every pass (it may have been stepped, loaded or broadcast since).
+      ldw = (L.in + 3) & ~3;
+      CHK(e->w0pad[role].ensure((size_t)L.out * ldw * sizeof(float)));
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((long)L.out * ldw, 256)), dim3(256), 0, s, L.W, L.in, L.out, e->w0pad[role].as<float>(), ldw);
+      LAUNCH_CHECK();
+      W = e->w0pad[role].as<float>();
+    }
+    CHK(linear_forward(cur, ld, W, ldw, L.b, acts[l].as<float>(), L.out, rows, L.in, L.out, ACT_LEAKY_DROPOUT, specs[l], s));
     cur = acts[l].as<float>();
     ld = L.out;
   }
@@ -2111,7 +2126,12 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   Net& G = e->net[GT_ROLE_G];
   const long N = e->N;
   const int B = e->B, T = e->T, Do = G.d.out_dim;
-  CHK(e->gy.ensure((size_t)N * Do * sizeof(float)));
+  // dloss/dy_hat is an engine buffer: for the MLP stacks its row pitch is rounded up to 4 floats, so that the last layer's
+  // two backward products (K = out_dim = 187 for the acoustic model) take the 16-byte loader and the 64x64 tiles; the
+  // pad column is never read as data (K tail / row clamp of the GEMM loader)
+  const bool mlp_body = !(has_lstm_body(G.d.arch) || G.d.arch == GT_ARCH_SRU);
+  const int ldgy = mlp_body && (is_i2o(G.d.arch) || e->g_used_mlpg) ? (Do + 3) & ~3 : Do;
+  CHK(e->gy.ensure((size_t)N * ldgy * sizeof(float)));
   float* gy = e->gy.as<float>();
   const float* gs = e->gs.as<float>();
   if (is_i2o(G.d.arch)) {
@@ -2125,9 +2145,9 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     CHK(linear_backward_weight(e->dtz.as<float>(), sd, x, G.d.in_dim, N, sd, sd, G.gate.dW, G.gate.db, G.grads_dirty, e->slabs,
                                e->colp, s));
     CHK(comm_grads_ready(e, GT_ROLE_G, G.gate.dW, (long)sd * sd + sd, s));
-    CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
+    CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, ldgy, B, T, mse_w, y_hat, y, Do, mask, s));
   } else if (e->g_used_mlpg) {
-    CHK(mlpg_backward(e, gs, e->Ds, e->d_scol, e->d_sstride, e->Ds, gy, Do, B, T, mse_w, y_hat, y, Do, mask, s));
+    CHK(mlpg_backward(e, gs, e->Ds, e->d_scol, e->d_sstride, e->Ds, gy, ldgy, B, T, mse_w, y_hat, y, Do, mask, s));
   } else {
     // no parameter generation: y_hat_static == y_hat, the gradient passes straight through,
     // plus the masked-MSE gradient (which also yields loss_mse's sum)
@@ -2142,13 +2162,13 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   }
   // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
   const Lin& Lt = G.hidden.back();
-  CHK(linear_backward_weight(gy, Do, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
+  CHK(linear_backward_weight(gy, ldgy, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
                              e->slabs, e->colp, s));
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
   const int H = G.d.hidden_dim;
   CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
   CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
-  CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
+  CHK(linear_backward_data(gy, ldgy, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
                            e->g_act.back().as<float>(), H, e->g_specs.back(), s));
   CHK(stack_backward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
                      nullptr, 0, 0, 0, 0, 0, s));

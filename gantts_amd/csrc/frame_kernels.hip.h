@@ -152,6 +152,14 @@ __global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const flo
   }
 }
 
+// out[r][0..ldo) = in[r][0..cols), zero in the pad columns (row pitch rounded up for 16-byte loads)
+__global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows, float* __restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * ldo) return;
+  const int r = (int)(i / ldo), c = (int)(i - (long)r * ldo);
+  out[i] = c < cols ? in[(long)r * cols + c] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------
 // MLPG.  The reference multiplies by a dense (T x nW*T) matrix R (nnmnkwii
 // unit_variance_mlpg, call sites gantts/multistream.py:120, models.py:66).  R is numerically

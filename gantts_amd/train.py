@@ -299,7 +299,8 @@ def train_loop(models, optimizers, dataset_loaders, w_d=0.0, mse_w=0.0, mge_w=1.
                     y_hat_static_ref = get_selected_static_stream(y_hat_static) \
                         if hp.adversarial_streams is not None else y_hat_static
                     target = reference_discriminator(y_hat_static_ref, lengths=cpu_sorted_lengths)
-                    regard_fake_as_natural += ((target > 0.5).float() * mask).sum().item()
+                    # accumulated on the device (float64 count); read once per epoch, no per-batch host synchronisation
+                    regard_fake_as_natural = regard_fake_as_natural + ((target > 0.5).float() * mask).sum(dtype=torch.float64)
 
                 if update_d:
                     loss_d, loss_fake_d, loss_real_d, _real, _fake = update_discriminator(
@@ -341,7 +342,7 @@ def train_loop(models, optimizers, dataset_loaders, w_d=0.0, mse_w=0.0, mge_w=1.
                 log_value("Real {} acc".format(phase), real_correct_count / total_num_frames, global_epoch)
                 log_value("Fake {} acc".format(phase), fake_correct_count / total_num_frames, global_epoch)
             if reference_discriminator is not None:
-                log_value("{} spoofing rate".format(phase), regard_fake_as_natural / total_num_frames, global_epoch)
+                log_value("{} spoofing rate".format(phase), float(regard_fake_as_natural) / total_num_frames, global_epoch)
 
         if global_epoch % checkpoint_interval == 0:
             for model, optimizer, enabled, name in [(model_g, optimizer_g, update_g, "Generator"),
