@@ -2108,14 +2108,18 @@ extern "C" int gt_update_discriminator(gt_engine* e, const float* x, const float
 // ------------------------------------------------------------------------------------------
 // update_generator
 // ------------------------------------------------------------------------------------------
+// e->partial: [0, 1024) MGE partials, [1024, 2048) MSE partials, [2048, ...) the optimizer's squared-norm partials.
+// deferred_blocks != null: the per-block partial sums stay in the MSE region and *deferred_blocks says how many -- the
+// caller folds their reduction into a later launch (finalize_g_kernel) instead of paying a launch for it here.
 static int sum_sqerr(gt_engine* e, const float* a, int lda, const float* b, int ldb, const float* mask, long rows, int D,
-                     double* out, float* g, int ldg, float gscale, hipStream_t s) {
+                     double* out, float* g, int ldg, float gscale, hipStream_t s, int* deferred_blocks = nullptr) {
   const int nblk = (int)std::min<long>(1024, cdiv(rows * D, RED_THREADS * 4));
   CHK(e->partial.ensure(4096 * sizeof(double)));
-  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, a, lda, b, ldb, mask, rows, D, e->partial.as<double>(),
-                     g, ldg, gscale, e->sc());
+  double* part = e->partial.as<double>() + 1024;
+  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, a, lda, b, ldb, mask, rows, D, part, g, ldg, gscale, e->sc());
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, out);
+  if (deferred_blocks) { *deferred_blocks = nblk; return GT_OK; }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, part, nblk, out);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -2170,7 +2174,17 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
   CHK(linear_backward_data(gy, ldgy, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
                            e->g_act.back().as<float>(), H, e->g_specs.back(), s));
-  CHK(stack_backward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
+  // The first layer's weight gradient reads G's input as its frame operand.  When the discriminator's input image of
+  // this step holds the very same x (linguistic conditioning on the generator's own input, no noise channels), the x
+  // columns of its rows are a bit-exact copy with a 16-byte row pitch: use it, and the product takes the 16-byte loader.
+  const float* xin = x;
+  int ldxin = G.d.in_dim;
+  if (e->fake_cat_valid && e->fake_cat_x == x && e->cfg.discriminator_linguistic_condition && cond_dim(e) == G.d.in_dim &&
+      e->dcat.p && (G.d.in_dim & 3)) {
+    ldxin = (d_in_dim(e) + 3) & ~3;
+    xin = e->dcat.as<float>() + N * ldxin;      // the generated half: the one that is valid whenever fake_cat_valid is
+  }
+  CHK(stack_backward(e, GT_ROLE_G, xin, ldxin, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
                      nullptr, 0, 0, 0, 0, 0, s));
   G.grads_dirty = true;
   return GT_OK;
@@ -2200,8 +2214,11 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
   const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
+  // (the fused single-GPU call reduces the MSE partials inside its finalisation launch: see early_now below)
+  const bool early_fold = e->early && !comm_on(e) && !(tr && direct && mse_w != 0.f);
+  int mse_blocks = 0;
   if (!(tr && direct && mse_w != 0.f))
-    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s));
+    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s, early_fold ? &mse_blocks : nullptr));
   // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
   e->g_has_adv = adv_w > 0.f;
   float* gadv = nullptr;
@@ -2252,7 +2269,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   e->early_done = false;
   if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
     hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), early_res_target(e), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
-                       (const double*)e->partial.as<double>(), mge_blocks, (const double*)nullptr, 0);
+                       (const double*)e->partial.as<double>(), mge_blocks,
+                       mse_blocks ? (const double*)(e->partial.as<double>() + 1024) : (const double*)nullptr, mse_blocks);
     LAUNCH_CHECK();
     CHK(post_early_results(e, s));
   }
