@@ -398,8 +398,28 @@ static int linear_backward_data(const float* dZ, int lddz, const float* W, int l
 
 // dW (+)= dZ^T X ; db (+)= colsum(dZ)   -- split over the frame dimension, fixed-order combine.
 // The bias gradient rides along in the weight-gradient kernel (column sums of its A operand).
+// Deferred combines (SlabDefer): the partial slabs of every layer go to their own piece of a pool and the combine is
+// only RECORDED; slab_defer_flush() runs all recorded combines in one launch.  Used by the fused single-GPU step, where
+// nothing reads a weight gradient between a network's backward pass and its optimizer step.
+struct SlabDefer {
+  Scratch pool;
+  size_t used = 0;
+  SlabJobs jobs;
+  int blocks = 0;
+  bool active = false;
+  SlabDefer() { jobs.n = 0; jobs.pad_ = 0; }
+};
+static int slab_defer_flush(SlabDefer& d, hipStream_t s) {
+  if (d.jobs.n > 0) {
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(d.blocks), dim3(256), 0, s, d.jobs);
+    LAUNCH_CHECK();
+  }
+  d.jobs.n = 0; d.blocks = 0; d.used = 0;
+  return GT_OK;
+}
 static int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
-                                  float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s) {
+                                  float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s,
+                                  SlabDefer* defer = nullptr) {
   if (dW) {
     // 64x64 tiles when both operands take 16-byte loads: the same workgroup count with 4x fewer partial slabs (less slab
     // traffic in the product's epilogue and in the combine: 512x512 over 16384 frames 8 slabs instead of 32)
@@ -413,20 +433,42 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     int k_chunk = cdiv(cdiv(rows, nslab), GEMM_BK) * GEMM_BK;
     nslab = cdiv(rows, k_chunk);
     const long slab_stride = (long)out * in;
-    CHK(slabs.ensure(((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float)));
-    float* bias_slabs = slabs.as<float>() + (size_t)nslab * slab_stride;
+    const size_t need = (((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float) + 255) & ~(size_t)255;
+    const bool can4 = slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0;
+    float* slab_base = nullptr;
+    if (defer && defer->active && accumulate) { CHK(slab_defer_flush(*defer, s)); defer = nullptr; }   // never two combines of one dW in a launch
+    if (defer && defer->active && can4) {
+      if (defer->jobs.n == SLAB_MAX_JOBS || defer->used + need > defer->pool.bytes) {
+        CHK(slab_defer_flush(*defer, s));                       // recorded combines first, then (maybe) a larger pool
+        if (need > defer->pool.bytes) CHK(defer->pool.ensure(std::max(need * 4, (size_t)64 << 20)));
+      }
+      slab_base = (float*)((char*)defer->pool.p + defer->used);
+      defer->used += need;
+    } else {
+      defer = nullptr;
+      CHK(slabs.ensure(need));
+      slab_base = slabs.as<float>();
+    }
+    float* bias_slabs = slab_base + (size_t)nslab * slab_stride;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = dZ; g.lda = lddz; g.B = X; g.ldb = ldx; g.C = slabs.as<float>(); g.ldc = in;
+    g.A = dZ; g.lda = lddz; g.B = X; g.ldb = ldx; g.C = slab_base; g.ldc = in;
     g.M = out; g.N = in; g.K = (int)rows; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
     g.colsum_slab = db ? bias_slabs : nullptr;
     g.drop = no_drop();
     g.n_tiles_m = t64 ? 64 : 128;        // tile height request (launch_gemm_t overwrites the field with the tile count)
     CHK(launch_gemm(GEMM_TN, g, nslab, s));
-    if (slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0) {
+    if (can4) {
       const int main_blocks = cdiv(slab_stride / 4, 256);
       const int bias_blocks = db ? cdiv(out, 256) : 0;
-      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slabs.as<float>(), slab_stride, nslab,
+      if (defer) {
+        SlabJob& J = defer->jobs.j[defer->jobs.n++];
+        J.slabs = slab_base; J.slab_stride = slab_stride; J.n4 = slab_stride / 4; J.out = dW; J.bslabs = bias_slabs; J.bout = db;
+        J.nslab = nslab; J.accumulate = accumulate ? 1 : 0; J.nb = out; J.main_blocks = main_blocks; J.block0 = defer->blocks; J.pad_ = 0;
+        defer->blocks += main_blocks + bias_blocks;
+        return GT_OK;
+      }
+      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slab_base, slab_stride, nslab,
                          slab_stride / 4, dW, accumulate ? 1 : 0, (const float*)bias_slabs, out, db, main_blocks);
       LAUNCH_CHECK();
     } else {
@@ -545,6 +587,7 @@ struct gt_engine {
   std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
   bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
+  SlabDefer sdefer[2];                             // per role: deferred weight-gradient combines of the fused step
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   Scratch chain_ctl;                               // layer-chain launches: queue heads + per-panel counters (gemm_chain.hip.h)
   std::vector<Scratch> dz_extra;                   // backward-data chains keep every layer's dZ until its weight gradient ran
@@ -657,6 +700,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
   e->w0pad[0].release(); e->w0pad[1].release(); e->chain_ctl.release();
+  e->sdefer[0].pool.release(); e->sdefer[1].pool.release();
   for (auto& z : e->dz_extra) z.release();
   e->mlpg.clear();
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
@@ -1125,7 +1169,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
       const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
       if (want_w) {
-        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s));
+        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role]));
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
         if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
       }
@@ -1167,7 +1211,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       const Lin& Lr = n.hidden[l];
       const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
       const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
-      CHK(linear_backward_weight(dz[l], Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s));
+      CHK(linear_backward_weight(dz[l], Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role]));
       CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
       if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's weight gradient
     }
@@ -1950,6 +1994,8 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   const int nblk = (int)std::min<long>(512, cdiv(np, RED_THREADS * 4));
   CHK(e->partial.ensure(4096 * sizeof(double)));
   double* part = e->partial.as<double>() + 2048;
+  CHK(slab_defer_flush(e->sdefer[role], s));            // the fused step's recorded weight-gradient combines, one launch
+  e->sdefer[role].active = false;
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, n.d.grads, np, part);
   LAUNCH_CHECK();
   n.step += 1;
@@ -2002,6 +2048,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const bool tr = train != 0;
   if (comm_on(e) && tr && D.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
+  { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && D.has_opt; }
   CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
@@ -2147,7 +2194,7 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
                        e->gx.as<float>(), sd, e->dgx.as<float>(), sd, e->dtz.as<float>(), sd, N, sd);
     LAUNCH_CHECK();
     CHK(linear_backward_weight(e->dtz.as<float>(), sd, x, G.d.in_dim, N, sd, sd, G.gate.dW, G.gate.db, G.grads_dirty, e->slabs,
-                               e->colp, s));
+                               e->colp, s, &e->sdefer[GT_ROLE_G]));
     CHK(comm_grads_ready(e, GT_ROLE_G, G.gate.dW, (long)sd * sd + sd, s));
     CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, ldgy, B, T, mse_w, y_hat, y, Do, mask, s));
   } else if (e->g_used_mlpg) {
@@ -2167,7 +2214,7 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
   const Lin& Lt = G.hidden.back();
   CHK(linear_backward_weight(gy, ldgy, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
-                             e->slabs, e->colp, s));
+                             e->slabs, e->colp, s, &e->sdefer[GT_ROLE_G]));
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
   const int H = G.d.hidden_dim;
   CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
@@ -2211,6 +2258,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
   if (comm_on(e) && tr && G.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_g.zero_grad() must precede update_generator");
+  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && G.has_opt; }
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
   const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;

@@ -721,12 +721,12 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nb
 
 // dW = (accumulate ? dW : 0) + sum_s slab[s]   (deterministic split-K combine of the TN GEMM)
 // 16 B per lane, 8 slabs in flight per lane; slab_stride and n4*4 must keep 16-byte alignment.
-__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
-                                                           float* __restrict__ out, int accumulate,
-                                                           const float* __restrict__ bslabs, int nb, float* __restrict__ bout, int main_blocks) {
-  if ((int)blockIdx.x >= main_blocks) {
+__device__ __forceinline__ void slab_reduce4_body(int blk, const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
+                                                  float* __restrict__ out, int accumulate,
+                                                  const float* __restrict__ bslabs, int nb, float* __restrict__ bout, int main_blocks) {
+  if (blk >= main_blocks) {
     // trailing workgroups: the bias-gradient slabs [nslab][nb] ride along in the same launch
-    const int c = (blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    const int c = (blk - main_blocks) * blockDim.x + threadIdx.x;
     if (c >= nb) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restri
     bout[c] = accumulate ? bout[c] + tot : tot;
     return;
   }
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = (long)blk * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;
   const long st4 = slab_stride / 4;
@@ -756,6 +756,26 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restri
   f32x4* o = reinterpret_cast<f32x4*>(out) + i;
   if (accumulate) s += *o;
   *o = s;
+}
+// Several combines in ONE launch (the fused single-GPU step defers the combines of a network's layers to just before its
+// optimizer step: one launch instead of one per layer).  Same arithmetic per element as slab_reduce4_kernel.
+constexpr int SLAB_MAX_JOBS = 8;
+struct SlabJob {
+  const float* slabs; long slab_stride; long n4; float* out;
+  const float* bslabs; float* bout;
+  int nslab, accumulate, nb, main_blocks, block0, pad_;
+};
+struct SlabJobs { int n, pad_; SlabJob j[SLAB_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabJobs jobs) {
+  int q = 0;
+  while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].block0) ++q;
+  const SlabJob& J = jobs.j[q];
+  slab_reduce4_body((int)blockIdx.x - J.block0, J.slabs, J.slab_stride, J.nslab, J.n4, J.out, J.accumulate, J.bslabs, J.nb, J.bout, J.main_blocks);
+}
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
+                                                           float* __restrict__ out, int accumulate,
+                                                           const float* __restrict__ bslabs, int nb, float* __restrict__ bout, int main_blocks) {
+  slab_reduce4_body((int)blockIdx.x, slabs, slab_stride, nslab, n4, out, accumulate, bslabs, nb, bout, main_blocks);
 }
 // small-n variant (bias gradients): 64 columns x 16 slab lanes per workgroup, fixed-order combine
 __global__ __launch_bounds__(1024) void slab_reduce_small_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, int n,
