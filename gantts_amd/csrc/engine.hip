@@ -1569,15 +1569,6 @@ static int launch_bwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool
                  : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_F32>, lstm_bwd_seq_lds<HP>(), a, s, launched);
 }
 
-template <int HP, int UPC>
-static int launch_bwd_rs(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
-  if (bf16)
-    return bt == 8 ? launch_seq(lstm_bwd_rs_kernel<HP, UPC, 8, PREC_BF16>, lstm_bwd_rs_lds<UPC>(), a, s, launched)
-                   : launch_seq(lstm_bwd_rs_kernel<HP, UPC, 16, PREC_BF16>, lstm_bwd_rs_lds<UPC>(), a, s, launched);
-  return bt == 8 ? launch_seq(lstm_bwd_rs_kernel<HP, UPC, 8, PREC_F32>, lstm_bwd_rs_lds<UPC>(), a, s, launched)
-                 : launch_seq(lstm_bwd_rs_kernel<HP, UPC, 16, PREC_F32>, lstm_bwd_rs_lds<UPC>(), a, s, launched);
-}
-
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
 // (H <= 512, grid co-resident); *launched = false leaves the work to the per-step kernels.
 static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, bool backward, const float* dout, hipStream_t s,
@@ -1604,25 +1595,15 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.fault = e->d_fault;
   a.timeout_ticks = 200000000ULL;          // 2 s at 100 MHz: far beyond any real wait, far below the watchdog
   const int ngroups = dirs * a.nbt;
-  // backward: reduce-scatter form (every workgroup multiplies its own gate gradients, partial dh go out as granules);
-  // GT_LSTM_BWD_GATHER=1 selects the older all-gather form (dG image + flags) for A/B measurements
-  static const bool bwd_gather = getenv("GT_LSTM_BWD_GATHER") != nullptr;
-  const int rs_upc = HP == 256 ? 8 : 16, rs_ncu = cdiv(H, rs_upc);
-  const size_t xch_n = (size_t)ngroups * (backward ? (bwd_gather ? lstm_bwd_xch_u64(HP) : lstm_bwd_rs_xch_u64(rs_ncu, rs_upc, bt)) : lstm_fwd_xch_u64(HP)),
-               chk_n = (size_t)ngroups * 256;
+  const size_t xch_n = (size_t)ngroups * (backward ? lstm_bwd_xch_u64(HP) : lstm_fwd_xch_u64(HP)), chk_n = (size_t)ngroups * 256;
   CHK(e->l_xch.ensure((xch_n + chk_n) * sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(e->l_xch.p, 0, (xch_n + chk_n) * sizeof(unsigned long long), s));   // no tag / flag of an earlier launch survives
   a.xch = e->l_xch.as<unsigned long long>();
   a.xcc_chk = a.xch + xch_n;              // [group][256]
   a.allow_xcd_local = e->lstm_xcd_local ? 1 : 0;
   if (backward) {
-    if (bwd_gather) {
-      a.ncu = cdiv(H, 16);
-      CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, e->matmul_bf16, s, launched) : launch_bwd_seq<512>(a, bt, e->matmul_bf16, s, launched));
-    } else {
-      a.ncu = rs_ncu;
-      CHK(HP == 256 ? (launch_bwd_rs<256, 8>(a, bt, e->matmul_bf16, s, launched)) : (launch_bwd_rs<512, 16>(a, bt, e->matmul_bf16, s, launched)));
-    }
+    a.ncu = cdiv(H, 16);
+    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, e->matmul_bf16, s, launched) : launch_bwd_seq<512>(a, bt, e->matmul_bf16, s, launched));
     if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     return GT_OK;
   }

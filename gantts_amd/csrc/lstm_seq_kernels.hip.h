@@ -548,201 +548,4 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward, reduce-scatter form.  The workgroup owns UPC hidden units and therefore HAS the gate gradients dG of those
-// units; instead of gathering everybody's dG (4H values per sequence, read by every workgroup) it multiplies its own
-// [BT x 4*UPC] block by its [4*UPC x H] rows of W_hh -- a partial dh_{t-1} for ALL hidden units, every wave its own
-// N tiles over the full K, no cross-wave reduction -- and publishes the slice each consumer owns as tagged granules
-// (value, tag = step + 1; the data is the flag, as in the forward kernel: no separate flag, no drain).  A consumer
-// sums the `ncu` partials of its (sequence, unit) pairs in a fixed order.
-// Exchange image of one group: [2 (step parity)][consumer][producer][UPC x BT] granules.
-// ------------------------------------------------------------------------------------------
-constexpr size_t lstm_bwd_rs_xch_u64(int ncu, int upc, int bt) { return (size_t)2 * ncu * ncu * upc * bt; }
-template <int UPC> constexpr size_t lstm_bwd_rs_lds() { return (size_t)(4 * UPC * 16 + 16) * sizeof(float); }
-
-template <int HP, int UPC, int BT, int PREC = PREC_F32>
-__global__ __launch_bounds__(256) void lstm_bwd_rs_kernel(const LstmSeqArgs a) {
-  constexpr int K = 4 * UPC;                // local reduction depth: k = gate * UPC + unit
-  constexpr int NTW = HP / 64;              // N tiles (16 hidden units) per wave
-  constexpr int NP = HP / UPC;              // most producers a group can have
-  constexpr int KPH = K + 8, KH = K / 32;   // PREC_BF16: image pitch, MFMAs per N tile
-  static_assert(UPC == 8 || UPC == 16, "UPC");
-  static_assert(BT == 8 || BT == 16, "BT");
-  static_assert(NP <= 32, "at most 32 partials per (sequence, unit)");
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sA = sm;                           // [K x 16] permuted (f32) / [16][KPH] bf16
-  int* sflag = reinterpret_cast<int*>(sm + K * 16);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int group, cu;
-  if (!seq_group_of(a, &group, &cu)) return;
-  const int d = group % a.dirs, bt = group / a.dirs;
-  const int H = a.H, T = a.T, B = a.B, ncu = a.ncu;
-  const int u0 = cu * UPC;
-  const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
-  const int n = lane & 15, kq = lane >> 4;
-
-  // B operand: rows (gate, own unit) of W_hh, columns j = (wave*NTW + nt)*16 + n
-  float wreg[PREC == PREC_BF16 ? 1 : NTW * UPC];
-  bf16x8 wregh[PREC == PREC_BF16 ? NTW * KH : 1];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int jcol = (wave * NTW + nt) * 16 + n;
-    const bool jok = jcol < H;
-    if (PREC == PREC_BF16) {
-#pragma unroll
-      for (int i = 0; i < KH; ++i)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = 32 * i + 8 * kq + q, gate = k / UPC, uu = k % UPC;
-          const bool ok = jok && u0 + uu < H;
-          wregh[nt * KH + i][q] = (__bf16)(ok ? a.Whh[d][(long)(gate * H + u0 + uu) * H + jcol] : 0.f);
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < UPC; ++i) {
-        const int k = 4 * i + kq, gate = k / UPC, uu = k % UPC;
-        const bool ok = jok && u0 + uu < H;
-        wreg[nt * UPC + i] = ok ? a.Whh[d][(long)(gate * H + u0 + uu) * H + jcol] : 0.f;
-      }
-    }
-  }
-  const bool gthread = tid < BT * UPC;      // whole waves: BT * UPC is a multiple of 64
-  const int gu = tid % UPC, gb = (tid / UPC) % BT;     // unit fastest: granule gb*UPC + gu == tid, 32-byte runs in the stashes
-  const int bg = bt * BT + gb, bgc = min(bg, B - 1);
-  const int j = u0 + gu, jc = min(j, H - 1);
-  const bool store_ok = gthread && bg < B && j < H;
-  const int len = (gthread && bg < B) ? a.lengths[bgc] : 0;
-  float dcs = 0.f;
-  unsigned long long* xb = a.xch + (size_t)group * lstm_bwd_rs_xch_u64(ncu, UPC, BT);
-  const size_t img = (size_t)ncu * ncu * UPC * BT;               // granules of one parity
-
-  const bool xcd_local = seq_colocated(a, group, cu, sA, LSTM_FAULT_TIMEOUT_BWD);
-  if (fault_load(a.fault) != 0u) return;
-  if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < K * 16 + 16; i += 256) sA[i] = 0.f;      // rows >= BT of the A image stay zero; sflag = 0
-  __syncthreads();
-
-  struct Stash { float dout, ig, fg, gg, og, c, cp; };
-  auto load_stash = [&](int s) {
-    Stash z;
-    const int t = d == 0 ? T - 1 - s : s;
-    const long row = (long)bgc * T + t;
-    z.dout = a.dout[row * ld1 + d * H + jc];
-    z.ig = a.gates[row * ld4 + d * 4 * H + 0 * H + jc];
-    z.fg = a.gates[row * ld4 + d * 4 * H + 1 * H + jc];
-    z.gg = a.gates[row * ld4 + d * 4 * H + 2 * H + jc];
-    z.og = a.gates[row * ld4 + d * 4 * H + 3 * H + jc];
-    z.c = a.cst[row * ld1 + d * H + jc];
-    const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);   // clamped; validity checked at use
-    z.cp = a.cst[rowp * ld1 + d * H + jc];
-    return z;
-  };
-  Stash st;
-  if (gthread) st = load_stash(0);
-  for (int s = 0; s < T; ++s) {
-    const int t = d == 0 ? T - 1 - s : s;
-    if (gthread) {
-      float rec = 0.f;                      // sum over the producers of their partial dh for (gb, j)
-      if (s > 0) {
-        const unsigned long long* src = xb + (size_t)((s - 1) & 1) * img + (size_t)cu * ncu * (UPC * BT) + (size_t)gb * UPC + gu;
-        unsigned long long v[NP];
-        unsigned spins = 0;
-        unsigned long long t_start = 0;
-        bool alive = true;
-        {   // one producer's block first (a different one per consumer and step): the producers publish within a fraction
-            // of a microsecond of each other, and re-reading all blocks from every workgroup while they are still being
-            // written is what loads the XCD's L2
-          const unsigned long long* sp = src + (size_t)((cu + s) % ncu) * (UPC * BT);
-          for (;;) {
-            const bool ok = (unsigned)(xch_load(sp) >> 32) == (unsigned)s;
-            if (__all(ok)) break;
-            if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) { alive = false; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        while (alive) {
-          bool ok = true;
-#pragma unroll
-          for (int p = 0; p < NP; ++p) v[p] = xch_load(src + (size_t)(p < ncu ? p : 0) * (UPC * BT));
-#pragma unroll
-          for (int p = 0; p < NP; ++p) ok &= p >= ncu || (unsigned)(v[p] >> 32) == (unsigned)s;
-          if (__all(ok)) break;
-          if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) { alive = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!alive) sflag[0] = 1;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) if (p < ncu) rec += __uint_as_float((unsigned)v[p]);
-      }
-      const bool active = t < len && j < H;
-      float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
-      if (active) {
-        const float dh = st.dout + rec;
-        float cp = 0.f;                                        // cell state entering this frame
-        if (d == 0) { if (t > 0) cp = st.cp; }
-        else        { if (t + 1 < len) cp = st.cp; }
-        const float tc = tanhf(st.c);
-        const float dc = dcs + dh * st.og * (1.f - tc * tc);
-        dgo = dh * tc * (st.og * (1.f - st.og));
-        dgi = dc * st.gg * (st.ig * (1.f - st.ig));
-        dgf = dc * cp * (st.fg * (1.f - st.fg));
-        dgg = dc * st.ig * (1.f - st.gg * st.gg);
-        dcn = dc * st.fg;
-      }
-      dcs = dcn;
-      if (s + 1 < T) {                      // A image of the local product: row = sequence, k = gate * UPC + unit
-        const float dg[4] = {dgi, dgf, dgg, dgo};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (PREC == PREC_BF16) reinterpret_cast<__bf16*>(sA)[a_imgh_idx(g * UPC + gu, gb, KPH)] = (__bf16)dg[g];
-          else sA[a_img_idx(g * UPC + gu, gb)] = dg[g];
-        }
-      }
-      if (store_ok) {
-        const long row = (long)bg * T + t;
-        a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
-        a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
-        a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
-        a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
-      }
-      if (s + 1 < T) st = load_stash(s + 1);
-    }
-    if (s + 1 == T) break;
-    __syncthreads();
-    if (sflag[0] != 0) return;              // a wait timed out (fault word raised): every wave leaves together
-    // partial dh_{t-1}[b][jcol] of this workgroup's units, published to the consumer that owns jcol
-    unsigned long long* dst = xb + (size_t)(s & 1) * img;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (PREC == PREC_BF16) {
-        const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + 8 * kq;
-#pragma unroll
-        for (int i = 0; i < KH; ++i)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(ah + 32 * i), wregh[nt * KH + i], acc, 0, 0, 0);
-      } else {
-        const float* ap = sA + ((kq * 16 + n) << 2);
-#pragma unroll
-        for (int kb = 0; kb < K / 16; ++kb) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb * 256);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wreg[nt * UPC + kb * 4 + q], acc, 0, 0, 0);
-        }
-      }
-      // C layout: row (sequence) = 4*kq + r, column = n
-      const int jcol = (wave * NTW + nt) * 16 + n;
-      const int cons = jcol / UPC, cu_unit = jcol % UPC;
-      if (cons < ncu) {
-        unsigned long long* q0 = dst + ((size_t)cons * ncu + cu) * (UPC * BT) + cu_unit;     // granule b * UPC + unit: the UPC
-#pragma unroll                                                                                // lanes of a consumer write one run
-        for (int r = 0; r < 4; ++r) {
-          const int b = 4 * kq + r;
-          if (b < BT) xch_store(q0 + (size_t)b * UPC, acc[r], (unsigned)(s + 1), xcd_local);
-        }
-      }
-    }
-    __syncthreads();                        // the A image is rewritten by the next step's gate stage
-  }
-}
-
 }  // namespace gt
