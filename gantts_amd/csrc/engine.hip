@@ -921,6 +921,7 @@ extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, 
 extern "C" int gt_zero_grad(gt_engine* e, int role) {
   if (!e || role < 0 || role > 1) return fail(GT_ERR_INVALID, "bad argument");
   e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
+  { SlabDefer& sd = e->sdefer[role]; sd.active = false; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; }   // nothing recorded survives a zero_grad
   e->tv_mask = nullptr; e->tv_inflight = false;
   if (role == GT_ROLE_G) e->leak_pending = false;
   return GT_OK;
@@ -2386,6 +2387,7 @@ extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
   Net& G = e->net[GT_ROLE_G];
   if (!G.bound || !G.d.grads || !e->g_pass_valid) return fail(GT_ERR_STATE, "no generator pass to back-propagate");
   hipStream_t s = (hipStream_t)stream;
+  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.active = false; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; }   // combines run in place here
   const long N = e->N;
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
   CHK(e->gs.ensure((size_t)N * Ds * sizeof(float)));
