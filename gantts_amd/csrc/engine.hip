@@ -1033,10 +1033,12 @@ static int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, 
                         float* ys, int ldys, int B, int T, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel, lds));
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_forward_kernel, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds,
-                     ys, ldys, B, T);
+  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+#define GT_MLPG_FWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F>, lds)); \
+    hipLaunchKernelGGL(mlpg_forward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
+  if (fpl == 1) GT_MLPG_FWD(1) else if (fpl == 2) GT_MLPG_FWD(2) else GT_MLPG_FWD(4)
+#undef GT_MLPG_FWD
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -1045,10 +1047,13 @@ static int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* sco
                          const float* mask, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel, lds));
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  hipLaunchKernelGGL(mlpg_backward_kernel, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds,
-                     gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc());
+  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+#define GT_MLPG_BWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F>, lds)); \
+    hipLaunchKernelGGL(mlpg_backward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
+                       gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
+  if (fpl == 1) GT_MLPG_BWD(1) else if (fpl == 2) GT_MLPG_BWD(2) else GT_MLPG_BWD(4)
+#undef GT_MLPG_BWD
   LAUNCH_CHECK();
   return GT_OK;
 }

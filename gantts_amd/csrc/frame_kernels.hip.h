@@ -213,6 +213,7 @@ constexpr int MLPG_PAD = 3;      // = frames per lane - 1
 constexpr int MLPG_MAXW = 4;
 constexpr int MLPG_THREADS = 1024; // all 16 waves stage the tile and band rows, waves 0-3 compute
 
+template <int FPL>   // frames per lane of the compute phase: 32 / FPL frame groups x 32 column pairs = 1024 / FPL compute threads
 __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
@@ -277,20 +278,21 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     }
   }
   __syncthreads();
-  if (threadIdx.x >= 256) return;        // every wave stages (memory-level parallelism), four compute
-  const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;     // column pair, frame group (4 frames)
-  const int tl0 = fg * 4;
-  float acc[4][2];
+  static_assert(FPL >= 1 && FPL <= MLPG_PAD + 1, "the band rows are padded for at most MLPG_PAD + 1 frames per lane");
+  if (threadIdx.x >= 1024 / FPL) return;  // every wave stages (memory-level parallelism); 16 / FPL of them compute
+  const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;     // column pair, frame group (FPL frames)
+  const int tl0 = fg * FPL;
+  float acc[FPL][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.f;
+  for (int i = 0; i < FPL; ++i) acc[i][0] = acc[i][1] = 0.f;
   for (int w = 0; w < nW; ++w) {
     const float* dcol = sm + w * MLPG_CC + 2 * cp;             // + r*nW*CC
     const float* cf = sb + (tl0 * nW + w) * nbp + MLPG_PAD;     // + i*nW*nbp + (r - tl0 - i)
-    for (int r = tl0; r < tl0 + 3 + nb; ++r) {
+    for (int r = tl0; r < tl0 + (FPL - 1) + nb; ++r) {
       const float2 d = *reinterpret_cast<const float2*>(dcol + r * nW * MLPG_CC);
       const int j0 = r - tl0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FPL; ++i) {
         const float cfi = cf[i * nW * nbp + j0 - i];
         acc[i][0] = fmaf(cfi, d.x, acc[i][0]);
         acc[i][1] = fmaf(cfi, d.y, acc[i][1]);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     if (c >= nc) continue;
     const bool pass = sstride[c0 + c] == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FPL; ++i) {
       const int t = t0 + tl0 + i;
       if (t >= T) continue;
       const float out = pass ? sm[((tl0 + i + kb) * nW + 0) * MLPG_CC + c] : acc[i][q];   // pass-through: bit-exact copy
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
 //   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
 // LDS: gs tile [(TT+2kb)][CC] + the band rows of the same frames, padded, [(TT+2kb)][nW][nb+2*PAD].
 // Lane = 2 columns x 4 frames x all windows: one ds_read_b64 of gs feeds 8*nW FMAs.
+template <int FPL>
 __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
@@ -376,24 +379,25 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     }
   }
   __syncthreads();
-  if (threadIdx.x >= 256) return;
+  static_assert(FPL >= 1 && FPL <= MLPG_PAD + 1, "the band rows are padded for at most MLPG_PAD + 1 frames per lane");
+  if (threadIdx.x >= 1024 / FPL) return;
   const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;
-  const int tl0 = fg * 4;
-  float acc[MLPG_MAXW][4][2];
+  const int tl0 = fg * FPL;
+  float acc[MLPG_MAXW][FPL][2];
 #pragma unroll
   for (int w = 0; w < MLPG_MAXW; ++w)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[w][i][0] = acc[w][i][1] = 0.f;
+    for (int i = 0; i < FPL; ++i) acc[w][i][0] = acc[w][i][1] = 0.f;
   // staged row r holds frame t = t0 - kb + r; it reaches output frame tl (t' = t0 + tl) with
   // q = r - tl in [0, nb) through the coefficient band[t][w][nb - 1 - q]
-  for (int r = tl0; r < tl0 + 3 + nb; ++r) {
+  for (int r = tl0; r < tl0 + (FPL - 1) + nb; ++r) {
     const float2 d = *reinterpret_cast<const float2*>(sm + r * MLPG_CC + 2 * cp);
     const float* cf = sb + (long)r * nW * nbp + MLPG_PAD + (nb - 1) - (r - tl0);   // + w*nbp + i
 #pragma unroll
     for (int w = 0; w < MLPG_MAXW; ++w) {
       if (w >= nW) break;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FPL; ++i) {
         const float cfi = cf[w * nbp + i];
         acc[w][i][0] = fmaf(cfi, d.x, acc[w][i][0]);
         acc[w][i][1] = fmaf(cfi, d.y, acc[w][i][1]);
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     if (c >= nc) continue;
     const int col0 = scol[c0 + c], st = sstride[c0 + c];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FPL; ++i) {
       const int tp = t0 + tl0 + i;
       if (tp >= T) continue;
       const long row = (long)b * T + tp;
