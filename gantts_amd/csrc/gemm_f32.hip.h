@@ -167,6 +167,151 @@ constexpr size_t gemm_lds_bytes() {
   return img > stg ? (img > cs ? img : cs) : (stg > cs ? stg : cs);
 }
 
+// ---- epilogue of one BM x BN tile whose accumulators are in the MFMA C layout (col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)): bias / activation / dropout / f' of the producer, stores.
+// LDS (`smem`, at least gemm_lds_bytes) must be free of K-loop readers on entry for the wide path: it starts with a barrier.
+template <int KIND, int BM, int BN, int PREC, int BKT>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
+                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN_ = WN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
+  const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
+  const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+
+  if (KIND != GEMM_TN && full_tile && g.wide_store) {
+    // Wide path: everything that is keyed by the MFMA layout (bias column, the 4 Philox words of rows
+    // mrow..mrow+3) is applied in the C layout, the 32 x WN strip is transposed through a wave-private
+    // LDS region, and the strip leaves row-wise: 16 B per lane, WN*4-byte contiguous row segments
+    // (4x fewer store instructions, full-line writes).  H (NN: f' of the producer) is read the same way.
+    constexpr int EP = WN + 4;                    // pitch (floats), keeps 16 B alignment
+    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN, PREC, BKT>(), "epilogue staging exceeds the LDS image");
+    constexpr int LPR = WN / 4;                   // lanes per row
+    constexpr int RPI = 64 / LPR;                 // rows per store instruction
+    __syncthreads();                              // the K loop's LDS image is dead from here on
+    float* stg = smem + wave * (32 * EP);
+    const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        float bias = 0.f;
+        if (KIND == GEMM_NT && g.bias) bias = g.bias[n];
+        uint32_t rnd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
+          if (philox && (q & 1) == 0)
+            philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
+            float v = acc[i][j][q * 4 + s4];
+            if (KIND == GEMM_NT) {
+              v += bias;
+              if (g.act == ACT_LEAKY_DROPOUT) {
+                v = leaky(v);
+                if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+                else if (g.drop.mode == DROP_BUFFER)
+                  v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
+              } else if (g.act == ACT_SIGMOID) {
+                v = 1.f / (1.f + expf(-v));
+              }
+            } else if (g.act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
+              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+              else if (g.drop.mode == DROP_BUFFER)
+                v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
+            }
+            stg[(8 * q + 4 * half + s4) * EP + j * 32 + l31] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + srow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EP + sc4);
+        const long m = m0 + wm * WM + i * 32 + row;
+        const int n = n0 + wn * WN + sc4;
+        if (KIND == GEMM_NN && g.act != ACT_NONE) {
+          const f32x4 h = *reinterpret_cast<const f32x4*>(g.H + m * g.ldh + n);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            v[c] *= g.act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
+        }
+        float* dst = C + m * g.ldc + n;
+        if (g.accumulate) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += o[c];
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) {
+      const int n = n0 + wn * WN + j * 32 + l31;
+      const bool n_ok = full_tile || n < g.N;
+      float bias = 0.f;
+      if (KIND == GEMM_NT && g.bias && n_ok) bias = g.bias[n];
+      uint32_t rnd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
+        if (philox && (q & 1) == 0)
+          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int m = mrow + s;
+          const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
+          if (!full_tile && (!n_ok || m >= g.M)) continue;
+          float v = acc[i][j][q * 4 + s];
+          if (KIND == GEMM_NT) {
+            v += bias;
+            if (g.act == ACT_LEAKY_DROPOUT) {
+              v = leaky(v);
+              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+              else if (g.drop.mode == DROP_BUFFER)
+                v = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
+            } else if (g.act == ACT_SIGMOID) {
+              v = 1.f / (1.f + expf(-v));
+            }
+          } else if (KIND == GEMM_NN) {
+            if (g.act == ACT_LEAKY_DROPOUT) {
+              const float h = g.H[(long)m * g.ldh + n];
+              bool keep = true;
+              float scale = 1.f;
+              if (g.drop.mode == DROP_PHILOX) { keep = keep_px; scale = g.drop.scale; }
+              else if (g.drop.mode == DROP_BUFFER) {
+                keep = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f; scale = g.drop.scale;
+              }
+              v *= leaky_drop_grad(h, keep, scale);
+            } else if (g.act == ACT_SIGMOID) {
+              const float h = g.H[(long)m * g.ldh + n];
+              v *= h * (1.f - h);
+            }
+          }
+          if (KIND != GEMM_TN && g.accumulate) v += C[(long)m * g.ldc + n];
+          C[(long)m * g.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
 // One BM x BN output tile (slab `slab` of the frame split for TN) of the product described by g, by the 256 threads of a
 // workgroup; `smem` = gemm_lds_bytes<KIND, BM, BN, PREC>() bytes of LDS, free on entry (callers that run several tiles in
 // one workgroup put a barrier between them).
@@ -566,137 +711,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     return;
   }
 #endif
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
-  const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
-  const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
-
-  if (KIND != GEMM_TN && full_tile && g.wide_store) {
-    // Wide path: everything that is keyed by the MFMA layout (bias column, the 4 Philox words of rows
-    // mrow..mrow+3) is applied in the C layout, the 32 x WN strip is transposed through a wave-private
-    // LDS region, and the strip leaves row-wise: 16 B per lane, WN*4-byte contiguous row segments
-    // (4x fewer store instructions, full-line writes).  H (NN: f' of the producer) is read the same way.
-    constexpr int EP = WN + 4;                    // pitch (floats), keeps 16 B alignment
-    static_assert((size_t)4 * 32 * EP * sizeof(float) <= gemm_lds_bytes<KIND, BM, BN, PREC, BKT>(), "epilogue staging exceeds the LDS image");
-    constexpr int LPR = WN / 4;                   // lanes per row
-    constexpr int RPI = 64 / LPR;                 // rows per store instruction
-    __syncthreads();                              // the K loop's LDS image is dead from here on
-    float* stg = smem + wave * (32 * EP);
-    const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN_; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        float bias = 0.f;
-        if (KIND == GEMM_NT && g.bias) bias = g.bias[n];
-        uint32_t rnd[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
-          if (philox && (q & 1) == 0)
-            philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
-            float v = acc[i][j][q * 4 + s4];
-            if (KIND == GEMM_NT) {
-              v += bias;
-              if (g.act == ACT_LEAKY_DROPOUT) {
-                v = leaky(v);
-                if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-                else if (g.drop.mode == DROP_BUFFER)
-                  v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
-              } else if (g.act == ACT_SIGMOID) {
-                v = 1.f / (1.f + expf(-v));
-              }
-            } else if (g.act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
-              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-              else if (g.drop.mode == DROP_BUFFER)
-                v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
-            }
-            stg[(8 * q + 4 * half + s4) * EP + j * 32 + l31] = v;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
-        const int row = it * RPI + srow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EP + sc4);
-        const long m = m0 + wm * WM + i * 32 + row;
-        const int n = n0 + wn * WN + sc4;
-        if (KIND == GEMM_NN && g.act != ACT_NONE) {
-          const f32x4 h = *reinterpret_cast<const f32x4*>(g.H + m * g.ldh + n);
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            v[c] *= g.act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
-        }
-        float* dst = C + m * g.ldc + n;
-        if (g.accumulate) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] += o[c];
-        }
-        *reinterpret_cast<f32x4*>(dst) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN_; ++j) {
-      const int n = n0 + wn * WN + j * 32 + l31;
-      const bool n_ok = full_tile || n < g.N;
-      float bias = 0.f;
-      if (KIND == GEMM_NT && g.bias && n_ok) bias = g.bias[n];
-      uint32_t rnd[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
-        if (philox && (q & 1) == 0)
-          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int m = mrow + s;
-          const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
-          if (!full_tile && (!n_ok || m >= g.M)) continue;
-          float v = acc[i][j][q * 4 + s];
-          if (KIND == GEMM_NT) {
-            v += bias;
-            if (g.act == ACT_LEAKY_DROPOUT) {
-              v = leaky(v);
-              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-              else if (g.drop.mode == DROP_BUFFER)
-                v = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
-            } else if (g.act == ACT_SIGMOID) {
-              v = 1.f / (1.f + expf(-v));
-            }
-          } else if (KIND == GEMM_NN) {
-            if (g.act == ACT_LEAKY_DROPOUT) {
-              const float h = g.H[(long)m * g.ldh + n];
-              bool keep = true;
-              float scale = 1.f;
-              if (g.drop.mode == DROP_PHILOX) { keep = keep_px; scale = g.drop.scale; }
-              else if (g.drop.mode == DROP_BUFFER) {
-                keep = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f; scale = g.drop.scale;
-              }
-              v *= leaky_drop_grad(h, keep, scale);
-            } else if (g.act == ACT_SIGMOID) {
-              const float h = g.H[(long)m * g.ldh + n];
-              v *= h * (1.f - h);
-            }
-          }
-          if (KIND != GEMM_TN && g.accumulate) v += C[(long)m * g.ldc + n];
-          C[(long)m * g.ldc + n] = v;
-        }
-      }
-    }
-  }
+  gemm_store_tile<KIND, BM, BN, PREC, BKT>(g, slab, m0, n0, acc, smem);
 }
 
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).

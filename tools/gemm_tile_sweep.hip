@@ -7,7 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
+#include <math.h>
 #include "../gantts_amd/csrc/gemm_f32.hip.h"
+#include "gemm_dma_variant.hip.h"
 using namespace gt;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 static float* dfill(size_t n, float scale, unsigned s) {
@@ -32,6 +35,42 @@ static double run(GemmArgs g, int nslab) {
   CK(hipGetLastError());
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
   return ms * 1e3 / g_reps;
+}
+template <int KIND>
+static double run_dma(GemmArgs g) {
+  const size_t lds = gemm_dma_lds_bytes();
+  auto kern = gemm_dma_kernel<KIND>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g.n_tiles_m = (g.M + 63) / 64; g.n_tiles_n = (g.N + 63) / 64;
+  const int grid = g.n_tiles_m * g.n_tiles_n;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, g);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1e3 / g_reps;
+}
+// max |difference| of the DMA kernel against the register-staged 64x64 kernel on the same arguments, relative to max |C|
+template <int KIND>
+static double check_dma(GemmArgs g, size_t n_out) {
+  std::vector<float> ref(n_out), got(n_out);
+  g.n_tiles_m = (g.M + 63) / 64; g.n_tiles_n = (g.N + 63) / 64;
+  const int grid = g.n_tiles_m * g.n_tiles_n;
+  const size_t l0 = gemm_lds_bytes<KIND, 64, 64>();
+  CK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, 64, 64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0));
+  CK(hipMemset(g.C, 0, n_out * 4));
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, 64, 64, true, true>), dim3(grid), dim3(256), l0, 0, g);
+  CK(hipMemcpy(ref.data(), g.C, n_out * 4, hipMemcpyDeviceToHost));
+  CK(hipFuncSetAttribute((const void*)gemm_dma_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_dma_lds_bytes()));
+  CK(hipMemset(g.C, 0, n_out * 4));
+  hipLaunchKernelGGL(gemm_dma_kernel<KIND>, dim3(grid), dim3(256), gemm_dma_lds_bytes(), 0, g);
+  CK(hipMemcpy(got.data(), g.C, n_out * 4, hipMemcpyDeviceToHost));
+  double mx = 0, sc = 0;
+  for (size_t i = 0; i < n_out; ++i) { mx = std::max(mx, (double)fabsf(ref[i] - got[i])); sc = std::max(sc, (double)fabsf(ref[i])); }
+  return mx / (sc > 0 ? sc : 1);
 }
 struct Bufs { float *A, *B, *C, *H, *bias; };
 static GemmArgs make(int kind, int M, int N, int K, const Bufs& b, bool philox, int* nslab, int bn_for_slabs) {
@@ -89,6 +128,19 @@ int main(int argc, char** argv) {
         g_target = 512;
       }
 #undef REP
+    }
+  }
+  printf("LDS-DMA 64x64 kernel vs the register-staged 64x64 kernel (philox on)\n");
+  for (const Shape& sh : shapes) {
+    if (sh.kind == GEMM_TN) continue;
+    int ns;
+    for (int M : {sh.M, sh.M - 37}) {       // a ragged row count too
+      GemmArgs g = make(sh.kind, M, sh.N, sh.K, b, true, &ns, 64);
+      const double fl = 2.0 * M * sh.N * sh.K;
+      double t0, t1, err;
+      if (sh.kind == GEMM_NT) { t0 = run<GEMM_NT, 64, 64>(g, 1); t1 = run_dma<GEMM_NT>(g); err = check_dma<GEMM_NT>(g, (size_t)M * sh.N); }
+      else { t0 = run<GEMM_NN, 64, 64>(g, 1); t1 = run_dma<GEMM_NN>(g); err = check_dma<GEMM_NN>(g, (size_t)M * sh.N); }
+      printf("   %s M=%d: staged %7.1f us %6.1f TF   dma %7.1f us %6.1f TF   max rel diff %.2e\n", sh.name, M, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, err);
     }
   }
   printf("K sweep, NT, M=16384 N=512, philox on\n");
