@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
 OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_GEMM_CHAIN = 2, 3, 4, 5, 6
-PROFILE_SLOTS = 8
+PROFILE_SLOTS = 9
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8

@@ -84,7 +84,7 @@ static int ensure_dyn_lds(const void* kernel, size_t bytes) {
 struct GemmProfiler {
   bool on = false;
   struct Rec { int kind, bn; double flops, bytes; hipEvent_t e0, e1; };
-  double last_bytes[GT_PROFILE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic bytes per slot of the last gt_profile_read
+  double last_bytes[GT_PROFILE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic bytes per slot of the last gt_profile_read
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
@@ -99,7 +99,8 @@ extern "C" int gt_profile_enable(int on) {
   return GT_OK;
 }
 // Drains the recorded launches into per-variant totals.  variant = kind*2 + (bn==128): 6 slots, then slot 6 = layer-chain
-// launches of forward products, slot 7 = layer-chain launches of backward-data products (gemm_chain.hip.h).
+// launches of forward products, slot 7 = layer-chain launches of backward-data products (gemm_chain.hip.h), slot 8 = pair
+// launches (backward-data + weight gradient of one layer, gemm_pair_kernel).
 // out_ms[v] = summed kernel time, out_flops[v] = summed algorithmic 2*M*N*K, out_count[v] = launches.
 extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_count) {
   for (int v = 0; v < GT_PROFILE_SLOTS; ++v) { out_ms[v] = 0; out_flops[v] = 0; out_count[v] = 0; g_prof.last_bytes[v] = 0; }
@@ -107,7 +108,7 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
     if (hipEventSynchronize(r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventSynchronize failed");
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventElapsedTime failed");
-    const int v = r.kind >= 3 ? 3 + r.kind : r.kind * 2 + (r.bn == 128 ? 1 : 0);     // kind 3 / 4: chain of NT / NN products
+    const int v = r.kind >= 3 ? 3 + r.kind : r.kind * 2 + (r.bn == 128 ? 1 : 0);     // kind 3 / 4: chain of NT / NN products, 5: pair
     out_ms[v] += ms; out_flops[v] += r.flops; out_count[v] += 1; g_prof.last_bytes[v] += r.bytes;
     g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1);
   }
@@ -386,14 +387,52 @@ static int linear_forward(const float* X, int ldx, const float* W, int ldw, cons
   return launch_gemm(GEMM_NT, g, 1, s);
 }
 // dX = (dZ W[:, col0:col0+ncols]) (.) f'(H)
-static int linear_backward_data(const float* dZ, int lddz, const float* W, int ldw, int col0, float* dX, int lddx,
-                                long rows, int out, int ncols, int act_prev, const float* H, int ldh,
-                                const DropoutSpec& drop, hipStream_t s) {
+static GemmArgs backward_data_args(const float* dZ, int lddz, const float* W, int ldw, int col0, float* dX, int lddx,
+                                   long rows, int out, int ncols, int act_prev, const float* H, int ldh, const DropoutSpec& drop) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = dZ; g.lda = lddz; g.B = W + col0; g.ldb = ldw; g.C = dX; g.ldc = lddx;
   g.M = (int)rows; g.N = ncols; g.K = out; g.act = act_prev; g.H = H; g.ldh = ldh; g.drop = drop;
-  return launch_gemm(GEMM_NN, g, 1, s);
+  return g;
+}
+static int linear_backward_data(const float* dZ, int lddz, const float* W, int ldw, int col0, float* dX, int lddx,
+                                long rows, int out, int ncols, int act_prev, const float* H, int ldh,
+                                const DropoutSpec& drop, hipStream_t s) {
+  return launch_gemm(GEMM_NN, backward_data_args(dZ, lddz, W, ldw, col0, dX, lddx, rows, out, ncols, act_prev, H, ldh, drop), 1, s);
+}
+// Pair launch (gemm_pair_kernel): the same layer's backward-data product rides in the weight gradient's launch when both
+// run on 64x64 tiles with 16-byte loadable operands.  GT_GEMM_PAIR=0 keeps them apart (measurement switch).
+static bool gemm_pair_enabled() {
+  static const bool on = [] { const char* v = getenv("GT_GEMM_PAIR"); return !(v && v[0] == '0'); }();
+  return on;
+}
+static bool gemm_pair_ok(const GemmArgs& nn) {
+  return gemm_pair_enabled() && gemm_small_tiles_ok() && !tl_chain.open && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda) && gemm_vec_ok(nn.B, nn.ldb);
+}
+static int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hipStream_t s) {
+  GemmArgs nn = nn_in, tn = tn_in;
+  gemm_set_wide_store(GEMM_NN, nn);
+  tn.wide_store = 0;
+  nn.n_tiles_m = cdiv(nn.M, 64); nn.n_tiles_n = cdiv(nn.N, 64);
+  tn.n_tiles_m = cdiv(tn.M, 64); tn.n_tiles_n = cdiv(tn.N, 64);
+  const int n1 = nn.n_tiles_m * nn.n_tiles_n, n2 = tn.n_tiles_m * tn.n_tiles_n * nslab;
+  const bool bf16 = tl_gemm_prec == PREC_BF16;
+  const size_t lds = bf16 ? std::max(gemm_lds_bytes<GEMM_NN, 64, 64, PREC_BF16>(), gemm_lds_bytes<GEMM_TN, 64, 64, PREC_BF16>())
+                          : std::max(gemm_lds_bytes<GEMM_NN, 64, 64>(), gemm_lds_bytes<GEMM_TN, 64, 64>());
+  const void* kern = bf16 ? (const void*)gemm_pair_kernel<PREC_BF16> : (const void*)gemm_pair_kernel<PREC_F32>;
+  CHK(ensure_dyn_lds(kern, lds));
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = 5; rec.bn = 64; rec.flops = 2.0 * nn.M * nn.N * nn.K + 2.0 * tn.M * tn.N * tn.K;
+    rec.bytes = gemm_algorithmic_bytes(GEMM_NN, nn) + gemm_algorithmic_bytes(GEMM_TN, tn);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1);
+  else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1);
+  LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
 }
 
 
@@ -418,9 +457,12 @@ static int slab_defer_flush(SlabDefer& d, hipStream_t s) {
   d.jobs.n = 0; d.blocks = 0; d.used = 0;
   return GT_OK;
 }
+// `ride_along` (optional): the backward-data product of the same layer; if it can share the weight gradient's launch it
+// does and *rode is set, otherwise the caller launches it itself.
 static int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
                                   float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s,
-                                  SlabDefer* defer = nullptr) {
+                                  SlabDefer* defer = nullptr, const GemmArgs* ride_along = nullptr, bool* rode = nullptr) {
+  if (rode) *rode = false;
   if (dW) {
     // 64x64 tiles when both operands take 16-byte loads: the same workgroup count with 4x fewer partial slabs (less slab
     // traffic in the product's epilogue and in the combine: 512x512 over 16384 frames 8 slabs instead of 32)
@@ -458,7 +500,12 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     g.colsum_slab = db ? bias_slabs : nullptr;
     g.drop = no_drop();
     g.n_tiles_m = t64 ? 64 : 128;        // tile height request (launch_gemm_t overwrites the field with the tile count)
-    CHK(launch_gemm(GEMM_TN, g, nslab, s));
+    if (t64 && ride_along && rode && gemm_pair_ok(*ride_along)) {
+      CHK(launch_gemm_pair(*ride_along, g, nslab, s));
+      *rode = true;
+    } else {
+      CHK(launch_gemm(GEMM_TN, g, nslab, s));
+    }
     if (can4) {
       const int main_blocks = cdiv(slab_stride / 4, 256);
       const int bias_blocks = db ? cdiv(out, 256) : 0;
@@ -1175,14 +1222,18 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       const Lin& Lr = n.hidden[l];
       const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
       const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
+      bool rode = false;
+      GemmArgs nn;
+      if (l > 0) nn = backward_data_args(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
+                                         acts[l - 1].as<float>(), Lr.in, specs[l - 1]);
       if (want_w) {
-        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role]));
+        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role],
+                                   l > 0 ? &nn : nullptr, &rode));
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
         if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
       }
       if (l > 0) {
-        CHK(linear_backward_data(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
-                                 acts[l - 1].as<float>(), Lr.in, specs[l - 1], s));
+        if (!rode) CHK(launch_gemm(GEMM_NN, nn, 1, s));
         std::swap(cur, other);
       } else if (dX) {
         CHK(linear_backward_data(cur + row0 * Lr.out, Lr.out, Lr.W, Lr.in, col0, dX, lddx, nrows, Lr.out, ncols, ACT_NONE, nullptr, 0,
@@ -2220,14 +2271,16 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   }
   // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
   const Lin& Lt = G.hidden.back();
-  CHK(linear_backward_weight(gy, ldgy, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
-                             e->slabs, e->colp, s, &e->sdefer[GT_ROLE_G]));
-  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
   const int H = G.d.hidden_dim;
   CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
   CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
-  CHK(linear_backward_data(gy, ldgy, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
-                           e->g_act.back().as<float>(), H, e->g_specs.back(), s));
+  const GemmArgs nn_last = backward_data_args(gy, ldgy, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
+                                              e->g_act.back().as<float>(), H, e->g_specs.back());
+  bool rode = false;
+  CHK(linear_backward_weight(gy, ldgy, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
+                             e->slabs, e->colp, s, &e->sdefer[GT_ROLE_G], &nn_last, &rode));
+  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
+  if (!rode) CHK(launch_gemm(GEMM_NN, nn_last, 1, s));
   // The first layer's weight gradient reads G's input as its frame operand.  When the discriminator's input image of
   // this step holds the very same x (linguistic conditioning on the generator's own input, no noise channels), the x
   // columns of its rows are a bit-exact copy with a 16-byte row pitch: use it, and the product takes the 16-byte loader.

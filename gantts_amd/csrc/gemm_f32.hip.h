@@ -714,19 +714,40 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   gemm_store_tile<KIND, BM, BN, PREC, BKT>(g, slab, m0, n0, acc, smem);
 }
 
+// XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous run of
+// tiles (neighbouring tiles share the weight panel in that XCD's L2).
+__device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// One launch = TWO independent products of a layer's backward pass: its backward-data product (g1: dX = (dZ . W) (.) f')
+// and its weight gradient (g2: partial slabs of dZ^T . X), both on 64x64 tiles with 16-byte loadable operands.  The
+// first n1 workgroups run g1's tiles, the rest g2's: one launch edge (ramp, first-tile latency, drain) instead of two,
+// and the second product's tiles start while the first one's last tiles finish.
+template <int PREC>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int bid = blockIdx.x;
+  if (bid < n1) {
+    bid = gemm_xcd_order(bid, n1);
+    const int tile_m = bid / g1.n_tiles_n, tile_n = bid - tile_m * g1.n_tiles_n;
+    gemm_tile<GEMM_NN, 64, 64, true, true, PREC>(g1, 0, tile_m, tile_n, smem);
+  } else {
+    bid = gemm_xcd_order(bid - n1, (int)gridDim.x - n1);
+    const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
+    const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
+    const int tile_m = t / g2.n_tiles_n, tile_n = t - tile_m * g2.n_tiles_n;
+    gemm_tile<GEMM_TN, 64, 64, true, true, PREC>(g2, slab, tile_m, tile_n, smem);
+  }
+}
+
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   gemm_start_stagger(g, smem);
-  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each
-  // XCD a contiguous run of tiles (neighbouring tiles share the weight panel in that XCD's L2).
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
   const int slab = bid / tiles_mn;
   const int t = bid - slab * tiles_mn;

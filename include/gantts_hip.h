@@ -305,9 +305,10 @@ int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, co
 
 /* ---- measurement (bench.py): HIP-event timing of every GEMM launch on its own stream --------
  * slot = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W), 2 backward-weight (dZ^T X);
- * slot 6 = layer-chain launches of forward products, slot 7 = layer-chain launches of backward-data products.
+ * slot 6 = layer-chain launches of forward products, slot 7 = layer-chain launches of backward-data products,
+ * slot 8 = pair launches (one layer's backward-data product and weight gradient in one launch).
  * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries. */
-#define GT_PROFILE_SLOTS 8
+#define GT_PROFILE_SLOTS 9
 int gt_profile_enable(int on);
 int gt_profile_read(double* ms_per_slot, double* flops_per_slot, int64_t* launches_per_slot);
 /* algorithmic HBM bytes (each operand once + the result once, fp32) of the launches the last gt_profile_read summed */

@@ -90,9 +90,12 @@ import re
 pmc = {}
 for k in mfma:
     mm = re.match(r"gemm_f32_kernel<(\d), (\d+), (\d+)", k)
-    if not mm:
+    if mm:
+        key = "%s,%s" % (mm.group(1), mm.group(3))
+    elif k.startswith("gemm_pair_kernel"):
+        key = "pair"
+    else:
         continue
-    key = "%s,%s" % (mm.group(1), mm.group(3))
     d = pmc.setdefault(key, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
     nl = max(1, nm[k])
     d["launches"] += nl
