@@ -8,8 +8,12 @@
 //   TN  dW = dZ^T . X  (+ column sums of dZ = bias gradient), split over the frame dimension into
 //                       deterministic partial slabs
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves, 2x2), each wave (BM/2)x(BN/2) in 32x32 MFMA
-// tiles; K step 32; 2 workgroups per CU.  LDS image is k-major  As[k][m] / Bs[k][n]; the MFMA
+// Tile: BM x BN (64 or 128 each) per 256-thread workgroup (4 waves, 2x2), each wave (BM/2)x(BN/2) in
+// 32x32 MFMA tiles; K step 32.  The engine runs 64x64 tiles (4 workgroups per CU) whenever both operands take
+// 16-byte loads and 128-wide tiles (2 per CU) otherwise (engine.hip: launch_gemm; measurements in DESIGN.md 3.1).
+// gemm_tile() is the tile body, gemm_store_tile() its epilogue; gemm_f32_kernel launches one product,
+// gemm_pair_kernel a layer's backward-data product + weight gradient, gemm_chain.hip.h a stack of layers.
+// LDS image is k-major  As[k][m] / Bs[k][n]; the MFMA
 // operand fetch `As[k][m0 + lane%32]` is a conflict-free ds_read_b32 for any pitch.  The pitch is
 // chosen per operand orientation so that the loader's LDS writes are conflict-free too:
 //   * k-contiguous source (rows of X / W): pitch BM+1 (== 1 mod 32): a lane holding k..k+3 of one
