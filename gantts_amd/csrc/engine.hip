@@ -1837,7 +1837,7 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       CHK(launch_gemm(GEMM_NN, g, 1, s));
     }
     SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
-    hipLaunchKernelGGL(sru_fwd_kernel, dim3(cdiv((long)B * ncols, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sru_fwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
     LAUNCH_CHECK();
     in = e->s_h[l].as<float>();
     ld_in = ncols;
@@ -1874,7 +1874,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     float* dx_res = L.k == 3 ? (rdrop ? e->s_dx.as<float>() : dh_other) : nullptr;
     a.dx = dx_res; a.lddx = ncols;
     a.dbias_part = e->s_dbias.as<float>();
-    hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(2 * ncols, 64)), dim3(1024), 0, s, e->s_dbias.as<float>(), (long)2 * ncols, B,
                        2 * ncols, L.db, acc ? 1 : 0);

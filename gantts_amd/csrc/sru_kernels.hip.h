@@ -50,10 +50,17 @@ __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
   return r[0] >= a.thresh ? a.keep_scale : 0.f;
 }
 
-constexpr int SRU_UNROLL = 4;
+// The scan has only B * ncols independent lanes (32 768 at B = 32, 6x512 bidirectional): its HBM rate is set by the bytes
+// each lane keeps in flight: SRU_UNROLL_F / _B frames of loads per lane (under the 63 the vmcnt counter can track) and
+// 64-lane workgroups, so that the 512 waves spread over all 256 CUs instead of 128.
+constexpr int SRU_UNROLL_F = 8;       // forward: 4 loads per frame -> 32 in flight
+constexpr int SRU_UNROLL_B = 8;       // backward: 7 loads per frame -> 56 in flight
+// (measured per layer at B = 32, T = 1024, 6x512 bidirectional: 4 frames x 256-lane workgroups 430 / 648 us forward /
+//  backward; 8 frames x 64 lanes 320 / 428 us; dwordx3 / dwordx4 loads of a frame's k values are SLOWER: 352 / 737 us)
+constexpr int SRU_THREADS = 64;
 
-// grid = ceil(B*ncols / 256)
-__global__ __launch_bounds__(256) void sru_fwd_kernel(const SruArgs a) {
+// grid = ceil(B*ncols / SRU_THREADS)
+__global__ __launch_bounds__(SRU_THREADS) void sru_fwd_kernel(const SruArgs a) {
   const int ncols = a.H * a.dirs;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)a.B * ncols) return;
@@ -67,10 +74,10 @@ __global__ __launch_bounds__(256) void sru_fwd_kernel(const SruArgs a) {
   float* hb = a.h + (long)b * T * ncols + col;
   float* cb = a.c + (long)b * T * ncols + col;
   float c = 0.f;
-  for (int t0 = 0; t0 < T; t0 += SRU_UNROLL) {
-    float u0[SRU_UNROLL], u1[SRU_UNROLL], u2[SRU_UNROLL], xp[SRU_UNROLL];
+  for (int t0 = 0; t0 < T; t0 += SRU_UNROLL_F) {
+    float u0[SRU_UNROLL_F], u1[SRU_UNROLL_F], u2[SRU_UNROLL_F], xp[SRU_UNROLL_F];
 #pragma unroll
-    for (int q = 0; q < SRU_UNROLL; ++q) {      // loads of the next frames: independent of c
+    for (int q = 0; q < SRU_UNROLL_F; ++q) {      // loads of the next frames: independent of c
       const int tt = min(t0 + q, T - 1);
       const int t = flip ? T - 1 - tt : tt;
       const float* u = Ub + (long)t * a.ldu;
@@ -78,22 +85,23 @@ __global__ __launch_bounds__(256) void sru_fwd_kernel(const SruArgs a) {
       xp[q] = k == 3 ? xb[(long)t * a.ldx] : u[3];
     }
 #pragma unroll
-    for (int q = 0; q < SRU_UNROLL; ++q) {
+    for (int q = 0; q < SRU_UNROLL_F; ++q) {
       const int tt = t0 + q;
-      if (tt >= T) break;
-      const int t = flip ? T - 1 - tt : tt;
-      const float f = 1.f / (1.f + expf(-(u1[q] + bf)));
-      const float r = 1.f / (1.f + expf(-(u2[q] + br)));
-      c = (c - u0[q]) * f + u0[q];
-      const float val = sru_act(c, a.act) * mk;
-      hb[(long)t * ncols] = (val - xp[q]) * r + xp[q];
-      cb[(long)t * ncols] = c;
+      if (tt < T) {                               // predicated, not a break: the frame loop stays fully unrolled (registers)
+        const int t = flip ? T - 1 - tt : tt;
+        const float f = 1.f / (1.f + expf(-(u1[q] + bf)));
+        const float r = 1.f / (1.f + expf(-(u2[q] + br)));
+        c = (c - u0[q]) * f + u0[q];
+        const float val = sru_act(c, a.act) * mk;
+        hb[(long)t * ncols] = (val - xp[q]) * r + xp[q];
+        cb[(long)t * ncols] = c;
+      }
     }
   }
 }
 
 // same thread mapping, time walked in the reverse of the forward order
-__global__ __launch_bounds__(256) void sru_bwd_kernel(const SruArgs a) {
+__global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
   const int ncols = a.H * a.dirs;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)a.B * ncols) return;
@@ -109,10 +117,10 @@ __global__ __launch_bounds__(256) void sru_bwd_kernel(const SruArgs a) {
   float* dUb = a.dU + (long)b * T * a.ldu + (long)col * k;
   float* dxb = a.dx ? a.dx + (long)b * T * a.lddx + col : nullptr;
   float dc = 0.f, dbf = 0.f, dbr = 0.f;
-  for (int s0 = 0; s0 < T; s0 += SRU_UNROLL) {
-    float u0[SRU_UNROLL], u1[SRU_UNROLL], u2[SRU_UNROLL], xp[SRU_UNROLL], cc[SRU_UNROLL], cp[SRU_UNROLL], dh[SRU_UNROLL];
+  for (int s0 = 0; s0 < T; s0 += SRU_UNROLL_B) {
+    float u0[SRU_UNROLL_B], u1[SRU_UNROLL_B], u2[SRU_UNROLL_B], xp[SRU_UNROLL_B], cc[SRU_UNROLL_B], cp[SRU_UNROLL_B], dh[SRU_UNROLL_B];
 #pragma unroll
-    for (int q = 0; q < SRU_UNROLL; ++q) {
+    for (int q = 0; q < SRU_UNROLL_B; ++q) {
       const int tt = max(T - 1 - (s0 + q), 0);          // forward-order index, descending
       const int t = flip ? T - 1 - tt : tt;
       const int tp = flip ? t + 1 : t - 1;              // frame of c_{tt-1}
@@ -124,9 +132,9 @@ __global__ __launch_bounds__(256) void sru_bwd_kernel(const SruArgs a) {
       dh[q] = dhb[(long)t * ncols];
     }
 #pragma unroll
-    for (int q = 0; q < SRU_UNROLL; ++q) {
+    for (int q = 0; q < SRU_UNROLL_B; ++q) {
       const int tt = T - 1 - (s0 + q);
-      if (tt < 0) break;
+      if (tt < 0) continue;                       // (the tail of the last block of frames)
       const int t = flip ? T - 1 - tt : tt;
       const float f = 1.f / (1.f + expf(-(u1[q] + bf)));
       const float r = 1.f / (1.f + expf(-(u2[q] + br)));
