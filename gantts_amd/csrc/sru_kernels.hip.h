@@ -53,10 +53,11 @@ __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
 // The scan has only B * ncols independent lanes (32 768 at B = 32, 6x512 bidirectional): its HBM rate is set by the bytes
 // each lane keeps in flight: SRU_UNROLL_F / _B frames of loads per lane (under the 63 the vmcnt counter can track) and
 // 64-lane workgroups, so that the 512 waves spread over all 256 CUs instead of 128.
-constexpr int SRU_UNROLL_F = 8;       // forward: 4 loads per frame -> 32 in flight
+constexpr int SRU_UNROLL_F = 12;      // forward: 4 loads per frame -> 48 in flight
 constexpr int SRU_UNROLL_B = 8;       // backward: 7 loads per frame -> 56 in flight
 // (measured per layer at B = 32, T = 1024, 6x512 bidirectional: 4 frames x 256-lane workgroups 430 / 648 us forward /
-//  backward; 8 frames x 64 lanes 320 / 428 us; dwordx3 / dwordx4 loads of a frame's k values are SLOWER: 352 / 737 us)
+//  backward; 8 frames x 64 lanes 320 / 428 us; 12 frames forward 284 us; dwordx3 / dwordx4 loads of a frame's k values are
+//  SLOWER: 352 / 737 us)
 constexpr int SRU_THREADS = 64;
 
 // grid = ceil(B*ncols / SRU_THREADS)
