@@ -171,6 +171,32 @@ constexpr size_t gemm_lds_bytes() {
   return img > stg ? (img > cs ? img : cs) : (stg > cs ? stg : cs);
 }
 
+// Result stores of the epilogue.  GT_EPI_STORE (compile-time, measurement): 0 = plain stores (the result stays dirty in the
+// XCD's L2 and is written back at the end of the kernel), 1 = non-temporal, 2 = write-through (sc0 sc1).  Measured: 1 / 2
+// shorten an isolated launch by 1-2 us (tools/gemm_tile_sweep.hip quick) but lengthen the training step (1.555 vs 1.540
+// ms): the next layer reads this result, and finds less of it in L2 / MALL.  0 it is.
+#ifndef GT_EPI_STORE
+#define GT_EPI_STORE 0
+#endif
+__device__ __forceinline__ void epi_store4(float* dst, const f32x4& v) {
+#if GT_EPI_STORE == 1
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#elif GT_EPI_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#else
+  *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void epi_store1(float* dst, float v) {
+#if GT_EPI_STORE == 1
+  __builtin_nontemporal_store(v, dst);
+#elif GT_EPI_STORE == 2
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#else
+  *dst = v;
+#endif
+}
+
 // ---- epilogue of one BM x BN tile whose accumulators are in the MFMA C layout (col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5)): bias / activation / dropout / f' of the producer, stores.
 // LDS (`smem`, at least gemm_lds_bytes) must be free of K-loop readers on entry for the wide path: it starts with a barrier.
@@ -256,7 +282,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += o[c];
         }
-        *reinterpret_cast<f32x4*>(dst) = v;
+        epi_store4(dst, v);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -309,7 +335,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
             }
           }
           if (KIND != GEMM_TN && g.accumulate) v += C[(long)m * g.ldc + n];
-          C[(long)m * g.ldc + n] = v;
+          epi_store1(C + (long)m * g.ldc + n, v);
         }
       }
     }

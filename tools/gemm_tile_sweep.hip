@@ -99,6 +99,23 @@ int main(int argc, char** argv) {
     {"bwdX G 16384x512x512", GEMM_NN, 16384, 512, 512}, {"bwdX D 32768x256x256", GEMM_NN, 32768, 256, 256}, {"bwdX D 16384x256x256", GEMM_NN, 16384, 256, 256},
     {"bwdW G 512x512x16384", GEMM_TN, 512, 512, 16384}, {"bwdW D 256x256x32768", GEMM_TN, 256, 256, 32768},
   };
+  const bool quick = argc > 2;          // quick: 64x64 tiles only, every shape twice (A/B of build variants, e.g. -DGT_EPI_STORE=n)
+  if (quick) {
+    for (int rep = 0; rep < 2; ++rep)
+      for (const Shape& sh : shapes) {
+        int ns; GemmArgs g = make(sh.kind, sh.M, sh.N, sh.K, b, true, &ns, 64);
+        g_bm = 64;
+        if (sh.kind == GEMM_TN) g = make(sh.kind, sh.M, sh.N, sh.K, b, false, &ns, 64);
+        const double fl = 2.0 * sh.M * sh.N * sh.K;
+        const double us = sh.kind == GEMM_NT ? run<GEMM_NT, 64, 64>(g, 1) : sh.kind == GEMM_NN ? run<GEMM_NN, 64, 64>(g, 1) : run<GEMM_TN, 64, 64>(g, ns);
+        printf("   %s 64x64: %7.1f us %6.1f TF\n", sh.name, us, fl / us / 1e6);
+      }
+    for (int K : {64, 256, 512, 2048}) {
+      int ns; GemmArgs g = make(GEMM_NT, 16384, 512, K, b, true, &ns, 64);
+      printf("   NT 16384x512 K %4d: %7.1f us\n", K, run<GEMM_NT, 64, 64>(g, 1));
+    }
+    return 0;
+  }
   for (const Shape& sh : shapes) {
     const double fl = 2.0 * sh.M * sh.N * sh.K;
     printf("%s  ideal %.1f us\n", sh.name, fl / 157.3e12 * 1e6);
