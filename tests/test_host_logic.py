@@ -135,3 +135,36 @@ def test_paramgen_matches_oracle_dense_inverse(T_):
         assert a.shape == (T_, n * T_) and a.dtype == np.float32
         np.testing.assert_allclose(a, b, atol=1e-6)
     assert paramgen.unit_variance_mlpg_matrix(C.WINDOWS, T_) is paramgen.unit_variance_mlpg_matrix(C.WINDOWS, T_)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r*_bench.json is the JSON line `bench.py` printed on the GPU box at the round's final build: it must carry
+    every field of the driver's contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline` objects, with
+    self-consistent numbers (value = frames / time, frac = achieved / peak, traffic >= algorithmic bytes)."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    assert files, "no committed bench line under profiles/"
+    d = json.load(open(files[-1]))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].split(" at ")[0] in base["metric"] and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    frames = d["config"]["frames_per_step"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] >= 0.95 * r["traffic_algorithmic"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
