@@ -10,8 +10,11 @@ dropout 0.5) + conditioned MLP D (483->256x3->1, dropout 0.5, sigmoid), Adagrad(
 w_d=1, mse_w=0, mge_w=1, adv_w=1, B=32 sequences x T=512 frames per GPU, float32, all lengths = T.
 One step = zero_grad x2 -> apply_generator -> update_discriminator("train") -> update_generator("train")
 including both optimizer steps and the D2H of the 9 scalars (train.py:538-585); inputs are resident
-in HBM before the timed region.  Weak scaling: every rank processes its own 32x512 shard; gradients
-and loss sums are all-reduced over RCCL.
+in HBM before the timed region.  Scaling (`--scaling`, printed in the JSON line): **strong** by default -- the metric
+is quoted on a GLOBAL minibatch of B=32 sequences ("frames = B*T padded frames per global step"), which N
+ranks split into B/N whole sequences each, dealt round-robin; `--scaling weak` gives every rank its own
+32x512 shard instead.  Gradients, loss sums and the valid-frame count are all-reduced over RCCL by the engine's
+communicator (gt_comm_*), overlapped with the backward pass.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the f32
 MFMA GEMM family, per-launch HIP-event timing on the launch stream) and `cpu_baseline` (the CPU
@@ -121,6 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --batch is the GLOBAL minibatch, every rank gets batch/N sequences; "
+                         "weak: every rank gets its own --batch sequences")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
@@ -167,14 +173,25 @@ def main():
     from gantts_amd.parallel import DataParallelStep
     from gantts_amd.seqloss import sequence_mask
 
-    B, Tn = args.batch, args.frames
+    Bglobal, Tn = args.batch, args.frames
+    if args.scaling == "strong":
+        if Bglobal % world:
+            raise SystemExit("bench.py --scaling strong: the global batch of %d sequences does not split over %d ranks" % (Bglobal, world))
+        B = Bglobal // world
+    else:
+        B, Bglobal = args.batch, args.batch * world
     hp = make_hp()
     T.hp = hp
     torch.manual_seed(0)
     mg = models.MLP(**G_SPEC).cuda().train()
     md = models.MLP(**D_SPEC).cuda().train()
     og, od = optim.Adagrad(mg.parameters(), **OPT), optim.Adagrad(md.parameters(), **OPT)
-    x, y = synthetic_batch(B, Tn, 1000 + rank, dev)        # every rank its own shard (weak scaling)
+    if args.scaling == "strong":       # one global batch, sequences dealt round-robin over the ranks
+        xg, yg = synthetic_batch(Bglobal, Tn, 1000, "cpu")
+        x, y = xg[rank::world].contiguous().to(dev), yg[rank::world].contiguous().to(dev)
+        del xg, yg
+    else:                              # every rank its own shard
+        x, y = synthetic_batch(B, Tn, 1000 + rank, dev)
     R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn, dev)
     lengths = torch.full((B,), Tn, dtype=torch.long, device=dev)
     cpu_lengths = [Tn] * B
@@ -297,22 +314,24 @@ def main():
     ctypes.CDLL(None).fflush(None)
     barrier()
     if rank == 0:
-        frames = world * B * Tn * args.steps
+        frames = Bglobal * Tn * args.steps
         value = frames / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
-        step_flops = algorithmic_flops_per_frame() * B * Tn
+        step_flops = algorithmic_flops_per_frame() * B * Tn          # per GPU
         out = {"metric": "acoustic frames/sec per G+D GAN step (B=32,T=512)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "cfg2: TTS acoustic MLP G 425-512x3-187 + conditioned MLP D 483-256x3-1, "
-                                      "Adagrad, MGE+ADV loss, B=%d T=%d per GPU, fp32, dropout 0.5 (Philox)" % (B, Tn),
-                          "global_batch": world * B, "frames_per_step": world * B * Tn, "parallelism": "dp%d" % world},
+                                      "Adagrad, MGE+ADV loss, global B=%d T=%d (%d sequences per GPU, %s scaling), fp32, "
+                                      "dropout 0.5 (Philox)" % (Bglobal, Tn, B, args.scaling),
+                          "global_batch": Bglobal, "per_gpu_batch": B, "frames_per_step": Bglobal * Tn,
+                          "parallelism": "dp%d" % world},
                "step_algorithmic_gflop": step_flops / 1e9,
                "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, Tn)
+            out["cpu_baseline"] = cpu_baseline(Bglobal, Tn)
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()

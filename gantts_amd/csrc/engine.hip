@@ -23,7 +23,6 @@
 #include "../../include/gantts_hip.h"
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
-#include "gemm_chain.hip.h"
 #include "lstm_kernels.hip.h"
 #include "lstm_seq_kernels.hip.h"
 #include "sru_kernels.hip.h"
@@ -233,115 +232,13 @@ struct Scratch {  // growable device buffer
   template <typename T> T* as() { return (T*)p; }
 };
 
-// ---- layer chains (gemm_chain.hip.h).  While a chain is open on this thread, products that qualify (forward / backward
-// -data, both operands 16-byte loadable, f32) are collected instead of launched; a product whose A operand is the previous
-// one's output becomes dependent on it panel by panel.  chain_flush() launches what was collected: one persistent
-// launch for two or more products, the ordinary launch for a single one.
-struct ChainBuild {
-  bool open = false;
-  int n = 0, nxcd = 8;
-  ChainArgs a;
-  Scratch* ctl = nullptr;          // engine-owned control block (queue heads, exit counter, per-panel counters)
-  unsigned int* fault = nullptr;
-  double flops = 0;
-};
-static thread_local ChainBuild tl_chain;
-static bool gemm_chain_enabled() { return true; }   // per engine: GT_OPT_GEMM_CHAIN / GT_GEMM_CHAIN=1
-static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s);
 static void gemm_set_wide_store(int kind, GemmArgs& g) {
   // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
   g.wide_store = kind != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
                  (kind != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
 }
-static int chain_flush(hipStream_t s) {
-  ChainBuild& cb = tl_chain;
-  const int n = cb.n;
-  cb.n = 0;
-  if (n == 0) return GT_OK;
-  if (n == 1) {
-    const bool was_open = cb.open;
-    cb.open = false;                                   // the single product takes the ordinary path
-    const int r = launch_gemm(cb.a.op[0].kind, cb.a.op[0].g, 1, s);
-    cb.open = was_open;
-    return r;
-  }
-  int words = cb.nxcd + 1, items = 0;
-  for (int i = 0; i < n; ++i) { cb.a.op[i].done_base = words - (cb.nxcd + 1); words += cb.a.op[i].g.n_tiles_m; items += cb.a.op[i].g.n_tiles_m * cb.a.op[i].g.n_tiles_n; }
-  const size_t bytes = (size_t)words * sizeof(unsigned int);
-  if (bytes > cb.ctl->bytes) {                         // a fresh (larger) block starts zeroed; afterwards the last
-    CHK(cb.ctl->ensure(bytes * 2));                    // workgroup of every launch leaves it zeroed for the next one
-    HIPCHK(hipMemsetAsync(cb.ctl->p, 0, cb.ctl->bytes, s));
-  }
-  cb.a.n_ops = n; cb.a.nxcd = cb.nxcd; cb.a.ctl = cb.ctl->as<unsigned int>(); cb.a.fault = cb.fault;
-  cb.a.ctl_words = words;
-  cb.a.timeout_ticks = 300000000ull;                   // 3 s of the 100 MHz wall clock
-  const size_t lds = std::max(gemm_lds_bytes<GEMM_NT, CHAIN_BM, CHAIN_BN>(), gemm_lds_bytes<GEMM_NN, CHAIN_BM, CHAIN_BN>());
-  CHK(ensure_dyn_lds((const void*)gemm_chain_kernel, lds));
-  const int grid = std::max(cb.nxcd, std::min(4 * gemm_cu_count(), cdiv(items, cb.nxcd) * cb.nxcd));
-  GemmProfiler::Rec rec;
-  if (g_prof.on) {
-    rec.kind = cb.a.op[0].kind == GEMM_NT ? 3 : 4; rec.bn = 64; rec.flops = cb.flops; rec.bytes = 0;
-    for (int i = 0; i < n; ++i) rec.bytes += gemm_algorithmic_bytes(cb.a.op[i].kind, cb.a.op[i].g);
-    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
-    HIPCHK(hipEventRecord(rec.e0, s));
-  }
-  static const bool chain_dbg = getenv("GT_CHAIN_DBG") != nullptr;     // diagnosis: per-workgroup phase times of every chain launch
-  static unsigned long long* dbg_buf = nullptr;
-  cb.a.dbg = nullptr;
-  if (chain_dbg) {
-    if (!dbg_buf) HIPCHK(hipMalloc((void**)&dbg_buf, 2048 * 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(dbg_buf, 0, 2048 * 8 * sizeof(unsigned long long), s));
-    cb.a.dbg = dbg_buf;
-  }
-  hipLaunchKernelGGL(gemm_chain_kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, cb.a);
-  LAUNCH_CHECK();
-  if (chain_dbg) {
-    std::vector<unsigned long long> h(2048 * 8);
-    HIPCHK(hipMemcpyAsync(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    double t[6] = {0, 0, 0, 0, 0, 0}, tmax = 0; int per_x[16] = {0};
-    for (int b = 0; b < grid; ++b) { for (int k = 0; k < 6; ++k) t[k] += (double)h[8 * b + k]; tmax = std::max(tmax, (double)h[8 * b + 5]); per_x[h[8 * b + 6] & 15]++; }
-    fprintf(stderr, "[chain] ops %d kind %d grid %d items %d: per workgroup avg: %.1f tiles, dequeue %.2f us, dep wait %.2f us, tile %.2f us, publish %.2f us per tile; "
-            "workgroup lifetime avg %.1f us max %.1f us; workgroups per XCD %d %d %d %d %d %d %d %d\n", n, cb.a.op[0].kind, grid, items, t[0] / grid,
-            t[1] / t[0] / 100, t[2] / t[0] / 100, t[3] / t[0] / 100, t[4] / t[0] / 100, t[5] / grid / 100, tmax / 100,
-            per_x[0], per_x[1], per_x[2], per_x[3], per_x[4], per_x[5], per_x[6], per_x[7]);
-  }
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
-  return GT_OK;
-}
-// true: the product was taken into the open chain
-static int chain_offer(int kind, const GemmArgs& g, hipStream_t s, bool* taken) {
-  ChainBuild& cb = tl_chain;
-  *taken = false;
-  const bool ok = (kind == GEMM_NT || kind == GEMM_NN) && tl_gemm_prec == PREC_F32 && gemm_tile_mode() == 0 &&
-                  gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb) && !g.accumulate;
-  if (!ok) return chain_flush(s);                      // keep the stream order: what was collected goes first
-  int dep = -1;
-  if (cb.n > 0) {
-    const GemmArgs& p = cb.a.op[cb.n - 1].g;
-    const bool follows = g.A == p.C && g.lda == p.ldc && g.M == p.M && g.K == p.N && kind == cb.a.op[0].kind;
-    if (!follows || cb.n == CHAIN_MAX_OPS) CHK(chain_flush(s));
-    else dep = cb.n - 1;
-  }
-  ChainOp& op = cb.a.op[cb.n];
-  op.g = g; op.kind = kind; op.dep = dep; op.done_base = 0; op.pad_ = 0;
-  op.g.n_tiles_m = cdiv(g.M, CHAIN_BM); op.g.n_tiles_n = cdiv(g.N, CHAIN_BN);
-  op.g.stagger_ticks = 0; op.g.stagger_dbg = nullptr;
-  gemm_set_wide_store(kind, op.g);
-  if (cb.n == 0) cb.flops = 0;
-  cb.flops += 2.0 * g.M * g.N * g.K;
-  cb.n += 1;
-  *taken = true;
-  return GT_OK;
-}
-
 static int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
-  if (tl_chain.open) {
-    bool taken = false;
-    CHK(chain_offer(kind, g, s, &taken));
-    if (taken) return GT_OK;
-  }
   const int bn = pick_bn(g.N);
   const bool vec = gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb);
   if (kind != GEMM_TN && vec && g.M > 64 && gemm_small_tiles_ok())
@@ -407,7 +304,7 @@ static bool gemm_pair_enabled() {
   return on;
 }
 static bool gemm_pair_ok(const GemmArgs& nn) {
-  return gemm_pair_enabled() && gemm_small_tiles_ok() && !tl_chain.open && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda) && gemm_vec_ok(nn.B, nn.ldb);
+  return gemm_pair_enabled() && gemm_small_tiles_ok() && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda) && gemm_vec_ok(nn.B, nn.ldb);
 }
 static int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hipStream_t s) {
   GemmArgs nn = nn_in, tn = tn_in;
@@ -637,9 +534,6 @@ struct gt_engine {
   bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
   SlabDefer sdefer[2];                             // per role: deferred weight-gradient combines of the fused step
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
-  Scratch chain_ctl;                               // layer-chain launches: queue heads + per-panel counters (gemm_chain.hip.h)
-  std::vector<Scratch> dz_extra;                   // backward-data chains keep every layer's dZ until its weight gradient ran
-  bool gemm_chain = getenv("GT_GEMM_CHAIN") && getenv("GT_GEMM_CHAIN")[0] == '1';   // GT_OPT_GEMM_CHAIN (default off)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
@@ -718,7 +612,7 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if (hipHostGetDevicePointer((void**)&e->h_res_dev, e->h_res, 0) != hipSuccess) { (void)hipGetLastError(); e->h_res_dev = nullptr; }
   if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
   if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
-  e->h_fault[0] = 0; e->h_fault[1] = 0;
+  for (int i = 0; i < 16; ++i) e->h_fault[i] = 0;   // [0] copy of the device word, [1] its mirror by the optimizer kernel, [2 + role] skipped steps
   if (hipHostGetDevicePointer((void**)&e->h_fault_dev, e->h_fault, 0) != hipSuccess) { (void)hipGetLastError(); e->h_fault_dev = nullptr; }
   else e->h_fault_dev += 1;
   *out = e;
@@ -747,9 +641,8 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
-  e->w0pad[0].release(); e->w0pad[1].release(); e->chain_ctl.release();
+  e->w0pad[0].release(); e->w0pad[1].release();
   e->sdefer[0].pool.release(); e->sdefer[1].pool.release();
-  for (auto& z : e->dz_extra) z.release();
   e->mlpg.clear();
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
   for (int* p : ints) if (p) (void)hipFree(p);
@@ -920,7 +813,6 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
     case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16: e->matmul_bf16 = value != 0; return GT_OK;
-    case GT_OPT_GEMM_CHAIN: e->gemm_chain = value != 0; return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -980,6 +872,7 @@ extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {
   return GT_OK;
 }
 
+static int comm_rank(const gt_engine* e);
 // Philox dropout site (role, pass, layer) of engine step `step`: the keep decision of element (row, col) is
 // philox_keep(key0, key1, thresh, row, col) (gemm_f32.hip.h) -- a function of the site and the element only, not of
 // the tiling of whichever kernel applies it.  The keep probability is quantised to 16 bits (thresh = round(p * 2^16)):
@@ -992,7 +885,9 @@ static DropoutSpec philox_site_spec(gt_engine* e, int role, int pass, int layer,
   d.mode = DROP_PHILOX;
   const double th = (double)p * 65536.0 + 0.5;
   d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
-  const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
+  // data parallel: every rank draws its own masks (the rank is part of the site), as the reference's single process
+  // draws an independent mask for every frame of the whole minibatch
+  const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer) + ((uint64_t)comm_rank(e) << 44);
   d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
   d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;
   return d;
@@ -1129,50 +1024,6 @@ static int stage_injected(gt_engine* e, int role, int layer, const int* passes, 
   return GT_OK;
 }
 
-// Layer chains are used on parts whose workgroups report the XCC ids 0 .. 7 (MI355X in its default partition mode):
-// checked once per device with a census launch.
-static int seq_xcds(int* nxcd, int* cus_per_xcd);
-static bool chain_topology_ok() {
-  static std::mutex mu;
-  static std::map<int, bool> ok;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = ok.find(dev);
-  if (it != ok.end()) return it->second;
-  bool good = false;
-  int nxcd = 1, cpx = 0;
-  if (seq_xcds(&nxcd, &cpx) == GT_OK && nxcd == 8) {
-    unsigned int* d = nullptr;
-    unsigned int h[512];
-    if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
-      hipLaunchKernelGGL(chain_census_kernel, dim3(512), dim3(64), 0, 0, d);
-      if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-        unsigned seen = 0; bool in_range = true;
-        for (unsigned v : h) { if (v >= 8) in_range = false; else seen |= 1u << v; }
-        good = in_range && seen == 0xffu;
-      }
-      (void)hipFree(d);
-    }
-    (void)hipGetLastError();
-  }
-  ok[dev] = good;
-  return good;
-}
-static bool chain_wanted(gt_engine* e) { return e->gemm_chain && gemm_chain_enabled() && chain_topology_ok(); }
-static void chain_begin(gt_engine* e) {
-  ChainBuild& cb = tl_chain;
-  cb.n = 0;
-  cb.open = chain_wanted(e);
-  cb.ctl = &e->chain_ctl; cb.fault = e->d_fault; cb.nxcd = 8;
-}
-static int chain_end(hipStream_t s) {
-  const int r = tl_chain.open ? chain_flush(s) : GT_OK;
-  tl_chain.open = false; tl_chain.n = 0;
-  return r;
-}
-#define CHAINED(e, s, call) do { chain_begin(e); const int r1_ = (call); const int r2_ = chain_end(s); if (r1_ != GT_OK) return r1_; if (r2_ != GT_OK) return r2_; } while (0)
-
 // hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
 static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
                          const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s) {
@@ -1216,7 +1067,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
                           float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s) {
   Net& n = e->net[role];
   const int L = (int)n.hidden.size();
-  if (!chain_wanted(e)) {
+  {
     // per-layer launches: each layer's weight gradient right behind the product that made its dZ (still warm in L2 / MALL)
     for (int l = L - 1; l >= 0; --l) {
       const Lin& Lr = n.hidden[l];
@@ -1242,39 +1093,6 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
     }
     return GT_OK;
   }
-  // Layer chains: dz[l] = gradient w.r.t. the pre-activation of hidden layer l, one buffer per layer; the backward-data
-  // products of all layers go first as ONE launch, the weight gradients after them.
-  std::vector<float*> dz(L, nullptr);
-  if ((int)e->dz_extra.size() < L) e->dz_extra.resize(L);
-  for (int l = L - 1; l >= 0; --l) {
-    if (l == L - 1) dz[l] = cur;
-    else if (l == L - 2) dz[l] = other;
-    else { CHK(e->dz_extra[l].ensure((size_t)rows * n.hidden[l].out * sizeof(float))); dz[l] = e->dz_extra[l].as<float>(); }
-  }
-  chain_begin(e);
-  for (int l = L - 1; l > 0; --l) {
-    const Lin& Lr = n.hidden[l];
-    const int r = linear_backward_data(dz[l], Lr.out, Lr.W, Lr.in, 0, dz[l - 1], Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
-                                       acts[l - 1].as<float>(), Lr.in, specs[l - 1], s);
-    if (r != GT_OK) { (void)chain_end(s); return r; }
-  }
-  CHK(chain_end(s));
-  if (dX && L > 0) {
-    const Lin& L0 = n.hidden[0];
-    CHK(linear_backward_data(dz[0] + row0 * L0.out, L0.out, L0.W, L0.in, col0, dX, lddx, nrows, L0.out, ncols, ACT_NONE, nullptr, 0,
-                             no_drop(), s));
-  }
-  if (want_w) {
-    for (int l = L - 1; l >= 0; --l) {
-      const Lin& Lr = n.hidden[l];
-      const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
-      const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
-      CHK(linear_backward_weight(dz[l], Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role]));
-      CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
-      if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's weight gradient
-    }
-  }
-  return GT_OK;
 }
 
 static int cond_dim(gt_engine* e);
@@ -1306,10 +1124,17 @@ static RcclApi* rccl_api() {
   static bool tried = false;
   if (tried) return api.lib ? &api : nullptr;
   tried = true;
-  // prefer the copy that is already in the process (PyTorch ships its own librccl), then the ROCm one
+  // GT_RCCL_LIB=<path>: bind that library instead (tests/fake_rccl.cpp -- a shared-memory test double that lets two
+  // processes on ONE GPU run a world-2 communicator; RCCL itself refuses two ranks on one device).  Otherwise prefer
+  // the copy that is already in the process (PyTorch ships its own librccl), then the ROCm one.
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
-  for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  const char* forced = getenv("GT_RCCL_LIB");
+  if (forced && forced[0]) {
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "gantts_hip: GT_RCCL_LIB=%s could not be loaded: %s\n", forced, dlerror()); return nullptr; }
+  }
+  if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
   if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
   if (!h) return nullptr;
 #define GT_SYM(field, name) *(void**)(&api.field) = dlsym(h, name)
@@ -1387,6 +1212,7 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
   return GT_OK;
 }
 
+static int comm_rank(const gt_engine* e) { return e->comm ? e->comm->rank : 0; }
 static inline bool comm_on(const gt_engine* e) {
   static const bool force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
   return e->comm != nullptr && (e->comm->world > 1 || force);
@@ -1567,11 +1393,24 @@ static int fault_seen(gt_engine* e) {
   const unsigned int f = e->h_fault ? (e->h_fault[0] | e->h_fault[1]) : 0u;
   if (f & 0xffu)
     return fail(GT_ERR_HIP, "persistent LSTM kernel fault %u: a workgroup timed out waiting for its peers (results of that "
-                "step are invalid; set GT_LSTM_STEPS=1 / GT_OPT_LSTM_PERSISTENT=0 to use the per-step kernels)", f);
-  if (f)
-    return fail(GT_ERR_HIP, "layer-chain launch fault 0x%x (%s): results of that step are invalid; GT_GEMM_CHAIN=0 / "
-                "GT_OPT_GEMM_CHAIN=0 selects the per-layer launches", f,
-                (f & CHAIN_FAULT_TIMEOUT) ? "a tile timed out waiting for its input panel" : "an XCD received no workgroup");
+                "step are invalid and its optimizer updates were skipped; gt_clear_faults() re-arms the engine, "
+                "GT_OPT_LSTM_PERSISTENT=0 / GT_LSTM_STEPS=1 selects the per-step kernels)", f);
+  if (f) return fail(GT_ERR_HIP, "device fault word 0x%x: results of that step are invalid", f);
+  return GT_OK;
+}
+// After a fault: parameters, gradients and optimizer state were left untouched by every optimizer launch that saw the
+// raised word (optim_step_kernel returns before its first write and counts the skipped step in pinned memory).  This
+// call waits for the stream, takes the skipped steps back out of the host-side step counters, and clears the word, so
+// that the engine is usable again (typically after gt_set_option(GT_OPT_LSTM_PERSISTENT, 0)).
+extern "C" int gt_clear_faults(gt_engine* e, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemset(e->d_fault, 0, 64));
+  for (int r = 0; r < 2; ++r) { e->net[r].step -= (long)e->h_fault[2 + r]; if (e->net[r].step < 0) e->net[r].step = 0; }
+  for (int i = 0; i < 4; ++i) e->h_fault[i] = 0;
+  e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false;
+  e->d_begin_done = e->g_begin_done = false; e->early_done = false;
   return GT_OK;
 }
 extern "C" int gt_check_faults(gt_engine* e, void* stream) {
@@ -1778,7 +1617,7 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
 // recurrent generator (GT_ARCH_SRU)
 // ------------------------------------------------------------------------------------------
 static void sru_keys(gt_engine* e, int layer, int which, uint32_t* k0, uint32_t* k1) {
-  const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which);
+  const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which) + ((uint64_t)comm_rank(e) << 44);
   *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
   *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site;
 }
@@ -1927,17 +1766,10 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
   } else if (G.d.arch == GT_ARCH_SRU) {
     CHK(sru_forward(e, x, B, T, y_hat, s));
   } else {
-    // hidden stack + last_linear: the layers whose operands take 16-byte loads run as one layer-chain launch
-    chain_begin(e);
-    int r = stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s);
-    if (r == GT_OK) {
-      const Lin& Lh = G.hidden.back();
-      r = linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
-                         G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
-    }
-    const int r2 = chain_end(s);
-    if (r != GT_OK) return r;
-    CHK(r2);
+    CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+    const Lin& Lh = G.hidden.back();
+    CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                       G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
   }
   if (is_i2o(G.d.arch)) {
     if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
@@ -2062,7 +1894,8 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step; o.max_norm = n.od.max_grad_norm;
   const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
   hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
-                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev);
+                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev,
+                     e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -2120,7 +1953,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
   e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-  CHAINED(e, s, stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
   const int H = D.d.hidden_dim;
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
@@ -2341,7 +2174,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
     }
     const float* cat = e->dcat.as<float>() + N * ldc;
-    CHAINED(e, s, stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
@@ -2445,6 +2278,8 @@ extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
   Net& G = e->net[GT_ROLE_G];
   if (!G.bound || !G.d.grads || !e->g_pass_valid) return fail(GT_ERR_STATE, "no generator pass to back-propagate");
   hipStream_t s = (hipStream_t)stream;
+  tl_gemm_prec = e->matmul_bf16 ? PREC_BF16 : PREC_F32;      // this entry point launches GEMMs without check_common
+  CHK(fault_seen(e));
   { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.active = false; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; }   // combines run in place here
   const long N = e->N;
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;

@@ -838,11 +838,20 @@ struct OptimSpec {
 __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
     const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o,
-    const unsigned int* __restrict__ fault_dev, unsigned int* fault_host /* pinned, or null */) {
+    const unsigned int* __restrict__ fault_dev, unsigned int* fault_host /* pinned, or null */,
+    unsigned int* skipped_host /* pinned, or null */) {
   __shared__ float coef_sh;
   __shared__ double shn[16];
-  // a persistent launch of this step that gave up raised the device fault word: mirror it to the host (no copy launch)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && fault_dev && fault_host && *fault_dev) *fault_host = *fault_dev;
+  // A persistent launch of this step that gave up raised the device fault word: its gradients are garbage.  Mirror the
+  // word to the host (no copy launch) and leave parameters, gradients and optimizer state untouched; the skipped step
+  // is counted so that gt_clear_faults can take it back out of the host's step counter.
+  if (fault_dev && *fault_dev) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (fault_host) *fault_host = *fault_dev;
+      if (skipped_host) *skipped_host += 1u;
+    }
+    return;
+  }
   double part = 0.0;
   for (int i = threadIdx.x; i < n_partial; i += blockDim.x) part += norm_partial[i];
   const double tot = block_sum_d(part, shn);      // same fixed order in every workgroup

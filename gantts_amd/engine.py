@@ -159,6 +159,11 @@ class StepEngine(object):
         """Synchronises the current stream and raises if a persistent kernel gave up waiting for a peer."""
         check(lib.gt_check_faults(self._h, L.current_stream()))
 
+    def clear_faults(self):
+        """Re-arms the engine after a reported fault (gt_clear_faults): the faulted step's optimizer updates were skipped
+        on the device, the step counters are put back, the next call must be apply_generator."""
+        check(lib.gt_clear_faults(self._h, L.current_stream()))
+
     def invalidate_mlpg_cache(self):
         check(lib.gt_invalidate_mlpg_cache(self._h))
 
@@ -186,7 +191,7 @@ class StepEngine(object):
         ``"lstm_fwd_units"``, ``"lstm_xcd_local"``; ``"matmul_bf16"`` switches the GEMMs to bf16 products with float32 accumulation."""
         opts = {"lstm_persistent": L.OPT_LSTM_PERSISTENT,
                 "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL,
-                "matmul_bf16": L.OPT_MATMUL_BF16, "gemm_chain": L.OPT_GEMM_CHAIN}
+                "matmul_bf16": L.OPT_MATMUL_BF16}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))
@@ -220,6 +225,7 @@ class StepEngine(object):
     def apply_generator(self, model_g, x, R, lengths=None):
         x = _check_frames(x, "x", model_g.in_dim)
         B, T, _ = x.shape
+        model_g._check_masks(B, T)
         self.bind_model(L.ROLE_G, model_g, with_grads=True)
         if getattr(model_g, "needs_lengths", False):
             self.set_lengths(lengths, B, T)
@@ -247,6 +253,7 @@ class StepEngine(object):
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
+        model_d._check_masks(B, T)
         self.bind_model(L.ROLE_D, model_d, with_grads=True)
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
@@ -274,6 +281,7 @@ class StepEngine(object):
         if train:
             self.bind_optimizer(L.ROLE_G, optimizer_g)
         if adv_w > 0:
+            model_d._check_masks(B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
             x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
         else:
@@ -304,6 +312,7 @@ class StepEngine(object):
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
+        model_d._check_masks(B, T)
         self.bind_model(L.ROLE_D, model_d, with_grads=True)
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
@@ -341,6 +350,7 @@ class StepEngine(object):
         if train:
             self.bind_optimizer(L.ROLE_G, optimizer_g)
         if adv_w > 0:
+            model_d._check_masks(B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
             x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
         else:
@@ -381,6 +391,7 @@ class StepEngine(object):
             x = x.unsqueeze(0)
         x = _check_frames(x, "x", model.in_dim)
         B, T, _ = x.shape
+        model._check_masks(B, T)
         self.bind_model(L.ROLE_G, model, with_grads=False)
         if getattr(model, "needs_lengths", False):
             self.set_lengths(lengths, B, T)
@@ -448,10 +459,7 @@ class HipStepBackend(object):
     def philox_mask(self, role, pass_index, layer, p, rows, cols, steps_ahead=1):
         """Parity hook: the (rows, cols) 0/1 keep mask of Philox dropout site (role, pass, layer) of the step that
         starts ``steps_ahead`` apply_generator calls from now (gt_op_philox_mask)."""
-        m = torch.empty(rows, cols, device="cuda", dtype=torch.float32)
-        check(lib.gt_op_philox_mask(self._h, role, pass_index, layer, int(steps_ahead), float(p), int(rows), int(cols),
-                                    ptr(m), L.current_stream()))
-        return m
+        return self.engine.philox_mask(role, pass_index, layer, p, rows, cols, steps_ahead)
 
     def set_option(self, name, value):
         self.engine.set_option(name, value)

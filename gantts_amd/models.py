@@ -162,6 +162,14 @@ class _FlatNetwork(AbstractModel, nn.Module):
             self._masks[(pass_index, layer)] = m
         self._version += 1
 
+    def _check_masks(self, B, T):
+        """Injected dropout masks are read by the kernels for every row of the batch: a mask with fewer rows than the
+        batch would be read out of bounds on the device (the C ABI carries no shape for them)."""
+        for (pass_idx, layer), m in self._masks.items():
+            if m is not None and m.numel() // m.size(-1) != B * T:
+                raise RuntimeError("injected dropout mask (pass %d, layer %d) has %d rows, the batch has B*T = %d frames"
+                                   % (pass_idx, layer, m.numel() // m.size(-1), B * T))
+
     def _desc(self, with_grads):
         d = L.ModelDesc()
         d.arch = self.ARCH
@@ -344,6 +352,12 @@ class SRURNN(_FlatNetwork):
         if masks:
             raise ValueError("too many dropout masks for this SRURNN")
         self._version += 1
+
+    def _check_masks(self, B, T):
+        for (_, site), m in self._masks.items():
+            if m is not None and m.size(0) != B:
+                raise RuntimeError("injected SRU dropout mask of layer %d has %d rows, the batch has %d sequences "
+                                   "(variational masks are (B, width))" % (site // 2, m.size(0), B))
 
     def forward(self, sequence, lengths=None):
         return self._own_engine().model_forward(self, sequence)

@@ -202,18 +202,17 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * accumulation; parameters ("master weights"), optimizer state, activations in memory, the recurrent state and every
  * reduction stay float32.  Results differ from the float32 path at the 1e-2 relative level (tests/test_gpu_parity.py). */
 #define GT_OPT_MATMUL_BF16 5
-/* GT_OPT_GEMM_CHAIN (default 0; env GT_GEMM_CHAIN=1 turns it on for new engines): consecutive layers of an MLP stack
- * (models.py:129-141) whose operands take 16-byte loads run as ONE persistent launch, forward and backward-data alike: a
- * 64-frame panel of layer l+1 starts as soon as that panel is complete in layer l (per-XCD tile queues, per-panel
- * counters; gemm_chain.hip.h).  Same tiles and arithmetic as the per-layer launches: identical results.  Measured
- * SLOWER than the per-layer launches on the cfg2 step (1.78 vs 1.62 ms), hence off; only ever used on
- * parts whose workgroups report the XCC ids 0..7 (checked once per device). */
-#define GT_OPT_GEMM_CHAIN 6
 int gt_set_option(gt_engine* e, int option, int value);
 /* The persistent recurrence kernels bound every inter-workgroup wait by a wall-clock timeout and raise a device fault
  * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;
  * this call synchronises `stream` and reports the current state. */
 int gt_check_faults(gt_engine* e, void* stream);
+/* A raised fault word makes every optimizer launch behind it a no-op (parameters, gradients and optimizer state of the
+ * faulted step stay as they were; optimizer.step() of train.py:276,318 is simply not taken).  This call synchronises,
+ * takes the skipped steps back out of the step counters, clears the word and resets the per-step call state, so the
+ * engine can be used again -- e.g. after gt_set_option(e, GT_OPT_LSTM_PERSISTENT, 0).  The next call must be
+ * gt_apply_generator. */
+int gt_clear_faults(gt_engine* e, void* stream);
 /* ---- data-parallel communicator (one process per GPU; RCCL == NCCL on ROCm, bound at run time) ----
  * The reference has no multi-device code; the step being sharded is train.py:538-585.  Every rank holds the
  * full G / D and whole sequences of the minibatch.  With a communicator attached the FUSED step functions above are
@@ -305,8 +304,7 @@ int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, co
 
 /* ---- measurement (bench.py): HIP-event timing of every GEMM launch on its own stream --------
  * slot = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W), 2 backward-weight (dZ^T X);
- * slot 6 = layer-chain launches of forward products, slot 7 = layer-chain launches of backward-data products,
- * slot 8 = pair launches (one layer's backward-data product and weight gradient in one launch).
+ * slots 6, 7 unused; slot 8 = pair launches (one layer's backward-data product and weight gradient in one launch).
  * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries. */
 #define GT_PROFILE_SLOTS 9
 int gt_profile_enable(int on);

@@ -198,6 +198,13 @@ class _DropoutSource(object):
         return m
 
 
+def cast_model(model, dtype):
+    """Re-creates the model's parameters in `dtype` (float64 = the arbiter run of the at-size fixtures and of the
+    tolerance tests: same inputs and masks, arithmetic exact to 1e-16).  Call before building its optimizer."""
+    model.params = [p.detach().to(dtype).clone().requires_grad_(True) for p in model.params]
+    return model
+
+
 class OracleMLP(object):
     """gantts/models.py:121-141.  state-dict keys: layers.{i}.weight/bias, last_linear.*"""
 

@@ -1,0 +1,126 @@
+"""At-size parity cases (BASELINE.json configs[2..4] at the sizes they name) and the compact fixture format.
+
+A full G+D step at these sizes is minutes of CPU work for the reference (nn.LSTM over 32 x 1024 frames) or for the
+oracle's python time loop (SRU over 16 x 2048 frames), and its tensors are tens of MB -- so the step is run ONCE in the
+build container by ``make_at_size.py`` (twice, in fact: float32, the reference's own arithmetic, and float64, the
+arbiter) and what is committed is a *digest*: for every tensor the float64 run's L2 norm, a seeded sample of its
+elements, and the relative rms error of the float32 run against the float64 run over the FULL tensor.  The ``-m gpu``
+test recomputes the same sample / norm from the HIP engine's tensors and requires
+
+    rms(hip - ref64) over the sample  <=  ARBITER_FACTOR * rms(ref32 - ref64) + ARBITER_FLOOR   (relative to rms(ref64))
+
+i.e. the engine may be as far from the exact result as the reference's own float32 arithmetic is, not further; no
+hand-set per-layer tolerance.  (The LeakyReLU kink -- a pre-activation within rounding of 0 picks slope 1 or 0.01,
+gantts/models.py:132 -- and the sign-like first Adam step make some tensors ill-conditioned; the float32-vs-float64
+distance measures exactly that, tensor by tensor.)
+"""
+import zlib
+
+import numpy as np
+
+import cases as C
+
+ARBITER_FACTOR = 3.0
+ARBITER_FLOOR = 2e-6          # relative rms: a few float32 ulps, for tensors the reference happens to get exactly
+SAMPLE = 4096                 # elements kept per parameter-shaped tensor
+FRAMES = 24                   # frames kept per sequence of a (B, T, D) tensor
+
+_ACOUSTIC = dict(stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+                 adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True, windows=3)
+_WARM = dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)
+
+AT_SIZE_CASES = {
+    # BASELINE.json configs[2]: BiLSTM 3 x 256 generator + conditioned MLP D, B = 32, T = 1024 (reference: gantts/models.py:193-213,
+    # train.py:245-320).  Source: the REAL reference (nn.LSTM over the packed batch).  D dropout 0.5 with injected masks.
+    "cfg3_lstm": dict(
+        _ACOUSTIC, hp="tts_acoustic", B=32, T=1024, din=425, dout=187, noise_dim=0, source="reference",
+        g=dict(kind="LSTMRNN", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True, dropout=0.0,
+               last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", _WARM), opt_d=("Adagrad", _WARM),
+        steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
+    # BASELINE.json configs[3]: SRU generator on VC mgc / lf0 / bap streams, B = 16, T = 2048 (gantts/models.py:144-167; the
+    # hparams-default SRU widths, hparams.py:211-222; the VC discriminator, hparams.py:56-64).  Source: the oracle's
+    # restated SRU cell (un-vendored third-party code: PARITY UNPINNED).  Both variational dropouts + D dropout injected.
+    "cfg4_sru": dict(
+        hp="vc", B=16, T=2048, din=183, dout=183, noise_dim=0, source="oracle",
+        stream_sizes=[177, 3, 3], has_dynamic_features=[True, True, True], adversarial_streams=[True, False, False],
+        mask_nth_mgc=0, cond=False, windows=3,
+        g=dict(kind="SRURNN", in_dim=183, out_dim=183, num_hidden=6, hidden_dim=512, bidirectional=True, dropout=0.2,
+               last_sigmoid=False, use_relu=1, rnn_dropout=0.2),
+        d=dict(kind="MLP", in_dim=59, out_dim=1, num_hidden=2, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=0, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=0, initial_accumulator_value=1e-4)),
+        steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
+    # BASELINE.json configs[4], acoustic pair: generator_add_noise (G sees cat(x, z), 425 + 200 wide; train.py:504-506, 542),
+    # conditioned D sees x alone (train.py:254-256), B = 64.  Source: the REAL reference.
+    "cfg5_acoustic": dict(
+        _ACOUSTIC, hp="tts_acoustic", B=64, T=512, din=425, dout=187, noise_dim=200, source="reference",
+        g=dict(kind="MLP", in_dim=625, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", _WARM), opt_d=("Adagrad", _WARM),
+        steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
+    # BASELINE.json configs[4], duration pair: phone-level, no dynamic features (R = None), Adam (hparams.py:125-130),
+    # noise + conditioned D, B = 64.  Source: the REAL reference.
+    "cfg5_duration": dict(
+        hp="tts_duration", B=64, T=40, din=416, dout=5, noise_dim=200, source="reference",
+        stream_sizes=[5], has_dynamic_features=[False], adversarial_streams=[True], mask_nth_mgc=0, cond=True, windows=1,
+        g=dict(kind="MLP", in_dim=616, out_dim=5, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=421, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
+}
+
+
+def make_inputs(case, seed=4242):
+    """(x, y, lengths, z): the batch of cases.make_batch (lengths sorted descending as train.py:494-501 leaves them)
+    plus, for generator_add_noise, z ~ U[0,1) of width noise_dim (train.py:504-506)."""
+    x, y, lengths = C.make_batch(case, seed=seed)
+    z = None
+    if case["noise_dim"]:
+        z = np.random.RandomState(seed + 7).rand(case["B"], case["T"], case["noise_dim"]).astype(np.float32)
+    return x, y, lengths, z
+
+
+def _rs(key):
+    return np.random.RandomState(zlib.crc32(key.encode()) & 0x7fffffff)
+
+
+def sample_of(key, a):
+    """The seeded sample of tensor `a` the fixture keeps under `key`: FRAMES frames per sequence (all columns) of a
+    (B, T, D) tensor, SAMPLE elements of anything else; scalars / small tensors whole."""
+    a = np.asarray(a)
+    if a.ndim == 3:
+        T = a.shape[1]
+        if T <= FRAMES + 2:
+            return a.reshape(-1)
+        t = np.unique(np.concatenate(([0, T - 1], _rs(key).choice(T, FRAMES, replace=False))))
+        return a[:, t, :].reshape(-1)
+    flat = a.reshape(-1)
+    if flat.size <= SAMPLE:
+        return flat
+    return flat[np.sort(_rs(key).choice(flat.size, SAMPLE, replace=False))]
+
+
+def rms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt((a * a).mean())) if a.size else 0.0
+
+
+def digest(run32, run64):
+    """Compact fixture from the float32 and the float64 run of one case (dicts name -> full tensor)."""
+    out = {}
+    for k, v64 in run64.items():
+        v64 = np.asarray(v64, dtype=np.float64)
+        v32 = np.asarray(run32[k], dtype=np.float64)
+        if "scalars" in k:
+            out[k + ".f64"], out[k + ".f32"] = v64, v32
+            continue
+        den = max(rms(v64), 1e-300)
+        out[k + ".norm"] = np.float64(np.sqrt((v64 * v64).sum()))
+        out[k + ".err32"] = np.float64(rms(v32 - v64) / den)          # the reference's own float32 distance, FULL tensor
+        out[k + ".sample"] = sample_of(k, v64).astype(np.float32)
+        s32 = sample_of(k, v32)
+        out[k + ".err32_sample"] = np.float64(rms(s32 - sample_of(k, v64)) / max(rms(sample_of(k, v64)), 1e-300))
+    return out

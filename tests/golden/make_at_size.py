@@ -1,0 +1,189 @@
+"""Generate the at-size fixtures tests/golden/at_size_<case>.npz (build container only; minutes of CPU per case).
+
+    python tests/golden/make_at_size.py [case ...]
+
+Every case of ``at_size.AT_SIZE_CASES`` is run twice -- float32 (the reference's arithmetic) and float64 (the arbiter) --
+and digested by ``at_size.digest``.  ``source="reference"`` cases execute the REAL reference (``train.apply_generator /
+update_discriminator / update_generator`` with ``gantts.models`` modules and ``torch.optim``, imported from
+/root/reference through oracle/ref_loader.py, in the order train.py:528-585 uses them; generator noise z is concatenated
+as train.py:542 does); ``source="oracle"`` cases (SRU: un-vendored third-party cell, parity unpinned) run
+oracle/gantts_oracle.py.  Dropout masks are injected exactly as in make_golden.py.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+import at_size as A  # noqa: E402
+import cases as C  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def run_reference(case, dtype):
+    """The real reference on one at-size case; returns {name: full tensor}."""
+    import ref_loader
+    train, hparams, gantts = ref_loader.load_reference()
+    from gantts.multistream import get_static_features
+    from gantts.seqloss import sequence_mask
+    from nnmnkwii.paramgen import unit_variance_mlpg_matrix
+    hp = getattr(hparams, case["hp"])
+    saved = dict(hp.__dict__)
+    orig_dropout = torch.nn.Dropout.forward
+    try:
+        windows = C.WINDOWS[:case["windows"]]
+        hp.__dict__.update(
+            stream_sizes=case["stream_sizes"], has_dynamic_features=case["has_dynamic_features"], windows=windows,
+            adversarial_streams=case["adversarial_streams"], mask_nth_mgc_for_adv_loss=case["mask_nth_mgc"],
+            discriminator_linguistic_condition=case["cond"])
+        train.hp = hp
+
+        def build(spec, seed):
+            kw = {k: v for k, v in spec.items() if k != "kind"}
+            m = getattr(gantts.models, spec["kind"])(**kw)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed).items()})
+            return m.to(dtype)
+
+        model_g, model_d = build(case["g"], 11), build(case["d"], 22)
+        w0 = {"G." + k: _np(v) for k, v in model_g.state_dict().items()}
+        w0.update({"D." + k: _np(v) for k, v in model_d.state_dict().items()})
+        og = getattr(torch.optim, case["opt_g"][0])(model_g.parameters(), **case["opt_g"][1])
+        od = getattr(torch.optim, case["opt_d"][0])(model_d.parameters(), **case["opt_d"][1])
+        queue = []
+
+        def patched(self, inp):
+            if not self.training or self.p == 0:
+                return inp
+            m = queue.pop(0)
+            assert m.shape == inp.shape, (m.shape, inp.shape)
+            return inp * m.to(inp.dtype) / (1.0 - self.p)
+
+        torch.nn.Dropout.forward = patched
+        model_g.train(), model_d.train()
+        x_np, y_np, lengths, z_np = A.make_inputs(case)
+        x, y = torch.from_numpy(x_np).to(dtype), torch.from_numpy(y_np).to(dtype)
+        gin = torch.cat((x, torch.from_numpy(z_np).to(dtype)), -1) if z_np is not None else x
+        T = case["T"]
+        has_dyn = bool(np.any(case["has_dynamic_features"]))
+        R = torch.from_numpy(unit_variance_mlpg_matrix(windows, T)).to(dtype) if has_dyn else None
+        sl = torch.from_numpy(lengths)
+        cpu_lengths = list(sl)
+        out = {}
+        for step in range(case["steps"]):
+            gm, dm = C.make_dropout_masks(case, step)
+            queue[:] = [torch.from_numpy(m) for m in gm + dm]
+            y_static = get_static_features(y, len(windows), hp.stream_sizes, hp.has_dynamic_features)
+            mask = sequence_mask(sl).unsqueeze(-1).to(dtype)
+            og.zero_grad(), od.zero_grad()
+            y_hat, y_hat_static = train.apply_generator(model_g, gin, R, cpu_lengths)
+            if step == 0:
+                out["y_hat"], out["y_hat_static"] = _np(y_hat), _np(y_hat_static)
+            res = train.update_discriminator(model_d, od, x, y_static, y_hat_static, cpu_lengths, mask, "train")
+            out["d_scalars_%d" % step] = np.array(res, dtype=np.float64)
+            if step == 0:
+                for (k, _), p in zip(model_d.state_dict().items(), model_d.parameters()):
+                    out["Dgrad." + k] = _np(p.grad)
+            res = train.update_generator(model_g, model_d, og, x, y, y_hat, y_static, y_hat_static, case["adv_w"],
+                                         cpu_lengths, mask, "train", mse_w=case["mse_w"], mge_w=case["mge_w"])
+            out["g_scalars_%d" % step] = np.array(res, dtype=np.float64)
+            if step == 0:
+                for (k, _), p in zip(model_g.state_dict().items(), model_g.parameters()):
+                    out["Ggrad." + k] = _np(p.grad)
+            assert not queue, "unused dropout masks: %d" % len(queue)
+        for k, v in model_g.state_dict().items():
+            out["Gupd." + k] = _np(v) - w0["G." + k]
+        for k, v in model_d.state_dict().items():
+            out["Dupd." + k] = _np(v) - w0["D." + k]
+        return out
+    finally:
+        torch.nn.Dropout.forward = orig_dropout
+        hp.__dict__.clear()
+        hp.__dict__.update(saved)
+
+
+def run_oracle(case, dtype):
+    """oracle/gantts_oracle.py on one at-size case (same record layout as run_reference)."""
+    import gantts_oracle as O
+    from oracle_runner import build_oracle_model, stream_config
+    cfg = stream_config(case)
+    mg, md = build_oracle_model(case["g"], 11), build_oracle_model(case["d"], 22)
+    O.cast_model(mg, dtype), O.cast_model(md, dtype)
+    mg.training = md.training = True
+    w0 = {"G." + n: _np(p) for n, p in zip(mg.names, mg.params)}
+    w0.update({"D." + n: _np(p) for n, p in zip(md.names, md.params)})
+    og = O.make_optimizer(case["opt_g"][0], mg.params, **case["opt_g"][1])
+    od = O.make_optimizer(case["opt_d"][0], md.params, **case["opt_d"][1])
+    x_np, y_np, lengths, z_np = A.make_inputs(case)
+    x, y = torch.from_numpy(x_np).to(dtype), torch.from_numpy(y_np).to(dtype)
+    gin = torch.cat((x, torch.from_numpy(z_np).to(dtype)), -1) if z_np is not None else x
+    T = case["T"]
+    has_dyn = bool(np.any(case["has_dynamic_features"]))
+    R = torch.from_numpy(O.unit_variance_mlpg_matrix(C.WINDOWS[:case["windows"]], T)).to(dtype) if has_dyn else None
+    mask = O.sequence_mask(lengths).unsqueeze(-1).to(dtype)
+    out = {}
+    for step in range(case["steps"]):
+        gm, dm = C.make_dropout_masks(case, step)
+        dg = O._DropoutSource([torch.from_numpy(m).to(dtype) for m in gm])
+        dd = O._DropoutSource([torch.from_numpy(m).to(dtype) for m in dm])
+        y_static = O.get_static_features(y, cfg.num_windows, cfg.stream_sizes, cfg.has_dynamic_features)
+        og.zero_grad(), od.zero_grad()
+        y_hat, y_hat_static = O.apply_generator(cfg, mg, gin, R, list(lengths), drop=dg)
+        if step == 0:
+            out["y_hat"], out["y_hat_static"] = _np(y_hat), _np(y_hat_static)
+        res = O.update_discriminator(cfg, md, od, x, y_static, y_hat_static, list(lengths), mask, "train", drop=dd)
+        out["d_scalars_%d" % step] = np.array(res, dtype=np.float64)
+        if step == 0:
+            for n, p in zip(md.names, md.params):
+                out["Dgrad." + n] = _np(p.grad)
+        res = O.update_generator(cfg, mg, md, og, x, y, y_hat, y_static, y_hat_static, case["adv_w"], list(lengths), mask,
+                                 "train", mse_w=case["mse_w"], mge_w=case["mge_w"], drop=dd)
+        out["g_scalars_%d" % step] = np.array(res, dtype=np.float64)
+        if step == 0:
+            for n, p in zip(mg.names, mg.params):
+                out["Ggrad." + n] = _np(p.grad)
+    for n, p in zip(mg.names, mg.params):
+        out["Gupd." + n] = _np(p) - w0["G." + n]
+    for n, p in zip(md.names, md.params):
+        out["Dupd." + n] = _np(p) - w0["D." + n]
+    return out
+
+
+def main():
+    only = sys.argv[1:]
+    torch.set_num_threads(os.cpu_count())
+    for name, case in A.AT_SIZE_CASES.items():
+        if only and name not in only:
+            continue
+        runner = run_reference if case["source"] == "reference" else run_oracle
+        runs, secs = {}, {}
+        for dtype in (torch.float32, torch.float64):
+            torch.manual_seed(0)
+            t0 = time.time()
+            runs[dtype] = runner(case, dtype)
+            secs[dtype] = time.time() - t0
+            print("%-14s %-8s %s: %.1f s" % (name, case["source"], str(dtype).split(".")[1], secs[dtype]), flush=True)
+        fx = A.digest(runs[torch.float32], runs[torch.float64])
+        fx["meta.source"] = np.array(case["source"])
+        fx["meta.seconds_f32"], fx["meta.seconds_f64"] = np.float64(secs[torch.float32]), np.float64(secs[torch.float64])
+        path = os.path.join(HERE, "at_size_%s.npz" % name)
+        np.savez_compressed(path, **fx)
+        print("%-14s -> %s (%.0f KB)" % (name, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024), flush=True)
+        for k in sorted(fx):
+            if "scalars" in k:
+                print("    %-22s %s" % (k, np.array2string(fx[k], precision=7)))
+        worst = sorted(((float(fx[k]), k) for k in fx if k.endswith(".err32")), reverse=True)[:6]
+        print("    largest float32-vs-float64 distances: " + ", ".join("%s %.2e" % (k[:-6], v) for v, k in worst), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,10 @@ def build_model(spec, seed):
     return m.cuda()
 
 
-def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False):
+def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False, shard=None, comm_id=None, extra=None):
+    """shard = (rank, world): this process holds sequences rank, rank + world, ... of the case's batch (whole
+    sequences dealt round-robin) and, with `comm_id`, attaches the engine's communicator (gt_comm_init) first -- the
+    fused step functions are then data-parallel by themselves and every rank must reproduce the WHOLE batch's result."""
     import gantts_amd.train as T
     from gantts_amd import optim, paramgen
     from gantts_amd.multistream import get_static_features
@@ -51,22 +54,33 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
         eng = engine_for(hp, mg)
         eng.comm_init(0, 1, eng.comm_unique_id())
     x_np, y_np, lengths = C.make_batch(case)
+    rows = slice(None)
+    if shard is not None:
+        rank, world = shard
+        rows = np.arange(case["B"])[rank::world]
+        x_np, y_np, lengths = x_np[rows], y_np[rows], lengths[rows]
+        if comm_id is not None:
+            from gantts_amd.engine import engine_for
+            eng = engine_for(hp, mg)
+            eng.comm_init(rank, world, comm_id)
+            if extra is not None:      # Philox masks of this rank's next step (data parallel: ranks must draw different ones)
+                extra["philox"] = eng.philox_mask(0, 0, 0, 0.5, 64, 48).cpu().numpy()
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
     Tn = case["T"]
     has_dyn = bool(np.any(case["has_dynamic_features"]))
     R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn) if has_dyn else None
-    sl = torch.from_numpy(lengths).cuda()
+    sl = torch.from_numpy(np.ascontiguousarray(lengths)).cuda()
     cpu_lengths = list(lengths)
     out = {}
     for step in range(case["steps"]):
         if case["dropout_on"]:
             gm, dm = C.make_dropout_masks(case, step)
             nh = case["d"]["num_hidden"]
-            mg.set_dropout_masks(0, [torch.from_numpy(m) for m in gm])
+            mg.set_dropout_masks(0, [torch.from_numpy(m[rows]) for m in gm])
             for p in range(3):
-                md.set_dropout_masks(p, [torch.from_numpy(m) for m in dm[p * nh:(p + 1) * nh]])
+                md.set_dropout_masks(p, [torch.from_numpy(m[rows]) for m in dm[p * nh:(p + 1) * nh]])
         y_static = get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features)
-        mask = sequence_mask(sl).unsqueeze(-1)
+        mask = sequence_mask(sl, max_len=Tn).unsqueeze(-1)
         og.zero_grad()
         od.zero_grad()
         y_hat, y_hat_static = T.apply_generator(mg, x, R, cpu_lengths)

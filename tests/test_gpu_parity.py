@@ -736,55 +736,6 @@ def test_lstm_full_size_persistent_equals_per_step_kernels():
     np.testing.assert_allclose(a[2][bshort, 1:], np.broadcast_to(bias, a[2][bshort, 1:].shape), rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,Tn", [(32, 512), (3, 171)])
-def test_layer_chain_launches_are_bit_identical_to_per_layer_launches(B, Tn):
-    """GT_OPT_GEMM_CHAIN (gemm_chain.hip.h): the hidden layers of an MLP stack as ONE persistent launch -- per-XCD tile
-    queues, a 64-frame panel of layer l+1 released by a counter when layer l has completed it -- forward (generator and
-    both discriminator passes) and backward-data.  Tiles and arithmetic are those of the per-layer launches, so two cfg2
-    steps with Philox dropout ON must agree BIT FOR BIT with the option off (every scalar, y_hat, both gradients, both
-    parameter sets), and the launch must not raise the fault word (timeout / unserved queue)."""
-    import types
-    import gantts_amd.train as T
-    from gantts_amd import hparams, optim, paramgen
-    from gantts_amd.engine import engine_for
-    from gantts_amd.multistream import get_static_features
-    from gantts_amd.seqloss import sequence_mask
-    from hip_runner import build_model
-    gs = dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
-    ds = dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
-    case = dict(B=B, T=Tn, din=425, dout=187, stream_sizes=[180, 3, 1, 3])
-    x_np, y_np, lengths = C.make_batch(case, seed=5)
-    hp = types.SimpleNamespace(**hparams.tts_acoustic.values())
-    T.hp = hp
-    R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn)
-    x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
-    ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
-    mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
-    res = {}
-    for chain in (1, 0):
-        mg, md = build_model(gs, 1).train(), build_model(ds, 2).train()
-        og = optim.Adagrad(mg.parameters(), lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)
-        od = optim.Adagrad(md.parameters(), lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)
-        eng = engine_for(hp, mg)
-        eng.set_option("gemm_chain", chain)
-        eng.set_seed(77)
-        rec = []
-        for _ in range(2):
-            og.zero_grad(), od.zero_grad()
-            yh, yhs = T.apply_generator(mg, x, R, list(lengths))
-            d = T.update_discriminator(md, od, x, ys, yhs, list(lengths), mask, "train")
-            g = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, list(lengths), mask, "train", mse_w=0.0, mge_w=1.0)
-            rec += [np.asarray(d, dtype=np.float64), np.asarray(g, dtype=np.float64), yh.cpu().numpy().copy(), yhs.cpu().numpy().copy(),
-                    mg.flat_grads().cpu().numpy().copy(), md.flat_grads().cpu().numpy().copy()]
-        eng.check_faults()
-        rec += [mg.flat_params().cpu().numpy().copy(), md.flat_params().cpu().numpy().copy()]
-        res[chain] = rec
-    assert all(np.isfinite(a).all() for a in res[1])
-    for i, (a, b) in enumerate(zip(res[1], res[0])):
-        assert np.array_equal(a, b), "record %d differs between the layer-chain launch and the per-layer launches: max |diff| %g" % (
-            i, float(np.abs(a - b).max()))
-
-
 def test_sru_full_size_cfg4_step_is_finite_and_reproducible():
     """BASELINE.json configs[3] at full size (hparams-default SRU 6 x 512 bidirectional with both dropouts, B = 16,
     T = 2048): the oracle's python time loop is out of reach there (its parity case runs at T = 64, same widths), so the

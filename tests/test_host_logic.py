@@ -154,7 +154,7 @@ def test_committed_bench_line_has_the_contract_fields():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].split(" at ")[0] in base["metric"] and d["unit"] == "frames/s" and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     frames = d["config"]["frames_per_step"]
     assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
