@@ -110,6 +110,7 @@ SIGNATURES = {
     "gt_op_mlpg_forward": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "gt_op_mlpg_backward": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "gt_op_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P]),
+    "gt_op_linear_bf16": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _F, _P, _P, _P, _I, _P, _F, _P, _P, _P, _P, _P, _P]),
     "gt_profile_enable": (_I, [_I]),
     "gt_profile_read": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
     "gt_profile_bytes": (_I, [C.POINTER(C.c_double)]),

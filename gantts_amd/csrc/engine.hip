@@ -23,6 +23,7 @@
 #include "../../include/gantts_hip.h"
 #include "frame_kernels.hip.h"
 #include "gemm_f32.hip.h"
+#include "gemm_bf16s.hip.h"
 #include "lstm_kernels.hip.h"
 #include "lstm_seq_kernels.hip.h"
 #include "sru_kernels.hip.h"
@@ -436,6 +437,101 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(out, 256)), dim3(256), 0, s, colp.as<float>(), nblk, out, db,
                        accumulate ? 1 : 0);
     LAUNCH_CHECK();
+  }
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16-storage products (gemm_bf16s.hip.h; GT_OPT_MATMUL_BF16)
+// ------------------------------------------------------------------------------------------
+static inline int pad8(long n) { return (int)((n + 7) & ~7L); }
+template <int BM, int BN>
+static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
+  const size_t lds = gemm_b16_lds_bytes<BM, BN>();
+  CHK(ensure_dyn_lds((const void*)gemm_b16_kernel<BM, BN>, lds));
+  g.n_tiles_m = cdiv(g.M, BM);
+  g.n_tiles_n = cdiv(g.N, BN);
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  if (grid <= 0) return GT_OK;
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = g.epi; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
+                (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  hipLaunchKernelGGL((gemm_b16_kernel<BM, BN>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
+}
+static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
+  if ((g.lda & 7) || (g.ldb & 7) || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15))
+    return fail(GT_ERR_INVALID, "bf16 product: operands must be 16-byte aligned with a row pitch that is a multiple of 8");
+  if (g.CbT && ((g.ldcbt & 3) || (((uintptr_t)g.CbT) & 7))) return fail(GT_ERR_INVALID, "bf16 product: transposed result must be 8-byte aligned");
+  // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
+  const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
+  if (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && t128 >= 2L * gemm_cu_count()) return launch_gemm_b16_t<128, 128>(g, nslab, s);
+  return launch_gemm_b16_t<64, 64>(g, nslab, s);
+}
+static GemmB16Args b16_args() {
+  GemmB16Args g;
+  memset(&g, 0, sizeof(g));
+  g.drop.mode = DROP_NONE; g.drop.scale = 1.f;
+  return g;
+}
+// [rows][ld_in] float32 / bf16  ->  bf16 [rows][ldo] and / or its transpose [cols][ldt] (+ per-column sums -> colsum, the
+// bias gradient of a dZ that no product wrote)
+template <typename TIN>
+static int cast_transpose(const TIN* in, int ld_in, long rows, int cols, __bf16* out, int ldo, __bf16* outT, long ldt,
+                          float* colsum, bool colsum_accumulate, Scratch* colp, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return GT_OK;
+  const int gx = cdiv(rows, 64);
+  float* part = nullptr;
+  if (colsum) { CHK(colp->ensure((size_t)gx * cols * sizeof(float))); part = colp->as<float>(); }
+  hipLaunchKernelGGL((cast_transpose_kernel<TIN>), dim3(gx, cdiv(cols, 64)), dim3(256), 0, s, in, ld_in, rows, cols, out, ldo, outT, ldt, part);
+  LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, (const float*)part, gx, cols, colsum, colsum_accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  return GT_OK;
+}
+// dW (+)= dZT . XT^T over the frame dimension (K = rows), db (+)= row sums of dZT; split into float32 slabs, fixed-order combine
+struct SlabDefer;
+static int slab_defer_flush(SlabDefer& d, hipStream_t s);
+static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long ldxt, long rows, int out, int in, float* dW, float* db,
+                           bool accumulate, Scratch& slabs, hipStream_t s) {
+  const int tiles = cdiv(out, 64) * cdiv(in, 64);
+  int nslab = std::max(1, 1024 / tiles);                     // four 64 x 64 workgroups per CU
+  nslab = std::min<long>(nslab, std::max<long>(1, rows / 512));
+  const int k_chunk = cdiv(cdiv(rows, nslab), B16_BK) * B16_BK;
+  nslab = cdiv(rows, k_chunk);
+  const long slab_stride = (long)out * in;
+  CHK(slabs.ensure((((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float) + 255) & ~(size_t)255));
+  float* slab_base = slabs.as<float>();
+  float* bias_slabs = slab_base + (size_t)nslab * slab_stride;
+  GemmB16Args g = b16_args();
+  g.A = dZT; g.lda = (int)lddzt; g.B = XT; g.ldb = (int)ldxt; g.M = out; g.N = in; g.K = (int)rows;
+  g.C = slab_base; g.ldc = in; g.epi = B16_SLAB; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+  g.rowsum_slab = db ? bias_slabs : nullptr;
+  CHK(launch_gemm_b16(g, nslab, s));
+  const bool can4 = slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0;
+  if (can4) {
+    const int main_blocks = cdiv(slab_stride / 4, 256), bias_blocks = db ? cdiv(out, 256) : 0;
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slab_base, slab_stride, nslab, slab_stride / 4,
+                       dW, accumulate ? 1 : 0, (const float*)bias_slabs, out, db, main_blocks);
+    LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slab_base, slab_stride, nslab, slab_stride, dW,
+                       accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+    if (db) {
+      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(out, 64)), dim3(1024), 0, s, bias_slabs, (long)out, nslab, out, db, accumulate ? 1 : 0);
+      LAUNCH_CHECK();
+    }
   }
   return GT_OK;
 }
@@ -887,9 +983,10 @@ static DropoutSpec philox_site_spec(gt_engine* e, int role, int pass, int layer,
   d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
   // data parallel: every rank draws its own masks (the rank is part of the site), as the reference's single process
   // draws an independent mask for every frame of the whole minibatch
-  const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer) + ((uint64_t)comm_rank(e) << 44);
-  d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
-  d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site;
+  const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
+  const uint32_t rk = (uint32_t)comm_rank(e);
+  d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL)) ^ (rk * 0x85EBCA6Bu);
+  d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site + rk * 0xC2B2AE35u;
   return d;
 }
 
@@ -1617,9 +1714,10 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
 // recurrent generator (GT_ARCH_SRU)
 // ------------------------------------------------------------------------------------------
 static void sru_keys(gt_engine* e, int layer, int which, uint32_t* k0, uint32_t* k1) {
-  const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which) + ((uint64_t)comm_rank(e) << 44);
-  *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
-  *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site;
+  const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which);
+  const uint32_t rk = (uint32_t)comm_rank(e);        // data parallel: every rank its own masks (see philox_site_spec)
+  *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL)) ^ (rk * 0x85EBCA6Bu);
+  *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site + rk * 0xC2B2AE35u;
 }
 static uint32_t drop_thresh(float p) {
   const double th = (double)p * 4294967296.0;
@@ -2476,5 +2574,67 @@ extern "C" int gt_op_linear_backward(const float* dY, int lddy, const float* X, 
     if (r) return r;
     if (err != hipSuccess) return fail(GT_ERR_HIP, "linear_backward: %s", hipGetErrorString(err));
   }
+  return GT_OK;
+}
+
+// nn.Linear forward / backward through the bf16-STORAGE products (gemm_bf16s.hip.h): operands are cast to bfloat16 images
+// (both orientations) exactly as the engine keeps them with GT_OPT_MATMUL_BF16, results come back as float32.  Parity
+// hook: against float64 arithmetic on the bf16-rounded operands the results agree to float32 accumulation error.
+extern "C" int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t rows, int in_dim, int out_dim, int act,
+                                 const float* keep_mask, float p, float* Y, const float* dY, const float* H_prev, int act_prev,
+                                 const float* keep_mask_prev, float p_prev, float* dX, float* dW, float* db,
+                                 float* Y_image, float* YT_image, void* stream) {
+  if (!X || !W || rows < 1 || in_dim < 1 || out_dim < 1) return fail(GT_ERR_INVALID, "bad argument");
+  if (act < 0 || act > 2 || act_prev < 0 || act_prev > 2) return fail(GT_ERR_INVALID, "unknown activation");
+  hipStream_t s = (hipStream_t)stream;
+  const int in8 = pad8(in_dim), out8 = pad8(out_dim);
+  const long rows8 = pad8(rows);
+  Scratch xb, xbt, wb, wbt, yb, ybt, dyb, dybt, hb, slabs, colp;
+  int r = GT_OK;
+  auto body = [&]() -> int {
+    CHK(xb.ensure((size_t)rows * in8 * 2)); CHK(xbt.ensure((size_t)in_dim * rows8 * 2));
+    CHK(wb.ensure((size_t)out_dim * in8 * 2)); CHK(wbt.ensure((size_t)in_dim * out8 * 2));
+    CHK(cast_transpose<float>(X, in_dim, rows, in_dim, xb.as<__bf16>(), in8, xbt.as<__bf16>(), rows8, nullptr, false, &colp, s));
+    CHK(cast_transpose<float>(W, in_dim, out_dim, in_dim, wb.as<__bf16>(), in8, wbt.as<__bf16>(), out8, nullptr, false, &colp, s));
+    if (Y) {
+      CHK(yb.ensure((size_t)rows * out8 * 2)); CHK(ybt.ensure((size_t)out_dim * rows8 * 2));
+      GemmB16Args g = b16_args();
+      g.A = xb.as<__bf16>(); g.lda = in8; g.B = wb.as<__bf16>(); g.ldb = in8; g.M = (int)rows; g.N = out_dim; g.K = in_dim;
+      g.C = Y; g.ldc = out_dim; g.Cb = yb.as<__bf16>(); g.ldcb = out8; g.CbT = ybt.as<__bf16>(); g.ldcbt = (int)rows8;
+      g.bias = bias; g.epi = B16_FWD; g.act = act; g.drop = buffer_spec(keep_mask, p, out_dim);
+      CHK(launch_gemm_b16(g, 1, s));
+      // the two bf16 images the same epilogue wrote ([frame][out] and [out][frame]), widened to float32 for inspection
+      if (Y_image) {
+        hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(cdiv(rows * out_dim, 256)), dim3(256), 0, s, (const __bf16*)yb.as<__bf16>(), (long)out8, rows, out_dim, Y_image);
+        LAUNCH_CHECK();
+      }
+      if (YT_image) {
+        hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(cdiv(rows * out_dim, 256)), dim3(256), 0, s, (const __bf16*)ybt.as<__bf16>(), rows8, (long)out_dim, (int)rows, YT_image);
+        LAUNCH_CHECK();
+      }
+    }
+    if (dY) {
+      CHK(dyb.ensure((size_t)rows * out8 * 2)); CHK(dybt.ensure((size_t)out_dim * rows8 * 2));
+      CHK(cast_transpose<float>(dY, out_dim, rows, out_dim, dyb.as<__bf16>(), out8, dybt.as<__bf16>(), rows8, nullptr, false, &colp, s));
+      if (dX) {
+        GemmB16Args g = b16_args();
+        g.A = dyb.as<__bf16>(); g.lda = out8; g.B = wbt.as<__bf16>(); g.ldb = out8; g.M = (int)rows; g.N = in_dim; g.K = out_dim;
+        g.C = dX; g.ldc = in_dim; g.epi = B16_BWD_DATA; g.act = ACT_NONE;
+        if (H_prev && act_prev != ACT_NONE) {
+          CHK(hb.ensure((size_t)rows * in8 * 2));
+          CHK(cast_transpose<float>(H_prev, in_dim, rows, in_dim, hb.as<__bf16>(), in8, nullptr, 0, nullptr, false, &colp, s));
+          g.act = act_prev; g.H = hb.as<__bf16>(); g.ldh = in8; g.drop = buffer_spec(keep_mask_prev, p_prev, in_dim);
+        }
+        CHK(launch_gemm_b16(g, 1, s));
+      }
+      if (dW) CHK(weight_grad_b16(dybt.as<__bf16>(), rows8, xbt.as<__bf16>(), rows8, rows, out_dim, in_dim, dW, db, false, slabs, s));
+    }
+    return GT_OK;
+  };
+  r = body();
+  const hipError_t err = hipStreamSynchronize(s);
+  for (Scratch* q : {&xb, &xbt, &wb, &wbt, &yb, &ybt, &dyb, &dybt, &hb, &slabs, &colp}) q->release();
+  if (r) return r;
+  if (err != hipSuccess) return fail(GT_ERR_HIP, "linear_bf16: %s", hipGetErrorString(err));
   return GT_OK;
 }

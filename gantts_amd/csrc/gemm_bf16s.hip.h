@@ -1,0 +1,317 @@
+// bf16-STORAGE GEMM family (BASELINE.json configs[2]: "bf16"; SURVEY 8(d) cfg3: bf16 storage / fp32 accumulate + fp32
+// master weights and optimizer state).  gfx950 only.
+//
+// With GT_OPT_MATMUL_BF16 the tensors that only feed matrix products live in HBM as bfloat16 -- hidden activations, the
+// gradients w.r.t. pre-activations (dZ), the network inputs' images and bf16 "shadow" copies of the weights, re-made from
+// the float32 masters before every pass -- so a product moves half the bytes of the float32 path and its loader neither
+// converts nor waits for 4-byte words.  ONE product form serves forward, backward-data and weight gradient:
+//
+//      C[m][n] = sum_k A[m][k] * B[n][k]            both operands bf16, k CONTIGUOUS in memory
+//
+//   forward         Y  [frame][out]  = X  [frame][in]   . W  [out][in]          epilogue: bias, LeakyReLU, dropout / sigmoid
+//   backward-data   dX [frame][in]   = dZ [frame][out]  . WT [in][out]          epilogue: (.) f'(H) of the producer
+//   weight gradient dW [out][in]     = dZT[out][frame]  . XT [in][frame]        split over frames into float32 slabs
+//
+// which is why every such tensor is kept in BOTH orientations ([frame][feature] and [feature][frame]): the transposed
+// copy of a product's result is written by the same epilogue -- in the 32x32 MFMA C layout a lane owns 4 consecutive rows
+// of one column, i.e. 8 contiguous bytes of the transposed image -- and tensors that do not come out of a product
+// (inputs, the head's seed gradient, MLPG's gradient, the recurrence's dG) go through cast_transpose_kernel once.
+//
+// Arithmetic: v_mfma_f32_32x32x16_bf16, float32 accumulation; bias / activation / dropout / f' in float32 on the
+// accumulators; results rounded to bf16 (RNE) once, on their way out.  Reductions, losses, gradients of the parameters
+// (slabs), parameters and optimizer state stay float32.
+#pragma once
+#include "gemm_f32.hip.h"
+
+namespace gt {
+
+enum GemmB16Epi { B16_FWD = 0, B16_BWD_DATA = 1, B16_SLAB = 2 };
+
+struct GemmB16Args {
+  const __bf16* A; int lda;      // [M][lda]; lda % 8 == 0, lda >= K rounded up to 8 (pad contents are never used)
+  const __bf16* B; int ldb;      // [N][ldb]; same rules
+  int M, N, K;
+  float* C; int ldc;             // float32 result [M][ldc] (or null); B16_SLAB: slab s at C + s * slab_stride
+  __bf16* Cb; int ldcb;          // bf16 result [M][ldcb] (or null)
+  __bf16* CbT; int ldcbt;        // transposed bf16 result [N][ldcbt] (or null); ldcbt % 4 == 0
+  const float* bias;             // B16_FWD: [N] or null
+  int epi;                       // GemmB16Epi
+  int act;                       // Act (B16_FWD: applied; B16_BWD_DATA: the PRODUCER's activation whose derivative multiplies)
+  const __bf16* H; int ldh;      // B16_BWD_DATA with act != NONE: the producer's stored activation [M][ldh]
+  int accumulate;                // float32 C += result (sum over LSTM directions)
+  DropoutSpec drop;
+  int k_chunk;                   // B16_SLAB: k per slab (multiple of 64)
+  long slab_stride;
+  float* rowsum_slab;            // B16_SLAB: per-slab row sums of A (= bias gradient when A = dZT), [nslab][M], or null
+  int n_tiles_m, n_tiles_n;
+};
+
+constexpr int B16_BK = 64;        // k depth of one LDS stage
+constexpr int B16_KP = 72;        // LDS row pitch in bf16 (144 B: the 16 rows of a ds_read_b128 lane group start in 16 different 16-byte slots)
+
+template <int BM, int BN>
+constexpr size_t gemm_b16_lds_bytes() { return (size_t)2 * (BM + BN) * B16_KP * 2; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// One BM x BN tile.  256 threads = 2 x 2 waves, each wave (BM/2) x (BN/2) in 32x32 MFMA tiles.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
+  constexpr int UA = BM * (B16_BK / 8) / GEMM_THREADS, UB = BN * (B16_BK / 8) / GEMM_THREADS;   // 16-byte chunks per thread per stage
+  static_assert(UA >= 1 && UB >= 1, "tile too small for 256 threads");
+  __bf16* Ah = smem;                                  // [2][BM][KP]
+  __bf16* Bh = smem + 2 * BM * B16_KP;                // [2][BN][KP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int k_begin = 0, k_end = g.K;
+  if (g.epi == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
+
+  // chunk u of this thread: row (tid + u*256) / 8 of the tile, k offset ((tid + u*256) % 8) * 8 inside the stage
+  const uint4* pa[UA];
+  const uint4* pb[UB];
+  int kca[UA], kcb[UB];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) {
+    const int c = tid + u * GEMM_THREADS, row = min(m0 + c / 8, g.M - 1);
+    kca[u] = (c % 8) * 8;
+    pa[u] = reinterpret_cast<const uint4*>(g.A + (long)row * g.lda + k_begin + kca[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int c = tid + u * GEMM_THREADS, row = min(n0 + c / 8, g.N - 1);
+    kcb[u] = (c % 8) * 8;
+    pb[u] = reinterpret_cast<const uint4*>(g.B + (long)row * g.ldb + k_begin + kcb[u]);
+  }
+  uint4 ra[UA], rb[UB];
+  const bool want_rs = g.epi == B16_SLAB && g.rowsum_slab != nullptr && tile_n == 0;
+  float rsum[UA];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) rsum[u] = 0.f;
+
+  // a chunk whose 8 k values are not all below krem (k left in this slab from the stage's first k): masked element-wise;
+  // a chunk that starts at or beyond krem is not loaded at all (its address may lie outside the row)
+  auto load_chunk = [&](const uint4* p, int kc, int krem) -> uint4 {
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (kc < krem) {
+      v = *p;
+      if (kc + 8 > krem) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kc + e >= krem) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return v;
+  };
+  auto request = [&](int t) {                 // global -> registers, stage t
+    const int krem = k_end - (k_begin + t * B16_BK);
+    if (krem >= B16_BK) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) ra[u] = pa[u][0];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) rb[u] = pb[u][0];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) ra[u] = load_chunk(pa[u], kca[u], krem);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) rb[u] = load_chunk(pb[u], kcb[u], krem);
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) pa[u] += B16_BK / 8;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) pb[u] += B16_BK / 8;
+  };
+  auto deposit = [&](int buf) {               // registers -> LDS buffer
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int c = tid + u * GEMM_THREADS;
+      *reinterpret_cast<uint4*>(Ah + (buf * BM + c / 8) * B16_KP + kca[u]) = ra[u];
+      if (want_rs) {
+        const unsigned w[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rsum[u] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int c = tid + u * GEMM_THREADS;
+      *reinterpret_cast<uint4*>(Bh + (buf * BN + c / 8) * B16_KP + kcb[u]) = rb[u];
+    }
+  };
+
+  f32x16 acc[TM][TN_];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (k_end - k_begin + B16_BK - 1) / B16_BK;
+  if (nk > 0) { request(0); deposit(0); }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) request(t + 1);
+    const int buf = t & 1;
+    const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * B16_KP + 8 * half;
+    const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * B16_KP + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < B16_BK / 16; ++kk) {
+      bf16x8 fa[TM], fb[TN_];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * B16_KP + kk * 16);
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * B16_KP + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) deposit((t + 1) & 1);
+    __syncthreads();
+  }
+
+  if (want_rs) {      // the 8 lanes that share a row hold its 8 k-chunks: sum them, lane 0 of the group writes
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      float v = rsum[u];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      const int row = m0 + (tid + u * GEMM_THREADS) / 8;
+      if ((tid & 7) == 0 && row < g.M) g.rowsum_slab[(long)slab * g.M + row] = v;
+    }
+  }
+
+  // ---- epilogue, in the MFMA C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* C = g.C ? g.C + (g.epi == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
+  const bool philox = g.epi != B16_SLAB && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) {
+      const int n = n0 + wn * WN + j * 32 + l31;
+      const bool n_ok = n < g.N;
+      const int nc = min(n, g.N - 1);
+      const float bias = (g.epi == B16_FWD && g.bias) ? g.bias[nc] : 0.f;
+      uint32_t rnd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;     // rows mrow .. mrow + 3
+        if (philox && (q & 1) == 0)
+          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)nc, g.drop.key0, g.drop.key1, rnd);
+        float v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int m = mrow + s;
+          const long mc = min(m, g.M - 1);
+          float x = acc[i][j][q * 4 + s];
+          if (g.epi == B16_FWD) {
+            x += bias;
+            if (g.act == ACT_LEAKY_DROPOUT) {
+              x = leaky(x);
+              if (g.drop.mode == DROP_PHILOX) x = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh ? x * g.drop.scale : 0.f;
+              else if (g.drop.mode == DROP_BUFFER) x = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f ? x * g.drop.scale : 0.f;
+            } else if (g.act == ACT_SIGMOID) {
+              x = 1.f / (1.f + expf(-x));
+            }
+          } else if (g.epi == B16_BWD_DATA && g.act != ACT_NONE) {
+            const float h = (float)g.H[mc * g.ldh + nc];
+            if (g.act == ACT_LEAKY_DROPOUT) {
+              bool keep = true;
+              float scale = 1.f;
+              if (g.drop.mode == DROP_PHILOX) { keep = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh; scale = g.drop.scale; }
+              else if (g.drop.mode == DROP_BUFFER) { keep = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f; scale = g.drop.scale; }
+              x *= leaky_drop_grad(h, keep, scale);
+            } else {
+              x *= h * (1.f - h);
+            }
+          }
+          v[s] = x;
+          if (n_ok && m < g.M) {
+            if (C) {
+              float* dst = C + (long)m * g.ldc + n;
+              *dst = g.accumulate ? *dst + x : x;
+            }
+            if (g.Cb) g.Cb[(long)m * g.ldcb + n] = (__bf16)x;
+          }
+        }
+        if (g.CbT && n_ok) {
+          __bf16* dst = g.CbT + (long)n * g.ldcbt + mrow;
+          if (mrow + 3 < g.M) {
+            bf16x4 p;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) p[s] = (__bf16)v[s];
+            *reinterpret_cast<bf16x4*>(dst) = p;                       // 8 contiguous bytes of the transposed image
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) if (mrow + s < g.M) dst[s] = (__bf16)v[s];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : 2) void gemm_b16_kernel(const GemmB16Args g) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
+  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
+  const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
+  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
+  gemm_b16_tile<BM, BN>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
+}
+
+// in [rows][ldi] (float32 or bf16)  ->  out [rows][ldo] bf16 (optional)  and  outT [cols][ldt] bf16 (optional), plus
+// per-block column sums of the float32 values (optional: colsum_part [gridDim.x][cols], the bias gradient of a dZ that
+// did not come out of a product).  64 x 64 tiles through LDS; pads of out / outT are not written.
+template <typename TIN>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const TIN* __restrict__ in, int ldi, long rows, int cols,
+                                                             __bf16* __restrict__ out, int ldo,
+                                                             __bf16* __restrict__ outT, long ldt,
+                                                             float* __restrict__ colsum_part) {
+  __shared__ float tile[64][65];
+  const long r0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 4 rows per pass
+#pragma unroll 4
+  for (int rr = ty; rr < 64; rr += 4) {
+    const long r = r0 + rr;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = (float)in[r * ldi + c];
+      if (out) out[r * ldo + c] = (__bf16)v;
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  if (outT) {
+#pragma unroll 4
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int c = c0 + cc;
+      const long r = r0 + tx;
+      if (c < cols && r < rows) outT[(long)c * ldt + r] = (__bf16)tile[tx][cc];
+    }
+  }
+  if (colsum_part && ty == 0 && c0 + tx < cols) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) s += tile[rr][tx];
+    colsum_part[(long)blockIdx.x * cols + c0 + tx] = s;
+  }
+}
+
+// out[r][c] (contiguous float32) = in[r][c] of a bf16 image with row pitch ld (inspection / parity hooks)
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ in, long ld, long rows, int cols, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const long r = e / cols;
+  const int c = (int)(e - r * cols);
+  out[e] = (float)in[r * ld + c];
+}
+
+}  // namespace gt

@@ -302,6 +302,16 @@ int gt_op_linear_backward(const float* dY, int lddy, const float* X, int ldx, co
                           float* dX, int lddx, const float* H_prev, int act_prev, const float* keep_mask_prev, float p_prev,
                           float* dW, float* db, void* stream);
 
+/* nn.Linear forward / backward through the bf16-STORAGE products of GT_OPT_MATMUL_BF16 (gemm_bf16s.hip.h): X, W, dY (and
+ * H_prev) are cast to bfloat16 images exactly as the engine keeps them, multiplied on the bf16 matrix cores with float32
+ * accumulation, and the results returned as float32.  Same argument meaning as gt_op_linear_forward / _backward; any of
+ * Y / dY / dX / dW / db may be NULL.  Y_image / YT_image (optional, (rows,out) / (out,rows) float32): the bf16 result
+ * image and its transposed twin as the forward epilogue wrote them.  Parity hook (tests/test_gpu_parity.py). */
+int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t rows, int in_dim, int out_dim, int act,
+                      const float* keep_mask, float p, float* Y, const float* dY, const float* H_prev, int act_prev,
+                      const float* keep_mask_prev, float p_prev, float* dX, float* dW, float* db,
+                      float* Y_image, float* YT_image, void* stream);
+
 /* ---- measurement (bench.py): HIP-event timing of every GEMM launch on its own stream --------
  * slot = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W), 2 backward-weight (dZ^T X);
  * slots 6, 7 unused; slot 8 = pair launches (one layer's backward-data product and weight gradient in one launch).

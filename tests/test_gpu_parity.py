@@ -155,6 +155,56 @@ def test_linear_forward_backward_vs_torch(rows, din, dout, act):
     _close(db.cpu().numpy(), br.grad.numpy(), msg="db")
 
 
+@pytest.mark.parametrize("rows,din,dout,act", [(300, 425, 512, 1), (1000, 512, 187, 0), (77, 483, 256, 1), (16384, 512, 512, 1),
+                                               (32768, 256, 256, 1), (129, 25, 25, 2), (33, 7, 3, 1), (4096, 256, 58, 0)])
+def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, dout, act):
+    """The bf16-STORAGE product family of GT_OPT_MATMUL_BF16 (gemm_bf16s.hip.h) in isolation: forward (bias + LeakyReLU +
+    injected dropout / sigmoid), backward-data with the producer's f', weight gradient with split-K slabs and the bias
+    gradient from the loader, 64 x 64 and 128 x 128 tiles, ragged edges, K tails that are not multiples of 8 / 64.  Operands
+    are rounded to bfloat16 on the host the way the engine's images hold them; against float64 arithmetic on those rounded
+    values only float32 accumulation error remains (1e-5 of the column scale).  The two bf16 result images the forward
+    epilogue writes ([frame][out] and its transposed twin) must be the bf16 rounding of the float32 result, bit for bit."""
+    import ctypes as Ct
+    from gantts_amd._lib import check, lib, ptr
+    rs = np.random.RandomState(rows + 3 * din)
+    bf = lambda t: t.bfloat16().double()
+    X = torch.from_numpy(rs.randn(rows, din).astype(np.float32))
+    W = torch.from_numpy((rs.randn(dout, din) / np.sqrt(din)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(dout).astype(np.float32))
+    p = 0.5 if act == 1 else 0.0
+    keep = torch.from_numpy((rs.rand(rows, dout) >= 0.5).astype(np.float32)) if act == 1 else None
+    z = bf(X) @ bf(W).t() + b.double()
+    if act == 1:
+        ref = torch.nn.functional.leaky_relu(z, 0.01) * keep.double() / (1 - p)
+    elif act == 2:
+        ref = torch.sigmoid(z)
+    else:
+        ref = z
+    dY = torch.from_numpy(rs.randn(rows, dout).astype(np.float32))
+    Hp = torch.from_numpy(rs.randn(rows, din).astype(np.float32))               # stored activation of a producing layer
+    keep_p = torch.from_numpy((rs.rand(rows, din) >= 0.5).astype(np.float32))
+    Hp = Hp * keep_p
+    fprime = torch.where(bf(Hp) > 0, 1.0, 0.01) * keep_p.double() * 2.0
+    ref_dX = (bf(dY) @ bf(W)) * fprime
+    ref_dW = bf(dY).t() @ bf(X)
+    ref_db = bf(dY).sum(0)
+    s = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    c = lambda t: None if t is None else t.cuda()
+    Xd, Wd, bd, kd, dYd, Hd, kpd = c(X), c(W), c(b), c(keep), c(dY), c(Hp), c(keep_p)
+    Y = torch.empty(rows, dout, device="cuda")
+    Yi, YTi = torch.empty(rows, dout, device="cuda"), torch.empty(dout, rows, device="cuda")
+    dX, dW, db = torch.empty(rows, din, device="cuda"), torch.empty(dout, din, device="cuda"), torch.empty(dout, device="cuda")
+    check(lib.gt_op_linear_bf16(ptr(Xd), ptr(Wd), ptr(bd), rows, din, dout, act, ptr(kd), p, ptr(Y), ptr(dYd), ptr(Hd), 1, ptr(kpd), 0.5,
+                                ptr(dX), ptr(dW), ptr(db), ptr(Yi), ptr(YTi), s))
+    torch.cuda.synchronize()
+    _close(Y.cpu().numpy(), ref.numpy(), rtol=1e-5, msg="bf16-storage Y")
+    assert torch.equal(Yi.cpu(), Y.cpu().bfloat16().float()), "bf16 result image != bf16(float32 result)"
+    assert torch.equal(YTi.cpu(), Yi.cpu().t()), "transposed bf16 image differs from the row-major one"
+    _close(dX.cpu().numpy(), ref_dX.numpy(), rtol=1e-5, msg="bf16-storage dX")
+    _close(dW.cpu().numpy(), ref_dW.numpy(), rtol=2e-5, msg="bf16-storage dW")
+    _close(db.cpu().numpy(), ref_db.numpy(), rtol=2e-5, msg="bf16-storage db")
+
+
 def test_linear_backward_fused_activation_derivative():
     """dX epilogue multiplies by f'(H_prev) of the producing layer (LeakyReLU + dropout keep mask)."""
     import ctypes as Ct
