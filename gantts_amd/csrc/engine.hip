@@ -230,7 +230,7 @@ struct Scratch {  // growable device buffer
     return GT_OK;
   }
   void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
-  template <typename T> T* as() { return (T*)p; }
+  template <typename T> T* as() const { return (T*)p; }
 };
 
 static void gemm_set_wide_store(int kind, GemmArgs& g) {
@@ -540,6 +540,22 @@ static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long
 // engine state
 // ------------------------------------------------------------------------------------------
 struct Lin { float *W, *b, *dW, *db; int in, out; };
+// a tensor kept as bf16 in both orientations: rm [rows][ld], tr [cols][ldt]   (gemm_bf16s.hip.h)
+struct B16Img {
+  Scratch rm, tr;
+  int ld = 0; long ldt = 0;
+  __bf16* r() { return rm.as<__bf16>(); }
+  __bf16* t() { return tr.as<__bf16>(); }
+  int ensure(long rows, int cols, bool want_t) {
+    ld = pad8(cols); ldt = pad8(rows);
+    CHK(rm.ensure((size_t)rows * ld * 2 + 64));
+    if (want_t) CHK(tr.ensure((size_t)cols * ldt * 2 + 64));
+    return GT_OK;
+  }
+  void release() { rm.release(); tr.release(); }
+};
+// bf16 shadows of one nn.Linear weight (out, in): w [out][ldw] feeds the forward product, wt [in][ldwt] backward-data
+struct LinShadow { Scratch w, wt; int ldw = 0, ldwt = 0; };
 static inline bool is_i2o(int arch) { return arch == GT_ARCH_IN2OUT || arch == GT_ARCH_IN2OUT_RNN; }
 static inline bool has_lstm_body(int arch) { return arch == GT_ARCH_LSTM || arch == GT_ARCH_IN2OUT_RNN; }
 struct LstmDirP { float *Wih, *Whh, *bih, *bhh, *dWih, *dWhh, *dbih, *dbhh; };
@@ -628,6 +644,18 @@ struct gt_engine {
   std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
   bool tv_inflight = false;                        // its all-reduce has been issued for the current mask
+  // GT_OPT_MATMUL_BF16 on MLP stacks: bf16 images (both orientations) of everything that only feeds products
+  std::vector<B16Img> g_actb, d_actb;              // hidden activations
+  B16Img xin_b, dcat_b, gy_b, dz_b[2], fwd_b;      // G's input, D's [x | adv] image (2N rows), dloss/dy_hat, dZ ping-pong, gt_model_forward's input
+  std::vector<B16Img> l_in_b;                      // recurrent generator: image of every layer's input (+ the top output, last entry)
+  std::vector<B16Img> l_dg_b;                      // per layer: dG image (both orientations; per layer because the side stream reads it late)
+  B16Img l_hs_b;                                   // h that entered each frame (transposed)
+  hipStream_t side = nullptr;                      // recurrent generator: weight-gradient products run beside the next layer's recurrence
+  hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
+  Scratch slabs_side, colp_side;
+  std::vector<LinShadow> lsh;                      // per LSTM layer: W_ih of all directions stacked [dirs*4H][in]; last entry: hidden2out
+  bool dcat_b_ok = false;                          // dcat_b's generated half mirrors the float32 image of the same step
+  std::vector<LinShadow> wsh[2];                   // per role: bf16 shadows of the hidden layers' weights, then of the last layer's
   SlabDefer sdefer[2];                             // per role: deferred weight-gradient combines of the fused step
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
@@ -738,6 +766,16 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
   e->w0pad[0].release(); e->w0pad[1].release();
+  for (auto* v : {&e->g_actb, &e->d_actb}) for (auto& b : *v) b.release();
+  e->xin_b.release(); e->dcat_b.release(); e->gy_b.release(); e->dz_b[0].release(); e->dz_b[1].release(); e->fwd_b.release();
+  for (int r = 0; r < 2; ++r) for (auto& w : e->wsh[r]) { w.w.release(); w.wt.release(); }
+  for (auto& b : e->l_in_b) b.release();
+  for (auto& b : e->l_dg_b) b.release();
+  e->l_hs_b.release(); e->slabs_side.release(); e->colp_side.release();
+  if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
+  if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
+  for (auto& w : e->lsh) { w.w.release(); w.wt.release(); }
   e->sdefer[0].pool.release(); e->sdefer[1].pool.release();
   e->mlpg.clear();
   int* ints[] = {e->d_scol, e->d_sstride, e->d_adv_cols, e->d_adv_inv, e->d_scol_i2o, e->d_sstride_i2o};
@@ -1192,6 +1230,99 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16-storage MLP stacks (GT_OPT_MATMUL_BF16; gemm_bf16s.hip.h): activations, dZ, the input images and weight shadows
+// live in HBM as bf16, in both orientations; every product is the k-contiguous form.
+// ------------------------------------------------------------------------------------------
+static bool use_b16(const gt_engine* e, int role) {
+  const Net& n = e->net[role];
+  if (!e->matmul_bf16 || !n.bound || n.d.arch != GT_ARCH_MLP || (n.d.hidden_dim & 7)) return false;
+  return true;
+}
+// re-made from the caller's float32 parameters before every pass (they may have been stepped, loaded or broadcast since)
+static int refresh_shadows(gt_engine* e, int role, bool with_last, hipStream_t s) {
+  Net& n = e->net[role];
+  auto& sh = e->wsh[role];
+  sh.resize(n.hidden.size() + 1);
+  for (size_t l = 0; l <= n.hidden.size(); ++l) {
+    if (l == n.hidden.size() && !with_last) break;
+    const Lin& L = l < n.hidden.size() ? n.hidden[l] : n.last;
+    LinShadow& w = sh[l];
+    w.ldw = pad8(L.in); w.ldwt = pad8(L.out);
+    CHK(w.w.ensure((size_t)L.out * w.ldw * 2 + 64));
+    CHK(w.wt.ensure((size_t)L.in * w.ldwt * 2 + 64));
+    CHK(cast_transpose<float>(L.W, L.in, L.out, L.in, w.w.as<__bf16>(), w.ldw, w.wt.as<__bf16>(), w.ldwt, nullptr, false, &e->colp, s));
+  }
+  return GT_OK;
+}
+// in_b [rows][ld_in] bf16 -> acts[l] (bf16, + transposed twin when want_t: the weight gradients read it)
+static int stack_forward_b16(gt_engine* e, int role, const __bf16* in_b, int ld_in, long rows, std::vector<B16Img>& acts,
+                             const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, bool want_t, hipStream_t s) {
+  Net& n = e->net[role];
+  specs.resize(n.hidden.size());
+  acts.resize(n.hidden.size());
+  const __bf16* cur = in_b;
+  int ld = ld_in;
+  for (size_t l = 0; l < n.hidden.size(); ++l) {
+    const Lin& L = n.hidden[l];
+    CHK(acts[l].ensure(rows, L.out, want_t));
+    const float* inj = nullptr;
+    CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out);
+    GemmB16Args g = b16_args();
+    g.A = cur; g.lda = ld; g.B = e->wsh[role][l].w.as<__bf16>(); g.ldb = e->wsh[role][l].ldw;
+    g.M = (int)rows; g.N = L.out; g.K = L.in; g.bias = L.b; g.epi = B16_FWD; g.act = ACT_LEAKY_DROPOUT; g.drop = specs[l];
+    g.Cb = acts[l].r(); g.ldcb = acts[l].ld;
+    if (want_t) { g.CbT = acts[l].t(); g.ldcbt = (int)acts[l].ldt; }
+    CHK(launch_gemm_b16(g, 1, s));
+    cur = acts[l].r();
+    ld = acts[l].ld;
+  }
+  return GT_OK;
+}
+static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
+static int comm_flush(gt_engine* e, int role, hipStream_t compute);
+// dz[cur]: gradient w.r.t. the pre-activation of the TOP hidden layer (both orientations when want_w).  in_t: transposed
+// image of the stack input [in][rows8] (weight gradient of layer 0).  dX (float32, optional): d loss / d input columns
+// [col0, col0 + ncols) for rows [row0, row0 + nrows).
+static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long ld_int, long rows, std::vector<B16Img>& acts,
+                              const std::vector<DropoutSpec>& specs, int cur, bool want_w, float* dX, int lddx, int col0, int ncols,
+                              long row0, long nrows, hipStream_t s) {
+  Net& n = e->net[role];
+  const int L = (int)n.hidden.size();
+  for (int l = L - 1; l >= 0; --l) {
+    const Lin& Lr = n.hidden[l];
+    B16Img& dz = e->dz_b[cur];
+    if (want_w) {
+      const __bf16* XT = l > 0 ? acts[l - 1].t() : in_t;
+      const long ldxt = l > 0 ? acts[l - 1].ldt : ld_int;
+      CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s));
+      CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+      if (l == 1) CHK(comm_flush(e, role, s));
+    }
+    if (l > 0) {
+      B16Img& nx = e->dz_b[cur ^ 1];
+      CHK(nx.ensure(rows, Lr.in, want_w));
+      GemmB16Args g = b16_args();
+      g.A = dz.r(); g.lda = dz.ld; g.B = e->wsh[role][l].wt.as<__bf16>(); g.ldb = e->wsh[role][l].ldwt;
+      g.M = (int)rows; g.N = Lr.in; g.K = Lr.out; g.epi = B16_BWD_DATA; g.act = ACT_LEAKY_DROPOUT;
+      g.H = acts[l - 1].r(); g.ldh = acts[l - 1].ld; g.drop = specs[l - 1];
+      g.Cb = nx.r(); g.ldcb = nx.ld;
+      if (want_w) { g.CbT = nx.t(); g.ldcbt = (int)nx.ldt; }
+      CHK(launch_gemm_b16(g, 1, s));
+      cur ^= 1;
+    } else if (dX) {
+      GemmB16Args g = b16_args();
+      g.A = dz.r() + row0 * dz.ld; g.lda = dz.ld;
+      g.B = e->wsh[role][0].wt.as<__bf16>() + (long)col0 * e->wsh[role][0].ldwt; g.ldb = e->wsh[role][0].ldwt;
+      g.M = (int)nrows; g.N = ncols; g.K = Lr.out; g.epi = B16_BWD_DATA; g.act = ACT_NONE;
+      g.C = dX; g.ldc = lddx;
+      CHK(launch_gemm_b16(g, 1, s));
+    }
+  }
+  return GT_OK;
+}
+
 static int cond_dim(gt_engine* e);
 
 // ------------------------------------------------------------------------------------------
@@ -1612,6 +1743,7 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   return GT_OK;
 }
 
+static bool lstm_b16(const gt_engine* e) { return e->matmul_bf16 && (e->net[GT_ROLE_G].d.hidden_dim & 7) == 0; }
 // x (N, in_dim) -> y_hat (N, out_dim); stashes X-projections / gates / cell states / layer outputs
 static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];
@@ -1620,15 +1752,49 @@ static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   const float* in = x;
   int ld_in = G.d.in_dim;
+  // GT_OPT_MATMUL_BF16: the layer inputs go through bf16 images (both orientations: the weight gradients read the
+  // transposed one) and W_ih of all directions is one stacked bf16 shadow -- the X-projection of a layer is ONE product
+  const bool b16 = lstm_b16(e);
+  const bool want_t = G.d.grads != nullptr;
+  const int Lc_ = G.d.num_hidden;
+  if (b16) {
+    e->l_in_b.resize(Lc_ + 1); e->lsh.resize(Lc_ + 1);
+    for (int l = 0; l <= Lc_; ++l) {
+      LinShadow& w = e->lsh[l];
+      if (l == Lc_) {
+        w.ldw = pad8(G.last.in); w.ldwt = pad8(G.last.out);
+        CHK(w.w.ensure((size_t)G.last.out * w.ldw * 2 + 64)); CHK(w.wt.ensure((size_t)G.last.in * w.ldwt * 2 + 64));
+        CHK(cast_transpose<float>(G.last.W, G.last.in, G.last.out, G.last.in, w.w.as<__bf16>(), w.ldw, w.wt.as<__bf16>(), w.ldwt, nullptr, false, &e->colp, s));
+        break;
+      }
+      const LstmLayerP& L = G.lstm[l];
+      w.ldw = pad8(L.in); w.ldwt = pad8(dirs * 4 * H);
+      CHK(w.w.ensure((size_t)dirs * 4 * H * w.ldw * 2 + 64)); CHK(w.wt.ensure((size_t)L.in * w.ldwt * 2 + 64));
+      for (int d = 0; d < dirs; ++d)
+        CHK(cast_transpose<float>(L.d[d].Wih, L.in, 4 * H, L.in, w.w.as<__bf16>() + (size_t)d * 4 * H * w.ldw, w.ldw,
+                                  w.wt.as<__bf16>() + (size_t)d * 4 * H, w.ldwt, nullptr, false, &e->colp, s));
+    }
+  }
   for (int l = 0; l < G.d.num_hidden; ++l) {
     const LstmLayerP& L = G.lstm[l];
     CHK(e->l_xproj[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
     CHK(e->l_gates[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
     CHK(e->l_cst[l].ensure((size_t)N * dirs * H * sizeof(float)));
     CHK(e->l_out[l].ensure((size_t)N * dirs * H * sizeof(float)));
-    for (int d = 0; d < dirs; ++d)   // Xp[:, d*4H:(d+1)*4H] = X W_ih^T (biases are added in the step kernel)
-      CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, e->l_xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
-                         4 * H, ACT_NONE, no_drop(), s));
+    if (b16) {
+      B16Img& I = e->l_in_b[l];
+      CHK(I.ensure(N, L.in, want_t));
+      CHK(cast_transpose<float>(in, ld_in, N, L.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+      GemmB16Args g = b16_args();
+      g.A = I.r(); g.lda = I.ld; g.B = e->lsh[l].w.as<__bf16>(); g.ldb = e->lsh[l].ldw;
+      g.M = (int)N; g.N = dirs * 4 * H; g.K = L.in; g.epi = B16_FWD; g.act = ACT_NONE;
+      g.C = e->l_xproj[l].as<float>(); g.ldc = dirs * 4 * H;
+      CHK(launch_gemm_b16(g, 1, s));
+    } else {
+      for (int d = 0; d < dirs; ++d)   // Xp[:, d*4H:(d+1)*4H] = X W_ih^T (biases are added in the step kernel)
+        CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, e->l_xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
+                           4 * H, ACT_NONE, no_drop(), s));
+    }
     bool seq = false;
     CHK(lstm_launch_seq(e, G, l, B, T, false, nullptr, s, &seq));
     if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
@@ -1644,6 +1810,16 @@ static int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat
       in = e->l_outd[l].as<float>();
     }
   }
+  if (b16) {
+    B16Img& I = e->l_in_b[Lc_];
+    CHK(I.ensure(N, G.last.in, want_t));
+    CHK(cast_transpose<float>(in, ld_in, N, G.last.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+    GemmB16Args g = b16_args();
+    g.A = I.r(); g.lda = I.ld; g.B = e->lsh[Lc_].w.as<__bf16>(); g.ldb = e->lsh[Lc_].ldw;
+    g.M = (int)N; g.N = G.last.out; g.K = G.last.in; g.bias = G.last.b; g.epi = B16_FWD;
+    g.act = G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = y_hat; g.ldc = G.d.out_dim;
+    return launch_gemm_b16(g, 1, s);
+  }
   return linear_forward(in, ld_in, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in, G.last.out,
                         G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
 }
@@ -1658,11 +1834,42 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
   CHK(e->l_hshift.ensure((size_t)N * H * sizeof(float)));
   float* dout = e->l_dout.as<float>();                       // gradient w.r.t. the current layer's output
   float* dout_other = dout + (size_t)N * dirs * H;
+  const bool b16 = lstm_b16(e) && (int)e->l_in_b.size() == Lc + 1 && (int)e->lsh.size() == Lc + 1;
+  if (b16) {
+    // hidden2out through the bf16 images: gy -> (gy, gyT); dW = gyT . topT^T, d out_top = gy . W_lastT^T
+    CHK(e->gy_b.ensure(N, Do, true));
+    CHK(cast_transpose<float>(gy, Do, N, Do, e->gy_b.r(), e->gy_b.ld, e->gy_b.t(), e->gy_b.ldt, nullptr, false, &e->colp, s));
+    B16Img& top = e->l_in_b[Lc];
+    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, dirs * H, G.last.dW, G.last.db, acc, e->slabs, s));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * dirs * H + Do, s));
+    GemmB16Args g = b16_args();
+    g.A = e->gy_b.r(); g.lda = e->gy_b.ld; g.B = e->lsh[Lc].wt.as<__bf16>(); g.ldb = e->lsh[Lc].ldwt;
+    g.M = (int)N; g.N = dirs * H; g.K = Do; g.epi = B16_BWD_DATA; g.act = ACT_NONE; g.C = dout; g.ldc = dirs * H;
+    CHK(launch_gemm_b16(g, 1, s));
+  } else {
   // hidden2out: dW = gy^T out_top, db, d out_top = gy W
   CHK(linear_backward_weight(gy, Do, e->l_out[Lc - 1].as<float>(), dirs * H, N, Do, dirs * H, G.last.dW, G.last.db, acc, e->slabs,
                              e->colp, s));
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * dirs * H + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
+  }
+  // Side stream: a layer's weight-gradient products (dW_ih, dW_hh, the shifts and combines: ~3 ms of a cfg3 step) depend
+  // on its dG only, and nothing on the way to the layer below depends on them -- the persistent recurrence of the layer
+  // below leaves the matrix pipes idle, so they run beside it.  The step stream carries recurrence -> d(input) product ->
+  // next recurrence; it joins the side stream before the caller's clip-norm + optimizer.  GT_LSTM_SIDE=0: all on one stream.
+  static const bool side_on = !(getenv("GT_LSTM_SIDE") && getenv("GT_LSTM_SIDE")[0] == '0');
+  hipStream_t ws = s;
+  if (side_on) {
+    if (!e->side) {
+      HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
+    }
+    ws = e->side;
+  }
+  Scratch& wsl = side_on ? e->slabs_side : e->slabs;
+  Scratch& wcp = side_on ? e->colp_side : e->colp;
+  if (b16) e->l_dg_b.resize(Lc);
   for (int l = Lc - 1; l >= 0; --l) {
     const LstmLayerP& L = G.lstm[l];
     bool seq = false;
@@ -1670,26 +1877,68 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
     if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));
     const float* dG = e->l_xproj[l].as<float>();
     const bool dropped_in = l > 0 && G.training && G.d.dropout > 0.f;
+    if (b16) {
+      B16Img& DG0 = e->l_dg_b[l];
+      CHK(DG0.ensure(N, dirs * 4 * H, true));
+      CHK(cast_transpose<float>(dG, dirs * 4 * H, N, dirs * 4 * H, DG0.r(), DG0.ld, DG0.t(), DG0.ldt, nullptr, false, &e->colp, s));
+    }
+    if (side_on) { HIPCHK(hipEventRecord(e->ev_side_go, s)); HIPCHK(hipStreamWaitEvent(ws, e->ev_side_go, 0)); }
+    if (b16) {
+      // dG -> bf16 image in both orientations (one pass), then every product of this layer reads bf16:
+      // dW_ih_d = dGT_d . inT^T (+ db from the loader), dW_hh_d = dGT_d . hshiftT^T, d in = dG . W_ihT^T (all directions in ONE product)
+      B16Img& DG = e->l_dg_b[l];
+      B16Img& I = e->l_in_b[l];
+      if (l > 0) {      // the step stream's part first: d(layer input), all directions in ONE product
+        GemmB16Args g = b16_args();
+        g.A = DG.r(); g.lda = DG.ld; g.B = e->lsh[l].wt.as<__bf16>(); g.ldb = e->lsh[l].ldwt;
+        g.M = (int)N; g.N = L.in; g.K = dirs * 4 * H; g.epi = B16_BWD_DATA; g.act = ACT_NONE; g.C = dout_other; g.ldc = L.in;
+        CHK(launch_gemm_b16(g, 1, s));
+        if (dropped_in) {
+          const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l - 1, G.inj[0][l - 1], dirs * H);
+          hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, dout_other, dout_other, N, dirs * H, ds);
+          LAUNCH_CHECK();
+        }
+        std::swap(dout, dout_other);
+      }
+      for (int d = 0; d < dirs; ++d) {
+        const __bf16* dgt = DG.t() + (size_t)d * 4 * H * DG.ldt;
+        CHK(weight_grad_b16(dgt, DG.ldt, I.t(), I.ldt, N, 4 * H, L.in, L.d[d].dWih, L.d[d].dbih, acc, wsl, ws));
+        hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(4 * H, 64)), dim3(1024), 0, ws, L.d[d].dbih, (long)4 * H, 1, 4 * H,
+                           L.d[d].dbhh, 0);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
+                           e->d_lengths(), e->l_hshift.as<float>());
+        LAUNCH_CHECK();
+        CHK(e->l_hs_b.ensure(N, H, true));
+        CHK(cast_transpose<float>(e->l_hshift.as<float>(), H, N, H, (__bf16*)nullptr, 0, e->l_hs_b.t(), e->l_hs_b.ldt, nullptr, false, &wcp, ws));
+        CHK(weight_grad_b16(dgt, DG.ldt, e->l_hs_b.t(), e->l_hs_b.ldt, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, wsl, ws));
+      }
+      CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
+      CHK(comm_flush(e, GT_ROLE_G, ws));
+      continue;
+    }
     const float* Xl = l == 0 ? x : (dropped_in ? e->l_outd[l - 1].as<float>() : e->l_out[l - 1].as<float>());
     const int ldx = l == 0 ? G.d.in_dim : dirs * H;
+    float* const dx_dst = dout_other;
     for (int d = 0; d < dirs; ++d) {
       const float* dGd = dG + (size_t)d * 4 * H;
       // dW_ih = dG_d^T X, db_ih = colsum(dG_d) (= db_hh)
-      CHK(linear_backward_weight(dGd, dirs * 4 * H, Xl, ldx, N, 4 * H, L.in, L.d[d].dWih, L.d[d].dbih, acc, e->slabs, e->colp, s));
+      CHK(linear_backward_weight(dGd, dirs * 4 * H, Xl, ldx, N, 4 * H, L.in, L.d[d].dWih, L.d[d].dbih, acc, wsl, wcp, ws));
       // bias_ih and bias_hh always receive the same gradient: keep them equal by copy
-      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(4 * H, 64)), dim3(1024), 0, s, L.d[d].dbih, (long)4 * H, 1, 4 * H,
+      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(4 * H, 64)), dim3(1024), 0, ws, L.d[d].dbih, (long)4 * H, 1, 4 * H,
                          L.d[d].dbhh, 0);
       LAUNCH_CHECK();
       // dW_hh = dG_d^T H_shift (h that entered each frame)
-      hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
+      hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
                          e->d_lengths(), e->l_hshift.as<float>());
       LAUNCH_CHECK();
-      CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, e->slabs,
-                                 e->colp, s));
+      CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, wsl,
+                                 wcp, ws));
     }
     // this layer's parameters (both directions: W_ih, W_hh, b_ih, b_hh each) are one contiguous bucket
-    CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), s));
-    CHK(comm_flush(e, GT_ROLE_G, s));               // with hidden2out above it: under the recurrence of the layer below
+    CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
+    CHK(comm_flush(e, GT_ROLE_G, ws));              // with hidden2out above it: under the recurrence of the layer below
+    (void)dx_dst;
     if (l > 0) {   // gradient w.r.t. the layer below's output: sum over directions of dG_d W_ih_d
       for (int d = 0; d < dirs; ++d) {
         GemmArgs g;
@@ -1706,6 +1955,7 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
       std::swap(dout, dout_other);
     }
   }
+  if (side_on) { HIPCHK(hipEventRecord(e->ev_side_done, ws)); HIPCHK(hipStreamWaitEvent(s, e->ev_side_done, 0)); }
   return GT_OK;
 }
 
@@ -1864,10 +2114,25 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
   } else if (G.d.arch == GT_ARCH_SRU) {
     CHK(sru_forward(e, x, B, T, y_hat, s));
   } else {
-    CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
-    const Lin& Lh = G.hidden.back();
-    CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
-                       G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+    if (use_b16(e, GT_ROLE_G)) {
+      const bool want_t = stash && G.d.grads != nullptr;
+      CHK(e->xin_b.ensure(N, G.d.in_dim, want_t));
+      CHK(cast_transpose<float>(x, G.d.in_dim, N, G.d.in_dim, e->xin_b.r(), e->xin_b.ld, want_t ? e->xin_b.t() : (__bf16*)nullptr, e->xin_b.ldt,
+                                nullptr, false, &e->colp, s));
+      CHK(refresh_shadows(e, GT_ROLE_G, true, s));
+      CHK(stack_forward_b16(e, GT_ROLE_G, e->xin_b.r(), e->xin_b.ld, N, e->g_actb, pass0, 1, N, specs, want_t, s));
+      const LinShadow& ws = e->wsh[GT_ROLE_G][G.hidden.size()];
+      GemmB16Args g = b16_args();
+      g.A = e->g_actb.back().r(); g.lda = e->g_actb.back().ld; g.B = ws.w.as<__bf16>(); g.ldb = ws.ldw;
+      g.M = (int)N; g.N = G.last.out; g.K = G.last.in; g.bias = G.last.b; g.epi = B16_FWD;
+      g.act = G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = y_hat; g.ldc = G.d.out_dim;
+      CHK(launch_gemm_b16(g, 1, s));
+    } else {
+      CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+      const Lin& Lh = G.hidden.back();
+      CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                         G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+    }
   }
   if (is_i2o(G.d.arch)) {
     if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
@@ -1912,7 +2177,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->step_counter++;
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
-  e->fake_cat_valid = false;
+  e->fake_cat_valid = false; e->dcat_b_ok = false;
   e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
   e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
@@ -1947,9 +2212,10 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
   return GT_OK;
 }
 
-static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
+// H: the top hidden activation, float32 [n_rows][K] or (h_ld > 0) its bf16 image with row pitch h_ld
+static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
-                    StepResults* early_res = nullptr) {
+                    StepResults* early_res = nullptr, int h_ld = 0) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -1957,13 +2223,18 @@ static int run_head(gt_engine* e, int mode, const float* H, int K, long n_rows, 
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
   const size_t lds = (size_t)4 * K * sizeof(float);
 #define GT_HEAD_LAUNCH(KP_)                                                                                              \
-  hipLaunchKernelGGL(d_head_kernel<KP_>, dim3(nblk), dim3(256), lds, s, H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
-                     (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
-                     e->headp.as<HeadPartials>(), e->headw.as<float>())
-  if (K <= 128) GT_HEAD_LAUNCH(2);
-  else if (K <= 256) GT_HEAD_LAUNCH(4);
-  else if (K <= 512) GT_HEAD_LAUNCH(8);
-  else if (K <= 1024) GT_HEAD_LAUNCH(16);
+  if (h_ld > 0)                                                                                                          \
+    hipLaunchKernelGGL((d_head_kernel<KP_, __bf16>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>());                                               \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((d_head_kernel<KP_, float>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>())
+  if (K <= 128) { GT_HEAD_LAUNCH(2); }
+  else if (K <= 256) { GT_HEAD_LAUNCH(4); }
+  else if (K <= 512) { GT_HEAD_LAUNCH(8); }
+  else if (K <= 1024) { GT_HEAD_LAUNCH(16); }
   else return fail(GT_ERR_INVALID, "discriminator hidden_dim > 1024 is not supported by the fused head kernel");
 #undef GT_HEAD_LAUNCH
   LAUNCH_CHECK();
@@ -2051,7 +2322,17 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
   e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-  CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  const bool b16 = use_b16(e, GT_ROLE_D);
+  if (b16) {    // bf16 storage: one cast of the input image (both orientations), then every product reads bf16
+    CHK(e->dcat_b.ensure(2 * N, K0, tr));
+    CHK(cast_transpose<float>(e->dcat.as<float>(), ldc, 2 * N, K0, e->dcat_b.r(), e->dcat_b.ld, tr ? e->dcat_b.t() : (__bf16*)nullptr,
+                              e->dcat_b.ldt, nullptr, false, &e->colp, s));
+    e->dcat_b_ok = true;
+    CHK(refresh_shadows(e, GT_ROLE_D, false, s));
+    CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
+  } else {
+    CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  }
   const int H = D.d.hidden_dim;
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
@@ -2060,8 +2341,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
   CHK(ensure_tv(e, mask, N, s));
-  CHK(run_head(e, HEAD_D_STEP, e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr, e->dzA.as<float>(),
-               e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr));
+  CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
+               e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0));
   e->early_done = false;
   if (plain_early) CHK(post_early_results(e, s));
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
@@ -2076,8 +2357,15 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     float* leak = nullptr;
     if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
     const int col0 = cond_dim(e);
-    CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
-                       e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
+    if (b16) {   // the head's seed gradient (float32) becomes the top dZ image, both orientations
+      CHK(e->dz_b[0].ensure(2 * N, H, true));
+      CHK(cast_transpose<float>(e->dzA.as<float>(), H, 2 * N, H, e->dz_b[0].r(), e->dz_b[0].ld, e->dz_b[0].t(), e->dz_b[0].ldt, nullptr, false,
+                                &e->colp, s));
+      CHK(stack_backward_b16(e, GT_ROLE_D, e->dcat_b.t(), e->dcat_b.ldt, 2 * N, e->d_actb, e->d_specs, 0, true, leak, e->Da, col0, e->Da, N, N, s));
+    } else {
+      CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
+                         e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
+    }
     D.grads_dirty = true;
     if (want_leak) e->leak_pending = true;
   }
@@ -2200,6 +2488,25 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     G.grads_dirty = true;
     return GT_OK;
   }
+  if (use_b16(e, GT_ROLE_G)) {
+    // dloss/dy_hat -> bf16 image (both orientations); last_linear: dW = gyT . H_topT^T, dZ_top = (gy . W_lastT^T) (.) f'(H_top)
+    const int H = G.d.hidden_dim;
+    CHK(e->gy_b.ensure(N, Do, true));
+    CHK(cast_transpose<float>(gy, ldgy, N, Do, e->gy_b.r(), e->gy_b.ld, e->gy_b.t(), e->gy_b.ldt, nullptr, false, &e->colp, s));
+    B16Img& top = e->g_actb.back();
+    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty, e->slabs, s));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
+    const LinShadow& ws = e->wsh[GT_ROLE_G][G.hidden.size()];
+    CHK(e->dz_b[0].ensure(N, H, true));
+    GemmB16Args g = b16_args();
+    g.A = e->gy_b.r(); g.lda = e->gy_b.ld; g.B = ws.wt.as<__bf16>(); g.ldb = ws.ldwt; g.M = (int)N; g.N = H; g.K = Do;
+    g.epi = B16_BWD_DATA; g.act = ACT_LEAKY_DROPOUT; g.H = top.r(); g.ldh = top.ld; g.drop = e->g_specs.back();
+    g.Cb = e->dz_b[0].r(); g.ldcb = e->dz_b[0].ld; g.CbT = e->dz_b[0].t(); g.ldcbt = (int)e->dz_b[0].ldt;
+    CHK(launch_gemm_b16(g, 1, s));
+    CHK(stack_backward_b16(e, GT_ROLE_G, e->xin_b.t(), e->xin_b.ldt, N, e->g_actb, e->g_specs, 0, true, nullptr, 0, 0, 0, 0, 0, s));
+    G.grads_dirty = true;
+    return GT_OK;
+  }
   // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
   const Lin& Lt = G.hidden.back();
   const int H = G.d.hidden_dim;
@@ -2270,20 +2577,38 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
       CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
       e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+      e->dcat_b_ok = false;
     }
     const float* cat = e->dcat.as<float>() + N * ldc;
-    CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    const bool b16 = use_b16(e, GT_ROLE_D);
+    if (b16) {   // the generated half of the bf16 image: rows N .. 2N (re-cast whenever the float32 image was rebuilt here)
+      CHK(e->dcat_b.ensure(2 * N, K0, false));
+      if (!e->dcat_b_ok) {
+        CHK(cast_transpose<float>(cat, ldc, N, K0, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
+        e->dcat_b_ok = true;
+      }
+      CHK(refresh_shadows(e, GT_ROLE_D, false, s));        // D has just been stepped (train.py:276 before :307)
+      CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, N, e->d_actb, passes, 1, N, e->d_specs, false, s));
+    } else {
+      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    }
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
-    CHK(run_head(e, HEAD_G_ADV, e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr, e->dzA.as<float>(), e->d_specs.back(),
-                 false, s));
+    CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
+                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0));
     if (tr) {
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
       const int col0 = cond_dim(e);
-      CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
-                         e->Da, col0, e->Da, 0, N, s));
+      if (b16) {
+        CHK(e->dz_b[0].ensure(N, H, false));
+        CHK(cast_transpose<float>(e->dzA.as<float>(), H, N, H, e->dz_b[0].r(), e->dz_b[0].ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
+        CHK(stack_backward_b16(e, GT_ROLE_D, nullptr, 0, N, e->d_actb, e->d_specs, 0, false, gadv, e->Da, col0, e->Da, 0, N, s));
+      } else {
+        CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
+                           e->Da, col0, e->Da, 0, N, s));
+      }
     }
   }
   // MGE loss + gradient assembly at y_hat_static
@@ -2424,6 +2749,19 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
   const int pass0[1] = {0};
   auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
   if (role == GT_ROLE_G) e->g_pass_valid = false;
+  if (use_b16(e, role)) {
+    auto& actb = role == GT_ROLE_G ? e->g_actb : e->d_actb;
+    CHK(e->fwd_b.ensure(N, n.d.in_dim, false));
+    CHK(cast_transpose<float>(x, n.d.in_dim, N, n.d.in_dim, e->fwd_b.r(), e->fwd_b.ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
+    CHK(refresh_shadows(e, role, true, s));
+    CHK(stack_forward_b16(e, role, e->fwd_b.r(), e->fwd_b.ld, N, actb, pass0, 1, N, specs, false, s));
+    const LinShadow& ws = e->wsh[role][n.hidden.size()];
+    GemmB16Args g = b16_args();
+    g.A = actb.back().r(); g.lda = actb.back().ld; g.B = ws.w.as<__bf16>(); g.ldb = ws.ldw;
+    g.M = (int)N; g.N = n.last.out; g.K = n.last.in; g.bias = n.last.b; g.epi = B16_FWD;
+    g.act = n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = out; g.ldc = n.d.out_dim;
+    return launch_gemm_b16(g, 1, s);
+  }
   CHK(stack_forward(e, role, x, n.d.in_dim, N, acts, pass0, 1, N, specs, s));
   return linear_forward(acts.back().as<float>(), n.hidden.back().out, n.last.W, n.last.in, n.last.b, out, n.d.out_dim, N, n.last.in,
                         n.last.out, n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);

@@ -478,9 +478,10 @@ struct HeadPartials {   // one per workgroup; summed in fixed order afterwards
 
 // KP = hidden units per lane (K <= 64*KP): the row, the weight vector and the dw accumulators live
 // in registers; the next row is prefetched while the current one goes through the reduction chain.
-template <int KP>
+// TH: storage type of the activation (float, or __bf16 with GT_OPT_MATMUL_BF16: the bf16 image the last hidden layer wrote)
+template <int KP, typename TH = float>
 __global__ __launch_bounds__(256) void d_head_kernel(
-    const float* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
+    const TH* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, int n_mask, int n_real, int n_rows, int mode, float eps,
     float* __restrict__ Dout, float* __restrict__ dH, int lddh, int want_grad, DropoutSpec drop,
     int has_act, const StepScalars* __restrict__ sc,
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     for (int ri = 0; ri < 8; ++ri) {
       const int r = min(16 * g + 8 * (ri >> 2) + 4 * h + (ri & 3), n_rows - 1);
 #pragma unroll
-      for (int j = 0; j < KP; ++j) hrow[ri][j] = H[(long)r * ldh + kidx[j]];
+      for (int j = 0; j < KP; ++j) hrow[ri][j] = (float)H[(long)r * ldh + kidx[j]];
     }
     uint32_t keepb[KP];
 #pragma unroll

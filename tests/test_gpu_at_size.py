@@ -158,3 +158,20 @@ def test_cfg3_full_length_bf16_tracks_the_reference():
         worst[kind] = max(worst.get(kind, 0.0), err)
         assert err <= BF16_LIMITS[kind], "bf16 %s: distance %.3e > %.1e" % (k, err, BF16_LIMITS[kind])
     assert worst["y_hat"] > 1e-5, "suspiciously exact: the bf16 path did not run"
+
+
+def test_cfg5_acoustic_bf16_storage_tracks_the_reference():
+    """The MLP pair of BASELINE.json configs[4] (B = 64, T = 512, generator noise, conditioned D) with GT_OPT_MATMUL_BF16:
+    bf16 storage of activations / dZ / input images / weight shadows in both networks, against the REAL reference's float64
+    digest with the measured limits."""
+    case = A.AT_SIZE_CASES["cfg5_acoustic"]
+    fx = np.load(os.path.join(GOLDEN, "at_size_cfg5_acoustic.npz"))
+    got = run_hip_at_size(case, engine_options={"matmul_bf16": 1})
+    seen = {}
+    compare_with_fixture("cfg5_acoustic/bf16", got, fx, measure=seen)
+    worst = {}
+    for k, (err, norm_err, _) in seen.items():
+        kind = "scalars" if "scalars" in k else ("grad" if "grad." in k else ("upd" if "upd." in k else k))
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        assert err <= BF16_LIMITS[kind], "bf16 %s: distance %.3e > %.1e" % (k, err, BF16_LIMITS[kind])
+    assert worst["y_hat"] > 1e-5, "suspiciously exact: the bf16 path did not run"

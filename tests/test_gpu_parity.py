@@ -494,27 +494,32 @@ def _rms(a):
     return float(np.sqrt((a * a).mean())) if a.size else 0.0
 
 
-def _close_within_conditioning(got, ref, ref_perturbed, msg, floor=1e-4, factor=3.0, cap=2e-2):
-    """rms(got - ref) / rms(ref) of ONE tensor must not exceed what the reference itself does when its weights move by a
-    float32 rounding error: ``floor + factor * rms(ref_perturbed - ref) / rms(ref)``, never more than ``cap``.
+ARBITER_FACTOR, ARBITER_FLOOR = 3.0, 2e-6
 
-    Why: LeakyReLU has a kink and the reference differentiates it by the SIGN of the stored output (in-place
-    LeakyReLU, gantts/models.py:132).  Among N x hidden pre-activations a few land within rounding of 0 (about one per
-    10^5..10^6 elements); there two correct float32 evaluations (CPU vs GPU summation order -- or the reference with its
-    weights nudged) pick different slopes (1 vs 0.01), and each such flip moves one element of dZ by its whole size
-    and, through the layers below, a rank-one piece of every lower weight gradient.  Measured on MI355X at full size
-    (tools/diag_grads.py; dropout off / Philox / injected masks alike): relative rms error 1e-4..4e-4 on hidden-layer
-    gradients -- equal to 3 digits to the reference's own conditioning measured this way (gpurun_out/call3) -- 1e-6 on
-    the layers above the last activation, 5e-7 everywhere when no pre-activation happens to sit on the kink.  A wrong
-    keep bit or a wrong tile, in contrast, shows up at 1e-1..1."""
-    den = max(_rms(ref), 1e-30)
-    err, cond = _rms(np.asarray(got, np.float64) - ref) / den, _rms(np.asarray(ref_perturbed, np.float64) - ref) / den
-    lim = min(cap, floor + factor * cond)
+
+def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_FLOOR):
+    """The float64 arbiter (same rule as tests/golden/at_size.py): the oracle is run twice on identical inputs and masks,
+    in float32 (the reference's arithmetic) and in float64 (exact to 1e-16); per tensor the engine must be no further from
+    the exact result than `factor` x the reference's own float32 arithmetic is:
+
+        rms(got - ref64) <= factor * rms(ref32 - ref64) + floor * rms(ref64)
+
+    No hand-set per-layer tolerance: where float32 itself is ill-conditioned -- a pre-activation within rounding of 0 picks
+    LeakyReLU slope 1 or 0.01 (in-place LeakyReLU, gantts/models.py:132: the derivative follows the sign of the stored output)
+    and moves a rank-one piece of every lower weight gradient -- rms(ref32 - ref64) shows it, tensor by tensor, and where it is
+    well-conditioned the limit is a few float32 ulps.  A wrong keep bit or tile shows at 1e-1..1.  The worst single element
+    is reported alongside (relative to the tensor's largest magnitude)."""
+    g, r32, r64 = (np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64))
+    den = max(_rms(r64), 1e-300)
+    err, e32 = _rms(g - r64) / den, _rms(r32 - r64) / den
+    lim = factor * e32 + floor
+    worst = float(np.abs(g - r64).max()) / max(float(np.abs(r64).max()), 1e-300) if g.size else 0.0
     if _REPORT:
         with open(_REPORT, "a") as f:
-            f.write("%-60s rel-rms err %.3e  ref conditioning %.3e  limit %.3e\n" % (msg, err, cond, lim))
+            f.write("%-60s rel-rms err %.3e  ref32-vs-ref64 %.3e  limit %.3e  worst element %.3e\n" % (msg, err, e32, lim, worst))
         return
-    assert err <= lim, "%s: relative rms error %.3e > %.3e (the reference's own float32 conditioning: %.3e)" % (msg, err, lim, cond)
+    assert err <= lim, "%s: relative rms distance to the float64 result %.3e > %.3e (the reference's own float32: %.3e); worst element %.3e" % (
+        msg, err, lim, e32, worst)
 
 
 @pytest.mark.parametrize("tag,B,Tn,gh,dh", [("cfg2-full-size", 32, 512, 512, 256),
@@ -529,8 +534,8 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
     row and column tiles, partial tiles, 2N-row discriminator pass, fused head).  Two steps, Adagrad with a warm
     accumulator (1e-4: as after some training, where the update is smooth in g).
     Forward quantities of the first step and all scalars: 1e-4 per column.  Gradients and what follows from them
-    (parameters, the second step's forward): per tensor, within the reference's own float32 conditioning, measured in
-    the test by running the oracle a second time with its weights moved by one ulp (_close_within_conditioning).
+    (parameters, the second step's forward): per tensor under the float64 arbiter (_close_arbiter): the oracle runs a second
+    time in float64 with the same masks, and the engine may be 3x as far from that as the float32 oracle is.
     Reference semantics: gantts/models.py:132-139, train.py:245-320."""
     import types
     import gantts_amd.train as T
@@ -578,23 +583,23 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
 
     # ---- oracle: the same masks injected; run twice -- as is, and with every weight moved by ~1 ulp ----
     cfg = O.StreamConfig([180, 3, 1, 3], [True, True, False, True], 3, [True, False, False, False], 2, True)
-    xc, yc, Rc = torch.from_numpy(x_np), torch.from_numpy(y_np), torch.from_numpy(R_np)
-    omask = O.sequence_mask(lengths, Tn).unsqueeze(-1)
-    oys = O.get_static_features(yc, 3, cfg.stream_sizes, cfg.has_dynamic_features)
+    xc32, yc32, Rc32 = torch.from_numpy(x_np), torch.from_numpy(y_np), torch.from_numpy(R_np)
+    omask32 = O.sequence_mask(lengths, Tn).unsqueeze(-1)
+    oys32 = O.get_static_features(yc32, 3, cfg.stream_sizes, cfg.has_dynamic_features)
     wg0, wd0 = C.make_weights(gs, 1), C.make_weights(ds, 2)
 
-    def oracle_run(nudge):
+    def oracle_run(dtype):
         omg = O.OracleMLP(**{k: v for k, v in gs.items() if k != "kind"})
         omd = O.OracleMLP(**{k: v for k, v in ds.items() if k != "kind"})
-        rs = np.random.RandomState(5)
-        jig = (lambda w: (w * (1.0 + nudge * rs.randn(*w.shape))).astype(np.float32)) if nudge else (lambda w: w)
-        omg.load_state_dict({k: jig(v) for k, v in wg0.items()}), omd.load_state_dict({k: jig(v) for k, v in wd0.items()})
+        omg.load_state_dict(wg0), omd.load_state_dict(wd0)
+        O.cast_model(omg, dtype), O.cast_model(omd, dtype)
+        xc, yc, Rc, omask, oys = (t.to(dtype) for t in (xc32, yc32, Rc32, omask32, oys32))
         omg.training = omd.training = True
         init_g, init_d = [q.detach().numpy().copy() for q in omg.params], [q.detach().numpy().copy() for q in omd.params]
         oog, ood = O.OracleAdagrad(omg.params, initial_accumulator_value=acc0, **okw), O.OracleAdagrad(omd.params, initial_accumulator_value=acc0, **okw)
         rec = []
         for st in range(steps):
-            gm, dm = masks[st]
+            gm, dm = ([m.to(dtype) for m in q] for q in masks[st])
             dd = O._DropoutSource(dm)
             oog.zero_grad(), ood.zero_grad()
             oyh, oyhs = O.apply_generator(cfg, omg, xc, Rc, list(lengths), drop=O._DropoutSource(gm))
@@ -607,14 +612,8 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
                             ggrad=[q.grad.numpy().copy() for q in omg.params]))
         return rec, [q.detach().numpy() - i for q, i in zip(omg.params, init_g)], [q.detach().numpy() - i for q, i in zip(omd.params, init_d)], omg.names, omd.names
 
-    ref, ref_gu, ref_du, gnames, dnames = oracle_run(0.0)         # records of both steps, total parameter updates
-    # the same with every weight moved by 2e-6 relative: the size of the rounding error of a K ~ 500 float32 dot product,
-    # i.e. of the difference between two correct evaluations of a pre-activation
-    alt, alt_gu, alt_du, _, _ = oracle_run(2e-6)
-    # layers big enough that a pre-activation on the kink is likely get the allowance of one flip even when the
-    # perturbed reference happens to show none (one flip among 2e5 elements measured 4e-4)
-    kink = lambda rows, width: 1.5e-3 if rows * width >= 1.5e5 else 1e-4
-    gfloor, dfloor = kink(N, gh), kink(2 * N, dh)
+    ref, ref_gu, ref_du, gnames, dnames = oracle_run(torch.float32)     # records of both steps, total parameter updates
+    alt, alt_gu, alt_du, _, _ = oracle_run(torch.float64)               # the arbiter: same inputs and masks, float64
 
     def split(flat, like):
         out, off = [], 0
@@ -633,17 +632,16 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
             _close(h["yh"], r["yh"], msg=t + "y_hat")
             _close(h["yhs"], r["yhs"], msg=t + "y_hat_static")
         else:       # inherits the parameter differences of the step before
-            _close_within_conditioning(h["yh"], r["yh"], a["yh"], t + "y_hat", floor=max(gfloor, dfloor))
-            _close_within_conditioning(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static", floor=max(gfloor, dfloor))
+            _close_arbiter(h["yh"], r["yh"], a["yh"], t + "y_hat")
+            _close_arbiter(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static")
         for nm, got, rr, aa in zip(dnames, split(h["dgrad"], r["dgrad"]), r["dgrad"], a["dgrad"]):
-            _close_within_conditioning(got, rr, aa, t + "D.grad " + nm, floor=dfloor)
+            _close_arbiter(got, rr, aa, t + "D.grad " + nm)
         for nm, got, rr, aa in zip(gnames, split(h["ggrad"], r["ggrad"]), r["ggrad"], a["ggrad"]):
-            _close_within_conditioning(got, rr, aa, t + "G.grad " + nm, floor=max(gfloor, dfloor))
-    # parameters after both steps: the UPDATE each tensor received, judged against its own size
+            _close_arbiter(got, rr, aa, t + "G.grad " + nm)
+    # parameters after both steps: the UPDATE each tensor received
     for tagm, m, ru, au, w0 in (("G", mg, ref_gu, alt_gu, wg0), ("D", md, ref_du, alt_du, wd0)):
         for (k, v), r_, a_ in zip(m.state_dict().items(), ru, au):
-            _close_within_conditioning(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k),
-                                       floor=10 * max(gfloor, dfloor), cap=5e-2)
+            _close_arbiter(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k))
 
 
 @pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])
@@ -732,6 +730,44 @@ def test_matmul_bf16_step_tracks_the_float32_oracle():
                 open(_REPORT, "a").write("bf16 update %-40s rel-rms %.3e\n" % (tag + name, err))
             assert err < 8e-2, (tag + name, err)
     assert worst > 1e-4, "suspiciously exact: the bf16 path did not run"
+
+
+@pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_multistream_adam", "duration_mlp"])
+def test_bf16_storage_mlp_steps_track_the_float32_oracle(name):
+    """GT_OPT_MATMUL_BF16 on MLP generators / discriminators = bf16 STORAGE (gemm_bf16s.hip.h): activations, dZ, input
+    images and weight shadows are bfloat16 in HBM, in both orientations, every product is the k-contiguous bf16 form with
+    float32 accumulation; master weights, gradients and optimizer state stay float32.  Reference-shaped cases (conditioned
+    and unconditioned D, injected dropout masks, multi-stream selection, R = None duration model, Adagrad with a warm
+    accumulator / Adam) against the FLOAT32 oracle at the measured bf16 rounding level: outputs and losses 2e-2, counts
+    within 2 %, parameter updates 0.25 relative rms per tensor (measured: up to 0.17 at these tiny hidden widths -- 32 .. 64
+    units, few terms to average the rounding over; 3e-3 .. 1.4e-2 at the real widths, tests/test_gpu_at_size.py)."""
+    from hip_runner import run_hip_case
+    from oracle_runner import run_oracle_case
+    case = dict(C.CASES[name])
+    if case["opt_g"][0] == "Adagrad":
+        case["opt_g"] = ("Adagrad", dict(case["opt_g"][1], initial_accumulator_value=1e-4))
+        case["opt_d"] = ("Adagrad", dict(case["opt_d"][1], initial_accumulator_value=1e-4))
+    case["steps"] = 2
+    got = run_hip_case(case, engine_options={"matmul_bf16": 1})
+    ref = run_oracle_case(case)
+    for k in ("y_hat", "y_hat_static"):
+        err = _rms(got[k] - ref[k]) / _rms(ref[k])
+        assert err < 2e-2, (k, err)
+    assert _rms(got["y_hat"] - ref["y_hat"]) > 0, "suspiciously exact: the bf16 path did not run"
+    for st in range(2):
+        for k, nl in (("d_scalars_%d" % st, 3), ("g_scalars_%d" % st, 4)):
+            a, b = np.asarray(got[k]), np.asarray(ref[k])
+            rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-2)
+            assert (rel[:nl] < 3e-2).all(), (k, a, b)
+            if k.startswith("d_"):
+                assert (np.abs(a[3:] - b[3:]) <= 0.02 * max(1.0, float(case["B"] * case["T"]))).all(), (k, a, b)
+    if case["opt_g"][0] == "Adagrad":      # Adam's first steps are sign-like (m / sqrt(v)): updates are not comparable at bf16 noise
+        w0g, w0d = C.make_weights(case["g"], 11), C.make_weights(case["d"], 22)
+        for tag, w0 in (("G.", w0g), ("D.", w0d)):
+            for nm, init in w0.items():
+                ug, ur = got[tag + nm] - init, ref[tag + nm] - init
+                err = _rms(ug - ur) / max(_rms(ur), 1e-30)
+                assert err < 0.25, (tag + nm, err)
 
 
 def test_lstm_full_size_persistent_equals_per_step_kernels():
