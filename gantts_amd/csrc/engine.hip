@@ -1853,11 +1853,14 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * dirs * H + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
   }
-  // Side stream: a layer's weight-gradient products (dW_ih, dW_hh, the shifts and combines: ~3 ms of a cfg3 step) depend
-  // on its dG only, and nothing on the way to the layer below depends on them -- the persistent recurrence of the layer
-  // below leaves the matrix pipes idle, so they run beside it.  The step stream carries recurrence -> d(input) product ->
-  // next recurrence; it joins the side stream before the caller's clip-norm + optimizer.  GT_LSTM_SIDE=0: all on one stream.
-  static const bool side_on = !(getenv("GT_LSTM_SIDE") && getenv("GT_LSTM_SIDE")[0] == '0');
+  // Side stream (GT_LSTM_SIDE=1; OFF by default): a layer's weight-gradient products (dW_ih, dW_hh, the shifts and combines:
+  // ~3 ms of a cfg3 step) depend on its dG only, and nothing on the way to the layer below depends on them, so they can
+  // run beside the persistent recurrence of the layer below, whose workgroups leave the matrix pipes idle: the step stream
+  // carries recurrence -> d(input) product -> next recurrence and joins the side stream before clip-norm + optimizer.
+  // Built, correct (the at-size cfg3 parity test passes with it) and MEASURED NOT TO PAY: cfg3 fp32 25.74 ms with it vs
+  // 25.68 ms without, bf16 19.04 vs 18.14 ms -- the recurrence is bound by its L2 hand-offs, and the products' operand
+  // traffic through the same L2s slows every one of its 1024 steps by about what the overlap hides.
+  static const bool side_on = getenv("GT_LSTM_SIDE") && getenv("GT_LSTM_SIDE")[0] == '1';
   hipStream_t ws = s;
   if (side_on) {
     if (!e->side) {

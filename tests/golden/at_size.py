@@ -7,12 +7,15 @@ arbiter) and what is committed is a *digest*: for every tensor the float64 run's
 elements, and the relative rms error of the float32 run against the float64 run over the FULL tensor.  The ``-m gpu``
 test recomputes the same sample / norm from the HIP engine's tensors and requires
 
-    rms(hip - ref64) over the sample  <=  ARBITER_FACTOR * rms(ref32 - ref64) + ARBITER_FLOOR   (relative to rms(ref64))
+    rms(hip - ref64) over the sample  <=  ARBITER_FACTOR * level + ARBITER_FLOOR  [+ KINK_ALLOWANCE]   (relative to rms(ref64))
 
-i.e. the engine may be as far from the exact result as the reference's own float32 arithmetic is, not further; no
-hand-set per-layer tolerance.  (The LeakyReLU kink -- a pre-activation within rounding of 0 picks slope 1 or 0.01,
-gantts/models.py:132 -- and the sign-like first Adam step make some tensors ill-conditioned; the float32-vs-float64
-distance measures exactly that, tensor by tensor.)
+where `level` is the reference's own float32-vs-float64 distance: of that tensor for forward outputs and D's last layer,
+and the largest one among the tensors of the same network and kind (gradients / updates of G / of D) for everything
+that sits downstream of the adversarial gradient path -- i.e. the engine may be as far from the exact result as the
+reference's own float32 arithmetic is on that network, not further.  (The sign-like first Adam step and the LeakyReLU kink
+make some tensors ill-conditioned; the float32-vs-float64 distance measures that.  KINK_ALLOWANCE, below, covers the one
+effect a single run cannot measure.)  The worst single element must stay within 10x the limit (of the tensor's largest
+magnitude): an rms cannot hide a handful of wrong elements.
 """
 import zlib
 
@@ -22,6 +25,16 @@ import cases as C
 
 ARBITER_FACTOR = 3.0
 ARBITER_FLOOR = 2e-6          # relative rms: a few float32 ulps, for tensors the reference happens to get exactly
+# The one quantity the float32-vs-float64 distance of a SINGLE run cannot measure: LeakyReLU slope flips.  A pre-activation
+# within rounding (~1e-7 relative) of 0 picks slope 1 or 0.01 by the sign of its stored output (in-place LeakyReLU,
+# gantts/models.py:132); two correct float32 evaluations disagree on a given activation with probability p ~ 1e-7, each
+# disagreement moves one element of dZ by its whole size, and n = p * (activations) of them move a gradient tensor by about
+# sqrt(n) / sqrt(activations) = sqrt(p) ~ 3e-4 relative rms -- independent of the layer's size, and a Poisson draw with a mean
+# of order one per network at these sizes: in the committed fixtures the REFERENCE's own float32 run shows it on some tensors
+# (cfg5 D layer 0: 1.8e-4, G layer 0: 2.3e-4) and not on others (cfg3 D: 4e-7 on every tensor), where the engine then shows
+# it instead (2.4e-4).  Gradient tensors downstream of a LeakyReLU layer therefore get this much on top of the arbiter's
+# limit; forward outputs, losses, counts and the gradient of D's last layer (pure forward quantities) do not.
+KINK_ALLOWANCE = 1e-3
 SAMPLE = 4096                 # elements kept per parameter-shaped tensor
 FRAMES = 24                   # frames kept per sequence of a (B, T, D) tensor
 

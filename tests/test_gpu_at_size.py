@@ -89,6 +89,10 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
     (used to MEASURE the bf16 tolerance)."""
     lines, bad = [], []
     keys = sorted(k[:-7] for k in fx.files if k.endswith(".sample"))
+    e32_of = {k: max(float(fx[k + ".err32"]), float(fx[k + ".err32_sample"])) for k in keys}
+    level = {}
+    for k in keys:
+        level[k.split(".")[0]] = max(level.get(k.split(".")[0], 0.0), e32_of[k])
     for k in keys:
         ref = fx[k + ".sample"].astype(np.float64)
         g_full = np.asarray(got[k], dtype=np.float64)
@@ -96,8 +100,10 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
         assert g.shape == ref.shape, (k, g.shape, ref.shape)
         den = max(A.rms(ref), 1e-300)
         err = A.rms(g - ref) / den
-        e32 = max(float(fx[k + ".err32"]), float(fx[k + ".err32_sample"]))
-        lim = factor * e32 + floor
+        kind = k.split(".")[0]
+        exposed = kind in ("Dgrad", "Ggrad", "Dupd", "Gupd") and not k.startswith("Dgrad.last_linear")
+        e32 = max(e32_of[k], level[kind]) if exposed else e32_of[k]
+        lim = factor * e32 + floor + (A.KINK_ALLOWANCE if exposed else 0.0)
         # the whole tensor, through its norm: nothing outside the sample can be far off without moving it
         norm_ref = float(fx[k + ".norm"])
         norm_err = abs(float(np.sqrt((g_full * g_full).sum())) - norm_ref) / max(norm_ref, 1e-300)
@@ -105,7 +111,7 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
         lines.append("%-14s %-44s rel-rms %.2e  limit %.2e (ref32 %.2e)  |norm| %.2e  worst elem %.2e" % (name, k, err, lim, e32, norm_err, worst))
         if measure is not None:
             measure[k] = (err, norm_err, e32)
-        elif not (err <= lim and norm_err <= max(lim, 10 * floor)):
+        elif not (err <= lim and norm_err <= max(lim, 10 * floor) and worst <= 10 * lim):
             bad.append(lines[-1])
     for k in sorted(k[:-4] for k in fx.files if k.endswith(".f64")):
         r64, r32, g = fx[k + ".f64"], fx[k + ".f32"], np.asarray(got[k], dtype=np.float64)

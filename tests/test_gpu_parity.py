@@ -494,10 +494,10 @@ def _rms(a):
     return float(np.sqrt((a * a).mean())) if a.size else 0.0
 
 
-ARBITER_FACTOR, ARBITER_FLOOR = 3.0, 2e-6
+ARBITER_FACTOR, ARBITER_FLOOR, KINK_ALLOWANCE = 3.0, 2e-6, 1e-3      # derivation of the last one: tests/golden/at_size.py
 
 
-def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_FLOOR):
+def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_FLOOR, kink=0.0):
     """The float64 arbiter (same rule as tests/golden/at_size.py): the oracle is run twice on identical inputs and masks,
     in float32 (the reference's arithmetic) and in float64 (exact to 1e-16); per tensor the engine must be no further from
     the exact result than `factor` x the reference's own float32 arithmetic is:
@@ -507,18 +507,21 @@ def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_
     No hand-set per-layer tolerance: where float32 itself is ill-conditioned -- a pre-activation within rounding of 0 picks
     LeakyReLU slope 1 or 0.01 (in-place LeakyReLU, gantts/models.py:132: the derivative follows the sign of the stored output)
     and moves a rank-one piece of every lower weight gradient -- rms(ref32 - ref64) shows it, tensor by tensor, and where it is
-    well-conditioned the limit is a few float32 ulps.  A wrong keep bit or tile shows at 1e-1..1.  The worst single element
-    is reported alongside (relative to the tensor's largest magnitude)."""
+    well-conditioned the limit is a few float32 ulps.  `kink` (KINK_ALLOWANCE, for gradient tensors downstream of a LeakyReLU
+    layer only): whether a given run HAS such a flip on a given tensor is a Poisson draw with a mean of order one per network,
+    so the reference's single float32 run may show none where the engine shows one (about 3e-4 relative rms each;
+    tests/golden/at_size.py has the derivation and the evidence).  A wrong keep bit or tile shows at 1e-1..1.  The worst
+    single element must stay within 10x the limit (relative to the tensor's largest magnitude)."""
     g, r32, r64 = (np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64))
     den = max(_rms(r64), 1e-300)
     err, e32 = _rms(g - r64) / den, _rms(r32 - r64) / den
-    lim = factor * e32 + floor
+    lim = factor * e32 + floor + kink
     worst = float(np.abs(g - r64).max()) / max(float(np.abs(r64).max()), 1e-300) if g.size else 0.0
     if _REPORT:
         with open(_REPORT, "a") as f:
             f.write("%-60s rel-rms err %.3e  ref32-vs-ref64 %.3e  limit %.3e  worst element %.3e\n" % (msg, err, e32, lim, worst))
         return
-    assert err <= lim, "%s: relative rms distance to the float64 result %.3e > %.3e (the reference's own float32: %.3e); worst element %.3e" % (
+    assert err <= lim and worst <= 10 * lim, "%s: relative rms distance to the float64 result %.3e > %.3e (the reference's own float32: %.3e); worst element %.3e" % (
         msg, err, lim, e32, worst)
 
 
@@ -632,16 +635,16 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
             _close(h["yh"], r["yh"], msg=t + "y_hat")
             _close(h["yhs"], r["yhs"], msg=t + "y_hat_static")
         else:       # inherits the parameter differences of the step before
-            _close_arbiter(h["yh"], r["yh"], a["yh"], t + "y_hat")
-            _close_arbiter(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static")
+            _close_arbiter(h["yh"], r["yh"], a["yh"], t + "y_hat", kink=KINK_ALLOWANCE)
+            _close_arbiter(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static", kink=KINK_ALLOWANCE)
         for nm, got, rr, aa in zip(dnames, split(h["dgrad"], r["dgrad"]), r["dgrad"], a["dgrad"]):
-            _close_arbiter(got, rr, aa, t + "D.grad " + nm)
+            _close_arbiter(got, rr, aa, t + "D.grad " + nm, kink=0.0 if nm.startswith("last_linear") and st == 0 else KINK_ALLOWANCE)
         for nm, got, rr, aa in zip(gnames, split(h["ggrad"], r["ggrad"]), r["ggrad"], a["ggrad"]):
-            _close_arbiter(got, rr, aa, t + "G.grad " + nm)
+            _close_arbiter(got, rr, aa, t + "G.grad " + nm, kink=KINK_ALLOWANCE)
     # parameters after both steps: the UPDATE each tensor received
     for tagm, m, ru, au, w0 in (("G", mg, ref_gu, alt_gu, wg0), ("D", md, ref_du, alt_du, wd0)):
         for (k, v), r_, a_ in zip(m.state_dict().items(), ru, au):
-            _close_arbiter(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k))
+            _close_arbiter(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k), kink=KINK_ALLOWANCE)
 
 
 @pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])
