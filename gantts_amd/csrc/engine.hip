@@ -326,8 +326,10 @@ static int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int ns
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1);
-  else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1);
+  // GT_PAIR_ORDER (default 1): weight-gradient workgroups first (longest work first); 0 = backward-data tiles first
+  static const int tn_first = getenv("GT_PAIR_ORDER") ? atoi(getenv("GT_PAIR_ORDER")) : 1;   // measured: 108.2 -> 104.4 us per pair launch, cfg2 step 1.523 -> 1.499 ms
+  if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
@@ -367,7 +369,8 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
     const bool t64 = gemm_vec_ok(dZ, lddz) && gemm_vec_ok(X, ldx) && gemm_small_tiles_ok();
     const int bn = t64 ? 64 : pick_bn(in);
     const int tiles = cdiv(out, t64 ? 64 : 128) * cdiv(in, bn);
-    int nslab = std::max(1, 512 / tiles);   // <= 2 workgroups per CU x 256 CUs: one resident round
+    static const int slab_wgs = getenv("GT_TN_WGS") ? atoi(getenv("GT_TN_WGS")) : 512;   // measurement switch
+    int nslab = std::max(1, slab_wgs / tiles);   // <= 2 workgroups per CU x 256 CUs: one resident round
     const int max_slab = (int)((rows + 255) / 256);
     if (nslab > max_slab) nslab = max_slab;
     if (nslab < 1) nslab = 1;
@@ -500,27 +503,47 @@ static int cast_transpose(const TIN* in, int ld_in, long rows, int cols, __bf16*
   return GT_OK;
 }
 // dW (+)= dZT . XT^T over the frame dimension (K = rows), db (+)= row sums of dZT; split into float32 slabs, fixed-order combine
-struct SlabDefer;
-static int slab_defer_flush(SlabDefer& d, hipStream_t s);
+// defer (optional, fused single-GPU step): the slabs go to the network's pool and the combine is only recorded; all
+// recorded combines of a network run as ONE launch in front of its optimizer step (slab_defer_flush).
 static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long ldxt, long rows, int out, int in, float* dW, float* db,
-                           bool accumulate, Scratch& slabs, hipStream_t s) {
+                           bool accumulate, Scratch& slabs, hipStream_t s, SlabDefer* defer = nullptr) {
   const int tiles = cdiv(out, 64) * cdiv(in, 64);
   int nslab = std::max(1, 1024 / tiles);                     // four 64 x 64 workgroups per CU
   nslab = std::min<long>(nslab, std::max<long>(1, rows / 512));
   const int k_chunk = cdiv(cdiv(rows, nslab), B16_BK) * B16_BK;
   nslab = cdiv(rows, k_chunk);
   const long slab_stride = (long)out * in;
-  CHK(slabs.ensure((((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float) + 255) & ~(size_t)255));
-  float* slab_base = slabs.as<float>();
+  const size_t need = (((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float) + 255) & ~(size_t)255;
+  const bool can4 = slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0;
+  float* slab_base = nullptr;
+  if (defer && defer->active && accumulate) { CHK(slab_defer_flush(*defer, s)); defer = nullptr; }
+  if (defer && defer->active && can4) {
+    if (defer->jobs.n == SLAB_MAX_JOBS || defer->used + need > defer->pool.bytes) {
+      CHK(slab_defer_flush(*defer, s));
+      if (need > defer->pool.bytes) CHK(defer->pool.ensure(std::max(need * 4, (size_t)64 << 20)));
+    }
+    slab_base = (float*)((char*)defer->pool.p + defer->used);
+    defer->used += need;
+  } else {
+    defer = nullptr;
+    CHK(slabs.ensure(need));
+    slab_base = slabs.as<float>();
+  }
   float* bias_slabs = slab_base + (size_t)nslab * slab_stride;
   GemmB16Args g = b16_args();
   g.A = dZT; g.lda = (int)lddzt; g.B = XT; g.ldb = (int)ldxt; g.M = out; g.N = in; g.K = (int)rows;
   g.C = slab_base; g.ldc = in; g.epi = B16_SLAB; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
   g.rowsum_slab = db ? bias_slabs : nullptr;
   CHK(launch_gemm_b16(g, nslab, s));
-  const bool can4 = slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0;
   if (can4) {
     const int main_blocks = cdiv(slab_stride / 4, 256), bias_blocks = db ? cdiv(out, 256) : 0;
+    if (defer) {
+      SlabJob& J = defer->jobs.j[defer->jobs.n++];
+      J.slabs = slab_base; J.slab_stride = slab_stride; J.n4 = slab_stride / 4; J.out = dW; J.bslabs = bias_slabs; J.bout = db;
+      J.nslab = nslab; J.accumulate = accumulate ? 1 : 0; J.nb = out; J.main_blocks = main_blocks; J.block0 = defer->blocks; J.pad_ = 0;
+      defer->blocks += main_blocks + bias_blocks;
+      return GT_OK;
+    }
     hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slab_base, slab_stride, nslab, slab_stride / 4,
                        dW, accumulate ? 1 : 0, (const float*)bias_slabs, out, db, main_blocks);
     LAUNCH_CHECK();
@@ -648,13 +671,17 @@ struct gt_engine {
   std::vector<B16Img> g_actb, d_actb;              // hidden activations
   B16Img xin_b, dcat_b, gy_b, dz_b[2], fwd_b;      // G's input, D's [x | adv] image (2N rows), dloss/dy_hat, dZ ping-pong, gt_model_forward's input
   std::vector<B16Img> l_in_b;                      // recurrent generator: image of every layer's input (+ the top output, last entry)
+  std::vector<B16Img> s_in_b;                      // SRU generator: image of every layer's (dropped) input (+ the top output, last entry)
+  B16Img s_du_b;                                   // SRU: dU of the current layer, both orientations
+  std::vector<LinShadow> ssh;                      // SRU: per layer W (n_in, ncols*k) as w [n_in][..] and wt [ncols*k][n_in]; last entry: hidden2out
   std::vector<B16Img> l_dg_b;                      // per layer: dG image (both orientations; per layer because the side stream reads it late)
   B16Img l_hs_b;                                   // h that entered each frame (transposed)
   hipStream_t side = nullptr;                      // recurrent generator: weight-gradient products run beside the next layer's recurrence
   hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
   Scratch slabs_side, colp_side;
   std::vector<LinShadow> lsh;                      // per LSTM layer: W_ih of all directions stacked [dirs*4H][in]; last entry: hidden2out
-  bool dcat_b_ok = false;                          // dcat_b's generated half mirrors the float32 image of the same step
+  bool dcat_b_ok = false;                          // dcat_b's generated half holds [x | adv(y_hat_static)] of the tensors below
+  const float* dcat_b_x = nullptr; const float* dcat_b_yhs = nullptr;
   std::vector<LinShadow> wsh[2];                   // per role: bf16 shadows of the hidden layers' weights, then of the last layer's
   SlabDefer sdefer[2];                             // per role: deferred weight-gradient combines of the fused step
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
@@ -770,6 +797,9 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   e->xin_b.release(); e->dcat_b.release(); e->gy_b.release(); e->dz_b[0].release(); e->dz_b[1].release(); e->fwd_b.release();
   for (int r = 0; r < 2; ++r) for (auto& w : e->wsh[r]) { w.w.release(); w.wt.release(); }
   for (auto& b : e->l_in_b) b.release();
+  for (auto& b : e->s_in_b) b.release();
+  e->s_du_b.release();
+  for (auto& w : e->ssh) { w.w.release(); w.wt.release(); }
   for (auto& b : e->l_dg_b) b.release();
   e->l_hs_b.release(); e->slabs_side.release(); e->colp_side.release();
   if (e->side) (void)hipStreamDestroy(e->side);
@@ -1244,16 +1274,31 @@ static int refresh_shadows(gt_engine* e, int role, bool with_last, hipStream_t s
   Net& n = e->net[role];
   auto& sh = e->wsh[role];
   sh.resize(n.hidden.size() + 1);
-  for (size_t l = 0; l <= n.hidden.size(); ++l) {
+  CastJobs jobs;
+  jobs.n = 0; jobs.pad_ = 0;
+  int blocks = 0;
+  auto flush = [&]() -> int {
+    if (jobs.n > 0) {
+      hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(blocks), dim3(256), 0, s, jobs);
+      LAUNCH_CHECK();
+    }
+    jobs.n = 0; blocks = 0;
+    return GT_OK;
+  };
+  for (size_t l = 0; l <= n.hidden.size(); ++l) {     // all layers of the network in ONE launch
     if (l == n.hidden.size() && !with_last) break;
     const Lin& L = l < n.hidden.size() ? n.hidden[l] : n.last;
     LinShadow& w = sh[l];
     w.ldw = pad8(L.in); w.ldwt = pad8(L.out);
     CHK(w.w.ensure((size_t)L.out * w.ldw * 2 + 64));
     CHK(w.wt.ensure((size_t)L.in * w.ldwt * 2 + 64));
-    CHK(cast_transpose<float>(L.W, L.in, L.out, L.in, w.w.as<__bf16>(), w.ldw, w.wt.as<__bf16>(), w.ldwt, nullptr, false, &e->colp, s));
+    if (jobs.n == CAST_MAX_JOBS) CHK(flush());
+    CastJob& J = jobs.j[jobs.n++];
+    J.in = L.W; J.ldi = L.in; J.rows = L.out; J.cols = L.in; J.out = w.w.as<__bf16>(); J.ldo = w.ldw; J.outT = w.wt.as<__bf16>(); J.ldt = w.ldwt;
+    J.gy = cdiv(L.in, 64); J.block0 = blocks; J.pad_ = 0;
+    blocks += cdiv(L.out, 64) * J.gy;
   }
-  return GT_OK;
+  return flush();
 }
 // in_b [rows][ld_in] bf16 -> acts[l] (bf16, + transposed twin when want_t: the weight gradients read it)
 static int stack_forward_b16(gt_engine* e, int role, const __bf16* in_b, int ld_in, long rows, std::vector<B16Img>& acts,
@@ -1296,7 +1341,7 @@ static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long l
     if (want_w) {
       const __bf16* XT = l > 0 ? acts[l - 1].t() : in_t;
       const long ldxt = l > 0 ? acts[l - 1].ldt : ld_int;
-      CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s));
+      CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
       CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
       if (l == 1) CHK(comm_flush(e, role, s));
     }
@@ -1995,12 +2040,29 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
   return a;
 }
 
+static bool sru_b16(const gt_engine* e) { return e->matmul_bf16 && (e->net[GT_ROLE_G].d.hidden_dim & 7) == 0; }
 static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];
   const long N = (long)B * T;
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, ncols = H * dirs;
   const float* in = x;
   int ld_in = G.d.in_dim;
+  // GT_OPT_MATMUL_BF16: the (dropped) layer inputs go through bf16 images in both orientations, W through bf16 shadows in
+  // both orientations: U = xin . WT^T, dW = xinT . dUT^T, d in = dU . W^T are all the k-contiguous bf16 product
+  const bool b16 = sru_b16(e);
+  const bool want_t = G.d.grads != nullptr;
+  const int Lc_ = G.d.num_hidden;
+  if (b16) {
+    e->s_in_b.resize(Lc_ + 1); e->ssh.resize(Lc_ + 1);
+    for (int l = 0; l <= Lc_; ++l) {
+      LinShadow& w = e->ssh[l];
+      const float* W = l < Lc_ ? G.sru[l].W : G.last.W;
+      const int rows = l < Lc_ ? G.sru[l].in : G.last.out, cols = l < Lc_ ? ncols * G.sru[l].k : G.last.in;
+      w.ldw = pad8(cols); w.ldwt = pad8(rows);
+      CHK(w.w.ensure((size_t)rows * w.ldw * 2 + 64)); CHK(w.wt.ensure((size_t)cols * w.ldwt * 2 + 64));
+      CHK(cast_transpose<float>(W, cols, rows, cols, w.w.as<__bf16>(), w.ldw, w.wt.as<__bf16>(), w.ldwt, nullptr, false, &e->colp, s));
+    }
+  }
   for (int l = 0; l < G.d.num_hidden; ++l) {
     const SruLayerP& L = G.sru[l];
     CHK(e->s_u[l].ensure((size_t)N * ncols * L.k * sizeof(float)));
@@ -2019,7 +2081,15 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       xin = e->s_xdrop[l].as<float>();
       ld_xin = L.in;
     }
-    {  // U = xin W   (W is (n_in, ncols*k): n-contiguous rows -> NN orientation)
+    if (b16) {
+      B16Img& I = e->s_in_b[l];
+      CHK(I.ensure(N, L.in, want_t));
+      CHK(cast_transpose<float>(xin, ld_xin, N, L.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+      GemmB16Args g = b16_args();
+      g.A = I.r(); g.lda = I.ld; g.B = e->ssh[l].wt.as<__bf16>(); g.ldb = e->ssh[l].ldwt;     // WT [ncols*k][n_in]: k = n_in contiguous
+      g.M = (int)N; g.N = ncols * L.k; g.K = L.in; g.epi = B16_FWD; g.act = ACT_NONE; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
+      CHK(launch_gemm_b16(g, 1, s));
+    } else {  // U = xin W   (W is (n_in, ncols*k): n-contiguous rows -> NN orientation)
       GemmArgs g;
       memset(&g, 0, sizeof(g));
       g.A = xin; g.lda = ld_xin; g.B = L.W; g.ldb = ncols * L.k; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
@@ -2031,6 +2101,16 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
     LAUNCH_CHECK();
     in = e->s_h[l].as<float>();
     ld_in = ncols;
+  }
+  if (b16) {
+    B16Img& I = e->s_in_b[Lc_];
+    CHK(I.ensure(N, G.last.in, want_t));
+    CHK(cast_transpose<float>(in, ld_in, N, G.last.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+    GemmB16Args g = b16_args();
+    g.A = I.r(); g.lda = I.ld; g.B = e->ssh[Lc_].w.as<__bf16>(); g.ldb = e->ssh[Lc_].ldw;    // hidden2out.weight (out, ncols): k = ncols contiguous
+    g.M = (int)N; g.N = G.last.out; g.K = G.last.in; g.bias = G.last.b; g.epi = B16_FWD;
+    g.act = G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = y_hat; g.ldc = G.d.out_dim;
+    return launch_gemm_b16(g, 1, s);
   }
   return linear_forward(in, ld_in, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in, G.last.out,
                         G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
@@ -2049,9 +2129,22 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
   CHK(e->s_dbias.ensure((size_t)B * 2 * ncols * sizeof(float)));
   float* dh = e->l_dout.as<float>();
   float* dh_other = dh + (size_t)N * std::max(ncols, inmax);
+  const bool b16 = sru_b16(e) && (int)e->s_in_b.size() == Lc + 1 && (int)e->ssh.size() == Lc + 1;
+  if (b16) {
+    CHK(e->gy_b.ensure(N, Do, true));
+    CHK(cast_transpose<float>(gy, Do, N, Do, e->gy_b.r(), e->gy_b.ld, e->gy_b.t(), e->gy_b.ldt, nullptr, false, &e->colp, s));
+    B16Img& top = e->s_in_b[Lc];
+    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, ncols, G.last.dW, G.last.db, acc, e->slabs, s));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * ncols + Do, s));
+    GemmB16Args g = b16_args();
+    g.A = e->gy_b.r(); g.lda = e->gy_b.ld; g.B = e->ssh[Lc].wt.as<__bf16>(); g.ldb = e->ssh[Lc].ldwt;   // hidden2out.weight^T [ncols][Do]
+    g.M = (int)N; g.N = ncols; g.K = Do; g.epi = B16_BWD_DATA; g.act = ACT_NONE; g.C = dh; g.ldc = ncols;
+    CHK(launch_gemm_b16(g, 1, s));
+  } else {
   CHK(linear_backward_weight(gy, Do, e->s_h[Lc - 1].as<float>(), ncols, N, Do, ncols, G.last.dW, G.last.db, acc, e->slabs, e->colp, s));
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * ncols + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dh, ncols, N, Do, ncols, ACT_NONE, nullptr, 0, no_drop(), s));
+  }
   for (int l = Lc - 1; l >= 0; --l) {
     const SruLayerP& L = G.sru[l];
     const float* in = l == 0 ? x : e->s_h[l - 1].as<float>();
@@ -2071,12 +2164,28 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     LAUNCH_CHECK();
     const float* xin = rdrop ? e->s_xdrop[l].as<float>() : in;
     const int ld_xin = rdrop ? L.in : ld_in;
+    if (b16) {
+      // dU -> bf16 image in both orientations (one pass); dW = xinT . dUT^T over the frames, d in = dU . W^T
+      B16Img& DU = e->s_du_b;
+      CHK(DU.ensure(N, ncols * L.k, true));
+      CHK(cast_transpose<float>(e->s_du.as<float>(), ncols * L.k, N, ncols * L.k, DU.r(), DU.ld, DU.t(), DU.ldt, nullptr, false, &e->colp, s));
+      B16Img& I = e->s_in_b[l];
+      CHK(weight_grad_b16(I.t(), I.ldt, DU.t(), DU.ldt, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs, s));
+    } else {
     // dW = xin^T dU   (TN: A = xin is m-contiguous over n_in, B = dU)
     CHK(linear_backward_weight(xin, ld_xin, e->s_du.as<float>(), ncols * L.k, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs,
                                e->colp, s));
+    }
     CHK(comm_grads_ready(e, GT_ROLE_G, L.dW, (long)L.in * ncols * L.k + 2L * ncols, s));
     if (l > 0) CHK(comm_flush(e, GT_ROLE_G, s));
     if (l > 0) {
+      if (b16) {
+        GemmB16Args g = b16_args();
+        g.A = e->s_du_b.r(); g.lda = e->s_du_b.ld; g.B = e->ssh[l].w.as<__bf16>(); g.ldb = e->ssh[l].ldw;    // W [n_in][ncols*k]: k contiguous
+        g.M = (int)N; g.N = L.in; g.K = ncols * L.k; g.epi = B16_BWD_DATA; g.act = ACT_NONE; g.C = dh_other; g.ldc = L.in;
+        g.accumulate = (L.k == 3 && !rdrop) ? 1 : 0;
+        CHK(launch_gemm_b16(g, 1, s));
+      } else {
       // d in = (dU W^T) (.) mask_in + highway term     (NT: B[n = i][k = c] = W[i*ldw + c])
       GemmArgs g;
       memset(&g, 0, sizeof(g));
@@ -2084,6 +2193,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
       g.M = (int)N; g.N = L.in; g.K = ncols * L.k; g.act = ACT_NONE; g.drop = no_drop();
       g.accumulate = (L.k == 3 && !rdrop) ? 1 : 0;
       CHK(launch_gemm(GEMM_NT, g, 1, s));
+      }
       if (rdrop) {
         uint32_t k0, k1;
         sru_keys(e, l, 0, &k0, &k1);
@@ -2218,7 +2328,7 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 // H: the top hidden activation, float32 [n_rows][K] or (h_ld > 0) its bf16 image with row pitch h_ld
 static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
-                    StepResults* early_res = nullptr, int h_ld = 0) {
+                    StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -2227,11 +2337,12 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
   const size_t lds = (size_t)4 * K * sizeof(float);
 #define GT_HEAD_LAUNCH(KP_)                                                                                              \
   if (h_ld > 0)                                                                                                          \
-    hipLaunchKernelGGL((d_head_kernel<KP_, __bf16>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
-                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
-                       e->headp.as<HeadPartials>(), e->headw.as<float>());                                               \
+    hipLaunchKernelGGL((d_head_kernel<KP_, __bf16, true>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
+                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L);                    \
   else                                                                                                                   \
-    hipLaunchKernelGGL((d_head_kernel<KP_, float>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
+    hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>())
   if (K <= 128) { GT_HEAD_LAUNCH(2); }
@@ -2315,6 +2426,20 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
+  const bool b16 = use_b16(e, GT_ROLE_D);
+  if (b16) {
+    // bf16 storage: the image is written ONCE, as bf16, in both orientations (no float32 image at all)
+    if (e->cfg.discriminator_linguistic_condition && (!x || cond_dim(e) <= 0))
+      return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+    CHK(e->dcat_b.ensure(2 * N, K0, tr));
+    CatSrc src;
+    src.x = x; src.cd = cond_dim(e); src.fa = y_static; src.fb = y_hat_static; src.ldf = e->Ds; src.idx = e->d_adv_cols; src.N = N; src.row_off = 0;
+    hipLaunchKernelGGL(cat_cast_transpose_kernel, dim3(cdiv(2 * N, 64), cdiv(K0, 64)), dim3(256), 0, s, src, 2 * N, K0, e->dcat_b.r(), e->dcat_b.ld,
+                       tr ? e->dcat_b.t() : (__bf16*)nullptr, e->dcat_b.ldt);
+    LAUNCH_CHECK();
+    e->dcat_b_ok = true;
+    e->fake_cat_valid = false;                 // the float32 image was not built
+  } else {
   CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
   if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
     hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
@@ -2325,12 +2450,9 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
   e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-  const bool b16 = use_b16(e, GT_ROLE_D);
-  if (b16) {    // bf16 storage: one cast of the input image (both orientations), then every product reads bf16
-    CHK(e->dcat_b.ensure(2 * N, K0, tr));
-    CHK(cast_transpose<float>(e->dcat.as<float>(), ldc, 2 * N, K0, e->dcat_b.r(), e->dcat_b.ld, tr ? e->dcat_b.t() : (__bf16*)nullptr,
-                              e->dcat_b.ldt, nullptr, false, &e->colp, s));
-    e->dcat_b_ok = true;
+  }
+  e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
+  if (b16) {
     CHK(refresh_shadows(e, GT_ROLE_D, false, s));
     CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
   } else {
@@ -2344,8 +2466,10 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
   CHK(ensure_tv(e, mask, N, s));
+  if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
-               e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0));
+               e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
+               (b16 && tr) ? &e->dz_b[0] : nullptr, true));
   e->early_done = false;
   if (plain_early) CHK(post_early_results(e, s));
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
@@ -2360,10 +2484,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     float* leak = nullptr;
     if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
     const int col0 = cond_dim(e);
-    if (b16) {   // the head's seed gradient (float32) becomes the top dZ image, both orientations
-      CHK(e->dz_b[0].ensure(2 * N, H, true));
-      CHK(cast_transpose<float>(e->dzA.as<float>(), H, 2 * N, H, e->dz_b[0].r(), e->dz_b[0].ld, e->dz_b[0].t(), e->dz_b[0].ldt, nullptr, false,
-                                &e->colp, s));
+    if (b16) {   // the head wrote its seed gradient as the top dZ image, both orientations
       CHK(stack_backward_b16(e, GT_ROLE_D, e->dcat_b.t(), e->dcat_b.ldt, 2 * N, e->d_actb, e->d_specs, 0, true, leak, e->Da, col0, e->Da, N, N, s));
     } else {
       CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
@@ -2497,7 +2618,8 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     CHK(e->gy_b.ensure(N, Do, true));
     CHK(cast_transpose<float>(gy, ldgy, N, Do, e->gy_b.r(), e->gy_b.ld, e->gy_b.t(), e->gy_b.ldt, nullptr, false, &e->colp, s));
     B16Img& top = e->g_actb.back();
-    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty, e->slabs, s));
+    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty, e->slabs, s,
+                        &e->sdefer[GT_ROLE_G]));
     CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
     const LinShadow& ws = e->wsh[GT_ROLE_G][G.hidden.size()];
     CHK(e->dz_b[0].ensure(N, H, true));
@@ -2576,19 +2698,27 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
     const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
     const int passes[1] = {2};
-    CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
-    if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
-      CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
-      e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
-      e->dcat_b_ok = false;
-    }
-    const float* cat = e->dcat.as<float>() + N * ldc;
     const bool b16 = use_b16(e, GT_ROLE_D);
-    if (b16) {   // the generated half of the bf16 image: rows N .. 2N (re-cast whenever the float32 image was rebuilt here)
+    const float* cat = nullptr;
+    if (!b16) {
+      CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+      if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
+        CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
+        e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+      }
+      cat = e->dcat.as<float>() + N * ldc;
+    }
+    if (b16) {   // the generated half of the bf16 image: rows N .. 2N, kept from the D step of the same batch or built here
       CHK(e->dcat_b.ensure(2 * N, K0, false));
-      if (!e->dcat_b_ok) {
-        CHK(cast_transpose<float>(cat, ldc, N, K0, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
-        e->dcat_b_ok = true;
+      if (!(e->dcat_b_ok && e->dcat_b_x == x && e->dcat_b_yhs == y_hat_static)) {
+        if (e->cfg.discriminator_linguistic_condition && (!x || cond_dim(e) <= 0))
+          return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+        CatSrc src;
+        src.x = x; src.cd = cond_dim(e); src.fa = y_hat_static; src.fb = y_hat_static; src.ldf = Ds; src.idx = e->d_adv_cols; src.N = N; src.row_off = N;
+        hipLaunchKernelGGL(cat_cast_transpose_kernel, dim3(cdiv(N, 64), cdiv(K0, 64)), dim3(256), 0, s, src, N, K0,
+                           e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, (__bf16*)nullptr, 0L);
+        LAUNCH_CHECK();
+        e->dcat_b_ok = true; e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
       }
       CHK(refresh_shadows(e, GT_ROLE_D, false, s));        // D has just been stepped (train.py:276 before :307)
       CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, N, e->d_actb, passes, 1, N, e->d_specs, false, s));
@@ -2598,15 +2728,14 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
+    if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
     CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
-                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0));
+                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false));
     if (tr) {
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
       const int col0 = cond_dim(e);
       if (b16) {
-        CHK(e->dz_b[0].ensure(N, H, false));
-        CHK(cast_transpose<float>(e->dzA.as<float>(), H, N, H, e->dz_b[0].r(), e->dz_b[0].ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
         CHK(stack_backward_b16(e, GT_ROLE_D, nullptr, 0, N, e->d_actb, e->d_specs, 0, false, gadv, e->Da, col0, e->Da, 0, N, s));
       } else {
         CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,

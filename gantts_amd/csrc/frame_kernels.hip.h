@@ -479,13 +479,15 @@ struct HeadPartials {   // one per workgroup; summed in fixed order afterwards
 // KP = hidden units per lane (K <= 64*KP): the row, the weight vector and the dw accumulators live
 // in registers; the next row is prefetched while the current one goes through the reduction chain.
 // TH: storage type of the activation (float, or __bf16 with GT_OPT_MATMUL_BF16: the bf16 image the last hidden layer wrote)
-template <int KP, typename TH = float>
+template <int KP, typename TH = float, bool B16OUT = false>
 __global__ __launch_bounds__(256) void d_head_kernel(
     const TH* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, int n_mask, int n_real, int n_rows, int mode, float eps,
     float* __restrict__ Dout, float* __restrict__ dH, int lddh, int want_grad, DropoutSpec drop,
     int has_act, const StepScalars* __restrict__ sc,
-    HeadPartials* __restrict__ hp, float* __restrict__ dw_partial /* [grid][K] */) {
+    HeadPartials* __restrict__ hp, float* __restrict__ dw_partial /* [grid][K] */,
+    __bf16* __restrict__ dHb = nullptr, int lddhb = 0,        // bf16 image of dH (GT_OPT_MATMUL_BF16), instead of / beside dH
+    __bf16* __restrict__ dHbT = nullptr, long lddhbt = 0) {   // and its transposed twin [K][rows]: 4 consecutive rows per 8-byte store
   extern __shared__ __attribute__((aligned(16))) float smf[];   // [4][K] dw staging
   __shared__ double shd[5][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -514,6 +516,11 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 #pragma unroll
       for (int j = 0; j < KP; ++j) hrow[ri][j] = (float)H[(long)r * ldh + kidx[j]];
     }
+    float outv[B16OUT ? 8 : 1][KP];      // B16OUT: the item's dH values, kept for the transposed 8-byte stores below
+#pragma unroll
+    for (int ri = 0; ri < (B16OUT ? 8 : 1); ++ri)
+#pragma unroll
+      for (int j = 0; j < KP; ++j) outv[ri][j] = 0.f;
     uint32_t keepb[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
@@ -565,7 +572,33 @@ __global__ __launch_bounds__(256) void d_head_kernel(
             if (drop.mode == DROP_BUFFER) keep = drop.mask[(long)r * drop.ld_mask + kidx[j]] != 0.f;
             f = leaky_drop_grad(hv, keep, drop.mode == DROP_NONE ? 1.f : drop.scale);
           }
-          if (k < K) dH[(long)r * lddh + k] = dz * wreg[j] * f;
+          const float val = dz * wreg[j] * f;
+          if (B16OUT) outv[ri][j] = val;
+          if (k < K) {
+            if (dH) dH[(long)r * lddh + k] = val;
+            if (B16OUT && dHb) dHb[(long)r * lddhb + k] = (__bf16)val;
+          }
+        }
+      }
+    }
+    if (B16OUT && want_grad && dHbT) {     // the item's rows are two runs of 4 consecutive rows: 16g + 4h + {0..3} and 16g + 8 + 4h + {0..3}
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        const int k = lane + 64 * j;
+        if (k >= K) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int rs = 16 * g + 8 * q + 4 * h;
+          __bf16* dst = dHbT + (long)k * lddhbt + rs;
+          if (rs + 3 < n_rows) {
+            bf16x4 pk;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) pk[s4] = (__bf16)outv[B16OUT ? 4 * q + s4 : 0][j];
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+          } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) if (rs + s4 < n_rows) dst[s4] = (__bf16)outv[B16OUT ? 4 * q + s4 : 0][j];
+          }
         }
       }
     }

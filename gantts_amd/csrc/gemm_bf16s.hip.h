@@ -53,6 +53,10 @@ template <int BM, int BN>
 constexpr size_t gemm_b16_lds_bytes() { return (size_t)2 * (BM + BN) * B16_KP * 2; }
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
 
 // One BM x BN tile.  256 threads = 2 x 2 waves, each wave (BM/2) x (BN/2) in 32x32 MFMA tiles.
 template <int BM, int BN>
@@ -188,6 +192,16 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   // ---- epilogue, in the MFMA C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* C = g.C ? g.C + (g.epi == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
   const bool philox = g.epi != B16_SLAB && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+  // Full tiles with 16-byte-addressable results leave through a wave-private 32 x 32 float32 staging tile in LDS (the
+  // K loop's image is dead: its last iteration ended with a barrier): every result image is then written as 16-byte
+  // stores of contiguous runs -- 8 bf16 along the columns for Cb, 8 bf16 along the rows for the transposed twin, 4 floats
+  // for C -- instead of one 2- / 4-byte store per element (80 -> 8 store instructions per lane of a 128 x 128 tile).
+  const bool staged = m0 + BM <= g.M && n0 + BN <= g.N &&
+                      (!g.Cb || ((g.ldcb & 7) == 0 && (((uintptr_t)g.Cb) & 15) == 0)) &&
+                      (!g.CbT || ((g.ldcbt & 7) == 0 && (((uintptr_t)g.CbT) & 15) == 0)) &&
+                      (!C || ((g.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0));
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+  static_assert((size_t)4 * 32 * 33 * sizeof(float) <= gemm_b16_lds_bytes<BM, BN>(), "epilogue staging exceeds the LDS image");
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -230,7 +244,9 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
             }
           }
           v[s] = x;
-          if (n_ok && m < g.M) {
+          if (staged) {
+            stg[(8 * q + 4 * half + s) * 33 + l31] = x;
+          } else if (n_ok && m < g.M) {
             if (C) {
               float* dst = C + (long)m * g.ldc + n;
               *dst = g.accumulate ? *dst + x : x;
@@ -238,7 +254,7 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
             if (g.Cb) g.Cb[(long)m * g.ldcb + n] = (__bf16)x;
           }
         }
-        if (g.CbT && n_ok) {
+        if (!staged && g.CbT && n_ok) {
           __bf16* dst = g.CbT + (long)n * g.ldcbt + mrow;
           if (mrow + 3 < g.M) {
             bf16x4 p;
@@ -250,6 +266,49 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
             for (int s = 0; s < 4; ++s) if (mrow + s < g.M) dst[s] = (__bf16)v[s];
           }
         }
+      }
+      if (staged) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long mb = m0 + wm * WM + i * 32;
+        const int nb = n0 + wn * WN + j * 32;
+        if (g.Cb) {          // chunk c = lane + 64 t: row c / 4, columns (c % 4) * 8 .. + 7
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int c = lane + 64 * t, row = c >> 2, cc = (c & 3) * 8;
+            const float* sp = stg + row * 33 + cc;
+            uint4 w;
+            w.x = pack_bf16x2(sp[0], sp[1]); w.y = pack_bf16x2(sp[2], sp[3]); w.z = pack_bf16x2(sp[4], sp[5]); w.w = pack_bf16x2(sp[6], sp[7]);
+            *reinterpret_cast<uint4*>(g.Cb + (mb + row) * g.ldcb + nb + cc) = w;
+          }
+        }
+        if (g.CbT) {         // chunk c: column c / 4 of the tile = row of the transposed image, rows (c % 4) * 8 .. + 7 of the tile
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int c = lane + 64 * t, col = c >> 2, rc = (c & 3) * 8;
+            const float* sp = stg + rc * 33 + col;
+            uint4 w;
+            w.x = pack_bf16x2(sp[0], sp[33]); w.y = pack_bf16x2(sp[66], sp[99]); w.z = pack_bf16x2(sp[132], sp[165]); w.w = pack_bf16x2(sp[198], sp[231]);
+            *reinterpret_cast<uint4*>(g.CbT + (long)(nb + col) * g.ldcbt + mb + rc) = w;
+          }
+        }
+        if (C) {             // chunk c = lane + 64 t: row c / 8, columns (c % 8) * 4 .. + 3
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t, row = c >> 3, cc = (c & 7) * 4;
+            const float* sp = stg + row * 33 + cc;
+            f32x4 w = {sp[0], sp[1], sp[2], sp[3]};
+            float* dst = C + (mb + row) * g.ldc + nb + cc;
+            if (g.accumulate) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] += o[e];
+            }
+            *reinterpret_cast<f32x4*>(dst) = w;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -267,42 +326,129 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : 2) void 
 
 // in [rows][ldi] (float32 or bf16)  ->  out [rows][ldo] bf16 (optional)  and  outT [cols][ldt] bf16 (optional), plus
 // per-block column sums of the float32 values (optional: colsum_part [gridDim.x][cols], the bias gradient of a dZ that
-// did not come out of a product).  64 x 64 tiles through LDS; pads of out / outT are not written.
-template <typename TIN>
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const TIN* __restrict__ in, int ldi, long rows, int cols,
-                                                             __bf16* __restrict__ out, int ldo,
-                                                             __bf16* __restrict__ outT, long ldt,
-                                                             float* __restrict__ colsum_part) {
-  __shared__ float tile[64][65];
-  const long r0 = (long)blockIdx.x * 64;
-  const int c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 4 rows per pass
-#pragma unroll 4
-  for (int rr = ty; rr < 64; rr += 4) {
-    const long r = r0 + rr;
-    const int c = c0 + tx;
-    float v = 0.f;
-    if (r < rows && c < cols) {
-      v = (float)in[r * ldi + c];
-      if (out) out[r * ldo + c] = (__bf16)v;
+// did not come out of a product).  64 x 64 tiles through LDS.  Full tiles leave as 16-byte stores in both orientations
+// (8 bf16 along the columns for `out`, 8 along the rows for `outT`: 128 contiguous bytes per 8 lanes) and arrive as
+// 16-byte loads when the source allows (float32, pitch % 4 == 0, 16-byte aligned base); pads of out / outT are not written.
+// One 64 x 64 tile (tile row bx, tile column by).  SRC(r, c) -> float supplies elements that are not read as 16-byte
+// vectors; `vin` (float32 source, pitch % 4 == 0, aligned) enables the vector read of full tiles.
+template <typename SRC>
+__device__ __forceinline__ void cast_transpose_tile(float (*tile)[65], const SRC& src, const float* vin, int ldvin, long rows, int cols,
+                                                    __bf16* __restrict__ out, int ldo, __bf16* __restrict__ outT, long ldt,
+                                                    float* __restrict__ colsum_part, int bx, int by) {
+  const long r0 = (long)bx * 64;
+  const int c0 = by * 64;
+  const int tid = threadIdx.x;
+  const bool full = r0 + 64 <= rows && c0 + 64 <= cols;
+  if (vin && full) {         // 16 float4 per row: thread -> (row = tid / 16 + 16 p, 4 columns)
+    const int cq = (tid & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rr = (tid >> 4) + 16 * p;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vin + (r0 + rr) * ldvin + c0 + cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[rr][cq + e] = v[e];
     }
-    tile[rr][tx] = v;
+  } else {                   // one wave per row, 16 rows in flight per thread
+    const int tx = tid & 63, ty = tid >> 6;
+    float v[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const long r = r0 + ty + 4 * p;
+      const int c = c0 + tx;
+      v[p] = (r < rows && c < cols) ? src(r, c) : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tile[ty + 4 * p][tx] = v[p];
   }
   __syncthreads();
-  if (outT) {
-#pragma unroll 4
+  if (full && out && (ldo & 7) == 0 && (((uintptr_t)out) & 15) == 0) {          // row-major: thread -> (row = tid / 8 + 32 p, 8 columns) = one 16-byte store
+    const int cc = (tid & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int rr = (tid >> 3) + 32 * p;
+      uint4 w;
+      w.x = pack_bf16x2(tile[rr][cc], tile[rr][cc + 1]); w.y = pack_bf16x2(tile[rr][cc + 2], tile[rr][cc + 3]);
+      w.z = pack_bf16x2(tile[rr][cc + 4], tile[rr][cc + 5]); w.w = pack_bf16x2(tile[rr][cc + 6], tile[rr][cc + 7]);
+      *reinterpret_cast<uint4*>(out + (r0 + rr) * ldo + c0 + cc) = w;
+    }
+  } else if (out) {
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+      const long r = r0 + rr;
+      const int c = c0 + tx;
+      if (r < rows && c < cols) out[r * ldo + c] = (__bf16)tile[rr][tx];
+    }
+  }
+  if (full && outT && (ldt & 7) == 0 && (((uintptr_t)outT) & 15) == 0) {        // transposed: thread -> (column = tid / 8 + 32 p, 8 rows) = one 16-byte store
+    const int rc = (tid & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int cc = (tid >> 3) + 32 * p;
+      uint4 w;
+      w.x = pack_bf16x2(tile[rc][cc], tile[rc + 1][cc]); w.y = pack_bf16x2(tile[rc + 2][cc], tile[rc + 3][cc]);
+      w.z = pack_bf16x2(tile[rc + 4][cc], tile[rc + 5][cc]); w.w = pack_bf16x2(tile[rc + 6][cc], tile[rc + 7][cc]);
+      *reinterpret_cast<uint4*>(outT + (long)(c0 + cc) * ldt + r0 + rc) = w;
+    }
+  } else if (outT) {
+    const int tx = tid & 63, ty = tid >> 6;
     for (int cc = ty; cc < 64; cc += 4) {
       const int c = c0 + cc;
       const long r = r0 + tx;
       if (c < cols && r < rows) outT[(long)c * ldt + r] = (__bf16)tile[tx][cc];
     }
   }
-  if (colsum_part && ty == 0 && c0 + tx < cols) {
-    float s = 0.f;
+  if (colsum_part && tid < 64 && c0 + tid < cols) {
+    float sum = 0.f;
 #pragma unroll 8
-    for (int rr = 0; rr < 64; ++rr) s += tile[rr][tx];
-    colsum_part[(long)blockIdx.x * cols + c0 + tx] = s;
+    for (int rr = 0; rr < 64; ++rr) sum += tile[rr][tid];
+    colsum_part[(long)bx * cols + c0 + tid] = sum;
   }
+}
+template <typename TIN>
+struct PlainSrc {
+  const TIN* in; int ldi;
+  __device__ __forceinline__ float operator()(long r, int c) const { return (float)in[r * ldi + c]; }
+};
+template <typename TIN>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const TIN* __restrict__ in, int ldi, long rows, int cols,
+                                                             __bf16* __restrict__ out, int ldo,
+                                                             __bf16* __restrict__ outT, long ldt,
+                                                             float* __restrict__ colsum_part) {
+  __shared__ float tile[64][65];
+  const PlainSrc<TIN> src{in, ldi};
+  const float* vin = (sizeof(TIN) == 4 && (ldi & 3) == 0 && ((((uintptr_t)in) & 15) == 0)) ? reinterpret_cast<const float*>(in) : nullptr;
+  cast_transpose_tile(tile, src, vin, ldi, rows, cols, out, ldo, outT, ldt, colsum_part, (int)blockIdx.x, (int)blockIdx.y);
+}
+// Several float32 matrices in ONE launch (the weight shadows of a network: one job per nn.Linear).
+constexpr int CAST_MAX_JOBS = 8;
+struct CastJob { const float* in; __bf16* out; __bf16* outT; long rows, ldt; int ldi, cols, ldo, gy, block0, pad_; };
+struct CastJobs { int n, pad_; CastJob j[CAST_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastJobs jobs) {
+  __shared__ float tile[64][65];
+  int q = 0;
+  while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].block0) ++q;
+  const CastJob& J = jobs.j[q];
+  const int b = (int)blockIdx.x - J.block0;
+  const PlainSrc<float> src{J.in, J.ldi};
+  const float* vin = ((J.ldi & 3) == 0 && ((((uintptr_t)J.in) & 15) == 0)) ? J.in : nullptr;
+  cast_transpose_tile(tile, src, vin, J.ldi, J.rows, J.cols, J.out, J.ldo, J.outT, J.ldt, nullptr, b / J.gy, b % J.gy);
+}
+// The discriminator's input image [x | feats[:, idx]] (train.py:254-256) written straight as bf16, both orientations, for
+// `nhalf` stacked halves: virtual row r of half h (rows [h*N, (h+1)*N) of the image) = [x[r - h*N] | f_h[r - h*N][idx]],
+// f_0 = fa (natural frames), f_1 = fb (generated frames).  row_off: first image row written (0, or N for the generated half alone).
+struct CatSrc {
+  const float* x; int cd; const float* fa; const float* fb; int ldf; const int* idx; long N, row_off;
+  __device__ __forceinline__ float operator()(long r, int c) const {
+    const long g = r + row_off;
+    const long rr = g >= N ? g - N : g;
+    if (c < cd) return x[rr * cd + c];
+    return (g >= N ? fb : fa)[rr * ldf + idx[c - cd]];
+  }
+};
+__global__ __launch_bounds__(256) void cat_cast_transpose_kernel(const CatSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
+                                                                 __bf16* __restrict__ outT, long ldt) {
+  __shared__ float tile[64][65];
+  cast_transpose_tile(tile, src, nullptr, 0, rows, cols, out, ldo, outT, ldt, nullptr, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // out[r][c] (contiguous float32) = in[r][c] of a bf16 image with row pitch ld (inspection / parity hooks)

@@ -755,16 +755,20 @@ __device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
 // and its weight gradient (g2: partial slabs of dZ^T . X), both on 64x64 tiles with 16-byte loadable operands.  The
 // first n1 workgroups run g1's tiles, the rest g2's: one launch edge (ramp, first-tile latency, drain) instead of two,
 // and the second product's tiles start while the first one's last tiles finish.
+// tn_first: the weight-gradient workgroups (K = frames / slabs: several times the work of a backward-data tile) take the
+// FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (engine.hip).
 template <int PREC>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int bid = blockIdx.x;
-  if (bid < n1) {
-    bid = gemm_xcd_order(bid, n1);
+  const int n2 = (int)gridDim.x - n1;
+  const bool is_nn = tn_first ? bid >= n2 : bid < n1;
+  if (is_nn) {
+    bid = gemm_xcd_order(tn_first ? bid - n2 : bid, n1);
     const int tile_m = bid / g1.n_tiles_n, tile_n = bid - tile_m * g1.n_tiles_n;
     gemm_tile<GEMM_NN, 64, 64, true, true, PREC>(g1, 0, tile_m, tile_n, smem);
   } else {
-    bid = gemm_xcd_order(bid - n1, (int)gridDim.x - n1);
+    bid = gemm_xcd_order(tn_first ? bid : bid - n1, n2);
     const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
     const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
     const int tile_m = t / g2.n_tiles_n, tile_n = t - tile_m * g2.n_tiles_n;

@@ -160,7 +160,7 @@ def run_oracle(case, dtype):
 
 def main():
     only = sys.argv[1:]
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("AT_SIZE_THREADS", os.cpu_count())))
     for name, case in A.AT_SIZE_CASES.items():
         if only and name not in only:
             continue
@@ -175,7 +175,7 @@ def main():
         fx = A.digest(runs[torch.float32], runs[torch.float64])
         fx["meta.source"] = np.array(case["source"])
         fx["meta.seconds_f32"], fx["meta.seconds_f64"] = np.float64(secs[torch.float32]), np.float64(secs[torch.float64])
-        path = os.path.join(HERE, "at_size_%s.npz" % name)
+        path = os.path.join(os.environ.get("AT_SIZE_OUT", HERE), "at_size_%s.npz" % name)
         np.savez_compressed(path, **fx)
         print("%-14s -> %s (%.0f KB)" % (name, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024), flush=True)
         for k in sorted(fx):

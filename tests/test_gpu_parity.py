@@ -773,6 +773,31 @@ def test_bf16_storage_mlp_steps_track_the_float32_oracle(name):
                 assert err < 0.25, (tag + nm, err)
 
 
+def test_bf16_storage_sru_step_tracks_the_float32_oracle():
+    """GT_OPT_MATMUL_BF16 on the hparams-default SRU generator at its real widths (6 x 512 bidirectional, both variational
+    dropouts, 425 -> 187; B = 16, T = 64): the layer inputs, dU and W go through bf16 images / shadows in both orientations
+    (U = xin . W, dW = xin^T . dU, d in = dU . W^T as k-contiguous bf16 products), the scans stay float32.  Against the
+    FLOAT32 oracle (the SRU cell is un-vendored: parity unpinned) at the bf16 rounding level."""
+    from hip_runner import run_hip_case
+    from oracle_runner import run_oracle_case
+    case = dict(C.ORACLE_ONLY_CASES["acoustic_sru_at_size"])
+    got = run_hip_case(case, engine_options={"matmul_bf16": 1})
+    ref = run_oracle_case(case)
+    for k in ("y_hat", "y_hat_static"):
+        err = _rms(got[k] - ref[k]) / _rms(ref[k])
+        assert 1e-5 < err < 2e-2, (k, err)
+    for k in ("d_scalars_0", "g_scalars_0"):
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+        assert (rel[:3] < 2e-2).all(), (k, a, b)
+    w0g, w0d = C.make_weights(case["g"], 11), C.make_weights(case["d"], 22)
+    for tag, w0 in (("G.", w0g), ("D.", w0d)):
+        for name, init in w0.items():
+            ug, ur = got[tag + name] - init, ref[tag + name] - init
+            err = _rms(ug - ur) / max(_rms(ur), 1e-30)
+            assert err < 8e-2, (tag + name, err)
+
+
 def test_lstm_full_size_persistent_equals_per_step_kernels():
     """cfg3 at full size (B=32, T=1024, BiLSTM 3x256, variable lengths): the persistent recurrence kernels (one launch
     per layer, W_hh resident on chip, h / dG exchanged between workgroups) against the per-step kernels the small
