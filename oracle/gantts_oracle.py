@@ -448,6 +448,10 @@ class OracleSRURNN(object):
                 drop = drop or _DropoutSource()
                 xin = inp * (drop.next(inp[:, 0], self.rnn_p) / (1.0 - self.rnn_p)).unsqueeze(1)
             U = (xin @ W).view(B, T, ncols, k)
+            # per-frame views taken ONCE (unbind): slicing U[:, t] inside the time loop makes autograd allocate a zero tensor
+            # of U's full size for every frame on the way back (O(T^2) traffic: hours at T = 2048); same values either way
+            Ut = U.unbind(1)
+            inp_t = inp.unbind(1) if k == 3 else None
             mask_h = None
             if self.training and self.p > 0 and l + 1 < self.L:
                 drop = drop or _DropoutSource()
@@ -459,14 +463,14 @@ class OracleSRURNN(object):
                 c = x.new_zeros(B, H)
                 seq = [None] * T
                 for t in (range(T - 1, -1, -1) if d else range(T)):
-                    u = U[:, t, sl]
+                    u = Ut[t][:, sl]
                     f = torch.sigmoid(u[..., 1] + bf[sl])
                     r = torch.sigmoid(u[..., 2] + br[sl])
                     c = (c - u[..., 0]) * f + u[..., 0]
                     val = self._g(c)
                     if mask_h is not None:
                         val = val * mask_h[:, sl]
-                    xp = inp[:, t, sl] if k == 3 else u[..., 3]
+                    xp = inp_t[t][:, sl] if k == 3 else u[..., 3]
                     seq[t] = (val - xp) * r + xp
                 outs.append(torch.stack(seq, 1))
             inp = torch.cat(outs, -1)
