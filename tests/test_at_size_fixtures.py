@@ -1,0 +1,90 @@
+"""CPU checks of the at-size fixtures (tests/golden/at_size_*.npz) and of the RCCL test double's ABI.
+
+The fixtures are digests of the REAL reference (or, for the un-vendored SRU, of the oracle) run once at the sizes
+BASELINE.json names, in float32 and float64 (tests/golden/make_at_size.py); the -m gpu tests judge the HIP engine against them."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import at_size as A
+import cases as C
+import gantts_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+@pytest.mark.parametrize("name", sorted(A.AT_SIZE_CASES))
+def test_fixture_is_complete_and_self_consistent(name):
+    case = A.AT_SIZE_CASES[name]
+    fx = np.load(os.path.join(GOLDEN, "at_size_%s.npz" % name))
+    assert str(fx["meta.source"]) == case["source"]
+    tensors = sorted(k[:-7] for k in fx.files if k.endswith(".sample"))
+    assert "y_hat" in tensors and "y_hat_static" in tensors
+    gnames = [n for n, _ in C.param_shapes(case["g"])]
+    dnames = [n for n, _ in C.param_shapes(case["d"])]
+    for pre, names in (("Ggrad.", gnames), ("Gupd.", gnames), ("Dgrad.", dnames), ("Dupd.", dnames)):
+        assert [k for k in tensors if k.startswith(pre)] == sorted(pre + n for n in names)
+    for k in tensors:
+        assert np.isfinite(fx[k + ".sample"]).all() and float(fx[k + ".norm"]) > 0
+        # the reference's own float32 run is close to its float64 run (1e-2 at the very worst: sign-like first Adam steps)
+        assert 0 <= float(fx[k + ".err32"]) < 1e-2, (k, float(fx[k + ".err32"]))
+        # the sample's norm cannot exceed the whole tensor's
+        assert float(np.sqrt((fx[k + ".sample"].astype(np.float64) ** 2).sum())) <= float(fx[k + ".norm"]) * (1 + 1e-6)
+    for st in range(case["steps"]):
+        for k in ("d_scalars_%d" % st, "g_scalars_%d" % st):
+            np.testing.assert_allclose(fx[k + ".f32"], fx[k + ".f64"], rtol=2e-5)
+    # the sample positions are a function of the key alone
+    a = np.arange(100000, dtype=np.float32)
+    assert np.array_equal(A.sample_of("Ggrad.x", a), A.sample_of("Ggrad.x", a)) and A.sample_of("Ggrad.x", a).size == A.SAMPLE
+
+
+def test_oracle_reproduces_the_reference_fixture_at_full_size():
+    """cfg5's duration pair at its real size (B = 64, generator noise 416 + 200 -> 5, conditioned D, Adam, two steps, injected
+    dropout masks): the ORACLE in float32 against the digest of the REAL reference's float64 run -- the oracle is the reference's
+    arithmetic, so it must sit within the reference's own float32 distance of it (the same arbiter rule the GPU tests apply)."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_at_size as M
+    case = A.AT_SIZE_CASES["cfg5_duration"]
+    fx = np.load(os.path.join(GOLDEN, "at_size_cfg5_duration.npz"))
+    got = M.run_oracle(case, torch.float32)
+    keys = sorted(k[:-7] for k in fx.files if k.endswith(".sample"))
+    level = {}
+    for k in keys:
+        level[k.split(".")[0]] = max(level.get(k.split(".")[0], 0.0), float(fx[k + ".err32"]))
+    for k in keys:
+        ref = fx[k + ".sample"].astype(np.float64)
+        g = A.sample_of(k, np.asarray(got[k])).astype(np.float64)
+        err = A.rms(g - ref) / max(A.rms(ref), 1e-300)
+        lim = A.ARBITER_FACTOR * max(float(fx[k + ".err32"]), level[k.split(".")[0]]) + A.ARBITER_FLOOR + A.KINK_ALLOWANCE
+        assert err <= lim, (k, err, lim)
+    for st in range(case["steps"]):
+        d, r = got["d_scalars_%d" % st], fx["d_scalars_%d.f64" % st]
+        np.testing.assert_allclose(d[:3], r[:3], rtol=1e-5)
+        assert d[3] == r[3] and d[4] == r[4]
+        np.testing.assert_allclose(got["g_scalars_%d" % st], fx["g_scalars_%d.f64" % st], rtol=1e-5)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.isfile("/opt/rocm/bin/hipcc"), reason="no HIP compiler")
+def test_rccl_test_double_exports_what_the_engine_binds():
+    """tests/fake_rccl.cpp must export exactly the seven nccl* symbols engine.hip resolves (rccl_api())."""
+    so = os.path.join(HERE, "libfake_rccl.so")
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.isfile("/opt/rocm/bin/hipcc") else "hipcc"
+        subprocess.check_call([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", src, "-o", so, "-lrt"])
+    lib = ctypes.CDLL(so)
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert hasattr(lib, sym), sym
+    eng = open(os.path.join(os.path.dirname(HERE), "gantts_amd", "csrc", "engine.hip")).read()
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert '"%s"' % sym in eng
+    buf = ctypes.create_string_buffer(128)
+    assert lib.ncclGetUniqueId(buf) == 0 and buf.raw.startswith(b"/gt_fake_rccl_")
+    assert "GT_RCCL_LIB" in eng
