@@ -448,10 +448,10 @@ static int linear_backward_weight(const float* dZ, int lddz, const float* X, int
 // bf16-storage products (gemm_bf16s.hip.h; GT_OPT_MATMUL_BF16)
 // ------------------------------------------------------------------------------------------
 static inline int pad8(long n) { return (int)((n + 7) & ~7L); }
-template <int BM, int BN>
+template <int BM, int BN, int EPI, int AMODE>
 static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   const size_t lds = gemm_b16_lds_bytes<BM, BN>();
-  CHK(ensure_dyn_lds((const void*)gemm_b16_kernel<BM, BN>, lds));
+  CHK(ensure_dyn_lds((const void*)gemm_b16_kernel<BM, BN, EPI, AMODE>, lds));
   g.n_tiles_m = cdiv(g.M, BM);
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -464,7 +464,7 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_b16_kernel<BM, BN>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  hipLaunchKernelGGL((gemm_b16_kernel<BM, BN, EPI, AMODE>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
@@ -476,8 +476,21 @@ static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s) {
   if (g.CbT && ((g.ldcbt & 3) || (((uintptr_t)g.CbT) & 7))) return fail(GT_ERR_INVALID, "bf16 product: transposed result must be 8-byte aligned");
   // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
   const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
-  if (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && t128 >= 2L * gemm_cu_count()) return launch_gemm_b16_t<128, 128>(g, nslab, s);
-  return launch_gemm_b16_t<64, 64>(g, nslab, s);
+  const bool big = g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && t128 >= 2L * gemm_cu_count();
+  // the epilogue flavour is a template parameter of the kernel (gemm_bf16s.hip.h: GemmB16Amode)
+  int amode = B16_A_NONE;
+  if (g.epi != B16_SLAB) {
+    if (g.act == ACT_SIGMOID) amode = B16_A_SIGMOID;
+    else if (g.act == ACT_LEAKY_DROPOUT) amode = g.drop.mode == DROP_PHILOX ? B16_A_LEAKY_PHILOX : (g.drop.mode == DROP_BUFFER ? B16_A_LEAKY_BUFFER : B16_A_LEAKY);
+  }
+#define GT_B16_CASE(E, A) if (g.epi == E && amode == A) return big ? launch_gemm_b16_t<128, 128, E, A>(g, nslab, s) : launch_gemm_b16_t<64, 64, E, A>(g, nslab, s);
+  GT_B16_CASE(B16_FWD, B16_A_NONE) GT_B16_CASE(B16_FWD, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_FWD, B16_A_LEAKY_BUFFER)
+  GT_B16_CASE(B16_FWD, B16_A_LEAKY) GT_B16_CASE(B16_FWD, B16_A_SIGMOID)
+  GT_B16_CASE(B16_BWD_DATA, B16_A_NONE) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_BUFFER)
+  GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY) GT_B16_CASE(B16_BWD_DATA, B16_A_SIGMOID)
+#undef GT_B16_CASE
+  if (g.epi == B16_SLAB) return launch_gemm_b16_t<64, 64, B16_SLAB, B16_A_NONE>(g, nslab, s);
+  return fail(GT_ERR_INVALID, "bf16 product: unknown epilogue");
 }
 static GemmB16Args b16_args() {
   GemmB16Args g;

@@ -58,8 +58,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
+// Epilogue flavour, COMPILE-TIME (the epilogue is fully unrolled over the tile's 16 .. 64 accumulators per lane: with the
+// flavour decided at run time per element the 128 x 128 kernel was 18 000 instructions, 17 000 of them epilogue).
+enum GemmB16Amode { B16_A_NONE = 0, B16_A_LEAKY_PHILOX = 1, B16_A_LEAKY_BUFFER = 2, B16_A_LEAKY = 3, B16_A_SIGMOID = 4 };
+
 // One BM x BN tile.  256 threads = 2 x 2 waves, each wave (BM/2) x (BN/2) in 32x32 MFMA tiles.
-template <int BM, int BN>
+// EPI (GemmB16Epi) and AMODE (GemmB16Amode) restate g.epi and (g.act, g.drop.mode) at compile time (launch_gemm_b16 dispatches).
+template <int BM, int BN, int EPI, int AMODE>
 __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
   constexpr int UA = BM * (B16_BK / 8) / GEMM_THREADS, UB = BN * (B16_BK / 8) / GEMM_THREADS;   // 16-byte chunks per thread per stage
@@ -70,7 +75,7 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   int k_begin = 0, k_end = g.K;
-  if (g.epi == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
+  if (EPI == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
 
   // chunk u of this thread: row (tid + u*256) / 8 of the tile, k offset ((tid + u*256) % 8) * 8 inside the stage
   const uint4* pa[UA];
@@ -89,7 +94,7 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
     pb[u] = reinterpret_cast<const uint4*>(g.B + (long)row * g.ldb + k_begin + kcb[u]);
   }
   uint4 ra[UA], rb[UB];
-  const bool want_rs = g.epi == B16_SLAB && g.rowsum_slab != nullptr && tile_n == 0;
+  const bool want_rs = EPI == B16_SLAB && g.rowsum_slab != nullptr && tile_n == 0;
   float rsum[UA];
 #pragma unroll
   for (int u = 0; u < UA; ++u) rsum[u] = 0.f;
@@ -190,8 +195,8 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   }
 
   // ---- epilogue, in the MFMA C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  float* C = g.C ? g.C + (g.epi == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
-  const bool philox = g.epi != B16_SLAB && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+  float* C = g.C ? g.C + (EPI == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
+  constexpr bool philox = EPI != B16_SLAB && AMODE == B16_A_LEAKY_PHILOX;
   // Full tiles with 16-byte-addressable results leave through a wave-private 32 x 32 float32 staging tile in LDS (the
   // K loop's image is dead: its last iteration ended with a barrier): every result image is then written as 16-byte
   // stores of contiguous runs -- 8 bf16 along the columns for Cb, 8 bf16 along the rows for the transposed twin, 4 floats
@@ -209,7 +214,7 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
       const int n = n0 + wn * WN + j * 32 + l31;
       const bool n_ok = n < g.N;
       const int nc = min(n, g.N - 1);
-      const float bias = (g.epi == B16_FWD && g.bias) ? g.bias[nc] : 0.f;
+      const float bias = (EPI == B16_FWD && g.bias) ? g.bias[nc] : 0.f;
       uint32_t rnd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -222,25 +227,25 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
           const int m = mrow + s;
           const long mc = min(m, g.M - 1);
           float x = acc[i][j][q * 4 + s];
-          if (g.epi == B16_FWD) {
+          if (EPI == B16_FWD) {
             x += bias;
-            if (g.act == ACT_LEAKY_DROPOUT) {
+            if (AMODE == B16_A_LEAKY_PHILOX || AMODE == B16_A_LEAKY_BUFFER || AMODE == B16_A_LEAKY) {
               x = leaky(x);
-              if (g.drop.mode == DROP_PHILOX) x = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh ? x * g.drop.scale : 0.f;
-              else if (g.drop.mode == DROP_BUFFER) x = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f ? x * g.drop.scale : 0.f;
-            } else if (g.act == ACT_SIGMOID) {
+              if (AMODE == B16_A_LEAKY_PHILOX) x = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh ? x * g.drop.scale : 0.f;
+              else if (AMODE == B16_A_LEAKY_BUFFER) x = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f ? x * g.drop.scale : 0.f;
+            } else if (AMODE == B16_A_SIGMOID) {
               x = 1.f / (1.f + expf(-x));
             }
-          } else if (g.epi == B16_BWD_DATA && g.act != ACT_NONE) {
+          } else if (EPI == B16_BWD_DATA && AMODE != B16_A_NONE) {
             const float h = (float)g.H[mc * g.ldh + nc];
-            if (g.act == ACT_LEAKY_DROPOUT) {
+            if (AMODE == B16_A_SIGMOID) {
+              x *= h * (1.f - h);
+            } else {
               bool keep = true;
               float scale = 1.f;
-              if (g.drop.mode == DROP_PHILOX) { keep = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh; scale = g.drop.scale; }
-              else if (g.drop.mode == DROP_BUFFER) { keep = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f; scale = g.drop.scale; }
+              if (AMODE == B16_A_LEAKY_PHILOX) { keep = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh; scale = g.drop.scale; }
+              else if (AMODE == B16_A_LEAKY_BUFFER) { keep = g.drop.mask[mc * g.drop.ld_mask + nc] != 0.f; scale = g.drop.scale; }
               x *= leaky_drop_grad(h, keep, scale);
-            } else {
-              x *= h * (1.f - h);
             }
           }
           v[s] = x;
@@ -314,14 +319,14 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int EPI, int AMODE>
 __global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : 2) void gemm_b16_kernel(const GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
   const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
   const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
-  gemm_b16_tile<BM, BN>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
+  gemm_b16_tile<BM, BN, EPI, AMODE>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
 }
 
 // in [rows][ldi] (float32 or bf16)  ->  out [rows][ldo] bf16 (optional)  and  outT [cols][ldt] bf16 (optional), plus
