@@ -476,7 +476,8 @@ static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s) {
   if (g.CbT && ((g.ldcbt & 3) || (((uintptr_t)g.CbT) & 7))) return fail(GT_ERR_INVALID, "bf16 product: transposed result must be 8-byte aligned");
   // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
   const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
-  const bool big = g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && t128 >= 2L * gemm_cu_count();
+  static const int force_tiles = getenv("GT_B16_TILES") ? atoi(getenv("GT_B16_TILES")) : 0;      // measurement switch: 64 / 128
+  const bool big = force_tiles == 64 ? false : (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && (force_tiles == 128 || t128 >= 2L * gemm_cu_count()));
   // the epilogue flavour is a template parameter of the kernel (gemm_bf16s.hip.h: GemmB16Amode)
   int amode = B16_A_NONE;
   if (g.epi != B16_SLAB) {

@@ -211,9 +211,7 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN_; ++j) {
-      const int n = n0 + wn * WN + j * 32 + l31;
-      const bool n_ok = n < g.N;
-      const int nc = min(n, g.N - 1);
+      const int nc = min(n0 + wn * WN + j * 32 + l31, g.N - 1);
       const float bias = (EPI == B16_FWD && g.bias) ? g.bias[nc] : 0.f;
       uint32_t rnd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -221,11 +219,9 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;     // rows mrow .. mrow + 3
         if (philox && (q & 1) == 0)
           philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)nc, g.drop.key0, g.drop.key1, rnd);
-        float v[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int m = mrow + s;
-          const long mc = min(m, g.M - 1);
+          const long mc = min(mrow + s, g.M - 1);
           float x = acc[i][j][q * 4 + s];
           if (EPI == B16_FWD) {
             x += bias;
@@ -248,35 +244,30 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
               x *= leaky_drop_grad(h, keep, scale);
             }
           }
-          v[s] = x;
-          if (staged) {
-            stg[(8 * q + 4 * half + s) * 33 + l31] = x;
-          } else if (n_ok && m < g.M) {
-            if (C) {
-              float* dst = C + (long)m * g.ldc + n;
-              *dst = g.accumulate ? *dst + x : x;
-            }
-            if (g.Cb) g.Cb[(long)m * g.ldcb + n] = (__bf16)x;
-          }
-        }
-        if (!staged && g.CbT && n_ok) {
-          __bf16* dst = g.CbT + (long)n * g.ldcbt + mrow;
-          if (mrow + 3 < g.M) {
-            bf16x4 p;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) p[s] = (__bf16)v[s];
-            *reinterpret_cast<bf16x4*>(dst) = p;                       // 8 contiguous bytes of the transposed image
-          } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) if (mrow + s < g.M) dst[s] = (__bf16)v[s];
-          }
+          stg[(8 * q + 4 * half + s) * 33 + l31] = x;      // every tile leaves through the staging tile (edge tiles: element-wise below)
         }
       }
-      if (staged) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const long mb = m0 + wm * WM + i * 32;
-        const int nb = n0 + wn * WN + j * 32;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const long mb = m0 + wm * WM + i * 32;
+      const int nb = n0 + wn * WN + j * 32;
+      if (!staged) {        // edge tile / unaligned result: guarded element-wise stores, a ROLLED loop (16 elements per lane)
+#pragma nounroll
+        for (int t = 0; t < 16; ++t) {
+          const int e = lane + 64 * t, row = e >> 5, col = e & 31;
+          const long m = mb + row;
+          const int nn = nb + col;
+          if (m < g.M && nn < g.N) {
+            const float x = stg[row * 33 + col];
+            if (C) {
+              float* dst = C + m * g.ldc + nn;
+              *dst = g.accumulate ? *dst + x : x;
+            }
+            if (g.Cb) g.Cb[m * g.ldcb + nn] = (__bf16)x;
+            if (g.CbT) g.CbT[(long)nn * g.ldcbt + m] = (__bf16)x;
+          }
+        }
+      } else {
         if (g.Cb) {          // chunk c = lane + 64 t: row c / 4, columns (c % 4) * 8 .. + 7
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -312,9 +303,9 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
             *reinterpret_cast<f32x4*>(dst) = w;
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
