@@ -156,10 +156,10 @@ static unsigned int* gemm_stagger_tickets() {
 // entry point for the launches it issues on this thread)
 static thread_local int tl_gemm_prec = PREC_F32;
 
-template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>
-static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC, int AM>
+static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   const size_t lds = gemm_lds_bytes<KIND, BM, BN, PREC>();
-  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC>, lds));
+  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>, lds));
   g.n_tiles_m = cdiv(g.M, BM);
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -180,10 +180,20 @@ static int launch_gemm_t(GemmArgs g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
+}
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>
+static int launch_gemm_t(const GemmArgs& g, int nslab, hipStream_t s) {
+  // the hot shape of the float32 step (64 x 64 tiles, 16-byte loadable operands) has its two common epilogue flavours
+  // compiled in: no activation, LeakyReLU + Philox dropout (gemm_f32.hip.h: GemmAmode); everything else decides at run time
+  if constexpr (KIND != GEMM_TN && BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) {
+    if (g.act == ACT_NONE) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_NONE>(g, nslab, s);
+    if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX>(g, nslab, s);
+  }
+  return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_RUNTIME>(g, nslab, s);
 }
 static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 : 128; }
 
@@ -317,7 +327,9 @@ static int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int ns
   const bool bf16 = tl_gemm_prec == PREC_BF16;
   const size_t lds = bf16 ? std::max(gemm_lds_bytes<GEMM_NN, 64, 64, PREC_BF16>(), gemm_lds_bytes<GEMM_TN, 64, 64, PREC_BF16>())
                           : std::max(gemm_lds_bytes<GEMM_NN, 64, 64>(), gemm_lds_bytes<GEMM_TN, 64, 64>());
-  const void* kern = bf16 ? (const void*)gemm_pair_kernel<PREC_BF16> : (const void*)gemm_pair_kernel<PREC_F32>;
+  const int am = bf16 ? GEMM_A_RUNTIME : (nn.act == ACT_NONE ? GEMM_A_NONE : ((nn.act == ACT_LEAKY_DROPOUT && nn.drop.mode == DROP_PHILOX) ? GEMM_A_LEAKY_PHILOX : GEMM_A_RUNTIME));
+  const void* kern = bf16 ? (const void*)gemm_pair_kernel<PREC_BF16> : (am == GEMM_A_NONE ? (const void*)gemm_pair_kernel<PREC_F32, GEMM_A_NONE> :
+                     (am == GEMM_A_LEAKY_PHILOX ? (const void*)gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX> : (const void*)gemm_pair_kernel<PREC_F32>));
   CHK(ensure_dyn_lds(kern, lds));
   GemmProfiler::Rec rec;
   if (g_prof.on) {
@@ -329,6 +341,8 @@ static int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int ns
   // GT_PAIR_ORDER (default 1): weight-gradient workgroups first (longest work first); 0 = backward-data tiles first
   static const int tn_first = getenv("GT_PAIR_ORDER") ? atoi(getenv("GT_PAIR_ORDER")) : 1;   // measured: 108.2 -> 104.4 us per pair launch, cfg2 step 1.523 -> 1.499 ms
   if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else if (am == GEMM_A_NONE) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_NONE>), dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else if (am == GEMM_A_LEAKY_PHILOX) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX>), dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }

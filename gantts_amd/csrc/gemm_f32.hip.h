@@ -200,9 +200,15 @@ __device__ __forceinline__ void epi_store1(float* dst, float v) {
 // ---- epilogue of one BM x BN tile whose accumulators are in the MFMA C layout (col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5)): bias / activation / dropout / f' of the producer, stores.
 // LDS (`smem`, at least gemm_lds_bytes) must be free of K-loop readers on entry for the wide path: it starts with a barrier.
-template <int KIND, int BM, int BN, int PREC, int BKT>
+// AMODE: epilogue flavour restated at COMPILE time for the hot instantiations (-1 = decided at run time from g.act /
+// g.drop.mode).  The epilogue is unrolled over the tile's accumulators; with run-time flavours every element carries the
+// branches of all of them (the 64 x 64 forward kernel: ~2500 of its 3100 instructions are prologue + epilogue).
+enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1 };
+template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
                                                 f32x16 (&acc)[BM / 64][BN / 64], float* smem) {
+  const int g_act = AMODE == GEMM_A_RUNTIME ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
+  const int g_dmode = AMODE == GEMM_A_RUNTIME ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN_ = WN / 32;
   const int tid = threadIdx.x;
@@ -212,7 +218,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
   const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
-  const bool philox = (KIND != GEMM_TN) && g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX;
+  const bool philox = (KIND != GEMM_TN) && g_act == ACT_LEAKY_DROPOUT && g_dmode == DROP_PHILOX;
 
   if (KIND != GEMM_TN && full_tile && g.wide_store) {
     // Wide path: everything that is keyed by the MFMA layout (bias column, the 4 Philox words of rows
@@ -245,17 +251,17 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
             float v = acc[i][j][q * 4 + s4];
             if (KIND == GEMM_NT) {
               v += bias;
-              if (g.act == ACT_LEAKY_DROPOUT) {
+              if (g_act == ACT_LEAKY_DROPOUT) {
                 v = leaky(v);
-                if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-                else if (g.drop.mode == DROP_BUFFER)
+                if (g_dmode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+                else if (g_dmode == DROP_BUFFER)
                   v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
-              } else if (g.act == ACT_SIGMOID) {
+              } else if (g_act == ACT_SIGMOID) {
                 v = 1.f / (1.f + expf(-v));
               }
-            } else if (g.act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
-              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-              else if (g.drop.mode == DROP_BUFFER)
+            } else if (g_act == ACT_LEAKY_DROPOUT) {   // NN: keep bit * scale here, sign factor row-wise below
+              if (g_dmode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+              else if (g_dmode == DROP_BUFFER)
                 v = g.drop.mask[(long)(mrow + s4) * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
             }
             stg[(8 * q + 4 * half + s4) * EP + j * 32 + l31] = v;
@@ -270,11 +276,11 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EP + sc4);
         const long m = m0 + wm * WM + i * 32 + row;
         const int n = n0 + wn * WN + sc4;
-        if (KIND == GEMM_NN && g.act != ACT_NONE) {
+        if (KIND == GEMM_NN && g_act != ACT_NONE) {
           const f32x4 h = *reinterpret_cast<const f32x4*>(g.H + m * g.ldh + n);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            v[c] *= g.act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
+            v[c] *= g_act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
         }
         float* dst = C + m * g.ldc + n;
         if (g.accumulate) {
@@ -311,25 +317,25 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
             v += bias;
-            if (g.act == ACT_LEAKY_DROPOUT) {
+            if (g_act == ACT_LEAKY_DROPOUT) {
               v = leaky(v);
-              if (g.drop.mode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
-              else if (g.drop.mode == DROP_BUFFER)
+              if (g_dmode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
+              else if (g_dmode == DROP_BUFFER)
                 v = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f ? v * g.drop.scale : 0.f;
-            } else if (g.act == ACT_SIGMOID) {
+            } else if (g_act == ACT_SIGMOID) {
               v = 1.f / (1.f + expf(-v));
             }
           } else if (KIND == GEMM_NN) {
-            if (g.act == ACT_LEAKY_DROPOUT) {
+            if (g_act == ACT_LEAKY_DROPOUT) {
               const float h = g.H[(long)m * g.ldh + n];
               bool keep = true;
               float scale = 1.f;
-              if (g.drop.mode == DROP_PHILOX) { keep = keep_px; scale = g.drop.scale; }
-              else if (g.drop.mode == DROP_BUFFER) {
+              if (g_dmode == DROP_PHILOX) { keep = keep_px; scale = g.drop.scale; }
+              else if (g_dmode == DROP_BUFFER) {
                 keep = g.drop.mask[(long)m * g.drop.ld_mask + n] != 0.f; scale = g.drop.scale;
               }
               v *= leaky_drop_grad(h, keep, scale);
-            } else if (g.act == ACT_SIGMOID) {
+            } else if (g_act == ACT_SIGMOID) {
               const float h = g.H[(long)m * g.ldh + n];
               v *= h * (1.f - h);
             }
@@ -347,7 +353,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 // one workgroup put a barrier between them).
 // VA / VB: operand is loaded 16 B per lane (requires 16-byte aligned base and pitch % 4 == 0)
 // BKT: K depth of one LDS stage (f32 only: 32, or 16 = half the LDS image, twice the workgroups per CU)
-template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32>
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32, int AMODE = GEMM_A_RUNTIME>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, const int tile_m, const int tile_n, float* smem) {
   static_assert(BKT == 32 || (BKT == 16 && PREC == PREC_F32), "K depth of an LDS stage");
   constexpr int GEMM_BK = BKT;                  // shadows the namespace constant inside this function
@@ -741,7 +747,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     return;
   }
 #endif
-  gemm_store_tile<KIND, BM, BN, PREC, BKT>(g, slab, m0, n0, acc, smem);
+  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0, n0, acc, smem);
 }
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous run of
@@ -757,7 +763,7 @@ __device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
 // and the second product's tiles start while the first one's last tiles finish.
 // tn_first: the weight-gradient workgroups (K = frames / slabs: several times the work of a backward-data tile) take the
 // FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (engine.hip).
-template <int PREC>
+template <int PREC, int AMODE = GEMM_A_RUNTIME>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int bid = blockIdx.x;
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmAr
   if (is_nn) {
     bid = gemm_xcd_order(tn_first ? bid - n2 : bid, n1);
     const int tile_m = bid / g1.n_tiles_n, tile_n = bid - tile_m * g1.n_tiles_n;
-    gemm_tile<GEMM_NN, 64, 64, true, true, PREC>(g1, 0, tile_m, tile_n, smem);
+    gemm_tile<GEMM_NN, 64, 64, true, true, PREC, 32, AMODE>(g1, 0, tile_m, tile_n, smem);
   } else {
     bid = gemm_xcd_order(tn_first ? bid : bid - n1, n2);
     const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmAr
 }
 
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).
-template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32>
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32, int AMODE = GEMM_A_RUNTIME>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   gemm_start_stagger(g, smem);
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArg
   const int t = bid - slab * tiles_mn;
   // n fastest: workgroups sharing an M panel (the big frame matrix) run back to back
   const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
-  gemm_tile<KIND, BM, BN, VA, VB, PREC, BKT>(g, slab, tile_m, tile_n, smem);
+  gemm_tile<KIND, BM, BN, VA, VB, PREC, BKT, AMODE>(g, slab, tile_m, tile_n, smem);
 }
 
 }  // namespace gt
