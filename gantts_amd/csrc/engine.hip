@@ -1251,6 +1251,14 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
 
 static int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
 static int comm_flush(gt_engine* e, int role, hipStream_t compute);
+// measurement switches of the data-parallel schedule
+static bool comm_d_one_message() { static const bool v = !(getenv("GT_COMM_D_ONE_MSG") && getenv("GT_COMM_D_ONE_MSG")[0] == '0'); return v; }
+static bool comm_early_g() { static const bool v = !(getenv("GT_COMM_EARLY_G") && getenv("GT_COMM_EARLY_G")[0] == '0'); return v; }
+static bool comm_group() { static const bool v = getenv("GT_COMM_GROUP") && getenv("GT_COMM_GROUP")[0] == '1'; return v; }
+// Measured with one rank and forced collectives (bench.py --force-dp, plain step 1.465 ms): round-2 schedule 1.577 ms; the
+// discriminator's gradient as ONE message 1.561 (kept); additionally ncclGroupStart/End around a step's closing messages
+// 1.571 (off); generator loss sums sent with the closing messages instead of early 1.604 (off: the host then waits for the
+// whole step before it can enqueue the next one).
 
 // hidden stack backward.  dz_top: gradient w.r.t. the pre-activation of the TOP hidden layer
 // (already multiplied by f'), in buffer `cur` (rows x hidden).  Produces dW/db (if want_w) and,
@@ -1274,7 +1282,9 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
         CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role],
                                    l > 0 ? &nn : nullptr, &rode));
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
-        if (l == 1) CHK(comm_flush(e, role, s));      // all layers above the first: one message, under the first layer's backward
+        // generator: all layers above the first leave as one message under the first layer's backward; the discriminator's
+        // whole gradient (1 MB) is ONE message at the end of its backward pass (a second launch costs more than it hides)
+        if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
       }
       if (l > 0) {
         if (!rode) CHK(launch_gemm(GEMM_NN, nn, 1, s));
@@ -1371,7 +1381,7 @@ static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long l
       const long ldxt = l > 0 ? acts[l - 1].ldt : ld_int;
       CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
       CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
-      if (l == 1) CHK(comm_flush(e, role, s));
+      if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
     }
     if (l > 0) {
       B16Img& nx = e->dz_b[cur ^ 1];
@@ -1569,6 +1579,8 @@ static int comm_flush(gt_engine* e, int role, hipStream_t compute) {
 static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute) {
   if (!comm_on(e)) return GT_OK;
   Net& n = e->net[role];
+  const bool grp = comm_group() && rccl_api();
+  if (grp) NCCLCHK(rccl_api()->GroupStart());       // the closing messages of a step (rest of the gradient + loss sums): one launch
   if (grads) {
     CHK(comm_flush(e, role, compute));
     auto& done = e->comm_done[role];
@@ -1583,6 +1595,7 @@ static int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, in
   e->comm_done[role].clear();
   e->comm_pending[role].clear();
   if (sums && n_sums > 0) CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
+  if (grp) NCCLCHK(rccl_api()->GroupEnd());
   return comm_join(e, compute);
 }
 
@@ -1749,13 +1762,15 @@ static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* l
   *launched = true;
   return GT_OK;
 }
+// forward: the EARLY request order and the fast gate functions (lstm_seq_kernels.hip.h: 2.15 -> 1.81 us per step in
+// bf16, 2.53 -> 1.99 in f32 on a cfg3 layer; tools/lstm_sched_bench keeps the round-2 variant as the A/B reference)
 template <int HP, int UPC>
 static int launch_fwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
   if (bf16)
-    return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_BF16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
-                   : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_BF16>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
-  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_F32>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
-                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_F32>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+    return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_BF16, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
+                   : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_BF16, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_F32, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
+                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_F32, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
 }
 template <int HP>
 static int launch_bwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
@@ -2773,7 +2788,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   // MGE loss + gradient assembly at y_hat_static
   const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
-  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e);
+  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e) && comm_early_g();
   int mge_blocks = 0;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));

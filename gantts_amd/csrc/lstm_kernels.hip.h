@@ -49,6 +49,10 @@ struct LstmStepArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate stash (post-activation i, f, g, o; read back by the backward recurrence only -- no GEMM sees it): the four gates
+// of one (frame, direction, unit) are ONE 16-byte record, [N][dirs][H][4].  (X-projections / dG keep the gate-major
+// [N][dirs][4][H] order of W_ih's rows: those are GEMM operands.)
+__device__ __forceinline__ long lstm_gate_idx(long row, int ld4, int d, int H, int j) { return row * ld4 + (long)d * 4 * H + 4 * j; }
 
 // Stage a 32-row, k-contiguous panel (row r at src + roff(r), valid iff rvalid(r)) transposed into
 // LDS [k][row] (pitch 33): branch-free (clamped address + select), 8 loads in flight per lane,
@@ -211,10 +215,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmStepArgs a
     c = fg * c_in + ig * gg;
     h = og * tanhf(c);
   }
-  a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
-  a.gates[row * ld4 + d * 4 * H + 1 * H + j] = fg;
-  a.gates[row * ld4 + d * 4 * H + 2 * H + j] = gg;
-  a.gates[row * ld4 + d * 4 * H + 3 * H + j] = og;
+  *reinterpret_cast<f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, j)) = f32x4{ig, fg, gg, og};
   a.cst[row * ld1 + d * H + j] = c;
   a.out[row * ld1 + d * H + j] = h;      // zero beyond the length (pad_packed_sequence)
   a.h_next[sidx] = h;                    // state is held at zero while inactive
@@ -251,8 +252,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmStepArgs a
     const long row = (long)bc * T + t;
     p_len[i] = a.lengths[bc];
     p_dout[i] = a.dout[row * ld1 + d * H + pj];
+    {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, pj));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) p_g[i][g] = a.gates[row * ld4 + d * 4 * H + g * H + pj];
+      for (int g = 0; g < 4; ++g) p_g[i][g] = gv[g];
+    }
     p_c[i] = a.cst[row * ld1 + d * H + pj];
     const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);     // clamped; validity checked at use
     p_cp[i] = a.cst[rowp * ld1 + d * H + pj];

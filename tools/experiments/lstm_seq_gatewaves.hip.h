@@ -32,8 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "gemm_f32.hip.h"
-#include "lstm_kernels.hip.h"
+#include "../../gantts_amd/csrc/gemm_f32.hip.h"
+#include "../../gantts_amd/csrc/lstm_kernels.hip.h"
 
 namespace gt {
 
@@ -47,6 +47,20 @@ enum { LSTM_FAULT_TIMEOUT_FWD = 1, LSTM_FAULT_TIMEOUT_BWD = 2 };
 #define GT_LSTM_SEQ_ABLATE 0
 #endif
 constexpr int LSTM_ABL = GT_LSTM_SEQ_ABLATE;
+
+// SCHED: which wave issues which memory operation.  A wave's vector-memory results come back in issue order, so an
+// exchange sweep issued behind HBM-latency stash traffic waits for it -- and the stash traffic of a step (X-projection /
+// gate stash loads, gate / dG stores) is per-step work of the GATE threads only.
+//   LSTM_SCHED_R2     the round-2 order: gate threads are the first threads of the 256, every wave sweeps; the next step's
+//                     stash is requested behind this step's stores.
+//   LSTM_SCHED_EARLY  forward only: the next step's X-projection is requested right behind the sweep's barrier.
+//   LSTM_SCHED_GATEW  the gate threads are EXTRA waves behind the 256 matrix threads (block = 256 + 64 * gate waves): the
+//                     matrix waves' queues carry the exchange and nothing else, the gate waves' queues carry the stash
+//                     traffic and the publish and never wait for a sweep.
+// Measured (tools/lstm_sched_bench, cfg3 layer, us per time step): DESIGN.md 3.4.
+enum { LSTM_SCHED_R2 = 0, LSTM_SCHED_EARLY = 1, LSTM_SCHED_GATEW = 2 };
+constexpr int lstm_fwd_block(int UPC, int BT, int SCHED) { return SCHED == LSTM_SCHED_GATEW ? 256 + 64 * ((BT * UPC + 63) / 64) : 256; }
+constexpr int lstm_bwd_block(int BT, int SCHED) { return SCHED == LSTM_SCHED_GATEW ? 256 + 16 * BT : 256; }
 
 struct LstmSeqArgs {
   int B, T, H, dirs;
@@ -86,7 +100,6 @@ __device__ __forceinline__ unsigned fault_load(const unsigned int* p) {
 // Gate non-linearities with FM (one v_exp_f32 + one v_rcp_f32 each instead of the library's expf / tanhf, which sit on
 // the per-step critical path of one wave): e^x = 2^(x log2 e) with the product's rounding error folded back in (a few
 // ulp); tanh by its odd Taylor polynomial below 0.3 (no cancellation) and by (1 - e^-2|x|) / (1 + e^-2|x|) above.
-// Against the library functions on a cfg3 layer (T = 1024 steps of feedback): max |difference| 3.6e-7 over gates, c, h.
 __device__ __forceinline__ float fast_exp(float x) {
   const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.6931471805599453f;
   const float t = x * L2E_HI;
@@ -233,14 +246,11 @@ constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64;
 // owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
 // wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
 // ------------------------------------------------------------------------------------------
-// EARLY: the next step's X-projection is requested right behind the sweep's barrier instead of behind this step's
-// stores (a wave's vector-memory results come back in issue order: requested late, the HBM-latency loads sit in front
-// of the next sweep's polls in the gate wave's queue).  FM: the fast gate functions above.  Measured on a cfg3 layer
-// (tools/lstm_sched_bench, us per time step, bf16 / f32): 2.15 / 2.53 -> EARLY 1.94 / 2.07 -> EARLY + FM 1.81 / 1.99.
-// Also measured and NOT kept: gate threads as extra waves, requests 2-4 steps ahead, sweeps by the
-// non-gate waves only, delayed stash stores.
-template <int HP, int UPC, int BT, int PREC = PREC_F32, bool EARLY = false, bool FM = false>
-__global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
+template <int HP, int UPC, int BT, int PREC = PREC_F32, int SCHED = LSTM_SCHED_R2, bool FM = false, int PD = 1>
+__global__ __launch_bounds__(lstm_fwd_block(UPC, BT, SCHED)) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
+  static_assert(PD >= 1 && PD <= 4 && (PD == 1 || SCHED != LSTM_SCHED_EARLY), "PD: steps the X-projection request runs ahead of its use");
+  constexpr bool GW = SCHED == LSTM_SCHED_GATEW;
+  constexpr int NTH = lstm_fwd_block(UPC, BT, SCHED);
   constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP * BT / 256;
   constexpr int KPH = HP + 8, WRH = KW / 32;     // PREC_BF16: image pitch, MFMAs (= 8-bf16 weight fragments) per wave
   static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
@@ -258,11 +268,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   const int ld4 = a.dirs * 4 * H, ld1 = a.dirs * H;
 
   // ---- this wave's W_hh slice -> registers (B operand: lane holds W[k = .. + kq][n = lane & 15])
-  const int tile = wave % NT, kpart = wave / NT;
+  const bool mthread = tid < 256;        // matrix threads: sweep, multiply
+  const int tile = (wave & 3) % NT, kpart = (wave & 3) / NT;
   const int n = lane & 15, kq = lane >> 4;
   float wreg[PREC == PREC_BF16 ? 1 : WR];
   bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
-  {
+  if (mthread) {
     const int c = tile * 16 + n, gate = c / UPC, uu = c % UPC;
     const bool wok = u0 + uu < H;
     const float* Wrow = a.Whh[d] + (long)(gate * H + min(u0 + uu, H - 1)) * H;
@@ -282,9 +293,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       }
     }
   }
-  // ---- gate stage: thread (sequence gb, unit gu) for tid < BT*UPC
-  const bool gthread = tid < BT * UPC;
-  const int gb = tid % BT, gu = (tid / BT) % UPC;
+  // ---- gate stage: thread (sequence gb, unit gu): the first BT*UPC threads, or (GATEW) the threads behind the matrix waves
+  const int gt = GW ? tid - 256 : tid;
+  const bool gthread = gt >= 0 && gt < BT * UPC;
+  const int gb = (gt & 1023) % BT, gu = ((gt & 1023) / BT) % UPC;
   const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
   const bool store_ok = gthread && bg < B && j < H;
@@ -298,29 +310,37 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_FWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // rows >= BT and columns without a producer stay zero for good
+  for (int i = tid; i < HP * 16; i += NTH) sA[i] = 0.f;     // rows >= BT and columns without a producer stay zero for good
   __syncthreads();
 
   auto row_of = [&](int s) { return (long)bgc * T + (d == 0 ? s : T - 1 - s); };
   float xin[4];
+  float xq[PD][4];                       // xq[i]: X-projection of step s + 1 + i (requested PD steps ahead of its use)
   {
     const long row = row_of(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+#pragma unroll
+    for (int i = 0; i + 1 < PD; ++i) {
+      const long rowi = row_of(min(i + 1, T - 1));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xq[i][g] = a.xproj[rowi * ld4 + d * 4 * H + g * H + jc];
+    }
   }
   float xnext[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     if (s > 0) {
-      if (!sweep_to_lds<NG, BT, PREC, KPH>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
+      if (mthread)
+        if (!sweep_to_lds<NG, BT, PREC, KPH>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
       __syncthreads();
     }
-    if (EARLY && gthread && s + 1 < T && !(LSTM_ABL & 4)) {
+    if (SCHED == LSTM_SCHED_EARLY && gthread && s + 1 < T && !(LSTM_ABL & 4)) {
       const long row = row_of(s + 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) xnext[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
     }
-    if (s > 0) {
+    if (s > 0 && mthread) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (PREC == PREC_BF16) {
         const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + kpart * KW + 8 * kq;     // row m = lane & 15
@@ -338,8 +358,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(kpart * 16 + kq * 4 + r) * NC + tile * 16 + n] = acc[r];   // C: row = kq*4 + r, col = n
-      __syncthreads();
     }
+    if (s > 0) __syncthreads();
     if (gthread) {
       float pre[4];
 #pragma unroll
@@ -366,17 +386,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (BT * HP) + (size_t)j * BT + gb, h, (unsigned)(s + 1), xcd_local);
       if (store_ok && !(LSTM_ABL & 1)) {
         const long row = (long)bg * T + t;
-        *reinterpret_cast<f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, j)) = f32x4{ig, fg, gg, og};
+        a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
+        a.gates[row * ld4 + d * 4 * H + 1 * H + j] = fg;
+        a.gates[row * ld4 + d * 4 * H + 2 * H + j] = gg;
+        a.gates[row * ld4 + d * 4 * H + 3 * H + j] = og;
         a.cst[row * ld1 + d * H + j] = c;
         a.out[row * ld1 + d * H + j] = h;
       }
-      if (EARLY) {
+      if (SCHED == LSTM_SCHED_EARLY) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) xin[g] = xnext[g];
-      } else if (s + 1 < T && !(LSTM_ABL & 4)) {     // next step's X-projection: in flight while the group exchanges h_t
-        const long row = row_of(s + 1);
+      } else if (!(LSTM_ABL & 4)) {      // the X-projection of step s + PD: in flight while the group exchanges h_t
+        if (s + PD < T) {
+          const long row = row_of(s + PD);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+          for (int g = 0; g < 4; ++g) xq[PD - 1][g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = xq[0][g];
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) xq[i][g] = xq[i + 1][g];
       }
     }
   }
@@ -414,8 +445,11 @@ __device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local)
 // Exchange image of one step: 16-byte chunk (u, b) = {dgi, dgf, dgg, dgo} at u*BT + b; flag word of producing wave
 // w of workgroup c at c*NW + w, monotonic (= steps published).
 // ------------------------------------------------------------------------------------------
-template <int HP, int BT, int PREC = PREC_F32>
-__global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
+template <int HP, int BT, int PREC = PREC_F32, int SCHED = LSTM_SCHED_R2, bool FM = false, int PD = 1>
+__global__ __launch_bounds__(lstm_bwd_block(BT, SCHED)) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
+  static_assert(PD >= 1 && PD <= 4, "PD: steps the stash request runs ahead of its use");
+  constexpr bool GW = SCHED == LSTM_SCHED_GATEW;
+  constexpr int NTH = lstm_bwd_block(BT, SCHED);
   constexpr int WR = HP / 4;
   constexpr int KPH = 4 * HP + 8, WRH = HP / 32;  // PREC_BF16: pitch of the [16][4*HP] bf16 image, MFMAs per wave
   constexpr int NW = 16 * BT / 64;                // producing waves per workgroup
@@ -436,9 +470,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   const int n = lane & 15, kq = lane >> 4;
 
   // B operand: W_hh[(gate = wave)*H + k][u0 + n], k = 16*(i>>2) + 4*(i&3) + kq
+  const bool mthread = tid < 256;        // matrix threads: flag wait, chunk loads, multiply
   float wreg[PREC == PREC_BF16 ? 1 : WR];
   bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
-  {
+  if (mthread) {
     const bool wok = u0 + n < H;
     const float* Wc = a.Whh[d] + (long)wave * H * H + min(u0 + n, H - 1);
     if (PREC == PREC_BF16) {       // lane: output unit n, k = 32*i + 8*kq + 0..7 (rows of gate `wave`'s block of W_hh)
@@ -457,8 +492,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
       }
     }
   }
-  const bool gthread = tid < 16 * BT;
-  const int gb = tid % BT, gu = (tid / BT) & 15;
+  const int gt = GW ? tid - 256 : tid;
+  const bool gthread = gt >= 0 && gt < 16 * BT;
+  const int gb = (gt & 1023) % BT, gu = ((gt & 1023) / BT) & 15;
+  const int gwave = (gt & 1023) >> 6;    // producing wave (flag index)
   const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
   const bool store_ok = gthread && bg < B && j < H;
@@ -472,30 +509,33 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_BWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
+  for (int i = tid; i < 4 * HP * 16; i += NTH) sA[i] = 0.f;
   __syncthreads();
 
-  // stash of one (b, u, t): requested one step ahead of its use.  Three requests per step: the 16-byte gate record, the
-  // upstream gradient, and the cell state ENTERING the frame -- which is the cell state OF the frame the walk visits
-  // next, so the state of the frame itself is carried over from the previous step instead of being read again.
-  struct Stash { float dout, ig, fg, gg, og, cp; };
+  // stash of one (b, u, t): requested one step ahead of its use
+  struct Stash { float dout, ig, fg, gg, og, c, cp; };
   auto load_stash = [&](int s) {
     Stash z;
     const int t = d == 0 ? T - 1 - s : s;
     const long row = (long)bgc * T + t;
     z.dout = a.dout[row * ld1 + d * H + jc];
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, jc));
-    z.ig = gv[0]; z.fg = gv[1]; z.gg = gv[2]; z.og = gv[3];
+    z.ig = a.gates[row * ld4 + d * 4 * H + 0 * H + jc];
+    z.fg = a.gates[row * ld4 + d * 4 * H + 1 * H + jc];
+    z.gg = a.gates[row * ld4 + d * 4 * H + 2 * H + jc];
+    z.og = a.gates[row * ld4 + d * 4 * H + 3 * H + jc];
+    z.c = a.cst[row * ld1 + d * H + jc];
     const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);   // clamped; validity checked at use
     z.cp = a.cst[rowp * ld1 + d * H + jc];
     return z;
   };
   Stash st = load_stash(0);
-  float c_here = a.cst[((long)bgc * T + (d == 0 ? T - 1 : 0)) * ld1 + d * H + jc];     // cell state of the first frame of the walk
+  Stash sq[PD];                          // sq[i]: stash of step s + 1 + i
+#pragma unroll
+  for (int i = 0; i + 1 < PD; ++i) sq[i] = load_stash(min(i + 1, T - 1));
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
-    if (s > 0) {
-      {   // every wave waits for every producing wave of the group to have published step s-1
+    if (s > 0 && mthread) {
+      {   // every matrix wave waits for every producing wave of the group to have published step s-1
         unsigned spins = 0;
         unsigned long long t_start = 0;
         for (;;) {
@@ -536,7 +576,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
           }
         }
       }
-      __syncthreads();
+    }
+    if (s > 0) __syncthreads();
+    if (s > 0 && mthread) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (PREC == PREC_BF16) {
         const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + wave * HP + 8 * kq;
@@ -554,8 +596,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + n] = acc[r];
-      __syncthreads();
     }
+    if (s > 0) __syncthreads();
     if (gthread) {
       const bool active = t < len && j < H;
       float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
@@ -565,7 +607,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         float cp = 0.f;                                        // cell state entering this frame
         if (d == 0) { if (t > 0) cp = st.cp; }
         else        { if (t + 1 < len) cp = st.cp; }
-        const float tc = (LSTM_ABL & 2) ? 0.1f * c_here : tanhf(c_here);
+        const float tc = (LSTM_ABL & 2) ? 0.1f * st.c : gate_tanh<FM>(st.c);
         const float dc = dcs + dh * st.og * (1.f - tc * tc);
         dgo = dh * tc * (st.og * (1.f - st.og));
         dgi = dc * st.gg * (st.ig * (1.f - st.ig));
@@ -581,7 +623,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         payload_store(dst + 2, dgg, xcd_local);
         payload_store(dst + 3, dgo, xcd_local);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's payload is in L2 (or written through) ...
-        if (lane == 0) flag_store(xflag + cu * NW + wave, (unsigned)(s + 1), xcd_local);   // ... before its flag says so
+        if (lane == 0) flag_store(xflag + cu * NW + gwave, (unsigned)(s + 1), xcd_local);  // ... before its flag says so
       }
       if (store_ok && !(LSTM_ABL & 1)) {
         const long row = (long)bg * T + t;
@@ -590,8 +632,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
         a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
       }
-      c_here = st.cp;                    // (at the ends of the walk rowp is clamped: the value is then not used)
-      if (s + 1 < T && !(LSTM_ABL & 4)) st = load_stash(s + 1);
+      if (!(LSTM_ABL & 4)) {
+        if (s + PD < T) sq[PD - 1] = load_stash(s + PD);
+        st = sq[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) sq[i] = sq[i + 1];
+      }
     }
   }
 }

@@ -32,8 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "gemm_f32.hip.h"
-#include "lstm_kernels.hip.h"
+#include "../../gantts_amd/csrc/gemm_f32.hip.h"
+#include "../../gantts_amd/csrc/lstm_kernels.hip.h"
 
 namespace gt {
 
@@ -83,10 +83,10 @@ __device__ __forceinline__ unsigned fault_load(const unsigned int* p) {
   return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Gate non-linearities with FM (one v_exp_f32 + one v_rcp_f32 each instead of the library's expf / tanhf, which sit on
-// the per-step critical path of one wave): e^x = 2^(x log2 e) with the product's rounding error folded back in (a few
-// ulp); tanh by its odd Taylor polynomial below 0.3 (no cancellation) and by (1 - e^-2|x|) / (1 + e^-2|x|) above.
-// Against the library functions on a cfg3 layer (T = 1024 steps of feedback): max |difference| 3.6e-7 over gates, c, h.
+// Gate non-linearities of SCHED >= 3 (one v_exp_f32 + one v_rcp_f32 each instead of the library's expf / tanhf, which
+// sit on the per-step critical path of ONE wave): e^x = 2^(x log2 e) with the product's rounding error folded back in
+// (a few ulp over the range that matters); tanh by its odd Taylor polynomial below 0.3 (no cancellation) and by
+// (1 - e^-2|x|) / (1 + e^-2|x|) above.
 __device__ __forceinline__ float fast_exp(float x) {
   const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.6931471805599453f;
   const float t = x * L2E_HI;
@@ -103,8 +103,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float q = copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
   return ax < 0.3f ? p : q;
 }
-template <bool FM> __device__ __forceinline__ float gate_sigmoid(float x) { return FM ? fast_sigmoid(x) : sigmoidf_(x); }
-template <bool FM> __device__ __forceinline__ float gate_tanh(float x) { return FM ? fast_tanh(x) : tanhf(x); }
 
 // LDS image of the MFMA A operand (16 rows x K): element (k, m) lives where ONE ds_read_b128 of lane
 // (m = lane & 15, kq = lane >> 4) returns the operands of four consecutive 16x16x4 MFMAs (k = 16*kb + 4*j + kq).
@@ -134,15 +132,16 @@ __device__ __forceinline__ bool spin_expired(const LstmSeqArgs& a, unsigned& spi
 // 16-byte slots of the 256-byte bank row (row pitch = 16 bytes mod 256 for K a multiple of 128).
 __device__ __forceinline__ int a_imgh_idx(int k, int m, int kp) { return m * kp + k; }
 
-template <int NG, int BT, int PREC, int KPH>
+// NSW sweeping threads (all 256, or the waves that do no gate work: SCHED 2 of the kernels below); `tid` counts
+// from the first of them.
+template <int NG, int BT, int PREC, int KPH, int NSW>
 __device__ __forceinline__ bool sweep_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int kvalid, float* sA,
-                                             const LstmSeqArgs& a, int rot, unsigned fault_code) {
-  constexpr int KS_ = 256 / BT;        // column stride between a thread's granules
-  const int tid = threadIdx.x;
+                                             const LstmSeqArgs& a, int rot, unsigned fault_code, int tid) {
+  constexpr int KS_ = NSW / BT;        // column stride between a thread's granules
   const int m = tid % BT, k0 = tid / BT;
   unsigned spins = 0;
   unsigned long long t_start = 0;
-  if (NG > 8) {      // measured (tools/lstm_seq_bench): the extra round trip pays only for the 16-granule sweeps
+  if (NG > 12) {     // measured (tools/lstm_seq_bench): the extra round trip pays only for the 16-granule sweeps
     const int ks = k0 + KS_ * (rot % NG);
     if (ks < kvalid) {
       const unsigned long long* sp = src + (size_t)ks * BT + m;
@@ -224,24 +223,29 @@ template <int HP, int UPC> constexpr size_t lstm_fwd_seq_lds() {
 }
 template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16) * sizeof(float); }
 // exchange area of one group, in 8-byte units (the launcher sizes and zeroes it): forward 2 granule images;
-// backward 2 images of 16-byte chunks + 128 flag words
+// backward 2 images of 16-byte chunks (SCHED >= 3: of GPC tagged granules per (unit, sequence)) + 128 flag words
 constexpr size_t lstm_fwd_xch_u64(int HP) { return (size_t)2 * 16 * HP; }
-constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64; }
+constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 4 + 64; }   // room for the tagged f32 form (32 B per (unit, sequence))
 
 // ------------------------------------------------------------------------------------------
 // forward.  grid = nxcd * ncu * ceil(ngroups / nxcd) workgroups of 256 (seq_group_of); the workgroup
 // owns hidden units [cu*UPC, cu*UPC + UPC), i.e. NC = 4*UPC gate columns c = gate*UPC + unit.
 // wave w: N tile w % NT of 16 columns, K part w / NT of HP/KS rows (NT = NC/16, KS = 4/NT).
 // ------------------------------------------------------------------------------------------
-// EARLY: the next step's X-projection is requested right behind the sweep's barrier instead of behind this step's
-// stores (a wave's vector-memory results come back in issue order: requested late, the HBM-latency loads sit in front
-// of the next sweep's polls in the gate wave's queue).  FM: the fast gate functions above.  Measured on a cfg3 layer
-// (tools/lstm_sched_bench, us per time step, bf16 / f32): 2.15 / 2.53 -> EARLY 1.94 / 2.07 -> EARLY + FM 1.81 / 1.99.
-// Also measured and NOT kept: gate threads as extra waves, requests 2-4 steps ahead, sweeps by the
-// non-gate waves only, delayed stash stores.
-template <int HP, int UPC, int BT, int PREC = PREC_F32, bool EARLY = false, bool FM = false>
+// SCHED: where a step's memory operations sit (a wave's vector-memory results come back in issue order, so a sweep
+// issued behind HBM-latency stash traffic waits for it).  0: the round-2 order (next step's X-projection requested
+// after this step's stores, every wave sweeps).  1: the X-projection of the next step is requested right behind the
+// sweep's barrier.  2: as 1, and only the waves without gate threads sweep (the gate waves' queues carry the stash
+// traffic, the sweeping waves' queues carry nothing else).  3: as 1 but TWO steps ahead (the request has a whole step to
+// come back before the next sweep queues behind it) + the fast gate functions.  4: as 3, and a step's stash stores are
+// issued behind the NEXT step's sweep barrier (not between the publish and the sweep that waits for the peers).
+// Measured (tools/lstm_sched_bench, cfg3 layer): see DESIGN.md 3.4.
+template <int HP, int UPC, int BT, int PREC = PREC_F32, int SCHED = 0>
 __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
-  constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP * BT / 256;
+  constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4;
+  constexpr int NGW = (BT * UPC + 63) / 64;                                   // waves that hold gate threads
+  constexpr int NSW = (SCHED == 2 && NGW < 4) ? 256 - 64 * NGW : 256;        // sweeping threads
+  constexpr int NG = (HP * BT + NSW - 1) / NSW;
   constexpr int KPH = HP + 8, WRH = KW / 32;     // PREC_BF16: image pitch, MFMAs (= 8-bf16 weight fragments) per wave
   static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
   static_assert(BT == 8 || BT == 16, "BT");
@@ -308,18 +312,42 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
 #pragma unroll
     for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
   }
-  float xnext[4] = {0.f, 0.f, 0.f, 0.f};
+  float xnext[4] = {0.f, 0.f, 0.f, 0.f}, xnext2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (SCHED >= 3 && T > 1 && gthread) {
+    const long row = row_of(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xnext[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+  }
+  float held[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // SCHED 4: i, f, g, o, c, h of the previous step
+  auto store_stash = [&](int tt, float ig, float fg, float gg, float og, float c, float h) {
+    const long row = (long)bg * T + tt;
+    a.gates[row * ld4 + d * 4 * H + 0 * H + j] = ig;
+    a.gates[row * ld4 + d * 4 * H + 1 * H + j] = fg;
+    a.gates[row * ld4 + d * 4 * H + 2 * H + j] = gg;
+    a.gates[row * ld4 + d * 4 * H + 3 * H + j] = og;
+    a.cst[row * ld1 + d * H + j] = c;
+    a.out[row * ld1 + d * H + j] = h;
+  };
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     if (s > 0) {
-      if (!sweep_to_lds<NG, BT, PREC, KPH>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu, LSTM_FAULT_TIMEOUT_FWD)) return;
+      if (tid >= 256 - NSW)
+        if (!sweep_to_lds<NG, BT, PREC, KPH, NSW>(xb + (size_t)((s - 1) & 1) * (BT * HP), (unsigned)s, kvalid, sA, a, cu,
+                                                  LSTM_FAULT_TIMEOUT_FWD, tid - (256 - NSW))) return;
       __syncthreads();
     }
-    if (EARLY && gthread && s + 1 < T && !(LSTM_ABL & 4)) {
+    if ((SCHED == 1 || SCHED == 2) && gthread && s + 1 < T && !(LSTM_ABL & 4)) {
       const long row = row_of(s + 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) xnext[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
     }
+    if (SCHED >= 3 && gthread && s + 2 < T && !(LSTM_ABL & 4)) {
+      const long row = row_of(s + 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xnext2[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+    }
+    if (SCHED >= 4 && s > 0 && store_ok && !(LSTM_ABL & 1))
+      store_stash(d == 0 ? s - 1 : T - s, held[0], held[1], held[2], held[3], held[4], held[5]);
     if (s > 0) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (PREC == PREC_BF16) {
@@ -357,20 +385,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
         ig = 0.1f * pre[0]; fg = 0.1f * pre[1]; gg = 0.1f * pre[2]; og = 0.1f * pre[3];
         c = fg * c_state + ig * gg;
         h = og * c;
-      } else if (active) {
-        ig = gate_sigmoid<FM>(pre[0]); fg = gate_sigmoid<FM>(pre[1]); gg = gate_tanh<FM>(pre[2]); og = gate_sigmoid<FM>(pre[3]);
+      } else if (active && SCHED >= 3) {
+        ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
         c = fg * c_state + ig * gg;
-        h = og * gate_tanh<FM>(c);
+        h = og * fast_tanh(c);
+      } else if (active) {
+        ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+        c = fg * c_state + ig * gg;
+        h = og * tanhf(c);
       }
       c_state = c;                       // state is held at zero while inactive
       if (s + 1 < T) xch_store(xb + (size_t)(s & 1) * (BT * HP) + (size_t)j * BT + gb, h, (unsigned)(s + 1), xcd_local);
-      if (store_ok && !(LSTM_ABL & 1)) {
-        const long row = (long)bg * T + t;
-        *reinterpret_cast<f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, j)) = f32x4{ig, fg, gg, og};
-        a.cst[row * ld1 + d * H + j] = c;
-        a.out[row * ld1 + d * H + j] = h;
+      if (SCHED >= 4 && s + 1 < T) {
+        held[0] = ig; held[1] = fg; held[2] = gg; held[3] = og; held[4] = c; held[5] = h;
+      } else if (store_ok && !(LSTM_ABL & 1)) {
+        store_stash(t, ig, fg, gg, og, c, h);
       }
-      if (EARLY) {
+      if (SCHED >= 3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { xin[g] = xnext[g]; xnext[g] = xnext2[g]; }
+      } else if (SCHED >= 1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) xin[g] = xnext[g];
       } else if (s + 1 < T && !(LSTM_ABL & 4)) {     // next step's X-projection: in flight while the group exchanges h_t
@@ -407,6 +441,70 @@ __device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local)
   flag_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), xcd_local);
 }
 
+// Backward exchange in the tagged form (SCHED >= 3): GPC granules per (unit u, sequence b) at (u*BT + b)*GPC + q --
+// PREC_BF16: q = 0 {bf16 dgi | bf16 dgf << 16, tag}, q = 1 {dgg | dgo << 16, tag} (the consumer rounds dG to bf16 on its
+// way into LDS anyway: rounding at the producer gives the same operand); PREC_F32: q = gate, {f32, tag}.  No flag, no
+// drain before a flag, no second round trip: one sweep as in the forward kernel.
+__device__ __forceinline__ void xch_store_u32(unsigned long long* p, unsigned v, unsigned tag, bool xcd_local) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)v;
+  if (xcd_local) __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else           __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+template <int HP, int BT, int PREC>
+__device__ __forceinline__ bool sweep_dg_to_lds(const unsigned long long* __restrict__ src, unsigned epoch, int uvalid, float* sA,
+                                                const LstmSeqArgs& a, int rot) {
+  constexpr int GPC = PREC == PREC_BF16 ? 2 : 4, KPH = 4 * HP + 8;
+  constexpr int NGB = HP * BT * GPC / 256, RN = NGB < 16 ? NGB : 16;
+  static_assert(NGB % RN == 0, "rounds");
+  const int tid = threadIdx.x;
+  unsigned spins = 0;
+  unsigned long long t_start = 0;
+  {   // sentinel: one granule per thread until it carries the step (the producers publish within a fraction of a
+      // microsecond of each other; whole sweeps from every workgroup before that only load the L2)
+    const int gi = tid + 256 * (rot % NGB);
+    if (gi / (GPC * BT) < uvalid) {
+      for (;;) {
+        const bool ok = (unsigned)(xch_load(src + gi) >> 32) == epoch;
+        if (__all(ok)) break;
+        if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) return false;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < NGB; r0 += RN) {
+    unsigned long long v[RN];
+    int gi[RN];
+#pragma unroll
+    for (int q = 0; q < RN; ++q) gi[q] = tid + 256 * ((r0 + q + rot) % NGB);
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < RN; ++q) v[q] = xch_load(src + (gi[q] / (GPC * BT) < uvalid ? gi[q] : 0));
+#pragma unroll
+      for (int q = 0; q < RN; ++q) ok &= (gi[q] / (GPC * BT) >= uvalid) || ((unsigned)(v[q] >> 32) == epoch);
+      if (__all(ok)) break;
+      if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) {
+      const int cell = gi[q] / GPC, part = gi[q] % GPC, u = cell / BT, b = cell % BT;
+      if (u < uvalid) {
+        if (PREC == PREC_BF16) {
+          unsigned short* ah = reinterpret_cast<unsigned short*>(sA) + b * KPH + (2 * part) * HP + u;
+          ah[0] = (unsigned short)((unsigned)v[q] & 0xffffu);
+          ah[HP] = (unsigned short)((unsigned)v[q] >> 16);
+        } else {
+          sA[part * HP * 16 + a_img_idx(u, b)] = __uint_as_float((unsigned)v[q]);
+        }
+      }
+    }
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // backward.  grid as forward with ncu = ceil(H/16): the workgroup owns 16 hidden units (one MFMA N tile) of dh;
 // K = 4*HP gate columns (k = gate*HP + unit), wave w multiplies gate w's block.  Direction 0 walks t = T-1..0,
@@ -414,12 +512,20 @@ __device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local)
 // Exchange image of one step: 16-byte chunk (u, b) = {dgi, dgf, dgg, dgo} at u*BT + b; flag word of producing wave
 // w of workgroup c at c*NW + w, monotonic (= steps published).
 // ------------------------------------------------------------------------------------------
-template <int HP, int BT, int PREC = PREC_F32>
+// SCHED 2 (BT = 8 only: two of the four waves hold no gate thread): the flag wait and the chunk loads are done by
+// those two waves alone; the gate waves' memory queues carry the stash loads / dG stores and nothing of the exchange.
+// SCHED 3: tagged exchange (sweep_dg_to_lds), the stash of step s+2 requested right behind step s's sweep barrier (the
+// flag protocol's drain would wait for it; the tagged form has no drain), fast tanh.  SCHED 4: as 3, and a step's dG
+// stores are issued behind the next step's sweep barrier.
+template <int HP, int BT, int PREC = PREC_F32, int SCHED = 0>
 __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
   constexpr int WR = HP / 4;
   constexpr int KPH = 4 * HP + 8, WRH = HP / 32;  // PREC_BF16: pitch of the [16][4*HP] bf16 image, MFMAs per wave
   constexpr int NW = 16 * BT / 64;                // producing waves per workgroup
-  constexpr int NCH = HP * BT / 256;              // 16-byte chunks per thread and step
+  constexpr int NSW = (SCHED == 2 && NW < 4) ? 256 - 64 * NW : 256;   // sweeping threads
+  constexpr int NCH = HP * BT / NSW;              // 16-byte chunks per sweeping thread and step
+  constexpr bool TAGGED = SCHED >= 3;
+  constexpr int GPC = PREC == PREC_BF16 ? 2 : 4;  // tagged granules per (unit, sequence)
   static_assert(BT == 8 || BT == 16, "BT");
   static_assert(NCH % 8 == 0, "chunks are loaded 8 at a time");
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -475,27 +581,44 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
   __syncthreads();
 
-  // stash of one (b, u, t): requested one step ahead of its use.  Three requests per step: the 16-byte gate record, the
-  // upstream gradient, and the cell state ENTERING the frame -- which is the cell state OF the frame the walk visits
-  // next, so the state of the frame itself is carried over from the previous step instead of being read again.
-  struct Stash { float dout, ig, fg, gg, og, cp; };
+  // stash of one (b, u, t): requested one step ahead of its use
+  struct Stash { float dout, ig, fg, gg, og, c, cp; };
   auto load_stash = [&](int s) {
     Stash z;
     const int t = d == 0 ? T - 1 - s : s;
     const long row = (long)bgc * T + t;
     z.dout = a.dout[row * ld1 + d * H + jc];
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gates + lstm_gate_idx(row, ld4, d, H, jc));
-    z.ig = gv[0]; z.fg = gv[1]; z.gg = gv[2]; z.og = gv[3];
+    z.ig = a.gates[row * ld4 + d * 4 * H + 0 * H + jc];
+    z.fg = a.gates[row * ld4 + d * 4 * H + 1 * H + jc];
+    z.gg = a.gates[row * ld4 + d * 4 * H + 2 * H + jc];
+    z.og = a.gates[row * ld4 + d * 4 * H + 3 * H + jc];
+    z.c = a.cst[row * ld1 + d * H + jc];
     const long rowp = d == 0 ? (t > 0 ? row - 1 : row) : (t + 1 < T ? row + 1 : row);   // clamped; validity checked at use
     z.cp = a.cst[rowp * ld1 + d * H + jc];
     return z;
   };
-  Stash st = load_stash(0);
-  float c_here = a.cst[((long)bgc * T + (d == 0 ? T - 1 : 0)) * ld1 + d * H + jc];     // cell state of the first frame of the walk
+  Stash st = load_stash(0), st1 = st, st2 = st;
+  if (TAGGED && T > 1) st1 = load_stash(1);
+  float held[4] = {0.f, 0.f, 0.f, 0.f};          // SCHED 4: dG of the previous step
+  auto store_dg = [&](int tt, float dgi, float dgf, float dgg, float dgo) {
+    const long row = (long)bg * T + tt;
+    a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
+    a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
+    a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
+    a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
+  };
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
-    if (s > 0) {
-      {   // every wave waits for every producing wave of the group to have published step s-1
+    if (TAGGED) {
+      if (s > 0) {
+        if (!sweep_dg_to_lds<HP, BT, PREC>(xb + (size_t)((s - 1) & 1) * (HP * BT * GPC), (unsigned)s, uvalid, sA, a, cu)) return;
+        __syncthreads();
+      }
+      if (gthread && s + 2 < T && !(LSTM_ABL & 4)) st2 = load_stash(s + 2);
+      if (SCHED >= 4 && s > 0 && store_ok && !(LSTM_ABL & 1)) store_dg(d == 0 ? T - s : s - 1, held[0], held[1], held[2], held[3]);
+    } else if (s > 0 && tid >= 256 - NSW) {
+      const int stid = tid - (256 - NSW);
+      {   // every sweeping wave waits for every producing wave of the group to have published step s-1
         unsigned spins = 0;
         unsigned long long t_start = 0;
         for (;;) {
@@ -515,7 +638,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int jr = c0 + q + cu;                      // workgroup-dependent start: spread the L2 channels
-          cc[q] = tid + 256 * (jr % NCH);
+          cc[q] = stid + NSW * (jr % NCH);
           const int u = cc[q] / BT;
           p[q] = src + (u < uvalid ? cc[q] : 0);
         }
@@ -536,7 +659,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
           }
         }
       }
-      __syncthreads();
+    }
+    if (s > 0) {
+      if (!TAGGED) __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (PREC == PREC_BF16) {
         const __bf16* ah = reinterpret_cast<const __bf16*>(sA) + n * KPH + wave * HP + 8 * kq;
@@ -565,7 +690,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         float cp = 0.f;                                        // cell state entering this frame
         if (d == 0) { if (t > 0) cp = st.cp; }
         else        { if (t + 1 < len) cp = st.cp; }
-        const float tc = (LSTM_ABL & 2) ? 0.1f * c_here : tanhf(c_here);
+        const float tc = (LSTM_ABL & 2) ? 0.1f * st.c : (SCHED >= 3 ? fast_tanh(st.c) : tanhf(st.c));
         const float dc = dcs + dh * st.og * (1.f - tc * tc);
         dgo = dh * tc * (st.og * (1.f - st.og));
         dgi = dc * st.gg * (st.ig * (1.f - st.ig));
@@ -574,7 +699,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         dcn = dc * st.fg;
       }
       dcs = dcn;
-      if (s + 1 < T) {
+      if (TAGGED && s + 1 < T) {
+        unsigned long long* dst = xb + (size_t)(s & 1) * (HP * BT * GPC) + ((size_t)j * BT + gb) * GPC;
+        if (PREC == PREC_BF16) {
+          xch_store_u32(dst + 0, bf16_bits(dgi) | (bf16_bits(dgf) << 16), (unsigned)(s + 1), xcd_local);
+          xch_store_u32(dst + 1, bf16_bits(dgg) | (bf16_bits(dgo) << 16), (unsigned)(s + 1), xcd_local);
+        } else {
+          xch_store(dst + 0, dgi, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 1, dgf, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 2, dgg, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 3, dgo, (unsigned)(s + 1), xcd_local);
+        }
+      } else if (s + 1 < T) {
         float* dst = reinterpret_cast<float*>(xdata + (size_t)(s & 1) * (HP * BT) + (size_t)j * BT + gb);
         payload_store(dst + 0, dgi, xcd_local);
         payload_store(dst + 1, dgf, xcd_local);
@@ -583,15 +719,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's payload is in L2 (or written through) ...
         if (lane == 0) flag_store(xflag + cu * NW + wave, (unsigned)(s + 1), xcd_local);   // ... before its flag says so
       }
-      if (store_ok && !(LSTM_ABL & 1)) {
-        const long row = (long)bg * T + t;
-        a.xproj[row * ld4 + d * 4 * H + 0 * H + j] = dgi;      // dG overwrites the X-projection storage
-        a.xproj[row * ld4 + d * 4 * H + 1 * H + j] = dgf;
-        a.xproj[row * ld4 + d * 4 * H + 2 * H + j] = dgg;
-        a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
+      if (SCHED >= 4 && s + 1 < T) {
+        held[0] = dgi; held[1] = dgf; held[2] = dgg; held[3] = dgo;
+      } else if (store_ok && !(LSTM_ABL & 1)) {
+        store_dg(t, dgi, dgf, dgg, dgo);
       }
-      c_here = st.cp;                    // (at the ends of the walk rowp is clamped: the value is then not used)
-      if (s + 1 < T && !(LSTM_ABL & 4)) st = load_stash(s + 1);
+      if (TAGGED) { st = st1; st1 = st2; }
+      else if (s + 1 < T && !(LSTM_ABL & 4)) st = load_stash(s + 1);
     }
   }
 }
