@@ -1746,39 +1746,41 @@ static int seq_xcds(int* nxcd, int* cus_per_xcd) {
   return GT_OK;
 }
 template <typename K>
-static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* launched) {
+static int launch_seq(K kern, size_t lds, LstmSeqArgs& a, hipStream_t s, bool* launched, int block = 256) {
   CHK(ensure_dyn_lds((const void*)kern, lds));
   int per_cu = 0, nxcd = 1, cpx = 1;
   CHK(seq_xcds(&nxcd, &cpx));
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds));
   if (per_cu > 1) per_cu -= 1;
   per_cu = std::min(per_cu, 4);
   const int ngroups = a.dirs * a.nbt;
   const int rounds = cdiv(ngroups, nxcd);                   // groups that share one XCD
   if ((long)a.ncu * rounds > (long)cpx * per_cu) { *launched = false; return GT_OK; }
   a.nxcd = nxcd;
-  hipLaunchKernelGGL(kern, dim3(nxcd * a.ncu * rounds), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(nxcd * a.ncu * rounds), dim3(block), lds, s, a);
   LAUNCH_CHECK();
   *launched = true;
   return GT_OK;
 }
-// forward: the EARLY request order and the fast gate functions (lstm_seq_kernels.hip.h: 2.15 -> 1.81 us per step in
-// bf16, 2.53 -> 1.99 in f32 on a cfg3 layer; tools/lstm_sched_bench keeps the round-2 variant as the A/B reference)
+// forward: loader waves + the fast gate functions (lstm_seq_kernels.hip.h: 2.15 -> 1.59 us per step in bf16, 2.54 -> 1.92
+// in f32 on a cfg3 layer; tools/lstm_sched_bench keeps the round-2 variant as the A/B reference)
 template <int HP, int UPC>
 static int launch_fwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
   if (bf16)
-    return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_BF16, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
-                   : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_BF16, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
-  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_F32, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched)
-                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_F32, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched);
+    return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_BF16, false, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched, lstm_fwd_block(UPC, 8, true))
+                   : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_BF16, false, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched, lstm_fwd_block(UPC, 16, true));
+  return bt == 8 ? launch_seq(lstm_fwd_seq_kernel<HP, UPC, 8, PREC_F32, false, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched, lstm_fwd_block(UPC, 8, true))
+                 : launch_seq(lstm_fwd_seq_kernel<HP, UPC, 16, PREC_F32, false, true, true>, lstm_fwd_seq_lds<HP, UPC>(), a, s, launched, lstm_fwd_block(UPC, 16, true));
 }
+// backward: loader waves in both precisions; the tagged exchange where dG travels as bf16 (in f32 it doubles the exchange
+// volume and loses).  cfg3 layer, us per step: bf16 2.38 -> 1.85, f32 3.13 -> 2.76 (tools/lstm_sched_bench).
 template <int HP>
 static int launch_bwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool* launched) {
   if (bf16)
-    return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_BF16>, lstm_bwd_seq_lds<HP>(), a, s, launched)
-                   : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_BF16>, lstm_bwd_seq_lds<HP>(), a, s, launched);
-  return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_F32>, lstm_bwd_seq_lds<HP>(), a, s, launched)
-                 : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_F32>, lstm_bwd_seq_lds<HP>(), a, s, launched);
+    return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_BF16, true, true>, lstm_bwd_seq_lds<HP>(), a, s, launched, lstm_bwd_block(8, true))
+                   : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_BF16, true, true>, lstm_bwd_seq_lds<HP>(), a, s, launched, lstm_bwd_block(16, true));
+  return bt == 8 ? launch_seq(lstm_bwd_seq_kernel<HP, 8, PREC_F32, true, false>, lstm_bwd_seq_lds<HP>(), a, s, launched, lstm_bwd_block(8, true))
+                 : launch_seq(lstm_bwd_seq_kernel<HP, 16, PREC_F32, true, false>, lstm_bwd_seq_lds<HP>(), a, s, launched, lstm_bwd_block(16, true));
 }
 
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits

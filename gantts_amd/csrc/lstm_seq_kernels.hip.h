@@ -220,13 +220,13 @@ __device__ __forceinline__ bool seq_colocated(const LstmSeqArgs& a, int group, i
 }
 
 template <int HP, int UPC> constexpr size_t lstm_fwd_seq_lds() {
-  return (size_t)(HP * 16 + (16 / UPC) * 16 * 4 * UPC) * sizeof(float);     // A image + KS x 16 x NC partials
+  return (size_t)(HP * 16 + (16 / UPC) * 16 * 4 * UPC + 2 * 4 * 256) * sizeof(float);     // A image + KS x 16 x NC partials + the loader waves' hand-off
 }
-template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16) * sizeof(float); }
+template <int HP> constexpr size_t lstm_bwd_seq_lds() { return (size_t)(4 * HP * 16 + 4 * 16 * 16 + 2 * 6 * 256) * sizeof(float); }   // + the loader waves' stash hand-off
 // exchange area of one group, in 8-byte units (the launcher sizes and zeroes it): forward 2 granule images;
 // backward 2 images of 16-byte chunks + 128 flag words
 constexpr size_t lstm_fwd_xch_u64(int HP) { return (size_t)2 * 16 * HP; }
-constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64; }
+constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 4 + 64; }   // sized for the tagged f32 form: 32 B per (unit, sequence)
 
 // ------------------------------------------------------------------------------------------
 // forward.  grid = nxcd * ncu * ceil(ngroups / nxcd) workgroups of 256 (seq_group_of); the workgroup
@@ -239,8 +239,13 @@ constexpr size_t lstm_bwd_xch_u64(int HP) { return (size_t)2 * 16 * HP * 2 + 64;
 // (tools/lstm_sched_bench, us per time step, bf16 / f32): 2.15 / 2.53 -> EARLY 1.94 / 2.07 -> EARLY + FM 1.81 / 1.99.
 // Also measured and NOT kept: gate threads as extra waves, requests 2-4 steps ahead, sweeps by the
 // non-gate waves only, delayed stash stores.
-template <int HP, int UPC, int BT, int PREC = PREC_F32, bool EARLY = false, bool FM = false>
-__global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
+// LW: the request is issued by extra loader waves (block = 256 + 64 * ceil(BT*UPC/64), loader thread i serves gate thread
+// i) behind the sweep's barrier and handed over through LDS, as in the backward kernel below.
+constexpr int lstm_fwd_block(int UPC, int BT, bool LW) { return LW ? 256 + 64 * ((BT * UPC + 63) / 64) : 256; }
+template <int HP, int UPC, int BT, int PREC = PREC_F32, bool EARLY = false, bool FM = false, bool LW = false>
+__global__ __launch_bounds__(lstm_fwd_block(UPC, BT, LW)) void lstm_fwd_seq_kernel(const LstmSeqArgs a) {
+  static_assert(!(LW && EARLY), "one request order");
+  constexpr int NTH = lstm_fwd_block(UPC, BT, LW);
   constexpr int NC = 4 * UPC, NT = NC / 16, KS = 4 / NT, KW = HP / KS, WR = KW / 4, NG = HP * BT / 256;
   constexpr int KPH = HP + 8, WRH = KW / 32;     // PREC_BF16: image pitch, MFMAs (= 8-bf16 weight fragments) per wave
   static_assert(UPC == 4 || UPC == 8 || UPC == 16, "UPC");
@@ -248,7 +253,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sA = sm;                       // [HP x 16] permuted
   float* red = sm + HP * 16;            // [KS][16][NC]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sxi = red + KS * 16 * NC;      // LW: [2][4][256] X-projection of the next step, by gate thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const bool loader = LW && tid >= 256;
   int group, cu;
   if (!seq_group_of(a, &group, &cu)) return;
   const int d = group % a.dirs, bt = group / a.dirs;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   const int n = lane & 15, kq = lane >> 4;
   float wreg[PREC == PREC_BF16 ? 1 : WR];
   bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
-  {
+  if (!loader) {
     const int c = tile * 16 + n, gate = c / UPC, uu = c % UPC;
     const bool wok = u0 + uu < H;
     const float* Wrow = a.Whh[d] + (long)(gate * H + min(u0 + uu, H - 1)) * H;
@@ -284,7 +291,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   }
   // ---- gate stage: thread (sequence gb, unit gu) for tid < BT*UPC
   const bool gthread = tid < BT * UPC;
-  const int gb = tid % BT, gu = (tid / BT) % UPC;
+  const int ct = loader ? tid - 256 : tid;        // the (sequence, unit) pair a gate thread owns / a loader thread serves
+  const int gb = ct % BT, gu = (ct / BT) % UPC;
   const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
   const bool store_ok = gthread && bg < B && j < H;
@@ -298,10 +306,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
   const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_FWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < HP * 16; i += 256) sA[i] = 0.f;     // rows >= BT and columns without a producer stay zero for good
+  for (int i = tid; i < HP * 16; i += NTH) sA[i] = 0.f;     // rows >= BT and columns without a producer stay zero for good
   __syncthreads();
 
   auto row_of = [&](int s) { return (long)bgc * T + (d == 0 ? s : T - 1 - s); };
+  if (loader) {       // two barriers per step s >= 1, as everybody else
+    for (int s = 0; s < T; ++s) {
+      if (s > 0) __syncthreads();
+      const bool have = s + 1 < T && ct < BT * UPC && !(LSTM_ABL & 4);
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (have) {
+        const long row = row_of(s + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
+      }
+      if (s > 0) __syncthreads();
+      if (have) {
+        float* q = sxi + ((s + 1) & 1) * 4 * 256 + ct;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) q[g * 256] = z[g];
+      }
+    }
+    return;
+  }
   float xin[4];
   {
     const long row = row_of(0);
@@ -341,6 +368,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       __syncthreads();
     }
     if (gthread) {
+      if (LW && s > 0 && !(LSTM_ABL & 4)) {          // written by the loader waves before this step's first barrier
+        const float* q = sxi + (s & 1) * 4 * 256 + tid;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = q[g * 256];
+      }
       float pre[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -373,7 +405,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_seq_kernel(const LstmSeqArgs a) 
       if (EARLY) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) xin[g] = xnext[g];
-      } else if (s + 1 < T && !(LSTM_ABL & 4)) {     // next step's X-projection: in flight while the group exchanges h_t
+      } else if (!LW && s + 1 < T && !(LSTM_ABL & 4)) {     // next step's X-projection: in flight while the group exchanges h_t
         const long row = row_of(s + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) xin[g] = a.xproj[row * ld4 + d * 4 * H + g * H + jc];
@@ -414,8 +446,29 @@ __device__ __forceinline__ void payload_store(float* p, float v, bool xcd_local)
 // Exchange image of one step: 16-byte chunk (u, b) = {dgi, dgf, dgg, dgo} at u*BT + b; flag word of producing wave
 // w of workgroup c at c*NW + w, monotonic (= steps published).
 // ------------------------------------------------------------------------------------------
-template <int HP, int BT, int PREC = PREC_F32>
-__global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
+// LW (loader waves): the stash of step s+1 is requested by EXTRA waves (block = 256 + 16*BT threads, loader thread i
+// serves gate thread i) right behind step s's sweep barrier and handed over through LDS.  The vector L1 returns a CU's
+// loads in issue order: requested at the end of a step (round 2), the HBM-latency stash loads sit in front of the next
+// step's flag polls of EVERY wave of the CU (measured: 0.5 us of a 2.4 us step, whichever wave issues them, however far
+// ahead); requested behind the sweep they come back while the CU has nothing urgent in flight.  The gate waves cannot issue
+// them there themselves: their drain in front of the flag store would wait for them.
+// TAG: the exchange in self-validating form, as in the forward kernel -- every 8-byte half of a 16-byte chunk is a
+// {data, tag = step + 1} granule written by one store: PREC_BF16 one chunk per (unit, sequence) {bf16 dgi | dgf << 16, tag,
+// bf16 dgg | dgo << 16, tag} (the consumer rounds dG to bf16 on its way into LDS anyway: rounding at the producer gives the
+// same operand), PREC_F32 two chunks {dgi, tag, dgf, tag} {dgg, tag, dgo, tag}.  No flag, no drain in front of a flag, no
+// flag poll in front of the payload loads: one sweep of 16-byte loads, repeated until every tag matches.
+constexpr int lstm_bwd_block(int BT, bool LW) { return LW ? 256 + 16 * BT : 256; }
+__device__ __forceinline__ void xch_store_u32(unsigned long long* p, unsigned v, unsigned tag, bool xcd_local) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)v;
+  if (xcd_local) __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else           __hip_atomic_store((gu64*)p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+template <int HP, int BT, int PREC = PREC_F32, bool LW = false, bool TAG = false>
+__global__ __launch_bounds__(lstm_bwd_block(BT, LW)) void lstm_bwd_seq_kernel(const LstmSeqArgs a) {
+  constexpr int NTH = lstm_bwd_block(BT, LW);
+  constexpr int CPC = PREC == PREC_BF16 ? 1 : 2;   // TAG: 16-byte chunks per (unit, sequence)
+  constexpr int NCT = HP * BT * CPC / 256;         // TAG: chunks per thread and step
   constexpr int WR = HP / 4;
   constexpr int KPH = 4 * HP + 8, WRH = HP / 32;  // PREC_BF16: pitch of the [16][4*HP] bf16 image, MFMAs per wave
   constexpr int NW = 16 * BT / 64;                // producing waves per workgroup
@@ -425,7 +478,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sA = sm;                       // [4*HP x 16] permuted
   float* red = sm + 4 * HP * 16;        // [4][16][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sst = red + 4 * 16 * 16;       // LW: [2][6][256] stash of the next step, by gate thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const bool loader = LW && tid >= 256;
   int group, cu;
   if (!seq_group_of(a, &group, &cu)) return;
   const int d = group % a.dirs, bt = group / a.dirs;
@@ -438,7 +493,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   // B operand: W_hh[(gate = wave)*H + k][u0 + n], k = 16*(i>>2) + 4*(i&3) + kq
   float wreg[PREC == PREC_BF16 ? 1 : WR];
   bf16x8 wregh[PREC == PREC_BF16 ? WRH : 1];
-  {
+  if (!loader) {
     const bool wok = u0 + n < H;
     const float* Wc = a.Whh[d] + (long)wave * H * H + min(u0 + n, H - 1);
     if (PREC == PREC_BF16) {       // lane: output unit n, k = 32*i + 8*kq + 0..7 (rows of gate `wave`'s block of W_hh)
@@ -458,7 +513,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
     }
   }
   const bool gthread = tid < 16 * BT;
-  const int gb = tid % BT, gu = (tid / BT) & 15;
+  const int ct = loader ? tid - 256 : tid;        // the (sequence, unit) pair a gate thread owns / a loader thread serves
+  const int gb = ct % BT, gu = (ct / BT) & 15;
   const int bg = bt * BT + gb, bgc = min(bg, B - 1);
   const int j = u0 + gu, jc = min(j, H - 1);
   const bool store_ok = gthread && bg < B && j < H;
@@ -472,7 +528,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
   const bool xcd_local = seq_colocated(a, group, cu, red, LSTM_FAULT_TIMEOUT_BWD);
   if (fault_load(a.fault) != 0u) return;
   if (a.dbg_protocol && cu == 0 && tid == 0) a.dbg_protocol[group] = xcd_local ? 1u : 2u;
-  for (int i = tid; i < 4 * HP * 16; i += 256) sA[i] = 0.f;
+  for (int i = tid; i < 4 * HP * 16; i += NTH) sA[i] = 0.f;
   __syncthreads();
 
   // stash of one (b, u, t): requested one step ahead of its use.  Three requests per step: the 16-byte gate record, the
@@ -490,11 +546,66 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
     z.cp = a.cst[rowp * ld1 + d * H + jc];
     return z;
   };
+  if (loader) {       // two barriers per step s >= 1, as everybody else
+    for (int s = 0; s < T; ++s) {
+      if (s > 0) __syncthreads();
+      const bool have = s + 1 < T && !(LSTM_ABL & 4);
+      Stash z = {};
+      if (have) z = load_stash(s + 1);
+      if (s > 0) __syncthreads();
+      if (have) {
+        float* q = sst + ((s + 1) & 1) * 6 * 256 + ct;
+        q[0 * 256] = z.dout; q[1 * 256] = z.ig; q[2 * 256] = z.fg; q[3 * 256] = z.gg; q[4 * 256] = z.og; q[5 * 256] = z.cp;
+      }
+    }
+    return;
+  }
   Stash st = load_stash(0);
   float c_here = a.cst[((long)bgc * T + (d == 0 ? T - 1 : 0)) * ld1 + d * H + jc];     // cell state of the first frame of the walk
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
-    if (s > 0) {
+    if (s > 0 && TAG) {
+      const u32x4* src = xdata + (size_t)((s - 1) & 1) * (HP * BT * CPC);
+      unsigned spins = 0;
+      unsigned long long t_start = 0;
+#pragma unroll
+      for (int c0 = 0; c0 < NCT; c0 += 8) {
+        const u32x4* p[8];
+        u32x4 v[8];
+        int cc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int jr = c0 + q + cu;                      // workgroup-dependent start: spread the L2 channels
+          cc[q] = tid + 256 * (jr % NCT);
+          const int u = cc[q] / (BT * CPC);
+          p[q] = src + (u < uvalid ? cc[q] : 0);
+        }
+        for (;;) {
+          load8_sc1(p, v);
+          bool ok = true;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ok &= cc[q] / (BT * CPC) >= uvalid || (v[q][1] == (unsigned)s && v[q][3] == (unsigned)s);
+          if (__all(ok)) break;
+          if (spin_expired(a, spins, t_start, LSTM_FAULT_TIMEOUT_BWD)) return;
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int cell = cc[q] / CPC, part = cc[q] % CPC, u = cell / BT, b = cell % BT;
+          if (u < uvalid) {
+            if (PREC == PREC_BF16) {
+              unsigned short* ah = reinterpret_cast<unsigned short*>(sA) + b * KPH + u;
+              ah[0 * HP] = (unsigned short)(v[q][0] & 0xffffu); ah[1 * HP] = (unsigned short)(v[q][0] >> 16);
+              ah[2 * HP] = (unsigned short)(v[q][2] & 0xffffu); ah[3 * HP] = (unsigned short)(v[q][2] >> 16);
+            } else {
+              const int ai = a_img_idx(u, b);
+              sA[(2 * part) * HP * 16 + ai] = __uint_as_float(v[q][0]);
+              sA[(2 * part + 1) * HP * 16 + ai] = __uint_as_float(v[q][2]);
+            }
+          }
+        }
+      }
+    } else if (s > 0) {
       {   // every wave waits for every producing wave of the group to have published step s-1
         unsigned spins = 0;
         unsigned long long t_start = 0;
@@ -536,6 +647,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
           }
         }
       }
+    }
+    if (s > 0) {
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (PREC == PREC_BF16) {
@@ -557,6 +670,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
       __syncthreads();
     }
     if (gthread) {
+      if (LW && s > 0 && !(LSTM_ABL & 4)) {          // written by the loader waves before this step's first barrier
+        const float* q = sst + (s & 1) * 6 * 256 + tid;
+        st.dout = q[0 * 256]; st.ig = q[1 * 256]; st.fg = q[2 * 256]; st.gg = q[3 * 256]; st.og = q[4 * 256]; st.cp = q[5 * 256];
+      }
       const bool active = t < len && j < H;
       float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f, dcn = 0.f;
       if (active) {
@@ -574,7 +691,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         dcn = dc * st.fg;
       }
       dcs = dcn;
-      if (s + 1 < T) {
+      if (TAG && s + 1 < T) {
+        unsigned long long* dst = xb + ((size_t)(s & 1) * (HP * BT * CPC) + ((size_t)j * BT + gb) * CPC) * 2;
+        if (PREC == PREC_BF16) {
+          xch_store_u32(dst + 0, bf16_bits(dgi) | (bf16_bits(dgf) << 16), (unsigned)(s + 1), xcd_local);
+          xch_store_u32(dst + 1, bf16_bits(dgg) | (bf16_bits(dgo) << 16), (unsigned)(s + 1), xcd_local);
+        } else {
+          xch_store(dst + 0, dgi, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 1, dgf, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 2, dgg, (unsigned)(s + 1), xcd_local);
+          xch_store(dst + 3, dgo, (unsigned)(s + 1), xcd_local);
+        }
+      } else if (s + 1 < T) {
         float* dst = reinterpret_cast<float*>(xdata + (size_t)(s & 1) * (HP * BT) + (size_t)j * BT + gb);
         payload_store(dst + 0, dgi, xcd_local);
         payload_store(dst + 1, dgf, xcd_local);
@@ -591,7 +719,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_seq_kernel(const LstmSeqArgs a) 
         a.xproj[row * ld4 + d * 4 * H + 3 * H + j] = dgo;
       }
       c_here = st.cp;                    // (at the ends of the walk rowp is clamped: the value is then not used)
-      if (s + 1 < T && !(LSTM_ABL & 4)) st = load_stash(s + 1);
+      if (!LW && s + 1 < T && !(LSTM_ABL & 4)) st = load_stash(s + 1);
     }
   }
 }

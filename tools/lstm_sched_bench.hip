@@ -104,33 +104,38 @@ int main(int argc, char** argv) {
   auto faultw = [&] { unsigned f; CK(hipMemcpy(&f, fault, 4, hipMemcpyDeviceToHost)); return f; };
 
   printf("forward   (us per time step; 'diff' = words that differ from the SCHED 0 result of the same geometry)\n");
-#define FWD(PREC, BT, UPC, EARLY, FM) { \
-    const bool ref = !EARLY && !FM; \
+#define FWD(PREC, BT, UPC, EARLY, FM, LW) { \
+    const bool ref = !EARLY && !FM && !LW; \
     Bufs& q = ref ? R : P; reset_xp(q); \
-    const void* kern = (const void*)lstm_fwd_seq_kernel<HP, UPC, BT, PREC, EARLY, FM>; \
+    const void* kern = (const void*)lstm_fwd_seq_kernel<HP, UPC, BT, PREC, EARLY, FM, LW>; \
     bool ok = true; \
-    const float ms = timed([&] { ok = launch(kern, lstm_fwd_seq_lds<HP, UPC>(), q, BT, cdiv(H, UPC), 256); }); \
+    const float ms = timed([&] { ok = launch(kern, lstm_fwd_seq_lds<HP, UPC>(), q, BT, cdiv(H, UPC), lstm_fwd_block(UPC, BT, LW)); }); \
     if (ok) { \
       size_t nd = ref ? 0 : ndiff(P.gates, R.gates, (size_t)N * dirs * 4 * H) + ndiff(P.out, R.out, (size_t)N * dirs * H) + ndiff(P.cst, R.cst, (size_t)N * dirs * H); \
       const double md = ref ? 0 : std::max(maxabs(P.gates, R.gates, (size_t)N * dirs * 4 * H), std::max(maxabs(P.out, R.out, (size_t)N * dirs * H), maxabs(P.cst, R.cst, (size_t)N * dirs * H))); \
-      printf("  %s bt%-2d upc%-2d early%d fm%d  %8.3f ms = %6.3f us/step   diff %zu max|d| %.2e  fault %u\n", PREC == PREC_BF16 ? "bf16" : "f32 ", BT, UPC, (int)EARLY, (int)FM, ms, 1e3 * ms / T, nd, md, faultw()); \
+      printf("  %s bt%-2d upc%-2d early%d fm%d lw%d  %8.3f ms = %6.3f us/step   diff %zu max|d| %.2e  fault %u\n", PREC == PREC_BF16 ? "bf16" : "f32 ", BT, UPC, (int)EARLY, (int)FM, (int)LW, ms, 1e3 * ms / T, nd, md, faultw()); \
     } }
-#define FWD3(PREC, BT, UPC) FWD(PREC, BT, UPC, false, false) FWD(PREC, BT, UPC, true, false) FWD(PREC, BT, UPC, true, true)
+#define FWD3(PREC, BT, UPC) FWD(PREC, BT, UPC, false, false, false) FWD(PREC, BT, UPC, true, false, false) FWD(PREC, BT, UPC, false, false, true) FWD(PREC, BT, UPC, true, true, false) FWD(PREC, BT, UPC, false, true, true)
   FWD3(PREC_BF16, 8, 8) FWD3(PREC_BF16, 8, 16) FWD3(PREC_BF16, 16, 8) FWD3(PREC_BF16, 16, 16)
   FWD3(PREC_F32, 8, 8) FWD3(PREC_F32, 8, 16) FWD3(PREC_F32, 16, 8) FWD3(PREC_F32, 16, 16)
 
   printf("backward\n");
   // stashes of one forward pass (f32, bt8, upc8, sched 0) feed every backward variant
-  reset_xp(R); launch((const void*)lstm_fwd_seq_kernel<HP, 8, 8, PREC_F32, false, false>, lstm_fwd_seq_lds<HP, 8>(), R, 8, cdiv(H, 8), 256);
+  reset_xp(R); launch((const void*)lstm_fwd_seq_kernel<HP, 8, 8, PREC_F32, false, false, false>, lstm_fwd_seq_lds<HP, 8>(), R, 8, cdiv(H, 8), 256);
   CK(hipStreamSynchronize(s));
   CK(hipMemcpy(P.gates, R.gates, (size_t)N * dirs * 4 * H * sizeof(float), hipMemcpyDeviceToDevice));
   CK(hipMemcpy(P.cst, R.cst, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
   CK(hipMemcpy(P.out, R.out, (size_t)N * dirs * H * sizeof(float), hipMemcpyDeviceToDevice));
-#define BWD(PREC, BT) { \
-    const void* kern = (const void*)lstm_bwd_seq_kernel<HP, BT, PREC>; \
+#define BWD(PREC, BT, LW, TAG) { \
+    const bool ref = !LW && !TAG; \
+    Bufs& q = ref ? R : P; \
+    const void* kern = (const void*)lstm_bwd_seq_kernel<HP, BT, PREC, LW, TAG>; \
     bool ok = true; \
-    const float ms = timed([&] { ok = launch(kern, lstm_bwd_seq_lds<HP>(), R, BT, cdiv(H, 16), 256); }); \
-    if (ok) printf("  %s bt%-2d  %8.3f ms = %6.3f us/step  fault %u\n", PREC == PREC_BF16 ? "bf16" : "f32 ", BT, ms, 1e3 * ms / T, faultw()); }
-  BWD(PREC_BF16, 8) BWD(PREC_BF16, 16) BWD(PREC_F32, 8) BWD(PREC_F32, 16)
+    const float ms = timed([&] { ok = launch(kern, lstm_bwd_seq_lds<HP>(), q, BT, cdiv(H, 16), lstm_bwd_block(BT, LW)); }); \
+    if (ok) { \
+      const size_t nd = ref ? 0 : ndiff(P.xproj, R.xproj, (size_t)N * dirs * 4 * H); \
+      printf("  %s bt%-2d loader-waves %d tagged %d  %8.3f ms = %6.3f us/step  diff %zu  fault %u\n", PREC == PREC_BF16 ? "bf16" : "f32 ", BT, (int)LW, (int)TAG, ms, 1e3 * ms / T, nd, faultw()); } }
+#define BWD4(PREC, BT) BWD(PREC, BT, false, false) BWD(PREC, BT, true, false) BWD(PREC, BT, false, true) BWD(PREC, BT, true, true)
+  BWD4(PREC_BF16, 8) BWD4(PREC_BF16, 16) BWD4(PREC_F32, 8) BWD4(PREC_F32, 16)
   return 0;
 }
