@@ -728,7 +728,7 @@ struct gt_engine {
   hipEvent_t len_ev[LEN_RING] = {nullptr, nullptr, nullptr, nullptr};
   int len_cap = 0, len_slot = -1;
   int* d_lengths() { return len_slot < 0 ? nullptr : len_dev[len_slot].as<int>(); }
-  std::vector<Scratch> s_u, s_h, s_c, s_xdrop;     // SRU per-layer stashes
+  std::vector<Scratch> s_u, s_h, s_c, s_xdrop, s_xmask;     // SRU per-layer stashes (s_xmask: input-dropout multipliers [B][n_in])
   Scratch s_du, s_dx, s_dbias;
   std::vector<int> h_lengths;
   StepScalars* sc() { return scal.as<StepScalars>(); }
@@ -815,7 +815,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
     if (e->len_host[i]) (void)hipHostFree(e->len_host[i]);
     if (e->len_ev[i]) (void)hipEventDestroy(e->len_ev[i]);
   }
-  for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop}) for (auto& s : *v) s.release();
+  for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop, &e->s_xmask}) for (auto& s : *v) s.release();
   e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
@@ -935,7 +935,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     }
     n.last = take(desc->out_dim, ncols);
     e->s_u.resize(desc->num_hidden); e->s_h.resize(desc->num_hidden);
-    e->s_c.resize(desc->num_hidden); e->s_xdrop.resize(desc->num_hidden);
+    e->s_c.resize(desc->num_hidden); e->s_xdrop.resize(desc->num_hidden); e->s_xmask.resize(desc->num_hidden);
   } else {
     if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
     int in = desc->in_dim;
@@ -2115,13 +2115,20 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
     CHK(e->s_c[l].ensure((size_t)N * ncols * sizeof(float)));
     const float* xin = in;
     int ld_xin = ld_in;
-    if (G.training && G.d.rnn_dropout > 0.f) {      // variational input dropout, mask shared over time
-      CHK(e->s_xdrop[l].ensure((size_t)N * L.in * sizeof(float)));
+    const bool rdrop = G.training && G.d.rnn_dropout > 0.f;
+    if (rdrop) {      // variational input dropout, mask shared over time: the multipliers of this step, [B][n_in]
+      CHK(e->s_xmask[l].ensure((size_t)B * L.in * sizeof(float)));
       uint32_t k0, k1;
       sru_keys(e, l, 0, &k0, &k1);
+      hipLaunchKernelGGL(sru_input_mask_kernel, dim3(cdiv((long)B * L.in, 256)), dim3(256), 0, s, e->s_xmask[l].as<float>(), B, L.in,
+                         1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1,
+                         (const float*)G.inj[0][2 * l]);                        // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
+      LAUNCH_CHECK();
+    }
+    if (rdrop && !b16) {      // float32 products read a dropped float32 copy
+      CHK(e->s_xdrop[l].ensure((size_t)N * L.in * sizeof(float)));
       hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, in, ld_in, e->s_xdrop[l].as<float>(),
-                         L.in, B, T, L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, 0,
-                         (const float*)nullptr, 0, G.inj[0][2 * l]);           // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
+                         L.in, B, T, L.in, (const float*)e->s_xmask[l].as<float>());
       LAUNCH_CHECK();
       xin = e->s_xdrop[l].as<float>();
       ld_xin = L.in;
@@ -2129,7 +2136,14 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
     if (b16) {
       B16Img& I = e->s_in_b[l];
       CHK(I.ensure(N, L.in, want_t));
-      CHK(cast_transpose<float>(xin, ld_xin, N, L.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+      if (rdrop) {            // bf16 products: dropout rides in the cast, the dropped input exists as bf16 images only
+        const SeqDropSrc src{in, ld_in, e->s_xmask[l].as<float>(), T, L.in};
+        hipLaunchKernelGGL(seqdrop_cast_transpose_kernel, dim3(cdiv(N, 64), cdiv(L.in, 64)), dim3(256), 0, s, src, N, L.in, I.r(), I.ld,
+                           want_t ? I.t() : (__bf16*)nullptr, I.ldt);
+        LAUNCH_CHECK();
+      } else {
+        CHK(cast_transpose<float>(xin, ld_xin, N, L.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+      }
       GemmB16Args g = b16_args();
       g.A = I.r(); g.lda = I.ld; g.B = e->ssh[l].wt.as<__bf16>(); g.ldb = e->ssh[l].ldwt;     // WT [ncols*k][n_in]: k = n_in contiguous
       g.M = (int)N; g.N = ncols * L.k; g.K = L.in; g.epi = B16_FWD; g.act = ACT_NONE; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
@@ -2170,7 +2184,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
   for (auto& L : G.sru) { kmax = std::max(kmax, L.k); inmax = std::max(inmax, L.in); }
   CHK(e->l_dout.ensure((size_t)2 * N * std::max(ncols, inmax) * sizeof(float)));
   CHK(e->s_du.ensure((size_t)N * ncols * kmax * sizeof(float)));
-  CHK(e->s_dx.ensure((size_t)N * ncols * sizeof(float)));
+  CHK(e->s_dx.ensure((size_t)2 * N * ncols * sizeof(float)));     // highway gradients of two consecutive layers (read by the layer underneath)
   CHK(e->s_dbias.ensure((size_t)B * 2 * ncols * sizeof(float)));
   float* dh = e->l_dout.as<float>();
   float* dh_other = dh + (size_t)N * std::max(ncols, inmax);
@@ -2199,8 +2213,14 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     a.dh = dh; a.dU = e->s_du.as<float>();
     // k == 3: the highway gradient goes straight to the layer input.  Without input dropout it is
     // written into the next dh buffer and the GEMM below accumulates onto it.
-    float* dx_res = L.k == 3 ? (rdrop ? e->s_dx.as<float>() : dh_other) : nullptr;
+    auto dx_of = [&](int layer) { return e->s_dx.as<float>() + (size_t)(layer & 1) * N * ncols; };
+    float* dx_res = L.k == 3 ? (rdrop ? dx_of(l) : dh_other) : nullptr;
     a.dx = dx_res; a.lddx = ncols;
+    if (rdrop && l + 1 < Lc) {      // dh is the raw dU.W^T of the layer above: its input dropout and highway gradient are applied by the scan
+      a.up_mul = e->s_xmask[l + 1].as<float>();
+      a.up_add = G.sru[l + 1].k == 3 ? dx_of(l + 1) : nullptr;
+      a.ld_up_add = ncols;
+    }
     a.dbias_part = e->s_dbias.as<float>();
     hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
     LAUNCH_CHECK();
@@ -2239,15 +2259,7 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
       g.accumulate = (L.k == 3 && !rdrop) ? 1 : 0;
       CHK(launch_gemm(GEMM_NT, g, 1, s));
       }
-      if (rdrop) {
-        uint32_t k0, k1;
-        sru_keys(e, l, 0, &k0, &k1);
-        hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, dh_other, L.in, dh_other, L.in, B, T,
-                           L.in, 1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1, L.k == 3 ? 1 : 0,
-                           (const float*)e->s_dx.as<float>(), ncols, G.inj[0][2 * l]);
-        LAUNCH_CHECK();
-      }
-      std::swap(dh, dh_other);
+      std::swap(dh, dh_other);         // (with input dropout: finished by the scan of layer l - 1, SruArgs::up_mul / up_add)
     }
   }
   return GT_OK;

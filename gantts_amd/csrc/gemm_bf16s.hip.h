@@ -415,6 +415,17 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const TIN* __restri
   const float* vin = (sizeof(TIN) == 4 && (ldi & 3) == 0 && ((((uintptr_t)in) & 15) == 0)) ? reinterpret_cast<const float*>(in) : nullptr;
   cast_transpose_tile(tile, src, vin, ldi, rows, cols, out, ldo, outT, ldt, colsum_part, (int)blockIdx.x, (int)blockIdx.y);
 }
+// Variational (per-sequence) input dropout fused into the cast: element (r, c) = in[r][c] * mul[r / T][c] -- the dropped
+// layer input of the SRU (sru_kernels.hip.h) exists as bf16 images only, never as a float32 copy.
+struct SeqDropSrc {
+  const float* in; int ldi; const float* mul; int T, n;
+  __device__ __forceinline__ float operator()(long r, int c) const { return in[r * ldi + c] * mul[(r / T) * n + c]; }
+};
+__global__ __launch_bounds__(256) void seqdrop_cast_transpose_kernel(const SeqDropSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
+                                                                     __bf16* __restrict__ outT, long ldt) {
+  __shared__ float tile[64][65];
+  cast_transpose_tile(tile, src, nullptr, 0, rows, cols, out, ldo, outT, ldt, nullptr, (int)blockIdx.x, (int)blockIdx.y);
+}
 // Several float32 matrices in ONE launch (the weight shadows of a network: one job per nn.Linear).
 constexpr int CAST_MAX_JOBS = 8;
 struct CastJob { const float* in; __bf16* out; __bf16* outT; long rows, ldt; int ldi, cols, ldo, gy, block0, pad_; };

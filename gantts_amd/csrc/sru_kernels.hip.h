@@ -36,6 +36,11 @@ struct SruArgs {
   // variational output dropout (one mask per (sequence, column), shared over time)
   int use_mask; float keep_scale; uint32_t thresh, key0, key1;
   const float* mask_buf;          // parity hook: injected 0/1 keep mask [B][ncols] instead of the Philox stream
+  // backward only: this layer's output is the NEXT layer's input, and that layer's variational input dropout (+ its k == 3
+  // highway gradient) is applied here, where the gradient is read: dh = g * up_mul[b][col] + up_add.  The multiplier is
+  // constant per lane (one (sequence, column) pair per lane).
+  const float* up_mul;            // [B][ncols] multipliers {0, 1/(1-p)} of the next layer's input dropout, or null
+  const float* up_add; int ld_up_add;   // [N][ncols] highway gradient of the next layer (k == 3), or null
 };
 
 __device__ __forceinline__ float sru_act(float c, int act) { return act == SRU_RELU ? fmaxf(c, 0.f) : (act == SRU_TANH ? tanhf(c) : c); }
@@ -54,7 +59,7 @@ __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
 // each lane keeps in flight: SRU_UNROLL_F / _B frames of loads per lane (under the 63 the vmcnt counter can track) and
 // 64-lane workgroups, so that the 512 waves spread over all 256 CUs instead of 128.
 constexpr int SRU_UNROLL_F = 12;      // forward: 4 loads per frame -> 48 in flight
-constexpr int SRU_UNROLL_B = 8;       // backward: 7 loads per frame -> 56 in flight
+constexpr int SRU_UNROLL_B = 8;       // backward: 6 loads per frame (7 with the next layer's highway gradient) -> 48 / 56 in flight
 // (measured per layer at B = 32, T = 1024, 6x512 bidirectional: 4 frames x 256-lane workgroups 430 / 648 us forward /
 //  backward; 8 frames x 64 lanes 320 / 428 us; 12 frames forward 284 us; dwordx3 / dwordx4 loads of a frame's k values are
 //  SLOWER: 352 / 737 us)
@@ -115,11 +120,17 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
   const float* xb = a.x + (long)b * T * a.ldx + col;
   const float* cb = a.c + (long)b * T * ncols + col;
   const float* dhb = a.dh + (long)b * T * ncols + col;
+  const float up_mul = a.up_mul ? a.up_mul[(long)b * ncols + col] : 1.f;
+  const float* upb = a.up_add ? a.up_add + (long)b * T * a.ld_up_add + col : nullptr;
   float* dUb = a.dU + (long)b * T * a.ldu + (long)col * k;
   float* dxb = a.dx ? a.dx + (long)b * T * a.lddx + col : nullptr;
   float dc = 0.f, dbf = 0.f, dbr = 0.f;
+  // c_{tt-1} of a frame is c_tt of the frame the walk visits next: the cell states are read once -- cc[q + 1] is frame
+  // q's predecessor, and the first state of the NEXT block of frames is requested with this block (cc[SRU_UNROLL_B])
+  float c_first = cb[(long)(flip ? 0 : T - 1) * ncols];
   for (int s0 = 0; s0 < T; s0 += SRU_UNROLL_B) {
-    float u0[SRU_UNROLL_B], u1[SRU_UNROLL_B], u2[SRU_UNROLL_B], xp[SRU_UNROLL_B], cc[SRU_UNROLL_B], cp[SRU_UNROLL_B], dh[SRU_UNROLL_B];
+    float u0[SRU_UNROLL_B], u1[SRU_UNROLL_B], u2[SRU_UNROLL_B], xp[SRU_UNROLL_B], cc[SRU_UNROLL_B + 1], dh[SRU_UNROLL_B];
+    cc[0] = c_first;
 #pragma unroll
     for (int q = 0; q < SRU_UNROLL_B; ++q) {
       const int tt = max(T - 1 - (s0 + q), 0);          // forward-order index, descending
@@ -128,10 +139,10 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
       const float* u = Ub + (long)t * a.ldu;
       u0[q] = u[0]; u1[q] = u[1]; u2[q] = u[2];
       xp[q] = k == 3 ? xb[(long)t * a.ldx] : u[3];
-      cc[q] = cb[(long)t * ncols];
-      cp[q] = tt > 0 ? cb[(long)min(max(tp, 0), T - 1) * ncols] : 0.f;
-      dh[q] = dhb[(long)t * ncols];
+      cc[q + 1] = tt > 0 ? cb[(long)min(max(tp, 0), T - 1) * ncols] : 0.f;
+      dh[q] = dhb[(long)t * ncols] * up_mul + (upb ? upb[(long)t * a.ld_up_add] : 0.f);
     }
+    c_first = cc[SRU_UNROLL_B];
 #pragma unroll
     for (int q = 0; q < SRU_UNROLL_B; ++q) {
       const int tt = T - 1 - (s0 + q);
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
       const float dxp = dh[q] * (1.f - r);
       const float dct = dc + dh[q] * r * mk * sru_dact(cc[q], val, a.act);
       const float du0 = dct * (1.f - f);
-      const float df = dct * (cp[q] - u0[q]);
+      const float df = dct * (cc[q + 1] - u0[q]);
       dc = dct * f;
       const float du1 = df * f * (1.f - f), du2 = dr * r * (1.f - r);
       float* du = dUb + (long)t * a.ldu;
@@ -157,25 +168,31 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
   a.dbias_part[(long)b * 2 * ncols + ncols + col] = dbr;
 }
 
-// variational input dropout: y[row][i] = x[row][i] * mask(b, i)    (mask shared over time)
+// The variational input-dropout mask of a layer as multipliers {0, 1/(1-p)}, [B][n]: drawn once per step (Philox, or the
+// injected 0/1 mask of the parity hook) and read by the forward pass (dropout kernel below, or the fused dropout + bf16
+// cast of GT_OPT_MATMUL_BF16) and by the backward scan of the layer underneath (SruArgs::up_mul).
+__global__ void sru_input_mask_kernel(float* __restrict__ mul, int B, int n, float keep_scale, uint32_t thresh, uint32_t key0, uint32_t key1,
+                                      const float* __restrict__ inj) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * n) return;
+  bool keep;
+  if (inj) keep = inj[e] != 0.f;
+  else {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(e / n), (uint32_t)(e % n), key0, key1, r);
+    keep = r[0] >= thresh;
+  }
+  mul[e] = keep ? keep_scale : 0.f;
+}
+
+// variational input dropout for the float32 products: y[row][i] = x[row][i] * mul[b][i]    (mask shared over time)
 __global__ void sru_input_dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int B, int T, int n,
-                                         float keep_scale, uint32_t thresh, uint32_t key0, uint32_t key1, int accumulate_from,
-                                         const float* __restrict__ add, int ldadd, const float* __restrict__ mask_buf) {
+                                         const float* __restrict__ mul) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)B * T * n) return;
   const int i = (int)(e % n);
   const long row = e / n;
-  const int b = (int)(row / T);
-  bool keep;
-  if (mask_buf) keep = mask_buf[(long)b * n + i] != 0.f;      // injected [B][n] keep mask (parity hook)
-  else {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)b, (uint32_t)i, key0, key1, r);
-    keep = r[0] >= thresh;
-  }
-  float v = x[row * ldx + i] * (keep ? keep_scale : 0.f);
-  if (accumulate_from) v += add[row * ldadd + i];
-  y[row * ldy + i] = v;
+  y[row * ldy + i] = x[row * ldx + i] * mul[(row / T) * n + i];
 }
 
 }  // namespace gt
