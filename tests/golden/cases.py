@@ -211,6 +211,20 @@ ORACLE_ONLY_CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # hidden width in (256, 512]: the 512-unit instances of the persistent recurrence kernels (38 / 19 workgroups per
+    # group, units padded to 304), three 8-sequence batch tiles per direction with a ragged last one
+    "acoustic_lstm_wide": dict(
+        hp="tts_acoustic", B=20, T=24, din=60, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="LSTMRNN", in_dim=60, out_dim=187, num_hidden=2, hidden_dim=300,
+               bidirectional=True, dropout=0.0, last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=118, out_dim=1, num_hidden=2, hidden_dim=32,
+               dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     "vc_in2out_rnn_dropout": dict(
         hp="vc", B=3, T=33, din=75, dout=75,
         stream_sizes=[75], has_dynamic_features=[True],

@@ -647,7 +647,8 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
             _close_arbiter(v.cpu().numpy() - w0[k], r_, a_, "%s %s.%s update after 2 steps" % (tag, tagm, k), kink=KINK_ALLOWANCE)
 
 
-@pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True)])
+@pytest.mark.parametrize("B,T,din,H,L,bi", [(5, 13, 20, 40, 2, True), (2, 30, 7, 8, 1, False), (37, 9, 12, 33, 3, True),
+                                            (3, 17, 10, 300, 1, True)])
 def test_lstmrnn_forward_matches_oracle_unsorted_lengths(B, T, din, H, L, bi):
     """LSTMRNN.forward(sequence, lengths) vs the oracle's masked time loop (== nn.LSTM over packed
     sequences, pinned by the golden case); lengths deliberately NOT sorted, B > 32 covers 2 batch tiles."""
