@@ -483,7 +483,30 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
-static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s) {
+// the LDS-DMA form of the 128 x 128 tile (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages, two workgroups per CU)
+template <int EPI, int AMODE>
+static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
+  const size_t lds = gemm_b16_dma_lds_bytes<128, 128, 2>();
+  CHK(ensure_dyn_lds((const void*)gemm_b16_dma_kernel<128, 128, EPI, AMODE, 2>, lds));
+  g.n_tiles_m = cdiv(g.M, 128);
+  g.n_tiles_n = cdiv(g.N, 128);
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  if (grid <= 0) return GT_OK;
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = g.epi; rec.bn = 128; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
+                (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  hipLaunchKernelGGL((gemm_b16_dma_kernel<128, 128, EPI, AMODE, 2>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
+}
+// tile: 0 = chosen here from the shape; 64 / 128 = the caller's choice (the weight gradient sizes its slabs for a tile)
+static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s, int tile = 0) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   if ((g.lda & 7) || (g.ldb & 7) || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15))
     return fail(GT_ERR_INVALID, "bf16 product: operands must be 16-byte aligned with a row pitch that is a multiple of 8");
@@ -491,20 +514,27 @@ static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s) {
   // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
   const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
   static const int force_tiles = getenv("GT_B16_TILES") ? atoi(getenv("GT_B16_TILES")) : 0;      // measurement switch: 64 / 128
-  const bool big = force_tiles == 64 ? false : (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && (force_tiles == 128 || t128 >= 2L * gemm_cu_count()));
+  const bool big = tile ? tile == 128
+                        : (force_tiles == 64 ? false : (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && (force_tiles == 128 || t128 >= 2L * gemm_cu_count())));
+  // operand stages by LDS-DMA when no element of a stage needs masking and no row sums ride in the loader
+  static const bool dma_on = !(getenv("GT_B16_DMA") && getenv("GT_B16_DMA")[0] == '0');
+  const bool dma = dma_on && big && g.K % 64 == 0 && (g.epi != B16_SLAB || (g.k_chunk % 64 == 0 && !g.rowsum_slab));
   // the epilogue flavour is a template parameter of the kernel (gemm_bf16s.hip.h: GemmB16Amode)
   int amode = B16_A_NONE;
   if (g.epi != B16_SLAB) {
     if (g.act == ACT_SIGMOID) amode = B16_A_SIGMOID;
     else if (g.act == ACT_LEAKY_DROPOUT) amode = g.drop.mode == DROP_PHILOX ? B16_A_LEAKY_PHILOX : (g.drop.mode == DROP_BUFFER ? B16_A_LEAKY_BUFFER : B16_A_LEAKY);
   }
-#define GT_B16_CASE(E, A) if (g.epi == E && amode == A) return big ? launch_gemm_b16_t<128, 128, E, A>(g, nslab, s) : launch_gemm_b16_t<64, 64, E, A>(g, nslab, s);
+#define GT_B16_CASE(E, A) if (g.epi == E && amode == A) \
+    return dma ? launch_gemm_b16_dma<E, A>(g, nslab, s) : (big ? launch_gemm_b16_t<128, 128, E, A>(g, nslab, s) : launch_gemm_b16_t<64, 64, E, A>(g, nslab, s));
   GT_B16_CASE(B16_FWD, B16_A_NONE) GT_B16_CASE(B16_FWD, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_FWD, B16_A_LEAKY_BUFFER)
   GT_B16_CASE(B16_FWD, B16_A_LEAKY) GT_B16_CASE(B16_FWD, B16_A_SIGMOID)
   GT_B16_CASE(B16_BWD_DATA, B16_A_NONE) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_BUFFER)
   GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY) GT_B16_CASE(B16_BWD_DATA, B16_A_SIGMOID)
 #undef GT_B16_CASE
-  if (g.epi == B16_SLAB) return launch_gemm_b16_t<64, 64, B16_SLAB, B16_A_NONE>(g, nslab, s);
+  if (g.epi == B16_SLAB)
+    return dma ? launch_gemm_b16_dma<B16_SLAB, B16_A_NONE>(g, nslab, s)
+               : (big ? launch_gemm_b16_t<128, 128, B16_SLAB, B16_A_NONE>(g, nslab, s) : launch_gemm_b16_t<64, 64, B16_SLAB, B16_A_NONE>(g, nslab, s));
   return fail(GT_ERR_INVALID, "bf16 product: unknown epilogue");
 }
 static GemmB16Args b16_args() {
@@ -535,8 +565,25 @@ static int cast_transpose(const TIN* in, int ld_in, long rows, int cols, __bf16*
 // recorded combines of a network run as ONE launch in front of its optimizer step (slab_defer_flush).
 static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long ldxt, long rows, int out, int in, float* dW, float* db,
                            bool accumulate, Scratch& slabs, hipStream_t s, SlabDefer* defer = nullptr) {
-  const int tiles = cdiv(out, 64) * cdiv(in, 64);
-  int nslab = std::max(1, 1024 / tiles);                     // four 64 x 64 workgroups per CU
+  // 128 x 128 tiles (two workgroups per CU) once the matrix has at least 16 of them, with the slab count that fills whole
+  // rounds of 2 x CUs workgroups best (r = 1 .. 3 rounds; tools/gemm_b16_sweep: 1024 x 3072 over 32 768 frames 450 us with
+  // 64 x 64 tiles -> 246 us with 8 slabs of 128 x 128; 512 x 2048: 124 -> 76 us); 64 x 64 (four per CU) below that
+  static const int force_wg_tile = getenv("GT_B16_WG_TILE") ? atoi(getenv("GT_B16_WG_TILE")) : 0;     // measurement switch: 64 / 128
+  const int t128 = cdiv(out, 128) * cdiv(in, 128);
+  const bool big = force_wg_tile ? force_wg_tile == 128 : (out >= 128 && in >= 128 && t128 >= 16);
+  int nslab;
+  if (big) {
+    const int slots = 2 * gemm_cu_count();
+    double best = 2.0;
+    nslab = 1;
+    for (int r = 1; r <= 3; ++r) {
+      const int ns = std::max(1, slots * r / t128);
+      const double waste = 1.0 - (double)t128 * ns / ((double)slots * cdiv((long)t128 * ns, slots));
+      if (waste < best - 1e-9) { best = waste; nslab = ns; }
+    }
+  } else {
+    nslab = std::max(1, 1024 / (cdiv(out, 64) * cdiv(in, 64)));       // four 64 x 64 workgroups per CU
+  }
   nslab = std::min<long>(nslab, std::max<long>(1, rows / 512));
   const int k_chunk = cdiv(cdiv(rows, nslab), B16_BK) * B16_BK;
   nslab = cdiv(rows, k_chunk);
@@ -562,7 +609,7 @@ static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long
   g.A = dZT; g.lda = (int)lddzt; g.B = XT; g.ldb = (int)ldxt; g.M = out; g.N = in; g.K = (int)rows;
   g.C = slab_base; g.ldc = in; g.epi = B16_SLAB; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
   g.rowsum_slab = db ? bias_slabs : nullptr;
-  CHK(launch_gemm_b16(g, nslab, s));
+  CHK(launch_gemm_b16(g, nslab, s, big ? 128 : 64));
   if (can4) {
     const int main_blocks = cdiv(slab_stride / 4, 256), bias_blocks = db ? cdiv(out, 256) : 0;
     if (defer) {

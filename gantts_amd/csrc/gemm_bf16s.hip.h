@@ -21,6 +21,7 @@
 // accumulators; results rounded to bf16 (RNE) once, on their way out.  Reductions, losses, gradients of the parameters
 // (slabs), parameters and optimizer state stay float32.
 #pragma once
+#include <type_traits>
 #include "gemm_f32.hip.h"
 
 namespace gt {
@@ -46,6 +47,12 @@ struct GemmB16Args {
   int n_tiles_m, n_tiles_n;
 };
 
+// Timing ablations of the K loop, set by tools/gemm_b16_sweep only (results are then wrong on purpose): bit 0 no operand loads
+// after the first stage, bit 1 no LDS deposit, bit 2 no MFMA, bit 3 no fragment reads.
+#ifndef GT_B16_ABLATE
+#define GT_B16_ABLATE 0
+#endif
+constexpr int B16_ABL = GT_B16_ABLATE;
 constexpr int B16_BK = 64;        // k depth of one LDS stage
 constexpr int B16_KP = 72;        // LDS row pitch in bf16 (144 B: the 16 rows of a ds_read_b128 lane group start in 16 different 16-byte slots)
 
@@ -64,136 +71,13 @@ enum GemmB16Amode { B16_A_NONE = 0, B16_A_LEAKY_PHILOX = 1, B16_A_LEAKY_BUFFER =
 
 // One BM x BN tile.  256 threads = 2 x 2 waves, each wave (BM/2) x (BN/2) in 32x32 MFMA tiles.
 // EPI (GemmB16Epi) and AMODE (GemmB16Amode) restate g.epi and (g.act, g.drop.mode) at compile time (launch_gemm_b16 dispatches).
+// Epilogue of one BM x BN tile whose accumulators are in the 2 x 2-wave layout of gemm_b16_tile / gemm_b16_tile_dma.
 template <int BM, int BN, int EPI, int AMODE>
-__device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
+__device__ __forceinline__ void gemm_b16_epilogue(const GemmB16Args& g, const int slab, const int m0, const int n0,
+                                                  f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
-  constexpr int UA = BM * (B16_BK / 8) / GEMM_THREADS, UB = BN * (B16_BK / 8) / GEMM_THREADS;   // 16-byte chunks per thread per stage
-  static_assert(UA >= 1 && UB >= 1, "tile too small for 256 threads");
-  __bf16* Ah = smem;                                  // [2][BM][KP]
-  __bf16* Bh = smem + 2 * BM * B16_KP;                // [2][BN][KP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int k_begin = 0, k_end = g.K;
-  if (EPI == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
-
-  // chunk u of this thread: row (tid + u*256) / 8 of the tile, k offset ((tid + u*256) % 8) * 8 inside the stage
-  const uint4* pa[UA];
-  const uint4* pb[UB];
-  int kca[UA], kcb[UB];
-#pragma unroll
-  for (int u = 0; u < UA; ++u) {
-    const int c = tid + u * GEMM_THREADS, row = min(m0 + c / 8, g.M - 1);
-    kca[u] = (c % 8) * 8;
-    pa[u] = reinterpret_cast<const uint4*>(g.A + (long)row * g.lda + k_begin + kca[u]);
-  }
-#pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int c = tid + u * GEMM_THREADS, row = min(n0 + c / 8, g.N - 1);
-    kcb[u] = (c % 8) * 8;
-    pb[u] = reinterpret_cast<const uint4*>(g.B + (long)row * g.ldb + k_begin + kcb[u]);
-  }
-  uint4 ra[UA], rb[UB];
-  const bool want_rs = EPI == B16_SLAB && g.rowsum_slab != nullptr && tile_n == 0;
-  float rsum[UA];
-#pragma unroll
-  for (int u = 0; u < UA; ++u) rsum[u] = 0.f;
-
-  // a chunk whose 8 k values are not all below krem (k left in this slab from the stage's first k): masked element-wise;
-  // a chunk that starts at or beyond krem is not loaded at all (its address may lie outside the row)
-  auto load_chunk = [&](const uint4* p, int kc, int krem) -> uint4 {
-    uint4 v = {0u, 0u, 0u, 0u};
-    if (kc < krem) {
-      v = *p;
-      if (kc + 8 > krem) {
-        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (kc + e >= krem) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    }
-    return v;
-  };
-  auto request = [&](int t) {                 // global -> registers, stage t
-    const int krem = k_end - (k_begin + t * B16_BK);
-    if (krem >= B16_BK) {
-#pragma unroll
-      for (int u = 0; u < UA; ++u) ra[u] = pa[u][0];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) rb[u] = pb[u][0];
-    } else {
-#pragma unroll
-      for (int u = 0; u < UA; ++u) ra[u] = load_chunk(pa[u], kca[u], krem);
-#pragma unroll
-      for (int u = 0; u < UB; ++u) rb[u] = load_chunk(pb[u], kcb[u], krem);
-    }
-#pragma unroll
-    for (int u = 0; u < UA; ++u) pa[u] += B16_BK / 8;
-#pragma unroll
-    for (int u = 0; u < UB; ++u) pb[u] += B16_BK / 8;
-  };
-  auto deposit = [&](int buf) {               // registers -> LDS buffer
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      const int c = tid + u * GEMM_THREADS;
-      *reinterpret_cast<uint4*>(Ah + (buf * BM + c / 8) * B16_KP + kca[u]) = ra[u];
-      if (want_rs) {
-        const unsigned w[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rsum[u] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int c = tid + u * GEMM_THREADS;
-      *reinterpret_cast<uint4*>(Bh + (buf * BN + c / 8) * B16_KP + kcb[u]) = rb[u];
-    }
-  };
-
-  f32x16 acc[TM][TN_];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN_; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (k_end - k_begin + B16_BK - 1) / B16_BK;
-  if (nk > 0) { request(0); deposit(0); }
-  __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) request(t + 1);
-    const int buf = t & 1;
-    const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * B16_KP + 8 * half;
-    const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * B16_KP + 8 * half;
-#pragma unroll
-    for (int kk = 0; kk < B16_BK / 16; ++kk) {
-      bf16x8 fa[TM], fb[TN_];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * B16_KP + kk * 16);
-#pragma unroll
-      for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * B16_KP + kk * 16);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN_; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nk) deposit((t + 1) & 1);
-    __syncthreads();
-  }
-
-  if (want_rs) {      // the 8 lanes that share a row hold its 8 k-chunks: sum them, lane 0 of the group writes
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      float v = rsum[u];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-      const int row = m0 + (tid + u * GEMM_THREADS) / 8;
-      if ((tid & 7) == 0 && row < g.M) g.rowsum_slab[(long)slab * g.M + row] = v;
-    }
-  }
-
   // ---- epilogue, in the MFMA C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* C = g.C ? g.C + (EPI == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
   constexpr bool philox = EPI != B16_SLAB && AMODE == B16_A_LEAKY_PHILOX;
@@ -310,14 +194,303 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
   }
 }
 
-template <int BM, int BN, int EPI, int AMODE>
-__global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : 2) void gemm_b16_kernel(const GemmB16Args g) {
+// PF: stages of operand loads in flight in registers (1: stage t+1 is requested when the multiplication of stage t starts;
+// 2: stage t+2 is -- one more stage of global-load latency covered, 16 .. 64 more registers).
+template <int BM, int BN, int EPI, int AMODE, int PF = 1>
+__device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
+  static_assert(PF == 1 || PF == 2, "PF");
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
+  constexpr int UA = BM * (B16_BK / 8) / GEMM_THREADS, UB = BN * (B16_BK / 8) / GEMM_THREADS;   // 16-byte chunks per thread per stage
+  static_assert(UA >= 1 && UB >= 1, "tile too small for 256 threads");
+  __bf16* Ah = smem;                                  // [2][BM][KP]
+  __bf16* Bh = smem + 2 * BM * B16_KP;                // [2][BN][KP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int k_begin = 0, k_end = g.K;
+  if (EPI == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
+
+  // chunk u of this thread: row (tid + u*256) / 8 of the tile, k offset ((tid + u*256) % 8) * 8 inside the stage
+  const uint4* pa[UA];
+  const uint4* pb[UB];
+  int kca[UA], kcb[UB];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) {
+    const int c = tid + u * GEMM_THREADS, row = min(m0 + c / 8, g.M - 1);
+    kca[u] = (c % 8) * 8;
+    pa[u] = reinterpret_cast<const uint4*>(g.A + (long)row * g.lda + k_begin + kca[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int c = tid + u * GEMM_THREADS, row = min(n0 + c / 8, g.N - 1);
+    kcb[u] = (c % 8) * 8;
+    pb[u] = reinterpret_cast<const uint4*>(g.B + (long)row * g.ldb + k_begin + kcb[u]);
+  }
+  uint4 ra[PF][UA], rb[PF][UB];
+  const bool want_rs = EPI == B16_SLAB && g.rowsum_slab != nullptr && tile_n == 0;
+  float rsum[UA];
+#pragma unroll
+  for (int u = 0; u < UA; ++u) rsum[u] = 0.f;
+
+  // a chunk whose 8 k values are not all below krem (k left in this slab from the stage's first k): masked element-wise;
+  // a chunk that starts at or beyond krem is not loaded at all (its address may lie outside the row)
+  auto load_chunk = [&](const uint4* p, int kc, int krem) -> uint4 {
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (kc < krem) {
+      v = *p;
+      if (kc + 8 > krem) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kc + e >= krem) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return v;
+  };
+  auto request = [&](int t, auto SET) {       // global -> register set SET, stage t
+    constexpr int S = decltype(SET)::value;
+    if ((B16_ABL & 1) && t > 1) return;
+    const int krem = k_end - (k_begin + t * B16_BK);
+    if (krem >= B16_BK) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) ra[S][u] = pa[u][0];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) rb[S][u] = pb[u][0];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) ra[S][u] = load_chunk(pa[u], kca[u], krem);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) rb[S][u] = load_chunk(pb[u], kcb[u], krem);
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) pa[u] += B16_BK / 8;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) pb[u] += B16_BK / 8;
+  };
+  auto deposit = [&](int buf, auto SET) {     // register set SET -> LDS buffer
+    constexpr int S = decltype(SET)::value;
+    if ((B16_ABL & 2) && buf >= 0) return;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int c = tid + u * GEMM_THREADS;
+      *reinterpret_cast<uint4*>(Ah + (buf * BM + c / 8) * B16_KP + kca[u]) = ra[S][u];
+      if (want_rs) {
+        const unsigned w[4] = {ra[S][u].x, ra[S][u].y, ra[S][u].z, ra[S][u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rsum[u] += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int c = tid + u * GEMM_THREADS;
+      *reinterpret_cast<uint4*>(Bh + (buf * BN + c / 8) * B16_KP + kcb[u]) = rb[S][u];
+    }
+  };
+
+  f32x16 acc[TM][TN_];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (k_end - k_begin + B16_BK - 1) / B16_BK;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF - 1>;
+  if (nk > 0) { request(0, S0{}); if (PF == 2 && nk > 1) request(1, S1{}); deposit(0, S0{}); }
+  __syncthreads();
+  auto multiply = [&](int buf) {
+    const __bf16* ah = Ah + (buf * BM + wm * WM + l31) * B16_KP + 8 * half;
+    const __bf16* bh = Bh + (buf * BN + wn * WN + l31) * B16_KP + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < B16_BK / 16; ++kk) {
+      bf16x8 fa[TM], fb[TN_];
+      if (B16_ABL & 8) {      // fragments from registers that the compiler cannot fold
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, ra[0][0]);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fb[j] = __builtin_bit_cast(bf16x8, rb[0][0]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * B16_KP + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * B16_KP + kk * 16);
+      }
+      if (B16_ABL & 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN_; ++j) acc[i][j][kk] += (float)fa[i][kk] * (float)fb[j][kk];
+      } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  if (PF == 1) {
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) request(t + 1, S0{});
+      multiply(t & 1);
+      if (t + 1 < nk) deposit((t + 1) & 1, S0{});
+      __syncthreads();
+    }
+  } else {      // stage t lives in register set t & 1 until it is deposited; the loop is unrolled by two so that the sets are static
+    for (int t = 0; t < nk; t += 2) {
+      if (t + 2 < nk) request(t + 2, S0{});          // set 0 was deposited (stage t) before this iteration
+      multiply(0);
+      if (t + 1 < nk) deposit(1, S1{});
+      __syncthreads();
+      if (t + 1 < nk) {
+        if (t + 3 < nk) request(t + 3, S1{});
+        multiply(1);
+        if (t + 2 < nk) deposit(0, S0{});
+        __syncthreads();
+      }
+    }
+  }
+
+  if (want_rs) {      // the 8 lanes that share a row hold its 8 k-chunks: sum them, lane 0 of the group writes
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      float v = rsum[u];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      const int row = m0 + (tid + u * GEMM_THREADS) / 8;
+      if ((tid & 7) == 0 && row < g.M) g.rowsum_slab[(long)slab * g.M + row] = v;
+    }
+  }
+
+  gemm_b16_epilogue<BM, BN, EPI, AMODE>(g, slab, m0, n0, acc, smem);
+}
+
+template <int BM, int BN, int EPI, int AMODE, int PF = 1>
+__global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BM * BN >= 256 * 256 ? 1 : 2)) void gemm_b16_kernel(const GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
   const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
   const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
-  gemm_b16_tile<BM, BN, EPI, AMODE>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
+  gemm_b16_tile<BM, BN, EPI, AMODE, PF>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA form of the same tile, for products whose K (per slab) is a multiple of 64 and that need no row sums: operand
+// stages go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write, no wait for the data in the
+// issue stream of the multiplying waves; lane l's 16 bytes land at base + 16 l, tools/lds_dma_probe.hip).  A stage is
+// [rows][64 k] bf16 = 128-byte rows WITHOUT padding; the 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7 -- every
+// lane chooses which global chunk it fetches, so the swizzle is free -- which makes the fragment reads (16 rows, one chunk
+// each, per ds_read_b128 pass) hit 16 different bank quads.  NS stages form a ring: stage t + NS - 1 is requested at the
+// top of iteration t into the buffer iteration t - 1 read; the end-of-iteration wait leaves the younger requests in flight
+// (vmcnt counts them in order).  Measured against the register-staged loop (tools/gemm_b16_sweep): DESIGN.md 3.6.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+constexpr size_t gemm_b16_dma_lds_bytes() { return (size_t)NS * (BM + BN) * 64 * 2; }
+
+template <int BM, int BN, int EPI, int AMODE, int NS>
+__device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
+  constexpr int NA = BM / 32, NB = BN / 32;            // 1-KiB blocks (8 rows) per wave and stage
+  constexpr int STAGE = (BM + BN) * 64;                // bf16 elements of one stage
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  static_assert((size_t)4 * 32 * 33 * sizeof(float) <= gemm_b16_dma_lds_bytes<BM, BN, NS>(), "epilogue staging exceeds the LDS image");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int k_begin = 0, k_end = g.K;
+  if (EPI == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
+  // block b of an operand = rows 8 b .. 8 b + 7 of the tile; this wave issues blocks wave, wave + 4, ...; lane -> row 8 b + (lane >> 3),
+  // LDS slot lane & 7, which holds the row's chunk (lane & 7) ^ ((row >> 1) & 7)
+  const __bf16* srcA[NA];
+  const __bf16* srcB[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    srcA[i] = g.A + (long)min(m0 + r, g.M - 1) * g.lda + k_begin + 8 * c;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (wave + 4 * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    srcB[i] = g.B + (long)min(n0 + r, g.N - 1) * g.ldb + k_begin + 8 * c;
+  }
+  auto issue = [&](int buf) {
+    __bf16* As = smem + buf * STAGE;
+    __bf16* Bs = As + BM * 64;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(As + (wave + 4 * i) * 512), 16, 0, 0);
+      srcA[i] += 64;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(Bs + (wave + 4 * i) * 512), 16, 0, 0);
+      srcB[i] += 64;
+    }
+  };
+  f32x16 acc[TM][TN_];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN_; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (k_end - k_begin) / 64;
+#pragma unroll
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < nk) issue(p);
+  // stage 0 has landed when at most the (NS - 2) younger stages' requests of this wave are outstanding
+  if (NS == 2 || nk < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (NS == 3 || nk < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
+  __syncthreads();
+  const int arow = wm * WM + l31, brow = wn * WN + l31;
+  const int fsw = (l31 >> 1) & 7;                      // (row >> 1) & 7 of every fragment row this lane reads (tiles start at multiples of 32)
+  int buf = 0;
+  for (int t = 0; t < nk; ++t) {
+    int nbuf = buf + NS - 1; if (nbuf >= NS) nbuf -= NS;
+    const bool more = t + NS - 1 < nk;
+    if (more) issue(nbuf);
+    const __bf16* ah = smem + buf * STAGE + arow * 64;
+    const __bf16* bh = smem + buf * STAGE + BM * 64 + brow * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int off = 8 * ((2 * kk + half) ^ fsw);
+      bf16x8 fa[TM], fb[TN_];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * 64 + off);
+#pragma unroll
+      for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * 64 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    // stage t + 1 (requested NS - 1 iterations ago) has landed for this wave once only the younger requests are outstanding
+    if (NS == 2 || !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
+    __syncthreads();                                   // ... for everybody, and everybody is done reading stage t
+    ++buf; if (buf >= NS) buf = 0;
+  }
+  gemm_b16_epilogue<BM, BN, EPI, AMODE>(g, slab, m0, n0, acc, smem);
+}
+
+constexpr int gemm_b16_dma_wgs(int BM, int BN, int NS) { return 2 * NS * (BM + BN) * 128 <= 160 * 1024 ? 2 : 1; }   // workgroups per CU the LDS ring allows
+template <int BM, int BN, int EPI, int AMODE, int NS>
+__global__ __launch_bounds__(GEMM_THREADS, gemm_b16_dma_wgs(BM, BN, NS)) void gemm_b16_dma_kernel(const GemmB16Args g) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
+  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
+  const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
+  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
+  gemm_b16_tile_dma<BM, BN, EPI, AMODE, NS>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
 }
 
 // in [rows][ldi] (float32 or bf16)  ->  out [rows][ldo] bf16 (optional)  and  outT [cols][ldt] bf16 (optional), plus

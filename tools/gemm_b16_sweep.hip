@@ -1,0 +1,103 @@
+// Tile-shape sweep of the bf16-storage product kernel (gemm_bf16s.hip.h) on the large shapes of the SRU step (no torch):
+//   forward U = x W (32768 x 3072 x 1024), backward-data (32768 x 1024 x 3072), weight gradient (1024 x 3072 over 32768 frames)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_b16_sweep.hip -o tools/bin/gemm_b16_sweep
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../gantts_amd/csrc/gemm_bf16s.hip.h"
+using namespace gt;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static __bf16* dfill(size_t n, unsigned seed) {
+  std::vector<unsigned short> h(n);
+  for (auto& v : h) { seed = seed * 1664525u + 1013904223u; const float f = ((seed >> 8) & 0xffff) / 65536.f - 0.5f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+  __bf16* p; CK(hipMalloc((void**)&p, n * 2)); CK(hipMemcpy(p, h.data(), n * 2, hipMemcpyHostToDevice));
+  return p;
+}
+template <int BM, int BN, int EPI, int PF = 1>
+static float run(GemmB16Args g, int nslab, hipStream_t s, int reps) {
+  const size_t lds = gemm_b16_lds_bytes<BM, BN>();
+  const void* k = (const void*)gemm_b16_kernel<BM, BN, EPI, B16_A_NONE, PF>;
+  CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL((gemm_b16_kernel<BM, BN, EPI, B16_A_NONE, PF>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) best = std::min(best, ms);
+  }
+  CK(hipGetLastError());
+  int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, GEMM_THREADS, lds));
+  printf("    %3d x %3d pf%d  grid %6d  %d wg/cu  %8.1f us  %7.1f TFLOP/s\n", BM, BN, PF, grid, occ, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
+  return best;
+}
+template <int BM, int BN, int EPI, int NS>
+static float run_dma(GemmB16Args g, int nslab, hipStream_t s, int reps) {
+  const size_t lds = gemm_b16_dma_lds_bytes<BM, BN, NS>();
+  const void* k = (const void*)gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS>;
+  CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL((gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) best = std::min(best, ms);
+  }
+  CK(hipGetLastError());
+  int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, GEMM_THREADS, lds));
+  printf("    %3d x %3d dma ring %d  grid %6d  %d wg/cu  %8.1f us  %7.1f TFLOP/s\n", BM, BN, NS, grid, occ, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
+  return best;
+}
+static double checksum(const float* d, size_t n) {
+  std::vector<float> h(n); CK(hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost));
+  double s = 0; for (size_t i = 0; i < n; i += 97) s += h[i];
+  return s;
+}
+int main() {
+  hipStream_t s; CK(hipStreamCreate(&s));
+  const int M = 32768, N = 3072, K = 1024;
+  __bf16* X = dfill((size_t)M * K, 1); __bf16* W = dfill((size_t)N * K, 2);      // forward: A = x [M][K], B = WT [N][K]
+  __bf16* DU = dfill((size_t)M * N, 3); __bf16* W2 = dfill((size_t)K * N, 4);    // backward-data: A = dU [M][N], B = W [K][N]
+  __bf16* XT = dfill((size_t)K * M, 5); __bf16* DUT = dfill((size_t)N * M, 6);   // weight gradient: A = xT [K][M], B = dUT [N][M]
+  float* C; CK(hipMalloc((void**)&C, (size_t)M * N * 4 * 2));
+  GemmB16Args g; memset(&g, 0, sizeof(g)); g.drop.mode = DROP_NONE; g.drop.scale = 1.f;
+#define CSUM printf("      checksum %.9e\n", checksum(C, (size_t)g.M * g.N));
+#define SWEEP(EPI, NSLAB) { run<64, 64, EPI, 1>(g, NSLAB, s, 3); CSUM \
+    run<128, 128, EPI, 1>(g, NSLAB, s, 3); CSUM run<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM \
+    run_dma<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 3>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 4>(g, NSLAB, s, 3); CSUM \
+    run_dma<64, 64, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<64, 64, EPI, 4>(g, NSLAB, s, 3); CSUM \
+    run_dma<256, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<256, 256, EPI, 2>(g, NSLAB, s, 3); CSUM }
+  printf("weight gradient 1024 x 3072 over 32768 frames (SRU layer), by slab count\n");
+  g.A = XT; g.lda = M; g.B = DUT; g.ldb = M; g.M = K; g.N = N; g.K = M; g.C = C; g.ldc = N; g.epi = B16_SLAB; g.slab_stride = (long)K * N;
+  for (int ns : {1, 2, 3, 4, 5, 6, 8}) {
+    g.k_chunk = ((M / ns + 63) / 64) * 64;
+    printf("  %d slabs (k_chunk %d)\n", ns, g.k_chunk);
+    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<256, 256, B16_SLAB, 2>(g, ns, s, 3);
+  }
+  printf("weight gradient 512 x 2048 over 32768 frames (cfg3 W_ih), by slab count\n");
+  g.M = 512; g.N = 2048; g.ldc = 2048; g.slab_stride = 512L * 2048;
+  for (int ns : {1, 2, 4, 8, 16}) {
+    g.k_chunk = ((M / ns + 63) / 64) * 64;
+    printf("  %d slabs\n", ns);
+    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3);
+  }
+  printf("weight gradient 512 x 512 over 16384 frames (cfg2 G), by slab count\n");
+  g.M = 512; g.N = 512; g.K = 16384; g.lda = 16384; g.ldb = 16384; g.ldc = 512; g.slab_stride = 512L * 512;
+  for (int ns : {4, 8, 16, 32}) {
+    g.k_chunk = ((16384 / ns + 63) / 64) * 64;
+    printf("  %d slabs\n", ns);
+    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<64, 64, B16_SLAB, 2>(g, ns, s, 3);
+  }
+  return 0;
+}
