@@ -2132,6 +2132,9 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
   return a;
 }
 
+// the scans with loader waves (sru_kernels.hip.h); GT_SRU_LW=0 selects the one-wave kernels (A/B reference, bit-identical results)
+// (read at every launch: the A/B test flips it between two steps of one process)
+static bool sru_loader_waves() { const char* v = getenv("GT_SRU_LW"); return !(v && v[0] == '0'); }
 static bool sru_b16(const gt_engine* e) { return e->matmul_bf16 && (e->net[GT_ROLE_G].d.hidden_dim & 7) == 0; }
 static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];
@@ -2203,7 +2206,12 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       CHK(launch_gemm(GEMM_NN, g, 1, s));
     }
     SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
-    hipLaunchKernelGGL(sru_fwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
+    if (sru_loader_waves()) {
+      CHK(ensure_dyn_lds((const void*)sru_fwd_lw_kernel, sru_fwd_lw_lds()));
+      hipLaunchKernelGGL(sru_fwd_lw_kernel, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_fwd_lw_lds(), s, a);
+    } else {
+      hipLaunchKernelGGL(sru_fwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
+    }
     LAUNCH_CHECK();
     in = e->s_h[l].as<float>();
     ld_in = ncols;
@@ -2269,7 +2277,12 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
       a.ld_up_add = ncols;
     }
     a.dbias_part = e->s_dbias.as<float>();
-    hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
+    if (sru_loader_waves()) {
+      CHK(ensure_dyn_lds((const void*)sru_bwd_lw_kernel, sru_bwd_lw_lds()));
+      hipLaunchKernelGGL(sru_bwd_lw_kernel, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_bwd_lw_lds(), s, a);
+    } else {
+      hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
+    }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(2 * ncols, 64)), dim3(1024), 0, s, e->s_dbias.as<float>(), (long)2 * ncols, B,
                        2 * ncols, L.db, acc ? 1 : 0);

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gemm_f32.hip.h"
+#include "fast_math.hip.h"
 
 namespace gt {
 
@@ -55,6 +56,36 @@ __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
   return r[0] >= a.thresh ? a.keep_scale : 0.f;
 }
 
+// One frame of the recurrence / of its adjoint: ONE definition used by the one-wave and the loader-wave kernels (written with
+// explicit fmaf / __fmul_rn so that the two kernels cannot end up with different contractions).
+struct SruFwdOut { float c, h; };
+// The two sigmoids are fast_sigmoid (fast_math.hip.h: v_exp_f32 + v_rcp_f32, a few ulp): with one or two waves per SIMD the
+// scan is bound by the instruction count of a frame, and the library expf was most of it.
+// The gates (f, r) of a block of frames do not depend on the carried state: the kernels evaluate them for the whole block first
+// (independent transcendental chains the scheduler can interleave), then walk the short dependent chain.
+__device__ __forceinline__ SruFwdOut sru_fwd_frame(float u0, float f, float r, float xp, float c_in, float mk, int act) {
+  SruFwdOut o;
+  o.c = fmaf(c_in - u0, f, u0);
+  const float val = __fmul_rn(sru_act(o.c, act), mk);
+  o.h = fmaf(val - xp, r, xp);
+  return o;
+}
+struct SruBwdOut { float du0, du1, du2, dxp, dc; };
+__device__ __forceinline__ SruBwdOut sru_bwd_frame(float u0, float f, float r, float xp, float c_here, float c_prev, float dh, float dc_in,
+                                                   float mk, int act) {
+  const float val = sru_act(c_here, act);
+  const float dr = __fmul_rn(dh, fmaf(val, mk, -xp));
+  SruBwdOut o;
+  o.dxp = __fmul_rn(dh, 1.f - r);
+  const float dct = fmaf(__fmul_rn(__fmul_rn(dh, r), mk), sru_dact(c_here, val, act), dc_in);
+  o.du0 = __fmul_rn(dct, 1.f - f);
+  const float df = __fmul_rn(dct, c_prev - u0);
+  o.dc = __fmul_rn(dct, f);
+  o.du1 = __fmul_rn(__fmul_rn(df, f), 1.f - f);
+  o.du2 = __fmul_rn(__fmul_rn(dr, r), 1.f - r);
+  return o;
+}
+
 // The scan has only B * ncols independent lanes (32 768 at B = 32, 6x512 bidirectional): its HBM rate is set by the bytes
 // each lane keeps in flight: SRU_UNROLL_F / _B frames of loads per lane (under the 63 the vmcnt counter can track) and
 // 64-lane workgroups, so that the 512 waves spread over all 256 CUs instead of 128.
@@ -91,15 +122,15 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_fwd_kernel(const SruArgs a) {
       xp[q] = k == 3 ? xb[(long)t * a.ldx] : u[3];
     }
 #pragma unroll
+    for (int q = 0; q < SRU_UNROLL_F; ++q) { u1[q] = fast_sigmoid(u1[q] + bf); u2[q] = fast_sigmoid(u2[q] + br); }     // f, r
+#pragma unroll
     for (int q = 0; q < SRU_UNROLL_F; ++q) {
       const int tt = t0 + q;
       if (tt < T) {                               // predicated, not a break: the frame loop stays fully unrolled (registers)
         const int t = flip ? T - 1 - tt : tt;
-        const float f = 1.f / (1.f + expf(-(u1[q] + bf)));
-        const float r = 1.f / (1.f + expf(-(u2[q] + br)));
-        c = (c - u0[q]) * f + u0[q];
-        const float val = sru_act(c, a.act) * mk;
-        hb[(long)t * ncols] = (val - xp[q]) * r + xp[q];
+        const SruFwdOut o = sru_fwd_frame(u0[q], u1[q], u2[q], xp[q], c, mk, a.act);
+        c = o.c;
+        hb[(long)t * ncols] = o.h;
         cb[(long)t * ncols] = c;
       }
     }
@@ -140,32 +171,202 @@ __global__ __launch_bounds__(SRU_THREADS) void sru_bwd_kernel(const SruArgs a) {
       u0[q] = u[0]; u1[q] = u[1]; u2[q] = u[2];
       xp[q] = k == 3 ? xb[(long)t * a.ldx] : u[3];
       cc[q + 1] = tt > 0 ? cb[(long)min(max(tp, 0), T - 1) * ncols] : 0.f;
-      dh[q] = dhb[(long)t * ncols] * up_mul + (upb ? upb[(long)t * a.ld_up_add] : 0.f);
+      dh[q] = fmaf(dhb[(long)t * ncols], up_mul, upb ? upb[(long)t * a.ld_up_add] : 0.f);
     }
     c_first = cc[SRU_UNROLL_B];
+#pragma unroll
+    for (int q = 0; q < SRU_UNROLL_B; ++q) { u1[q] = fast_sigmoid(u1[q] + bf); u2[q] = fast_sigmoid(u2[q] + br); }     // f, r
 #pragma unroll
     for (int q = 0; q < SRU_UNROLL_B; ++q) {
       const int tt = T - 1 - (s0 + q);
       if (tt < 0) continue;                       // (the tail of the last block of frames)
       const int t = flip ? T - 1 - tt : tt;
-      const float f = 1.f / (1.f + expf(-(u1[q] + bf)));
-      const float r = 1.f / (1.f + expf(-(u2[q] + br)));
-      const float val = sru_act(cc[q], a.act);
-      const float dr = dh[q] * (val * mk - xp[q]);
-      const float dxp = dh[q] * (1.f - r);
-      const float dct = dc + dh[q] * r * mk * sru_dact(cc[q], val, a.act);
-      const float du0 = dct * (1.f - f);
-      const float df = dct * (cc[q + 1] - u0[q]);
-      dc = dct * f;
-      const float du1 = df * f * (1.f - f), du2 = dr * r * (1.f - r);
+      const SruBwdOut o = sru_bwd_frame(u0[q], u1[q], u2[q], xp[q], cc[q], cc[q + 1], dh[q], dc, mk, a.act);
+      dc = o.dc;
       float* du = dUb + (long)t * a.ldu;
-      du[0] = du0; du[1] = du1; du[2] = du2;
-      if (k == 3) dxb[(long)t * a.lddx] = dxp; else du[3] = dxp;
-      dbf += du1; dbr += du2;
+      du[0] = o.du0; du[1] = o.du1; du[2] = o.du2;
+      if (k == 3) dxb[(long)t * a.lddx] = o.dxp; else du[3] = o.dxp;
+      dbf += o.du1; dbr += o.du2;
     }
   }
   a.dbias_part[(long)b * 2 * ncols + col] = dbf;
   a.dbias_part[(long)b * 2 * ncols + ncols + col] = dbr;
+}
+
+// ------------------------------------------------------------------------------------------
+// Loader-wave form of the two scans.  The scan has B * ncols independent lanes and nothing more (two waves per CU at
+// B = 32, 6 x 512 bidirectional): its HBM rate is the bytes those lanes keep in flight over the load latency, ~3 TB/s with
+// 48 / 56 loads per lane.  Here a workgroup is 64 lanes' worth of columns handled by FOUR waves: wave 0 does the recurrence,
+// waves 1-3 only load -- loader l fetches frame blocks l, l+3, l+6, ... (FB frames each) into registers and hands them to
+// wave 0 through a 3-slot LDS ring, so three blocks per column are in flight instead of one.  Same arithmetic in the same
+// order as sru_fwd_kernel / sru_bwd_kernel: results are bit-identical.  One s_barrier per block; the barrier is a bare
+// s_barrier behind lgkmcnt(0) (the ring is LDS; __syncthreads() would also drain the loaders' global loads, i.e. undo the
+// run-ahead).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sru_ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int SRU_LW_THREADS = 256;
+constexpr int SRU_LW_FBF = 12, SRU_LW_FBB = 8;      // frames per block, forward / backward
+constexpr size_t sru_fwd_lw_lds() { return (size_t)3 * SRU_LW_FBF * 4 * 64 * sizeof(float); }
+constexpr size_t sru_bwd_lw_lds() { return (size_t)3 * SRU_LW_FBB * 7 * 64 * sizeof(float); }
+
+// grid = ceil(B*ncols / 64) workgroups of 256
+__global__ __launch_bounds__(SRU_LW_THREADS) void sru_fwd_lw_kernel(const SruArgs a) {
+  constexpr int FB = SRU_LW_FBF;
+  extern __shared__ __attribute__((aligned(16))) float ring[];      // [3][FB][4][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncols = a.H * a.dirs;
+  const long gid0 = (long)blockIdx.x * 64 + lane;
+  const bool valid = gid0 < (long)a.B * ncols;
+  const long gid = valid ? gid0 : 0;
+  const int col = (int)(gid % ncols), b = (int)(gid / ncols);
+  const bool flip = col >= a.H;
+  const int T = a.T, k = a.k;
+  const int nblk = (T + FB - 1) / FB;
+  const float* Ub = a.U + (long)b * T * a.ldu + (long)col * k;
+  const float* xb = a.x + (long)b * T * a.ldx + col;
+  if (wave > 0) {
+    const int l = wave - 1;
+    float v[FB][4];
+    auto request = [&](int blk) {
+#pragma unroll
+      for (int q = 0; q < FB; ++q) {
+        const int tt = min(blk * FB + q, T - 1);
+        const int t = flip ? T - 1 - tt : tt;
+        const float* u = Ub + (long)t * a.ldu;
+        v[q][0] = u[0]; v[q][1] = u[1]; v[q][2] = u[2];
+        v[q][3] = k == 3 ? xb[(long)t * a.ldx] : u[3];
+      }
+    };
+    auto deposit = [&](int slot) {
+      float* r = ring + (size_t)slot * FB * 4 * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < FB; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[(q * 4 + j) * 64] = v[q][j];
+    };
+    if (l < nblk) request(l);
+    if (l == 0) { deposit(0); if (3 < nblk) request(3); }
+    for (int i = 0; i < nblk; ++i) {
+      sru_ring_barrier();
+      const int kb = i + 1;                 // the block the recurrence reads next
+      if (kb < nblk && kb % 3 == l) { deposit(l); if (kb + 3 < nblk) request(kb + 3); }
+    }
+    return;
+  }
+  const float bf = a.bias[col], br = a.bias[ncols + col];
+  const float mk = sru_mask(a, b, col);
+  float* hb = a.h + (long)b * T * ncols + col;
+  float* cb = a.c + (long)b * T * ncols + col;
+  float c = 0.f;
+  for (int i = 0; i < nblk; ++i) {
+    sru_ring_barrier();
+    const float* r = ring + (size_t)(i % 3) * FB * 4 * 64 + lane;
+    float fg[FB], rg[FB];
+#pragma unroll
+    for (int q = 0; q < FB; ++q) { fg[q] = fast_sigmoid(r[(q * 4 + 1) * 64] + bf); rg[q] = fast_sigmoid(r[(q * 4 + 2) * 64] + br); }
+#pragma unroll
+    for (int q = 0; q < FB; ++q) {
+      const int tt = i * FB + q;
+      if (tt < T) {
+        const int t = flip ? T - 1 - tt : tt;
+        const float u0 = r[(q * 4 + 0) * 64], xp = r[(q * 4 + 3) * 64];
+        const SruFwdOut o = sru_fwd_frame(u0, fg[q], rg[q], xp, c, mk, a.act);
+        c = o.c;
+        if (valid) {
+          hb[(long)t * ncols] = o.h;
+          cb[(long)t * ncols] = c;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArgs a) {
+  constexpr int FB = SRU_LW_FBB;
+  extern __shared__ __attribute__((aligned(16))) float ring[];      // [3][FB][7][64]: u0, u1, u2, x', c of the predecessor frame, dh, highway gradient
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncols = a.H * a.dirs;
+  const long gid0 = (long)blockIdx.x * 64 + lane;
+  const bool valid = gid0 < (long)a.B * ncols;
+  const long gid = valid ? gid0 : 0;
+  const int col = (int)(gid % ncols), b = (int)(gid / ncols);
+  const bool flip = col >= a.H;
+  const int T = a.T, k = a.k;
+  const int nblk = (T + FB - 1) / FB;
+  const float* Ub = a.U + (long)b * T * a.ldu + (long)col * k;
+  const float* xb = a.x + (long)b * T * a.ldx + col;
+  const float* cb = a.c + (long)b * T * ncols + col;
+  const float* dhb = a.dh + (long)b * T * ncols + col;
+  const float* upb = a.up_add ? a.up_add + (long)b * T * a.ld_up_add + col : nullptr;
+  if (wave > 0) {
+    const int l = wave - 1;
+    float v[FB][7];
+    auto request = [&](int blk) {
+#pragma unroll
+      for (int q = 0; q < FB; ++q) {
+        const int tt = max(T - 1 - (blk * FB + q), 0);     // forward-order index, descending
+        const int t = flip ? T - 1 - tt : tt;
+        const int tp = flip ? t + 1 : t - 1;               // frame of c_{tt-1}
+        const float* u = Ub + (long)t * a.ldu;
+        v[q][0] = u[0]; v[q][1] = u[1]; v[q][2] = u[2];
+        v[q][3] = k == 3 ? xb[(long)t * a.ldx] : u[3];
+        v[q][4] = tt > 0 ? cb[(long)min(max(tp, 0), T - 1) * ncols] : 0.f;
+        v[q][5] = dhb[(long)t * ncols];
+        v[q][6] = upb ? upb[(long)t * a.ld_up_add] : 0.f;
+      }
+    };
+    auto deposit = [&](int slot) {
+      float* r = ring + (size_t)slot * FB * 7 * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < FB; ++q)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) r[(q * 7 + j) * 64] = v[q][j];
+    };
+    if (l < nblk) request(l);
+    if (l == 0) { deposit(0); if (3 < nblk) request(3); }
+    for (int i = 0; i < nblk; ++i) {
+      sru_ring_barrier();
+      const int kb = i + 1;
+      if (kb < nblk && kb % 3 == l) { deposit(l); if (kb + 3 < nblk) request(kb + 3); }
+    }
+    return;
+  }
+  const float bf = a.bias[col], br = a.bias[ncols + col];
+  const float mk = sru_mask(a, b, col);
+  const float up_mul = a.up_mul ? a.up_mul[(long)b * ncols + col] : 1.f;
+  float* dUb = a.dU + (long)b * T * a.ldu + (long)col * k;
+  float* dxb = a.dx ? a.dx + (long)b * T * a.lddx + col : nullptr;
+  float dc = 0.f, dbf = 0.f, dbr = 0.f;
+  float c_here = cb[(long)(flip ? 0 : T - 1) * ncols];      // cell state of the first frame of the walk
+  for (int i = 0; i < nblk; ++i) {
+    sru_ring_barrier();
+    const float* r = ring + (size_t)(i % 3) * FB * 7 * 64 + lane;
+    float fg[FB], rg[FB];
+#pragma unroll
+    for (int q = 0; q < FB; ++q) { fg[q] = fast_sigmoid(r[(q * 7 + 1) * 64] + bf); rg[q] = fast_sigmoid(r[(q * 7 + 2) * 64] + br); }
+#pragma unroll
+    for (int q = 0; q < FB; ++q) {
+      const int tt = T - 1 - (i * FB + q);
+      if (tt < 0) continue;
+      const int t = flip ? T - 1 - tt : tt;
+      const float u0 = r[(q * 7 + 0) * 64], xp = r[(q * 7 + 3) * 64];
+      const float c_prev = r[(q * 7 + 4) * 64];
+      const float dh = fmaf(r[(q * 7 + 5) * 64], up_mul, r[(q * 7 + 6) * 64]);
+      const SruBwdOut o = sru_bwd_frame(u0, fg[q], rg[q], xp, c_here, c_prev, dh, dc, mk, a.act);
+      dc = o.dc;
+      if (valid) {
+        float* du = dUb + (long)t * a.ldu;
+        du[0] = o.du0; du[1] = o.du1; du[2] = o.du2;
+        if (k == 3) dxb[(long)t * a.lddx] = o.dxp; else du[3] = o.dxp;
+      }
+      dbf += o.du1; dbr += o.du2;
+      c_here = c_prev;
+    }
+  }
+  if (valid) {
+    a.dbias_part[(long)b * 2 * ncols + col] = dbf;
+    a.dbias_part[(long)b * 2 * ncols + ncols + col] = dbr;
+  }
 }
 
 // The variational input-dropout mask of a layer as multipliers {0, 1/(1-p)}, [B][n]: drawn once per step (Philox, or the

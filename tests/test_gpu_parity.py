@@ -799,6 +799,24 @@ def test_bf16_storage_sru_step_tracks_the_float32_oracle():
             assert err < 8e-2, (tag + name, err)
 
 
+@pytest.mark.parametrize("name", ["acoustic_sru_at_size", "acoustic_sru_uni_k3_dropout", "vc_sru_multistream"])
+def test_sru_loader_wave_scans_equal_the_one_wave_scans_bit_for_bit(name, monkeypatch):
+    """The SRU scans with loader waves (three frame blocks per column in flight through an LDS ring, sru_kernels.hip.h)
+    against the one-wave scans (GT_SRU_LW=0): same arithmetic in the same order, so a whole G+D step -- outputs, scalars,
+    parameters after the update, optimizer state -- must agree bit for bit (widths 6 x 512 bidirectional with both
+    dropouts, a unidirectional tanh k = 3 net, a 3-stream net with ragged T = 19: partial blocks, partial workgroups)."""
+    from hip_runner import run_hip_case
+    case = C.ORACLE_ONLY_CASES[name]
+    monkeypatch.setenv("GT_SRU_LW", "0")
+    ref = run_hip_case(case)
+    monkeypatch.setenv("GT_SRU_LW", "1")
+    got = run_hip_case(case)
+    assert set(got) == set(ref)
+    for k in ref:
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), k
+
+
 def test_lstm_full_size_persistent_equals_per_step_kernels():
     """cfg3 at full size (B=32, T=1024, BiLSTM 3x256, variable lengths): the persistent recurrence kernels (one launch
     per layer, W_hh resident on chip, h / dG exchanged between workgroups) against the per-step kernels the small
