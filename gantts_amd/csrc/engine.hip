@@ -775,6 +775,7 @@ struct gt_engine {
   hipEvent_t len_ev[LEN_RING] = {nullptr, nullptr, nullptr, nullptr};
   int len_cap = 0, len_slot = -1;
   int* d_lengths() { return len_slot < 0 ? nullptr : len_dev[len_slot].as<int>(); }
+  std::vector<Scratch> s_wt;                                 // SRU float32 mode: transposed copies of the layers' W
   std::vector<Scratch> s_u, s_h, s_c, s_xdrop, s_xmask;     // SRU per-layer stashes (s_xmask: input-dropout multipliers [B][n_in])
   Scratch s_du, s_dx, s_dbias;
   std::vector<int> h_lengths;
@@ -862,7 +863,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
     if (e->len_host[i]) (void)hipHostFree(e->len_host[i]);
     if (e->len_ev[i]) (void)hipEventDestroy(e->len_ev[i]);
   }
-  for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop, &e->s_xmask}) for (auto& s : *v) s.release();
+  for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop, &e->s_xmask, &e->s_wt}) for (auto& s : *v) s.release();
   e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
@@ -982,7 +983,7 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
     }
     n.last = take(desc->out_dim, ncols);
     e->s_u.resize(desc->num_hidden); e->s_h.resize(desc->num_hidden);
-    e->s_c.resize(desc->num_hidden); e->s_xdrop.resize(desc->num_hidden); e->s_xmask.resize(desc->num_hidden);
+    e->s_c.resize(desc->num_hidden); e->s_xdrop.resize(desc->num_hidden); e->s_xmask.resize(desc->num_hidden); e->s_wt.resize(desc->num_hidden);
   } else {
     if (desc->arch == GT_ARCH_IN2OUT) n.gate = take(desc->static_dim, desc->static_dim);
     int in = desc->in_dim;
@@ -2198,6 +2199,19 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       g.A = I.r(); g.lda = I.ld; g.B = e->ssh[l].wt.as<__bf16>(); g.ldb = e->ssh[l].ldwt;     // WT [ncols*k][n_in]: k = n_in contiguous
       g.M = (int)N; g.N = ncols * L.k; g.K = L.in; g.epi = B16_FWD; g.act = ACT_NONE; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
       CHK(launch_gemm_b16(g, 1, s));
+    } else if ((L.in & 3) == 0 && N >= 4096) {
+      // U = xin W with W (n_in, ncols*k): the k-contiguous (NT) product runs at 146 TFLOP/s on these shapes, the n-contiguous (NN)
+      // one at 114 (profiles/r03_sru_fp32_summary.md: 1.41 vs 1.80 ms per layer) -- multiply by a transposed copy of W, re-made
+      // from the caller's parameter buffer before every pass (12 MB, ~10 us)
+      CHK(e->s_wt[l].ensure((size_t)ncols * L.k * L.in * sizeof(float)));
+      hipLaunchKernelGGL(transpose_f32_kernel, dim3(cdiv(ncols * L.k, 32), cdiv(L.in, 32)), dim3(256), 0, s, L.W, L.in, ncols * L.k, ncols * L.k,
+                         e->s_wt[l].as<float>(), L.in);
+      LAUNCH_CHECK();
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = xin; g.lda = ld_xin; g.B = e->s_wt[l].as<float>(); g.ldb = L.in; g.C = e->s_u[l].as<float>(); g.ldc = ncols * L.k;
+      g.M = (int)N; g.N = ncols * L.k; g.K = L.in; g.act = ACT_NONE; g.drop = no_drop();
+      CHK(launch_gemm(GEMM_NT, g, 1, s));
     } else {  // U = xin W   (W is (n_in, ncols*k): n-contiguous rows -> NN orientation)
       GemmArgs g;
       memset(&g, 0, sizeof(g));

@@ -152,6 +152,24 @@ __global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const flo
   }
 }
 
+// out[c][r] = in[r][c]  (float32, rows x cols -> cols x rows), 32 x 32 tiles through LDS.  grid = (ceil(cols/32), ceil(rows/32)), 256 threads
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int rows, int cols, int ldi, float* __restrict__ out, int ldo) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(long)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < cols && r < rows) out[(long)c * ldo + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 // out[r][0..ldo) = in[r][0..cols), zero in the pad columns (row pitch rounded up for 16-byte loads)
 __global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows, float* __restrict__ out, int ldo) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
