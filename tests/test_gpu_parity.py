@@ -156,7 +156,8 @@ def test_linear_forward_backward_vs_torch(rows, din, dout, act):
 
 
 @pytest.mark.parametrize("rows,din,dout,act", [(300, 425, 512, 1), (1000, 512, 187, 0), (77, 483, 256, 1), (16384, 512, 512, 1),
-                                               (32768, 256, 256, 1), (129, 25, 25, 2), (33, 7, 3, 1), (4096, 256, 58, 0)])
+                                               (32768, 256, 256, 1), (129, 25, 25, 2), (33, 7, 3, 1), (4096, 256, 58, 0),
+                                               (16384, 512, 512, 0), (16320, 640, 1152, 2), (16384, 1024, 768, -1)])
 def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, dout, act):
     """The bf16-STORAGE product family of GT_OPT_MATMUL_BF16 (gemm_bf16s.hip.h) in isolation: forward (bias + LeakyReLU +
     injected dropout / sigmoid), backward-data with the producer's f', weight gradient with split-K slabs and the bias
@@ -166,6 +167,11 @@ def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, 
     epilogue writes ([frame][out] and its transposed twin) must be the bf16 rounding of the float32 result, bit for bit."""
     import ctypes as Ct
     from gantts_amd._lib import check, lib, ptr
+    # the last three shapes take the LDS-DMA form of the 128 x 128 tile (K a multiple of 64, >= 512 tiles) in the forward and
+    # backward-data products with every epilogue (none / sigmoid / LeakyReLU + mask) and a ragged M; act = -1: no bias gradient
+    # is asked for, so the weight gradient (128 x 128 tiles, whole rounds of slabs) goes through the DMA loader as well
+    want_db = act >= 0
+    act = max(act, 0)
     rs = np.random.RandomState(rows + 3 * din)
     bf = lambda t: t.bfloat16().double()
     X = torch.from_numpy(rs.randn(rows, din).astype(np.float32))
@@ -195,14 +201,15 @@ def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, 
     Yi, YTi = torch.empty(rows, dout, device="cuda"), torch.empty(dout, rows, device="cuda")
     dX, dW, db = torch.empty(rows, din, device="cuda"), torch.empty(dout, din, device="cuda"), torch.empty(dout, device="cuda")
     check(lib.gt_op_linear_bf16(ptr(Xd), ptr(Wd), ptr(bd), rows, din, dout, act, ptr(kd), p, ptr(Y), ptr(dYd), ptr(Hd), 1, ptr(kpd), 0.5,
-                                ptr(dX), ptr(dW), ptr(db), ptr(Yi), ptr(YTi), s))
+                                ptr(dX), ptr(dW), ptr(db) if want_db else None, ptr(Yi), ptr(YTi), s))
     torch.cuda.synchronize()
     _close(Y.cpu().numpy(), ref.numpy(), rtol=1e-5, msg="bf16-storage Y")
     assert torch.equal(Yi.cpu(), Y.cpu().bfloat16().float()), "bf16 result image != bf16(float32 result)"
     assert torch.equal(YTi.cpu(), Yi.cpu().t()), "transposed bf16 image differs from the row-major one"
     _close(dX.cpu().numpy(), ref_dX.numpy(), rtol=1e-5, msg="bf16-storage dX")
     _close(dW.cpu().numpy(), ref_dW.numpy(), rtol=2e-5, msg="bf16-storage dW")
-    _close(db.cpu().numpy(), ref_db.numpy(), rtol=2e-5, msg="bf16-storage db")
+    if want_db:
+        _close(db.cpu().numpy(), ref_db.numpy(), rtol=2e-5, msg="bf16-storage db")
 
 
 def test_linear_backward_fused_activation_derivative():
