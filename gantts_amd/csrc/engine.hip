@@ -483,24 +483,27 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
-// the LDS-DMA form of the 128 x 128 tile (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages, two workgroups per CU)
-template <int EPI, int AMODE>
+// the LDS-DMA forms (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages): T = 128: 128 x 128 tile, 4 waves, two workgroups
+// per CU; T = 256: 256 x 256 tile, 8 waves (2 x 4), one workgroup per CU -- half the operand bytes per flop and twice the waves
+// pulling them (tools/gemm_b16_sweep: 32768 x 3072 x 1024 forward 312 -> 248 us, backward-data 259 -> 208 us)
+template <int EPI, int AMODE, int T>
 static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
-  const size_t lds = gemm_b16_dma_lds_bytes<128, 128, 2>();
-  CHK(ensure_dyn_lds((const void*)gemm_b16_dma_kernel<128, 128, EPI, AMODE, 2>, lds));
-  g.n_tiles_m = cdiv(g.M, 128);
-  g.n_tiles_n = cdiv(g.N, 128);
+  constexpr int WGN = T == 256 ? 4 : 2;
+  const size_t lds = gemm_b16_dma_lds_bytes<T, T, 2>();
+  CHK(ensure_dyn_lds((const void*)gemm_b16_dma_kernel<T, T, EPI, AMODE, 2, 2, WGN>, lds));
+  g.n_tiles_m = cdiv(g.M, T);
+  g.n_tiles_n = cdiv(g.N, T);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = g.epi; rec.bn = 128; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.kind = g.epi; rec.bn = T; rec.flops = 2.0 * g.M * g.N * g.K;
     rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
                 (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_b16_dma_kernel<128, 128, EPI, AMODE, 2>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  hipLaunchKernelGGL((gemm_b16_dma_kernel<T, T, EPI, AMODE, 2, 2, WGN>), dim3(grid), dim3(64 * 2 * WGN), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
@@ -514,11 +517,15 @@ static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s, int t
   // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
   const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
   static const int force_tiles = getenv("GT_B16_TILES") ? atoi(getenv("GT_B16_TILES")) : 0;      // measurement switch: 64 / 128
-  const bool big = tile ? tile == 128
+  const bool big = tile ? tile >= 128
                         : (force_tiles == 64 ? false : (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && (force_tiles == 128 || t128 >= 2L * gemm_cu_count())));
   // operand stages by LDS-DMA when no element of a stage needs masking and no row sums ride in the loader
   static const bool dma_on = !(getenv("GT_B16_DMA") && getenv("GT_B16_DMA")[0] == '0');
   const bool dma = dma_on && big && g.K % 64 == 0 && (g.epi != B16_SLAB || (g.k_chunk % 64 == 0 && !g.rowsum_slab));
+  // 256 x 256 tiles when they fill whole rounds of CUs (one workgroup per CU) to within 15 %
+  const long t256 = (long)cdiv(g.M, 256) * cdiv(g.N, 256) * nslab, cus = gemm_cu_count();
+  const bool huge = dma && (tile ? tile == 256 : (force_tiles == 256 || (force_tiles == 0 && g.epi != B16_SLAB && g.M >= 256 && g.N >= 256 && t256 >= cus &&
+                                                   (double)(cdiv(t256, cus) * cus - t256) <= 0.15 * (double)(cdiv(t256, cus) * cus))));
   // the epilogue flavour is a template parameter of the kernel (gemm_bf16s.hip.h: GemmB16Amode)
   int amode = B16_A_NONE;
   if (g.epi != B16_SLAB) {
@@ -526,15 +533,17 @@ static int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s, int t
     else if (g.act == ACT_LEAKY_DROPOUT) amode = g.drop.mode == DROP_PHILOX ? B16_A_LEAKY_PHILOX : (g.drop.mode == DROP_BUFFER ? B16_A_LEAKY_BUFFER : B16_A_LEAKY);
   }
 #define GT_B16_CASE(E, A) if (g.epi == E && amode == A) \
-    return dma ? launch_gemm_b16_dma<E, A>(g, nslab, s) : (big ? launch_gemm_b16_t<128, 128, E, A>(g, nslab, s) : launch_gemm_b16_t<64, 64, E, A>(g, nslab, s));
+    return huge ? launch_gemm_b16_dma<E, A, 256>(g, nslab, s) \
+                : (dma ? launch_gemm_b16_dma<E, A, 128>(g, nslab, s) : (big ? launch_gemm_b16_t<128, 128, E, A>(g, nslab, s) : launch_gemm_b16_t<64, 64, E, A>(g, nslab, s)));
   GT_B16_CASE(B16_FWD, B16_A_NONE) GT_B16_CASE(B16_FWD, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_FWD, B16_A_LEAKY_BUFFER)
   GT_B16_CASE(B16_FWD, B16_A_LEAKY) GT_B16_CASE(B16_FWD, B16_A_SIGMOID)
   GT_B16_CASE(B16_BWD_DATA, B16_A_NONE) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_PHILOX) GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY_BUFFER)
   GT_B16_CASE(B16_BWD_DATA, B16_A_LEAKY) GT_B16_CASE(B16_BWD_DATA, B16_A_SIGMOID)
 #undef GT_B16_CASE
   if (g.epi == B16_SLAB)
-    return dma ? launch_gemm_b16_dma<B16_SLAB, B16_A_NONE>(g, nslab, s)
-               : (big ? launch_gemm_b16_t<128, 128, B16_SLAB, B16_A_NONE>(g, nslab, s) : launch_gemm_b16_t<64, 64, B16_SLAB, B16_A_NONE>(g, nslab, s));
+    return huge ? launch_gemm_b16_dma<B16_SLAB, B16_A_NONE, 256>(g, nslab, s)
+                : (dma ? launch_gemm_b16_dma<B16_SLAB, B16_A_NONE, 128>(g, nslab, s)
+                       : (big ? launch_gemm_b16_t<128, 128, B16_SLAB, B16_A_NONE>(g, nslab, s) : launch_gemm_b16_t<64, 64, B16_SLAB, B16_A_NONE>(g, nslab, s)));
   return fail(GT_ERR_INVALID, "bf16 product: unknown epilogue");
 }
 static GemmB16Args b16_args() {
@@ -569,16 +578,18 @@ static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long
   // rounds of 2 x CUs workgroups best (r = 1 .. 3 rounds; tools/gemm_b16_sweep: 1024 x 3072 over 32 768 frames 450 us with
   // 64 x 64 tiles -> 246 us with 8 slabs of 128 x 128; 512 x 2048: 124 -> 76 us); 64 x 64 (four per CU) below that
   static const int force_wg_tile = getenv("GT_B16_WG_TILE") ? atoi(getenv("GT_B16_WG_TILE")) : 0;     // measurement switch: 64 / 128
-  const int t128 = cdiv(out, 128) * cdiv(in, 128);
-  const bool big = force_wg_tile ? force_wg_tile == 128 : (out >= 128 && in >= 128 && t128 >= 16);
+  const int t128 = cdiv(out, 128) * cdiv(in, 128), t256 = cdiv(out, 256) * cdiv(in, 256);
+  const bool big = force_wg_tile ? force_wg_tile >= 128 : (out >= 128 && in >= 128 && t128 >= 16);
+  // 256 x 256 tiles (one 8-wave workgroup per CU, LDS-DMA only: no bias gradient, whole 64-frame stages) for the largest matrices
+  const bool huge = big && !db && rows % 64 == 0 && (force_wg_tile ? force_wg_tile == 256 : (out >= 512 && in >= 512 && t256 >= 32));
   int nslab;
   if (big) {
-    const int slots = 2 * gemm_cu_count();
+    const int slots = huge ? gemm_cu_count() : 2 * gemm_cu_count(), tl = huge ? t256 : t128;
     double best = 2.0;
     nslab = 1;
     for (int r = 1; r <= 3; ++r) {
-      const int ns = std::max(1, slots * r / t128);
-      const double waste = 1.0 - (double)t128 * ns / ((double)slots * cdiv((long)t128 * ns, slots));
+      const int ns = std::max(1, slots * r / tl);
+      const double waste = 1.0 - (double)tl * ns / ((double)slots * cdiv((long)tl * ns, slots)) + 0.05 * (r - 1);   // every round has its own epilogues
       if (waste < best - 1e-9) { best = waste; nslab = ns; }
     }
   } else {
@@ -609,7 +620,7 @@ static int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long
   g.A = dZT; g.lda = (int)lddzt; g.B = XT; g.ldb = (int)ldxt; g.M = out; g.N = in; g.K = (int)rows;
   g.C = slab_base; g.ldc = in; g.epi = B16_SLAB; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
   g.rowsum_slab = db ? bias_slabs : nullptr;
-  CHK(launch_gemm_b16(g, nslab, s, big ? 128 : 64));
+  CHK(launch_gemm_b16(g, nslab, s, huge ? 256 : (big ? 128 : 64)));
   if (can4) {
     const int main_blocks = cdiv(slab_stride / 4, 256), bias_blocks = db ? cdiv(out, 256) : 0;
     if (defer) {

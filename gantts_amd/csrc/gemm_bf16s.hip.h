@@ -45,6 +45,7 @@ struct GemmB16Args {
   long slab_stride;
   float* rowsum_slab;            // B16_SLAB: per-slab row sums of A (= bias gradient when A = dZT), [nslab][M], or null
   int n_tiles_m, n_tiles_n;
+  int band_c;                    // > 0: L2-aware tile order (gemm_b16_tile_of): the 8 XCDs form a (8 / band_c) x band_c grid over the tiles
 };
 
 // Timing ablations of the K loop, set by tools/gemm_b16_sweep only (results are then wrong on purpose): bit 0 no operand loads
@@ -53,6 +54,27 @@ struct GemmB16Args {
 #define GT_B16_ABLATE 0
 #endif
 constexpr int B16_ABL = GT_B16_ABLATE;
+// Workgroup -> (slab, tile).  Default: every XCD takes a contiguous run of tiles in n-fastest order (gemm_xcd_order).  band_c > 0
+// (one slab, n_tiles_n % band_c == 0, n_tiles_m % (8 / band_c) == 0): XCD x owns the tile rows of row group x / band_c and the tile
+// columns of column band x % band_c, and walks its columns fastest -- its band of B stays in that XCD's L2 for the whole
+// launch and an A row panel is used band-width times back to back, instead of every tile row re-reading all of B through the
+// fabric when B is larger than one L2 (4 MB).
+__device__ __forceinline__ void gemm_b16_tile_of(const GemmB16Args& g, int* slab, int* tile_m, int* tile_n) {
+  if (g.band_c > 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int R = 8 / g.band_c, rows = g.n_tiles_m / R, cols = g.n_tiles_n / g.band_c;
+    *slab = 0;
+    *tile_m = (xcd / g.band_c) * rows + idx / cols;
+    *tile_n = (xcd % g.band_c) * cols + idx % cols;
+    return;
+  }
+  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
+  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
+  *slab = bid / tiles_mn;
+  const int t = bid - *slab * tiles_mn;
+  *tile_m = t / g.n_tiles_n;
+  *tile_n = t - *tile_m * g.n_tiles_n;
+}
 constexpr int B16_BK = 64;        // k depth of one LDS stage
 constexpr int B16_KP = 72;        // LDS row pitch in bf16 (144 B: the 16 rows of a ds_read_b128 lane group start in 16 different 16-byte slots)
 
@@ -72,12 +94,13 @@ enum GemmB16Amode { B16_A_NONE = 0, B16_A_LEAKY_PHILOX = 1, B16_A_LEAKY_BUFFER =
 // One BM x BN tile.  256 threads = 2 x 2 waves, each wave (BM/2) x (BN/2) in 32x32 MFMA tiles.
 // EPI (GemmB16Epi) and AMODE (GemmB16Amode) restate g.epi and (g.act, g.drop.mode) at compile time (launch_gemm_b16 dispatches).
 // Epilogue of one BM x BN tile whose accumulators are in the 2 x 2-wave layout of gemm_b16_tile / gemm_b16_tile_dma.
-template <int BM, int BN, int EPI, int AMODE>
+// (WGM x WGN waves per workgroup, 2 x 2 unless stated: the 8-wave 256 x 256 tile of gemm_b16_tile_dma uses 2 x 4)
+template <int BM, int BN, int EPI, int AMODE, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_b16_epilogue(const GemmB16Args& g, const int slab, const int m0, const int n0,
-                                                  f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem) {
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
+                                                  f32x16 (&acc)[BM / (32 * WGM)][BN / (32 * WGN)], __bf16* smem) {
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN_ = WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5, wm = wave / WGN, wn = wave % WGN;
   // ---- epilogue, in the MFMA C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* C = g.C ? g.C + (EPI == B16_SLAB ? (long)slab * g.slab_stride : 0L) : nullptr;
   constexpr bool philox = EPI != B16_SLAB && AMODE == B16_A_LEAKY_PHILOX;
@@ -90,7 +113,7 @@ __device__ __forceinline__ void gemm_b16_epilogue(const GemmB16Args& g, const in
                       (!g.CbT || ((g.ldcbt & 7) == 0 && (((uintptr_t)g.CbT) & 15) == 0)) &&
                       (!C || ((g.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0));
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 33);
-  static_assert((size_t)4 * 32 * 33 * sizeof(float) <= gemm_b16_lds_bytes<BM, BN>(), "epilogue staging exceeds the LDS image");
+  static_assert((size_t)WGM * WGN * 32 * 33 * sizeof(float) <= gemm_b16_lds_bytes<BM, BN>(), "epilogue staging exceeds the LDS image");
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -370,10 +393,8 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
 template <int BM, int BN, int EPI, int AMODE, int PF = 1>
 __global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BM * BN >= 256 * 256 ? 1 : 2)) void gemm_b16_kernel(const GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
-  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
-  const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
-  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
+  int slab, tile_m, tile_n;
+  gemm_b16_tile_of(g, &slab, &tile_m, &tile_n);
   gemm_b16_tile<BM, BN, EPI, AMODE, PF>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
 }
 
@@ -390,32 +411,34 @@ __global__ __launch_bounds__(GEMM_THREADS, (BM == 64 && BN == 64) ? 4 : (BM * BN
 template <int BM, int BN, int NS>
 constexpr size_t gemm_b16_dma_lds_bytes() { return (size_t)NS * (BM + BN) * 64 * 2; }
 
-template <int BM, int BN, int EPI, int AMODE, int NS>
+template <int BM, int BN, int EPI, int AMODE, int NS, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const int slab, const int tile_m, const int tile_n, __bf16* smem) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN_ = WN / 32;
-  constexpr int NA = BM / 32, NB = BN / 32;            // 1-KiB blocks (8 rows) per wave and stage
+  constexpr int NW = WGM * WGN;                        // waves per workgroup
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN_ = WN / 32;
+  constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);  // 1-KiB blocks (8 rows) per wave and stage
+  static_assert(NA >= 1 && NB >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "blocks per wave");
   constexpr int STAGE = (BM + BN) * 64;                // bf16 elements of one stage
   static_assert(NS >= 2 && NS <= 4, "ring depth");
-  static_assert((size_t)4 * 32 * 33 * sizeof(float) <= gemm_b16_dma_lds_bytes<BM, BN, NS>(), "epilogue staging exceeds the LDS image");
+  static_assert((size_t)NW * 32 * 33 * sizeof(float) <= gemm_b16_dma_lds_bytes<BM, BN, NS>(), "epilogue staging exceeds the LDS image");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5, wm = wave / WGN, wn = wave % WGN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   int k_begin = 0, k_end = g.K;
   if (EPI == B16_SLAB) { k_begin = slab * g.k_chunk; k_end = min(g.K, k_begin + g.k_chunk); }
-  // block b of an operand = rows 8 b .. 8 b + 7 of the tile; this wave issues blocks wave, wave + 4, ...; lane -> row 8 b + (lane >> 3),
+  // block b of an operand = rows 8 b .. 8 b + 7 of the tile; this wave issues blocks wave, wave + NW, ...; lane -> row 8 b + (lane >> 3),
   // LDS slot lane & 7, which holds the row's chunk (lane & 7) ^ ((row >> 1) & 7)
   const __bf16* srcA[NA];
   const __bf16* srcB[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int r = (wave + 4 * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    const int r = (wave + NW * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
     srcA[i] = g.A + (long)min(m0 + r, g.M - 1) * g.lda + k_begin + 8 * c;
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int r = (wave + 4 * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    const int r = (wave + NW * i) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
     srcB[i] = g.B + (long)min(n0 + r, g.N - 1) * g.ldb + k_begin + 8 * c;
   }
   auto issue = [&](int buf) {
@@ -423,12 +446,12 @@ __device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const in
     __bf16* Bs = As + BM * 64;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(As + (wave + 4 * i) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(As + (wave + NW * i) * 512), 16, 0, 0);
       srcA[i] += 64;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(Bs + (wave + 4 * i) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(Bs + (wave + NW * i) * 512), 16, 0, 0);
       srcB[i] += 64;
     }
   };
@@ -441,6 +464,9 @@ __device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const in
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (k_end - k_begin) / 64;
+#ifdef GT_B16_CLK_DBG
+  const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
 #pragma unroll
   for (int p = 0; p < NS - 1; ++p)
     if (p < nk) issue(p);
@@ -479,18 +505,23 @@ __device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const in
     __syncthreads();                                   // ... for everybody, and everybody is done reading stage t
     ++buf; if (buf >= NS) buf = 0;
   }
-  gemm_b16_epilogue<BM, BN, EPI, AMODE>(g, slab, m0, n0, acc, smem);
+#ifdef GT_B16_CLK_DBG     // tools/gemm_b16_sweep: shader cycles and 100 MHz wall ticks of this workgroup's K loop
+  if (g.rowsum_slab && tid == 0) {
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(g.rowsum_slab) + 2 * (size_t)blockIdx.x;
+    d[0] = c1 - dbg_c0; d[1] = w1 - dbg_w0;
+  }
+#endif
+  gemm_b16_epilogue<BM, BN, EPI, AMODE, WGM, WGN>(g, slab, m0, n0, acc, smem);
 }
 
 constexpr int gemm_b16_dma_wgs(int BM, int BN, int NS) { return 2 * NS * (BM + BN) * 128 <= 160 * 1024 ? 2 : 1; }   // workgroups per CU the LDS ring allows
-template <int BM, int BN, int EPI, int AMODE, int NS>
-__global__ __launch_bounds__(GEMM_THREADS, gemm_b16_dma_wgs(BM, BN, NS)) void gemm_b16_dma_kernel(const GemmB16Args g) {
+template <int BM, int BN, int EPI, int AMODE, int NS, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN, gemm_b16_dma_wgs(BM, BN, NS)) void gemm_b16_dma_kernel(const GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
-  const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
-  const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
-  const int tile_m = t / g.n_tiles_n, tile_n = t - tile_m * g.n_tiles_n;
-  gemm_b16_tile_dma<BM, BN, EPI, AMODE, NS>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
+  int slab, tile_m, tile_n;
+  gemm_b16_tile_of(g, &slab, &tile_m, &tile_n);
+  gemm_b16_tile_dma<BM, BN, EPI, AMODE, NS, WGM, WGN>(g, slab, tile_m, tile_n, reinterpret_cast<__bf16*>(smem_f));
 }
 
 // in [rows][ldi] (float32 or bf16)  ->  out [rows][ldo] bf16 (optional)  and  outT [cols][ldt] bf16 (optional), plus

@@ -157,7 +157,8 @@ def test_linear_forward_backward_vs_torch(rows, din, dout, act):
 
 @pytest.mark.parametrize("rows,din,dout,act", [(300, 425, 512, 1), (1000, 512, 187, 0), (77, 483, 256, 1), (16384, 512, 512, 1),
                                                (32768, 256, 256, 1), (129, 25, 25, 2), (33, 7, 3, 1), (4096, 256, 58, 0),
-                                               (16384, 512, 512, 0), (16320, 640, 1152, 2), (16384, 1024, 768, -1)])
+                                               (16384, 512, 512, 0), (16320, 640, 1152, 2), (16384, 1024, 768, -1),
+                                               (32768, 512, 1024, 1), (8192, 1024, 2048, -1)])
 def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, dout, act):
     """The bf16-STORAGE product family of GT_OPT_MATMUL_BF16 (gemm_bf16s.hip.h) in isolation: forward (bias + LeakyReLU +
     injected dropout / sigmoid), backward-data with the producer's f', weight gradient with split-K slabs and the bias
@@ -167,9 +168,11 @@ def test_linear_bf16_storage_products_vs_float64_on_rounded_operands(rows, din, 
     epilogue writes ([frame][out] and its transposed twin) must be the bf16 rounding of the float32 result, bit for bit."""
     import ctypes as Ct
     from gantts_amd._lib import check, lib, ptr
-    # the last three shapes take the LDS-DMA form of the 128 x 128 tile (K a multiple of 64, >= 512 tiles) in the forward and
+    # shapes 9 - 11 take the LDS-DMA form of the 128 x 128 tile (K a multiple of 64, >= 512 tiles) in the forward and
     # backward-data products with every epilogue (none / sigmoid / LeakyReLU + mask) and a ragged M; act = -1: no bias gradient
-    # is asked for, so the weight gradient (128 x 128 tiles, whole rounds of slabs) goes through the DMA loader as well
+    # is asked for, so the weight gradient (128 x 128 tiles, whole rounds of slabs) goes through the DMA loader as well.
+    # The last two fill whole rounds of CUs with 256 x 256 tiles (8-wave workgroups): forward and backward-data with the
+    # LeakyReLU + mask epilogue, and (2048 x 1024 weights, no bias gradient) the weight gradient
     want_db = act >= 0
     act = max(act, 0)
     rs = np.random.RandomState(rows + 3 * din)

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 #include "../gantts_amd/csrc/gemm_bf16s.hip.h"
+#include "experiments/gemm_b16_big.hip.h"
 using namespace gt;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -38,10 +39,10 @@ static float run(GemmB16Args g, int nslab, hipStream_t s, int reps) {
   printf("    %3d x %3d pf%d  grid %6d  %d wg/cu  %8.1f us  %7.1f TFLOP/s\n", BM, BN, PF, grid, occ, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
   return best;
 }
-template <int BM, int BN, int EPI, int NS>
+template <int BM, int BN, int EPI, int NS, int WGM = 2, int WGN = 2>
 static float run_dma(GemmB16Args g, int nslab, hipStream_t s, int reps) {
   const size_t lds = gemm_b16_dma_lds_bytes<BM, BN, NS>();
-  const void* k = (const void*)gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS>;
+  const void* k = (const void*)gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS, WGM, WGN>;
   CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g.n_tiles_m = (g.M + BM - 1) / BM; g.n_tiles_n = (g.N + BN - 1) / BN;
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
@@ -49,14 +50,34 @@ static float run_dma(GemmB16Args g, int nslab, hipStream_t s, int reps) {
   float best = 1e30f;
   for (int r = 0; r < reps + 1; ++r) {
     CK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL((gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    hipLaunchKernelGGL((gemm_b16_dma_kernel<BM, BN, EPI, B16_A_NONE, NS, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, s, g);
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0) best = std::min(best, ms);
   }
   CK(hipGetLastError());
-  int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, GEMM_THREADS, lds));
-  printf("    %3d x %3d dma ring %d  grid %6d  %d wg/cu  %8.1f us  %7.1f TFLOP/s\n", BM, BN, NS, grid, occ, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
+  int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 64 * WGM * WGN, lds));
+  printf("    %3d x %3d dma ring %d, %d x %d waves  grid %6d  %d wg/cu  %8.1f us  %7.1f TFLOP/s\n", BM, BN, NS, WGM, WGN, grid, occ, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
+  return best;
+}
+template <int EPI>
+static float run_big(GemmB16Args g, int nslab, hipStream_t s, int reps) {
+  const size_t lds = gemm_b16_big_lds_bytes();
+  const void* k = (const void*)gemm_b16_big_kernel<EPI, B16_A_NONE>;
+  CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  g.n_tiles_m = (g.M + 255) / 256; g.n_tiles_n = (g.N + 255) / 256;
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    CK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL((gemm_b16_big_kernel<EPI, B16_A_NONE>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) best = std::min(best, ms);
+  }
+  CK(hipGetLastError());
+  printf("    256 x 256 big (ring 4 x 32 k, pipelined fragments)  grid %6d  %8.1f us  %7.1f TFLOP/s\n", grid, best * 1e3, 2.0 * g.M * g.N * g.K / best / 1e9);
   return best;
 }
 static double checksum(const float* d, size_t n) {
@@ -78,26 +99,24 @@ int main() {
     run_dma<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 3>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 4>(g, NSLAB, s, 3); CSUM \
     run_dma<64, 64, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<64, 64, EPI, 4>(g, NSLAB, s, 3); CSUM \
     run_dma<256, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<256, 256, EPI, 2>(g, NSLAB, s, 3); CSUM }
-  printf("weight gradient 1024 x 3072 over 32768 frames (SRU layer), by slab count\n");
-  g.A = XT; g.lda = M; g.B = DUT; g.ldb = M; g.M = K; g.N = N; g.K = M; g.C = C; g.ldc = N; g.epi = B16_SLAB; g.slab_stride = (long)K * N;
-  for (int ns : {1, 2, 3, 4, 5, 6, 8}) {
-    g.k_chunk = ((M / ns + 63) / 64) * 64;
-    printf("  %d slabs (k_chunk %d)\n", ns, g.k_chunk);
-    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<256, 256, B16_SLAB, 2>(g, ns, s, 3);
-  }
-  printf("weight gradient 512 x 2048 over 32768 frames (cfg3 W_ih), by slab count\n");
-  g.M = 512; g.N = 2048; g.ldc = 2048; g.slab_stride = 512L * 2048;
-  for (int ns : {1, 2, 4, 8, 16}) {
-    g.k_chunk = ((M / ns + 63) / 64) * 64;
-    printf("  %d slabs\n", ns);
-    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3);
-  }
-  printf("weight gradient 512 x 512 over 16384 frames (cfg2 G), by slab count\n");
-  g.M = 512; g.N = 512; g.K = 16384; g.lda = 16384; g.ldb = 16384; g.ldc = 512; g.slab_stride = 512L * 512;
-  for (int ns : {4, 8, 16, 32}) {
-    g.k_chunk = ((16384 / ns + 63) / 64) * 64;
-    printf("  %d slabs\n", ns);
-    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<64, 64, B16_SLAB, 2>(g, ns, s, 3);
+  for (int rep = 0; rep < 1; ++rep) {
+    printf("forward 32768 x 3072 x 1024 (float32 result)\n");
+    g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = N; g.epi = B16_FWD; g.act = ACT_NONE;
+    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2>(g, 1, s, 3); CSUM
+    run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 4, 2>(g, 1, s, 3); CSUM
+    run_dma<256, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 128, B16_FWD, 3, 2, 4>(g, 1, s, 3); CSUM run_dma<128, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
+    printf("backward-data 32768 x 1024 x 3072 (float32 result)\n");
+    g.A = DU; g.lda = N; g.B = W2; g.ldb = N; g.M = M; g.N = K; g.K = N; g.C = C; g.ldc = K; g.epi = B16_BWD_DATA;
+    run_dma<128, 128, B16_BWD_DATA, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_BWD_DATA, 2>(g, 1, s, 3); CSUM
+    run_dma<256, 256, B16_BWD_DATA, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_BWD_DATA, 2, 4, 2>(g, 1, s, 3); CSUM
+    run_dma<256, 128, B16_BWD_DATA, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 128, B16_BWD_DATA, 3, 2, 4>(g, 1, s, 3); CSUM
+    printf("weight gradient 1024 x 3072 over 32768 frames\n");
+    g.A = XT; g.lda = M; g.B = DUT; g.ldb = M; g.M = K; g.N = N; g.K = M; g.C = C; g.ldc = N; g.epi = B16_SLAB; g.slab_stride = (long)K * N;
+    for (int ns : {5, 8, 16, 21}) {
+      g.k_chunk = ((M / ns + 63) / 64) * 64;
+      printf("  %d slabs (k_chunk %d)\n", ns, g.k_chunk);
+      run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<256, 256, B16_SLAB, 2, 2, 4>(g, ns, s, 3); run_dma<256, 128, B16_SLAB, 2, 2, 4>(g, ns, s, 3);
+    }
   }
   return 0;
 }
