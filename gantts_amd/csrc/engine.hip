@@ -483,12 +483,13 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
-// the LDS-DMA forms (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages): T = 128: 128 x 128 tile, 4 waves, two workgroups
-// per CU; T = 256: 256 x 256 tile, 8 waves (2 x 4), one workgroup per CU -- half the operand bytes per flop and twice the waves
-// pulling them (tools/gemm_b16_sweep: 32768 x 3072 x 1024 forward 312 -> 248 us, backward-data 259 -> 208 us)
+// the LDS-DMA forms (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages), 8-wave workgroups (2 x 4): T = 128: 128 x 128
+// tile, two workgroups per CU; T = 256: 256 x 256 tile, one workgroup per CU -- half the operand bytes per flop.  More waves pull
+// more operand bytes per CU (tools/gemm_b16_sweep: 32768 x 3072 x 1024 forward, 128 x 128 with 4 waves 309 us, with 8 waves
+// 296 us, 256 x 256 with 4 waves 301 us, with 8 waves 248 us; backward-data 259 -> 208 us; 32768 x 2048 x 512: 136 / 119 / 105 us)
 template <int EPI, int AMODE, int T>
 static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
-  constexpr int WGN = T == 256 ? 4 : 2;
+  constexpr int WGN = 4;
   const size_t lds = gemm_b16_dma_lds_bytes<T, T, 2>();
   CHK(ensure_dyn_lds((const void*)gemm_b16_dma_kernel<T, T, EPI, AMODE, 2, 2, WGN>, lds));
   g.n_tiles_m = cdiv(g.M, T);

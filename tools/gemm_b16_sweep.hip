@@ -99,24 +99,21 @@ int main() {
     run_dma<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 3>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 4>(g, NSLAB, s, 3); CSUM \
     run_dma<64, 64, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<64, 64, EPI, 4>(g, NSLAB, s, 3); CSUM \
     run_dma<256, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<256, 256, EPI, 2>(g, NSLAB, s, 3); CSUM }
-  for (int rep = 0; rep < 1; ++rep) {
+  {
     printf("forward 32768 x 3072 x 1024 (float32 result)\n");
     g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = N; g.epi = B16_FWD; g.act = ACT_NONE;
-    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2>(g, 1, s, 3); CSUM
-    run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 4, 2>(g, 1, s, 3); CSUM
-    run_dma<256, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 128, B16_FWD, 3, 2, 4>(g, 1, s, 3); CSUM run_dma<128, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
-    printf("backward-data 32768 x 1024 x 3072 (float32 result)\n");
-    g.A = DU; g.lda = N; g.B = W2; g.ldb = N; g.M = M; g.N = K; g.K = N; g.C = C; g.ldc = K; g.epi = B16_BWD_DATA;
-    run_dma<128, 128, B16_BWD_DATA, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_BWD_DATA, 2>(g, 1, s, 3); CSUM
-    run_dma<256, 256, B16_BWD_DATA, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_BWD_DATA, 2, 4, 2>(g, 1, s, 3); CSUM
-    run_dma<256, 128, B16_BWD_DATA, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 128, B16_BWD_DATA, 3, 2, 4>(g, 1, s, 3); CSUM
-    printf("weight gradient 1024 x 3072 over 32768 frames\n");
-    g.A = XT; g.lda = M; g.B = DUT; g.ldb = M; g.M = K; g.N = N; g.K = M; g.C = C; g.ldc = N; g.epi = B16_SLAB; g.slab_stride = (long)K * N;
-    for (int ns : {5, 8, 16, 21}) {
-      g.k_chunk = ((M / ns + 63) / 64) * 64;
-      printf("  %d slabs (k_chunk %d)\n", ns, g.k_chunk);
-      run_dma<128, 128, B16_SLAB, 2>(g, ns, s, 3); run_dma<256, 256, B16_SLAB, 2, 2, 4>(g, ns, s, 3); run_dma<256, 128, B16_SLAB, 2, 2, 4>(g, ns, s, 3);
-    }
+    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 4, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
+    printf("cfg2 forward 16384 x 512 x 512\n");
+    g.A = X; g.lda = 512; g.B = W; g.ldb = 512; g.M = 16384; g.N = 512; g.K = 512; g.C = C; g.ldc = 512; g.epi = B16_FWD;
+    run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
+    run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
+    printf("cfg2 D forward 32768 x 256 x 256\n");
+    g.lda = 256; g.ldb = 256; g.M = 32768; g.N = 256; g.K = 256; g.ldc = 256;
+    run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
+    run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
+    printf("cfg3 X-projection 32768 x 2048 x 512\n");
+    g.lda = 512; g.ldb = 512; g.M = 32768; g.N = 2048; g.K = 512; g.ldc = 2048;
+    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
   }
   return 0;
 }
