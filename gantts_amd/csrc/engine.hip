@@ -2303,9 +2303,18 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
       a.ld_up_add = ncols;
     }
     a.dbias_part = e->s_dbias.as<float>();
-    if (sru_loader_waves()) {
-      CHK(ensure_dyn_lds((const void*)sru_bwd_lw_kernel, sru_bwd_lw_lds()));
-      hipLaunchKernelGGL(sru_bwd_lw_kernel, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_bwd_lw_lds(), s, a);
+    // bf16 storage with loader waves, whole blocks of 8 frames, whole workgroups inside one sequence and one direction: dU leaves
+    // the scan as the bf16 images the two products read (no float32 dU, no cast pass)
+    const bool du_b16 = b16 && sru_loader_waves() && T % 8 == 0 && H % 64 == 0;
+    if (du_b16) {
+      B16Img& DU = e->s_du_b;
+      CHK(DU.ensure(N, ncols * L.k, true));
+      a.dU = nullptr; a.dU_b = DU.r(); a.ld_dub = DU.ld; a.dU_bt = DU.t(); a.ld_dubt = DU.ldt;
+      CHK(ensure_dyn_lds((const void*)sru_bwd_lw_kernel<true>, sru_bwd_lw_lds()));
+      hipLaunchKernelGGL(sru_bwd_lw_kernel<true>, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_bwd_lw_lds(), s, a);
+    } else if (sru_loader_waves()) {
+      CHK(ensure_dyn_lds((const void*)sru_bwd_lw_kernel<false>, sru_bwd_lw_lds()));
+      hipLaunchKernelGGL(sru_bwd_lw_kernel<false>, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_bwd_lw_lds(), s, a);
     } else {
       hipLaunchKernelGGL(sru_bwd_kernel, dim3(cdiv((long)B * ncols, SRU_THREADS)), dim3(SRU_THREADS), 0, s, a);
     }
@@ -2318,8 +2327,10 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     if (b16) {
       // dU -> bf16 image in both orientations (one pass); dW = xinT . dUT^T over the frames, d in = dU . W^T
       B16Img& DU = e->s_du_b;
-      CHK(DU.ensure(N, ncols * L.k, true));
-      CHK(cast_transpose<float>(e->s_du.as<float>(), ncols * L.k, N, ncols * L.k, DU.r(), DU.ld, DU.t(), DU.ldt, nullptr, false, &e->colp, s));
+      if (!du_b16) {
+        CHK(DU.ensure(N, ncols * L.k, true));
+        CHK(cast_transpose<float>(e->s_du.as<float>(), ncols * L.k, N, ncols * L.k, DU.r(), DU.ld, DU.t(), DU.ldt, nullptr, false, &e->colp, s));
+      }
       B16Img& I = e->s_in_b[l];
       CHK(weight_grad_b16(I.t(), I.ldt, DU.t(), DU.ldt, N, L.in, ncols * L.k, L.dW, nullptr, acc, e->slabs, s));
     } else {

@@ -40,6 +40,10 @@ struct SruArgs {
   // backward only: this layer's output is the NEXT layer's input, and that layer's variational input dropout (+ its k == 3
   // highway gradient) is applied here, where the gradient is read: dh = g * up_mul[b][col] + up_add.  The multiplier is
   // constant per lane (one (sequence, column) pair per lane).
+  // backward, GT_OPT_MATMUL_BF16 with loader waves (T % 8 == 0, H % 64 == 0, B * ncols % 64 == 0): dU leaves the scan as the two
+  // bf16 images the products read (row-major [N][ld_dub], transposed [ncols*k][ld_dubt]) instead of float32 + a cast pass
+  __bf16* dU_b; int ld_dub;
+  __bf16* dU_bt; long ld_dubt;
   const float* up_mul;            // [B][ncols] multipliers {0, 1/(1-p)} of the next layer's input dropout, or null
   const float* up_add; int ld_up_add;   // [N][ncols] highway gradient of the next layer (k == 3), or null
 };
@@ -207,7 +211,7 @@ __device__ __forceinline__ void sru_ring_barrier() { asm volatile("s_waitcnt lgk
 constexpr int SRU_LW_THREADS = 256;
 constexpr int SRU_LW_FBF = 12, SRU_LW_FBB = 8;      // frames per block, forward / backward
 constexpr size_t sru_fwd_lw_lds() { return (size_t)3 * SRU_LW_FBF * 4 * 64 * sizeof(float); }
-constexpr size_t sru_bwd_lw_lds() { return (size_t)3 * SRU_LW_FBB * 7 * 64 * sizeof(float); }
+constexpr size_t sru_bwd_lw_lds() { return (size_t)(3 * SRU_LW_FBB * 7 * 64 + 2 * SRU_LW_FBB * 4 * 64) * sizeof(float); }   // in ring + (B16OUT) out ring
 
 // grid = ceil(B*ncols / 64) workgroups of 256
 __global__ __launch_bounds__(SRU_LW_THREADS) void sru_fwd_lw_kernel(const SruArgs a) {
@@ -281,9 +285,19 @@ __global__ __launch_bounds__(SRU_LW_THREADS) void sru_fwd_lw_kernel(const SruArg
   }
 }
 
+__device__ __forceinline__ unsigned sru_pack_bf16x2(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+// B16OUT: dU as bf16 images.  The recurrence wave leaves a block's dU (8 frames x k values x 64 columns, float32) in a 2-slot LDS
+// ring; during the next block the three loader waves -- which have issue slots to spare -- round it to bf16 and write both images
+// with 16-byte stores: one chunk of the row-major image (8 consecutive gate columns of one frame) and one of the transposed image
+// (8 consecutive frames of one gate column) per lane.  The recurrence wave issues no dU store at all.
+template <bool B16OUT>
 __global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArgs a) {
   constexpr int FB = SRU_LW_FBB;
+  static_assert(FB == 8, "a transposed-image chunk is 8 frames");
   extern __shared__ __attribute__((aligned(16))) float ring[];      // [3][FB][7][64]: u0, u1, u2, x', c of the predecessor frame, dh, highway gradient
+  float* oring = ring + 3 * FB * 7 * 64;                             // B16OUT: [2][FB][4][64] dU of the block just walked
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ncols = a.H * a.dirs;
   const long gid0 = (long)blockIdx.x * 64 + lane;
@@ -322,19 +336,50 @@ __global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArg
 #pragma unroll
         for (int j = 0; j < 7; ++j) r[(q * 7 + j) * 64] = v[q][j];
     };
+    // B16OUT: block j's dU -> bf16 images.  The workgroup's 64 columns are one sequence's (B * ncols % 64 == 0 and ncols % 64 == 0)
+    // and one direction's (H % 64 == 0): col0 = first column, frames t_lo .. t_lo + 7 ascending = walk order (flip) or reversed
+    const int col0 = (int)(((long)blockIdx.x * 64) % ncols);
+    auto store_block = [&](int j) {
+      const float* o = oring + (size_t)(j & 1) * FB * 4 * 64;
+      const int t_lo = flip ? FB * j : T - FB * (j + 1);
+      const long row0 = (long)b * T + t_lo;
+      const int nchunk = FB * 8 * k;                       // 16-byte chunks of either image: 8 frames x (64 k / 8), resp. 64 k gate columns
+      for (int c = l * 64 + lane; c < nchunk; c += 192) {
+        {   // row-major: frame f (ascending), chunk cc of its 64 k values
+          const int f = c / (8 * k), cc = c % (8 * k), q = flip ? f : FB - 1 - f;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const int idx = 8 * cc + e; v[e] = o[(q * 4 + idx % k) * 64 + idx / k]; }
+          uint4 w;
+          w.x = sru_pack_bf16x2(v[0], v[1]); w.y = sru_pack_bf16x2(v[2], v[3]); w.z = sru_pack_bf16x2(v[4], v[5]); w.w = sru_pack_bf16x2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(a.dU_b + (row0 + f) * a.ld_dub + (long)col0 * k + 8 * cc) = w;
+        }
+        {   // transposed: gate column gc = c (local column c / k, value c % k), its 8 frames ascending
+          const int lc = c / k, jv = c % k;
+          float v[8];
+#pragma unroll
+          for (int f = 0; f < 8; ++f) v[f] = o[((flip ? f : FB - 1 - f) * 4 + jv) * 64 + lc];
+          uint4 w;
+          w.x = sru_pack_bf16x2(v[0], v[1]); w.y = sru_pack_bf16x2(v[2], v[3]); w.z = sru_pack_bf16x2(v[4], v[5]); w.w = sru_pack_bf16x2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(a.dU_bt + ((long)(col0 + lc) * k + jv) * a.ld_dubt + row0) = w;
+        }
+      }
+    };
     if (l < nblk) request(l);
     if (l == 0) { deposit(0); if (3 < nblk) request(3); }
     for (int i = 0; i < nblk; ++i) {
       sru_ring_barrier();
+      if (B16OUT && i > 0) store_block(i - 1);
       const int kb = i + 1;
       if (kb < nblk && kb % 3 == l) { deposit(l); if (kb + 3 < nblk) request(kb + 3); }
     }
+    if (B16OUT) { sru_ring_barrier(); store_block(nblk - 1); }
     return;
   }
   const float bf = a.bias[col], br = a.bias[ncols + col];
   const float mk = sru_mask(a, b, col);
   const float up_mul = a.up_mul ? a.up_mul[(long)b * ncols + col] : 1.f;
-  float* dUb = a.dU + (long)b * T * a.ldu + (long)col * k;
+  float* dUb = B16OUT ? nullptr : a.dU + (long)b * T * a.ldu + (long)col * k;
   float* dxb = a.dx ? a.dx + (long)b * T * a.lddx + col : nullptr;
   float dc = 0.f, dbf = 0.f, dbr = 0.f;
   float c_here = cb[(long)(flip ? 0 : T - 1) * ncols];      // cell state of the first frame of the walk
@@ -354,7 +399,11 @@ __global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArg
       const float dh = fmaf(r[(q * 7 + 5) * 64], up_mul, r[(q * 7 + 6) * 64]);
       const SruBwdOut o = sru_bwd_frame(u0, fg[q], rg[q], xp, c_here, c_prev, dh, dc, mk, a.act);
       dc = o.dc;
-      if (valid) {
+      if (B16OUT) {
+        float* od = oring + ((size_t)(i & 1) * FB + q) * 4 * 64 + lane;
+        od[0 * 64] = o.du0; od[1 * 64] = o.du1; od[2 * 64] = o.du2; od[3 * 64] = o.dxp;
+        if (k == 3) dxb[(long)t * a.lddx] = o.dxp;
+      } else if (valid) {
         float* du = dUb + (long)t * a.ldu;
         du[0] = o.du0; du[1] = o.du1; du[2] = o.du2;
         if (k == 3) dxb[(long)t * a.lddx] = o.dxp; else du[3] = o.dxp;
@@ -363,6 +412,7 @@ __global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArg
       c_here = c_prev;
     }
   }
+  if (B16OUT) sru_ring_barrier();        // the last block's dU is in LDS: the loader waves write it out
   if (valid) {
     a.dbias_part[(long)b * 2 * ncols + col] = dbf;
     a.dbias_part[(long)b * 2 * ncols + ncols + col] = dbr;
