@@ -168,3 +168,43 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_fast_gate_functions_stay_at_rounding_level():
+    """The fast gate functions of the recurrent kernels (gantts_amd/csrc/fast_math.hip.h: e^x = 2^(x log2 e) with the product's
+    rounding error folded back in, sigmoid = rcp(1 + e^-x), tanh by its odd polynomial below 0.3 and (1 - e^-2|x|) / (1 + e^-2|x|)
+    above) restated in float32 numpy -- np.exp2 / the division stand in for v_exp_f32 / v_rcp_f32 (1 ulp each on the device) --
+    against float64: a few 1e-7 relative everywhere, i.e. what the library functions deliver."""
+    f = np.float32
+
+    def fast_exp(x):
+        l2e_hi, l2e_lo, ln2 = f(1.44269502162933349609375), f(1.925963033500011e-8), f(0.6931471805599453)
+        t = (x * l2e_hi).astype(f)
+        r = (x.astype(np.float64) * np.float64(l2e_hi) - t.astype(np.float64)).astype(f)           # fmaf(x, L2E_HI, -t)
+        r = (x.astype(np.float64) * np.float64(l2e_lo) + r.astype(np.float64)).astype(f)           # fmaf(x, L2E_LO, r)
+        e = np.exp2(t.astype(np.float64)).astype(f)
+        return (e.astype(np.float64) * (r * ln2).astype(f).astype(np.float64) + e.astype(np.float64)).astype(f)
+
+    x = np.linspace(-30, 30, 400001).astype(f)
+    ref = np.exp(x.astype(np.float64))
+    assert (np.abs(fast_exp(x).astype(np.float64) - ref) / ref).max() < 3e-7
+    sig = (1.0 / (1.0 + fast_exp(-x).astype(np.float64))).astype(f)
+    refs = 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    assert (np.abs(sig - refs) / refs).max() < 4e-7
+
+    def fast_tanh(x):
+        ax, x2 = np.abs(x), (x * x).astype(f)
+        p = f(-1382. / 155925.)
+        for c in (62. / 2835., -17. / 315., 2. / 15., -1. / 3., 1.):
+            p = (x2.astype(np.float64) * np.float64(p) + np.float64(f(c))).astype(f)
+        p = (x * p).astype(f)
+        t = fast_exp((f(-2.) * ax).astype(f))
+        q = np.copysign(((f(1.) - t).astype(f).astype(np.float64) / (1.0 + t.astype(np.float64))).astype(f), x)
+        return np.where(ax < f(0.3), p, q)
+
+    x = np.linspace(-12, 12, 400001).astype(f)
+    ref = np.tanh(x.astype(np.float64))
+    got = fast_tanh(x).astype(np.float64)
+    assert np.abs(got - ref).max() < 2e-7
+    big = np.abs(x) > 1e-3
+    assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() < 4e-7
