@@ -94,26 +94,55 @@ int main() {
   float* C; CK(hipMalloc((void**)&C, (size_t)M * N * 4 * 2));
   GemmB16Args g; memset(&g, 0, sizeof(g)); g.drop.mode = DROP_NONE; g.drop.scale = 1.f;
 #define CSUM printf("      checksum %.9e\n", checksum(C, (size_t)g.M * g.N));
-#define SWEEP(EPI, NSLAB) { run<64, 64, EPI, 1>(g, NSLAB, s, 3); CSUM \
-    run<128, 128, EPI, 1>(g, NSLAB, s, 3); CSUM run<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM \
-    run_dma<128, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 3>(g, NSLAB, s, 3); CSUM run_dma<128, 128, EPI, 4>(g, NSLAB, s, 3); CSUM \
-    run_dma<64, 64, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<64, 64, EPI, 4>(g, NSLAB, s, 3); CSUM \
-    run_dma<256, 128, EPI, 2>(g, NSLAB, s, 3); CSUM run_dma<256, 256, EPI, 2>(g, NSLAB, s, 3); CSUM }
-  {
-    printf("forward 32768 x 3072 x 1024 (float32 result)\n");
-    g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = N; g.epi = B16_FWD; g.act = ACT_NONE;
-    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 4, 2>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
-    printf("cfg2 forward 16384 x 512 x 512\n");
-    g.A = X; g.lda = 512; g.B = W; g.ldb = 512; g.M = 16384; g.N = 512; g.K = 512; g.C = C; g.ldc = 512; g.epi = B16_FWD;
-    run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
-    run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
-    printf("cfg2 D forward 32768 x 256 x 256\n");
-    g.lda = 256; g.ldb = 256; g.M = 32768; g.N = 256; g.K = 256; g.ldc = 256;
-    run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
-    run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5); CSUM
-    printf("cfg3 X-projection 32768 x 2048 x 512\n");
-    g.lda = 512; g.ldb = 512; g.M = 32768; g.N = 2048; g.K = 512; g.ldc = 2048;
-    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); CSUM run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); CSUM
+  // every tile shape / loader on one product: register-staged 64 and 128 tiles (1 / 2 stages in flight), LDS-DMA rings with 4- and
+  // 8-wave workgroups, the 256 x 256 tile, the experiment of tools/experiments/gemm_b16_big.hip.h
+#define VARIANTS(EPI) { run<64, 64, EPI, 1>(g, 1, s, 3); CSUM run<128, 128, EPI, 1>(g, 1, s, 3); CSUM run<128, 128, EPI, 2>(g, 1, s, 3); CSUM \
+    run_dma<128, 128, EPI, 2>(g, 1, s, 3); CSUM run_dma<128, 128, EPI, 3>(g, 1, s, 3); CSUM run_dma<128, 128, EPI, 2, 2, 4>(g, 1, s, 3); CSUM \
+    run_dma<256, 256, EPI, 2>(g, 1, s, 3); CSUM run_dma<256, 256, EPI, 2, 2, 4>(g, 1, s, 3); CSUM run_big<EPI>(g, 1, s, 3); CSUM }
+  printf("forward 32768 x 3072 x 1024 (float32 result)\n");
+  g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = N; g.epi = B16_FWD; g.act = ACT_NONE;
+  VARIANTS(B16_FWD)
+  printf("  ... with the L2-aware band order (band_c = 4)\n");
+  g.band_c = 4; run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3); g.band_c = 0;
+  printf("backward-data 32768 x 1024 x 3072 (float32 result)\n");
+  g.A = DU; g.lda = N; g.B = W2; g.ldb = N; g.M = M; g.N = K; g.K = N; g.C = C; g.ldc = K; g.epi = B16_BWD_DATA;
+  VARIANTS(B16_BWD_DATA)
+  printf("weight gradient 1024 x 3072 over 32768 frames, by slab count\n");
+  g.A = XT; g.lda = M; g.B = DUT; g.ldb = M; g.M = K; g.N = N; g.K = M; g.C = C; g.ldc = N; g.epi = B16_SLAB; g.slab_stride = (long)K * N;
+  for (int ns : {1, 2, 4, 5, 8, 16}) {
+    g.k_chunk = ((M / ns + 63) / 64) * 64;
+    printf("  %d slabs (k_chunk %d)\n", ns, g.k_chunk);
+    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2, 2, 4>(g, ns, s, 3); run_dma<256, 256, B16_SLAB, 2, 2, 4>(g, ns, s, 3);
   }
+  printf("weight gradient 512 x 2048 over 32768 frames (cfg3 W_ih), by slab count\n");
+  g.M = 512; g.N = 2048; g.ldc = 2048; g.slab_stride = 512L * 2048;
+  for (int ns : {2, 4, 8, 16}) {
+    g.k_chunk = ((M / ns + 63) / 64) * 64;
+    printf("  %d slabs\n", ns);
+    run<64, 64, B16_SLAB, 1>(g, ns, s, 3); run<128, 128, B16_SLAB, 1>(g, ns, s, 3); run_dma<128, 128, B16_SLAB, 2, 2, 4>(g, ns, s, 3);
+  }
+  g.k_chunk = 0;
+  printf("cfg2 forward 16384 x 512 x 512\n");
+  g.A = X; g.lda = 512; g.B = W; g.ldb = 512; g.M = 16384; g.N = 512; g.K = 512; g.C = C; g.ldc = 512; g.epi = B16_FWD;
+  run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5);
+  run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5);
+  printf("cfg3 X-projection 32768 x 2048 x 512\n");
+  g.M = 32768; g.N = 2048; g.ldc = 2048;
+  run<128, 128, B16_FWD, 1>(g, 1, s, 3); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3);
+#ifdef GT_B16_CLK_DBG
+  {   // shader clock under this load: per-workgroup clock64() / wall_clock64() deltas around the K loop
+    unsigned long long* dbg; CK(hipMalloc((void**)&dbg, 16 * 8192));
+    printf("forward 32768 x 3072 x 1024, 128 x 128 dma ring 2, clock probe\n");
+    g.A = X; g.lda = K; g.B = W; g.ldb = K; g.M = M; g.N = N; g.K = K; g.C = C; g.ldc = N; g.epi = B16_FWD;
+    CK(hipMemset(dbg, 0, 16 * 8192));
+    g.rowsum_slab = reinterpret_cast<float*>(dbg);
+    run_dma<128, 128, B16_FWD, 2>(g, 1, s, 1);
+    std::vector<unsigned long long> h(2 * 6144); CK(hipMemcpy(h.data(), dbg, 16 * 6144, hipMemcpyDeviceToHost));
+    double mhz_min = 1e9, mhz_max = 0, mhz_sum = 0, us_sum = 0; int n = 0;
+    for (int i = 0; i < 6144; ++i) if (h[2 * i + 1]) { const double mhz = 100.0 * h[2 * i] / h[2 * i + 1]; mhz_min = std::min(mhz_min, mhz); mhz_max = std::max(mhz_max, mhz); mhz_sum += mhz; us_sum += h[2 * i + 1] / 100.0; ++n; }
+    printf("    %d workgroups: shader clock %.0f .. %.0f MHz, mean %.0f; K loop of a tile %.1f us on average (16 stages)\n", n, mhz_min, mhz_max, mhz_sum / n, us_sum / n);
+    g.rowsum_slab = nullptr;
+  }
+#endif
   return 0;
 }
