@@ -93,6 +93,7 @@ SIGNATURES = {
     "gt_comm_init": (_I, [_P, _I, _I, _P]),
     "gt_comm_destroy": (_I, [_P]),
     "gt_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "gt_set_shard": (_I, [_P, _I, _I]),
     "gt_update_discriminator_begin": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "gt_update_discriminator_end": (_I, [_P, _I, C.POINTER(DResult), _P]),
     "gt_update_generator_begin": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _F, _F, _P]),

@@ -750,6 +750,9 @@ struct gt_engine {
   Scratch l_state, l_dout, l_hshift;
   Scratch l_xch;                                   // persistent recurrence: exchange granules
   struct GtComm* comm = nullptr;                   // gt_comm_init: RCCL communicator + comm stream (data parallel)
+  int dp_rank = 0, dp_world = 1;                   // this engine's shard of the minibatch (gt_comm_init / gt_set_shard): sequence b here
+                                                   // is sequence dp_rank + dp_world * b of the whole minibatch (round-robin dealing)
+  int chk_B = 0, chk_T = 0;                        // (B, T) of the entry point that is running (check_common)
   std::vector<std::pair<long, long>> comm_done[2]; // per role: gradient ranges (offset, count) already handed to RCCL this step
   std::vector<std::pair<long, long>> comm_pending[2];   // final on the step stream, not handed over yet (merged into few messages)
   Scratch comm_tv;                                 // device double: global valid-frame count
@@ -1064,7 +1067,16 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_LSTM_PERSISTENT: e->lstm_persistent = value != 0; return GT_OK;
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
     case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
-    case GT_OPT_MATMUL_BF16: e->matmul_bf16 = value != 0; return GT_OK;
+    case GT_OPT_MATMUL_BF16:
+      // the storage precision belongs to a PASS: buffers of a stashed forward pass (bf16 images vs float32 stashes) are not
+      // interchangeable, so a change drops whatever is stashed -- the next update_* then asks for a fresh apply_generator
+      // instead of back-propagating through buffers the forward never filled
+      if (e->matmul_bf16 != (value != 0)) {
+        e->g_pass_valid = false; e->fake_cat_valid = false; e->dcat_b_ok = false; e->leak_pending = false;
+        e->d_begin_done = false; e->g_begin_done = false;
+      }
+      e->matmul_bf16 = value != 0;
+      return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
 }
@@ -1124,30 +1136,47 @@ extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {
   return GT_OK;
 }
 
-static int comm_rank(const gt_engine* e);
 // Philox dropout site (role, pass, layer) of engine step `step`: the keep decision of element (row, col) is
 // philox_keep(key0, key1, thresh, row, col) (gemm_f32.hip.h) -- a function of the site and the element only, not of
 // the tiling of whichever kernel applies it.  The keep probability is quantised to 16 bits (thresh = round(p * 2^16)):
 // exact for p = k / 65536 (0.5, 0.25, ...), otherwise |P(keep) - (1-p)| <= 2^-17 while the survivors are scaled by
 // the nominal 1/(1-p) like nn.Dropout does.
-static DropoutSpec philox_site_spec(gt_engine* e, int role, int pass, int layer, uint64_t step, float p) {
+// Data parallel ("Dropout/noise RNG keyed by global sequence index so DP=k reproduces DP=1"): with world > 1 the
+// site's row groups are mapped to the groups the same frames have in the one-process minibatch (DropoutSpec::dp_*,
+// philox_group in gemm_f32.hip.h), so a world-k run draws exactly the masks a world-1 run draws for the whole minibatch
+// (the reference draws ONE mask over the whole minibatch: models.py:139, train.py:538-585).  `half_rows`: rows of one half of
+// a [real | generated] two-half pass, 0 for a single block.  The map needs whole 16-row groups per sequence (T % 16 == 0);
+// for other T the rank is folded into the key instead (independent masks per rank: valid dropout, not world-1's bits).
+static DropoutSpec philox_site_spec(gt_engine* e, int role, int pass, int layer, uint64_t step, float p, long half_rows = 0) {
   DropoutSpec d = no_drop();
   d.p = p;
   d.scale = 1.f / (1.f - p);
   d.mode = DROP_PHILOX;
   const double th = (double)p * 65536.0 + 0.5;
   d.thresh = th >= 65535.0 ? 65535u : (uint32_t)th;
-  // data parallel: every rank draws its own masks (the rank is part of the site), as the reference's single process
-  // draws an independent mask for every frame of the whole minibatch
   const uint64_t site = step * 64ULL + (uint64_t)(role * 32 + pass * 16 + layer);
-  const uint32_t rk = (uint32_t)comm_rank(e);
+  uint32_t rk = 0;
+  if (e->dp_world > 1) {
+    const int T = e->chk_T, B = e->chk_B;
+    const long groups = ((long)B * T / 16) * e->dp_world * 2;
+    if (T > 0 && T % 16 == 0 && groups < (1L << 21) && (half_rows == 0 || half_rows == (long)B * T)) {
+      d.dp_t16 = (uint32_t)(T / 16);
+      d.dp_inv_t16 = 1.f / (float)d.dp_t16;
+      d.dp_nl16 = half_rows ? (uint32_t)(half_rows / 16) : 0xffffffffu;
+      d.dp_half = half_rows ? (uint32_t)((long)B * e->dp_world * (T / 16) - half_rows / 16) : 0u;
+      d.dp_add = (uint32_t)e->dp_rank * d.dp_t16;
+      d.dp_mul = (uint32_t)(e->dp_world - 1) * d.dp_t16;
+    } else {
+      rk = (uint32_t)e->dp_rank;
+    }
+  }
   d.key0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL)) ^ (rk * 0x85EBCA6Bu);
   d.key1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0xA5A5A5A5u) + (uint32_t)site + rk * 0xC2B2AE35u;
   return d;
 }
 
 // dropout spec of (role, pass, layer).  rows_off: first row of `pass` inside the stacked mask buffer.
-static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const float* stacked_mask, int ld) {
+static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const float* stacked_mask, int ld, long half_rows = 0) {
   Net& n = e->net[role];
   DropoutSpec d = no_drop();
   if (!n.training || n.d.dropout <= 0.f) return d;
@@ -1157,7 +1186,7 @@ static DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const 
     d.mode = DROP_BUFFER; d.mask = stacked_mask; d.ld_mask = ld;
     return d;
   }
-  return philox_site_spec(e, role, pass, layer, e->step_counter, n.d.dropout);
+  return philox_site_spec(e, role, pass, layer, e->step_counter, n.d.dropout, half_rows);
 }
 
 // Parity hook: the 0/1 keep mask the engine's Philox stream assigns to dropout site (role, pass, layer) of the step
@@ -1167,7 +1196,9 @@ extern "C" int gt_op_philox_mask(gt_engine* e, int role, int pass, int layer, in
   if (!e || !mask || role < 0 || role > 1 || pass < 0 || pass > 2 || layer < 0 || layer > 15 || rows < 1 || cols < 1 ||
       steps_ahead < 0 || !(p > 0.f && p < 1.f) || rows > 0x7fffffffL)
     return fail(GT_ERR_INVALID, "bad argument");
-  const DropoutSpec d = philox_site_spec(e, role, pass, layer, e->step_counter + (uint64_t)steps_ahead, p);
+  // (data parallel: the row-group map of the last entry point's (B, T); a 2*B*T-row request is the D step's two-half pass)
+  const DropoutSpec d = philox_site_spec(e, role, pass, layer, e->step_counter + (uint64_t)steps_ahead, p,
+                                         rows == 2L * e->chk_B * e->chk_T ? (long)e->chk_B * e->chk_T : 0L);
   hipLaunchKernelGGL(philox_mask_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d, rows, cols, mask);
   LAUNCH_CHECK();
   return GT_OK;
@@ -1289,7 +1320,7 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
     CHK(acts[l].ensure((size_t)rows * L.out * sizeof(float)));
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
-    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out);
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
     const float* W = L.W;
     int ldw = L.in;
     if (l == 0 && (L.in & 3) && gemm_vec_ok(cur, ld) && tl_gemm_prec == PREC_F32) {
@@ -1411,7 +1442,7 @@ static int stack_forward_b16(gt_engine* e, int role, const __bf16* in_b, int ld_
     CHK(acts[l].ensure(rows, L.out, want_t));
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
-    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out);
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
     GemmB16Args g = b16_args();
     g.A = cur; g.lda = ld; g.B = e->wsh[role][l].w.as<__bf16>(); g.ldb = e->wsh[role][l].ldw;
     g.M = (int)rows; g.N = L.out; g.K = L.in; g.bias = L.b; g.epi = B16_FWD; g.act = ACT_LEAKY_DROPOUT; g.drop = specs[l];
@@ -1556,6 +1587,7 @@ extern "C" int gt_comm_destroy(gt_engine* e) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   e->comm = nullptr;
+  e->dp_rank = 0; e->dp_world = 1;
   return GT_OK;
 }
 extern "C" int gt_comm_init(gt_engine* e, int rank, int world, const void* id) {
@@ -1566,6 +1598,7 @@ extern "C" int gt_comm_init(gt_engine* e, int rank, int world, const void* id) {
   GtComm* c = new GtComm();
   c->rank = rank; c->world = world;
   e->comm = c;
+  e->dp_rank = rank; e->dp_world = world;
   GtNcclId nid;
   memcpy(&nid, id, sizeof(nid));
   int r = api->CommInitRank(&c->comm, world, nid, rank);
@@ -1576,6 +1609,16 @@ extern "C" int gt_comm_init(gt_engine* e, int rank, int world, const void* id) {
   CHK(e->comm_tv.ensure(64));
   return GT_OK;
 }
+// The engine's shard of the minibatch without a communicator (hosts that all-reduce themselves between the split-phase
+// calls, gantts_amd/parallel.py): sequence b of this engine is sequence rank + world * b of the whole minibatch.  Keys the
+// dropout streams globally, so that every rank draws its own rows of the ONE mask a single process would draw.
+extern "C" int gt_set_shard(gt_engine* e, int rank, int world) {
+  if (!e || world < 1 || rank < 0 || rank >= world) return fail(GT_ERR_INVALID, "bad argument");
+  if (e->comm && (e->comm->rank != rank || e->comm->world != world))
+    return fail(GT_ERR_STATE, "gt_set_shard(%d, %d) contradicts the attached communicator (%d, %d)", rank, world, e->comm->rank, e->comm->world);
+  e->dp_rank = rank; e->dp_world = world;
+  return GT_OK;
+}
 extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
   if (!e || !rank || !world) return fail(GT_ERR_INVALID, "null argument");
   *rank = e->comm ? e->comm->rank : 0;
@@ -1583,7 +1626,6 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
   return GT_OK;
 }
 
-static int comm_rank(const gt_engine* e) { return e->comm ? e->comm->rank : 0; }
 static inline bool comm_on(const gt_engine* e) {
   static const bool force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
   return e->comm != nullptr && (e->comm->world > 1 || force);
@@ -1708,6 +1750,7 @@ static int check_common(gt_engine* e, int B, int T) {
   tl_gemm_prec = e->matmul_bf16 ? PREC_BF16 : PREC_F32;       // every step / forward entry point passes through here
   if (B < 1 || T < 1) return fail(GT_ERR_INVALID, "B and T must be positive");
   if ((long)B * T > 0x3fffffffL) return fail(GT_ERR_INVALID, "B*T too large");
+  e->chk_B = B; e->chk_T = T;
   return GT_OK;
 }
 
@@ -2117,10 +2160,11 @@ static int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, i
 // recurrent generator (GT_ARCH_SRU)
 // ------------------------------------------------------------------------------------------
 static void sru_keys(gt_engine* e, int layer, int which, uint32_t* k0, uint32_t* k1) {
+  // data parallel: the masks are per (sequence, column); the kernels count sequences globally (SruArgs::seq_mul / seq_add), so a
+  // world-k run draws the whole minibatch's masks of a world-1 run -- no rank in the key
   const uint64_t site = e->step_counter * 64ULL + 40 + (uint64_t)(layer * 2 + which);
-  const uint32_t rk = (uint32_t)comm_rank(e);        // data parallel: every rank its own masks (see philox_site_spec)
-  *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL)) ^ (rk * 0x85EBCA6Bu);
-  *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site + rk * 0xC2B2AE35u;
+  *k0 = (uint32_t)(e->seed ^ (site * 0x9E3779B97F4A7C15ULL));
+  *k1 = (uint32_t)((e->seed >> 32) ^ (site >> 7) ^ 0x5A5A5A5Au) + (uint32_t)site;
 }
 static uint32_t drop_thresh(float p) {
   const double th = (double)p * 4294967296.0;
@@ -2137,6 +2181,7 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
   a.x = in; a.ldx = ld_in;
   a.bias = L.b;
   a.h = e->s_h[l].as<float>(); a.c = e->s_c[l].as<float>();
+  a.seq_mul = e->dp_world; a.seq_add = e->dp_rank;
   if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {   // the last layer has dropout 0 (SRU.__init__)
     a.use_mask = 1; a.keep_scale = 1.f / (1.f - G.d.dropout); a.thresh = drop_thresh(G.d.dropout);
     sru_keys(e, l, 1, &a.key0, &a.key1);
@@ -2185,7 +2230,7 @@ static int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat,
       sru_keys(e, l, 0, &k0, &k1);
       hipLaunchKernelGGL(sru_input_mask_kernel, dim3(cdiv((long)B * L.in, 256)), dim3(256), 0, s, e->s_xmask[l].as<float>(), B, L.in,
                          1.f / (1.f - G.d.rnn_dropout), drop_thresh(G.d.rnn_dropout), k0, k1,
-                         (const float*)G.inj[0][2 * l]);                        // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
+                         (const float*)G.inj[0][2 * l], e->dp_world, e->dp_rank);     // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
       LAUNCH_CHECK();
     }
     if (rdrop && !b16) {      // float32 products read a dropped float32 copy
@@ -2298,6 +2343,8 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
     float* dx_res = L.k == 3 ? (rdrop ? dx_of(l) : dh_other) : nullptr;
     a.dx = dx_res; a.lddx = ncols;
     if (rdrop && l + 1 < Lc) {      // dh is the raw dU.W^T of the layer above: its input dropout and highway gradient are applied by the scan
+      if (G.sru[l + 1].in != ncols || !e->s_xmask[l + 1].p)
+        return fail(GT_ERR_STATE, "SRU backward: layer %d's input-dropout table is missing or not %d wide", l + 1, ncols);
       a.up_mul = e->s_xmask[l + 1].as<float>();
       a.up_add = G.sru[l + 1].k == 3 ? dx_of(l + 1) : nullptr;
       a.ld_up_add = ncols;
@@ -2358,6 +2405,9 @@ static int sru_backward(gt_engine* e, const float* x, const float* gy, int B, in
       }
       std::swap(dh, dh_other);         // (with input dropout: finished by the scan of layer l - 1, SruArgs::up_mul / up_add)
     }
+    // l == 0: no gradient with respect to the network input is produced on this path (nothing upstream of the generator
+    // takes one: x is data, train.py:542).  NOTE for anything that wants to read `dh` between layers: with rnn_dropout it
+    // is the RAW dU.W^T -- the input-dropout mask and the k = 3 highway term are applied by the next scan's loads.
   }
   return GT_OK;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 }
 
 __device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int col) {
-  if (d.mode == DROP_PHILOX) return philox_keep(d.key0, d.key1, d.thresh, row, col);
+  if (d.mode == DROP_PHILOX) return philox_keep_spec(d, row, col);
   if (d.mode == DROP_BUFFER) return d.mask[(long)row * d.ld_mask + col] != 0.f;
   return true;
 }
@@ -57,7 +57,7 @@ __global__ void philox_mask_kernel(const DropoutSpec d, long rows, int cols, flo
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
   const int r = (int)(e / cols), c = (int)(e - (long)r * cols);
-  mask[e] = philox_keep(d.key0, d.key1, d.thresh, r, c) ? 1.f : 0.f;
+  mask[e] = philox_keep_spec(d, r, c) ? 1.f : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
       keepb[j] = 0xffu;
       if (want_grad && has_act && drop.mode == DROP_PHILOX) {
         uint32_t rnd[4];
-        philox4x32_10((uint32_t)(2 * g + h), (uint32_t)kidx[j], drop.key0, drop.key1, rnd);
+        philox4x32_10(2u * philox_group(drop, (uint32_t)g) + (uint32_t)h, (uint32_t)kidx[j], drop.key0, drop.key1, rnd);
         uint32_t bits = 0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) bits |= (philox_piece(rnd, p) >= drop.thresh ? 1u : 0u) << p;
@@ -901,6 +901,7 @@ __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (fault_host) *fault_host = *fault_dev;
       if (skipped_host) *skipped_host += 1u;
+      if (norm2_out) *norm2_out = __longlong_as_double(0x7ff8000000000000LL);   // no update, no norm: NaN, not the previous step's value
     }
     return;
   }

@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_b16_epilogue(const GemmB16Args& g, const in
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;     // rows mrow .. mrow + 3
         if (philox && (q & 1) == 0)
-          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)nc, g.drop.key0, g.drop.key1, rnd);
+          philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)nc, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const long mc = min(mrow + s, g.M - 1);

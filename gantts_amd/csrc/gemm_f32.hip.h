@@ -62,7 +62,24 @@ struct DropoutSpec {
   uint32_t key0, key1;  // philox key: (seed, site/step)
   const float* mask;  // DROP_BUFFER: [rows][ld_mask] 0/1 floats
   int ld_mask;
+  // Data parallel ("RNG keyed by global sequence index so DP=k reproduces DP=1"; world > 1, T % 16 == 0): the
+  // 16-row group g of this rank's LOCAL rows holds frames t0..t0+15 of local sequence b of half h ([real | generated] pass);
+  // its keep bits are those of the group the same frames have in the one-process minibatch, where local sequence b of
+  // rank r is sequence r + world * b (round-robin dealing):  philox_group().  dp_t16 == 0: identity (one rank).
+  uint32_t dp_t16;    // T / 16
+  uint32_t dp_nl16;   // 16-row groups per half of a two-half pass (local), 0xffffffff for a single block of rows
+  uint32_t dp_half;   // added to the groups of the second half: B_global * T / 16 - dp_nl16
+  uint32_t dp_add;    // rank * T / 16
+  uint32_t dp_mul;    // (world - 1) * T / 16 per local sequence
+  float dp_inv_t16;   // 1 / dp_t16
 };
+__device__ __forceinline__ uint32_t philox_group(const DropoutSpec& d, uint32_t g) {
+  if (d.dp_t16 == 0u) return g;                   // kernel-argument uniform
+  const uint32_t h = g >= d.dp_nl16 ? 1u : 0u;
+  const uint32_t gg = g - h * d.dp_nl16;
+  const uint32_t b = (uint32_t)(((float)gg + 0.5f) * d.dp_inv_t16);   // exact for gg < 2^21 (the engine checks)
+  return g + h * d.dp_half + d.dp_add + b * d.dp_mul;
+}
 
 // ---- Philox4x32-10, counter = (row>>2, col, 0, 0): word j decides row (row&~3)+j ------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1,
@@ -90,6 +107,13 @@ __device__ __forceinline__ bool philox_keep(uint32_t key0, uint32_t key1, uint32
   uint32_t r[4];
   philox4x32_10((uint32_t)(2 * (row >> 4) + ((row >> 2) & 1)), (uint32_t)col, key0, key1, r);
   return philox_piece(r, 4 * ((row >> 3) & 1) + (row & 3)) >= thresh;
+}
+
+// the same decision for a dropout site (applies the data-parallel row-group map)
+__device__ __forceinline__ bool philox_keep_spec(const DropoutSpec& d, int row, int col) {
+  uint32_t r[4];
+  philox4x32_10(2u * philox_group(d, (uint32_t)row >> 4) + (((uint32_t)row >> 2) & 1u), (uint32_t)col, d.key0, d.key1, r);
+  return philox_piece(r, 4 * ((row >> 3) & 1) + (row & 3)) >= d.thresh;
 }
 
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : 0.01f * z; }
@@ -244,7 +268,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
         for (int q = 0; q < 4; ++q) {
           const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
           if (philox && (q & 1) == 0)
-            philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+            philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
             const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
@@ -308,7 +332,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
         if (philox && (q & 1) == 0)
-          philox4x32_10((uint32_t)(2 * (mrow >> 4) + half), (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
+          philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;

@@ -36,6 +36,7 @@ struct SruArgs {
   float* dbias_part;              // [B][2*ncols]
   // variational output dropout (one mask per (sequence, column), shared over time)
   int use_mask; float keep_scale; uint32_t thresh, key0, key1;
+  int seq_mul, seq_add;           // data parallel: local sequence b is sequence seq_add + seq_mul * b of the whole minibatch (1, 0 on one rank)
   const float* mask_buf;          // parity hook: injected 0/1 keep mask [B][ncols] instead of the Philox stream
   // backward only: this layer's output is the NEXT layer's input, and that layer's variational input dropout (+ its k == 3
   // highway gradient) is applied here, where the gradient is read: dh = g * up_mul[b][col] + up_add.  The multiplier is
@@ -56,7 +57,7 @@ __device__ __forceinline__ float sru_mask(const SruArgs& a, int b, int col) {
   if (!a.use_mask) return 1.f;
   if (a.mask_buf) return a.mask_buf[(long)b * (a.H * a.dirs) + col] != 0.f ? a.keep_scale : 0.f;
   uint32_t r[4];
-  philox4x32_10((uint32_t)b, (uint32_t)col, a.key0, a.key1, r);
+  philox4x32_10((uint32_t)(a.seq_add + a.seq_mul * b), (uint32_t)col, a.key0, a.key1, r);
   return r[0] >= a.thresh ? a.keep_scale : 0.f;
 }
 
@@ -423,14 +424,14 @@ __global__ __launch_bounds__(SRU_LW_THREADS) void sru_bwd_lw_kernel(const SruArg
 // injected 0/1 mask of the parity hook) and read by the forward pass (dropout kernel below, or the fused dropout + bf16
 // cast of GT_OPT_MATMUL_BF16) and by the backward scan of the layer underneath (SruArgs::up_mul).
 __global__ void sru_input_mask_kernel(float* __restrict__ mul, int B, int n, float keep_scale, uint32_t thresh, uint32_t key0, uint32_t key1,
-                                      const float* __restrict__ inj) {
+                                      const float* __restrict__ inj, int seq_mul, int seq_add) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * n) return;
   bool keep;
   if (inj) keep = inj[e] != 0.f;
   else {
     uint32_t r[4];
-    philox4x32_10((uint32_t)(e / n), (uint32_t)(e % n), key0, key1, r);
+    philox4x32_10((uint32_t)(seq_add + seq_mul * (e / n)), (uint32_t)(e % n), key0, key1, r);
     keep = r[0] >= thresh;
   }
   mul[e] = keep ? keep_scale : 0.f;

@@ -150,6 +150,11 @@ class StepEngine(object):
     def comm_destroy(self):
         check(lib.gt_comm_destroy(self._h))
 
+    def set_shard(self, rank, world):
+        """This engine holds sequences rank, rank + world, ... of the minibatch (no communicator: the host all-reduces between
+        the split-phase calls).  Keys the dropout streams globally, so a world-k run reproduces the one-process masks."""
+        check(lib.gt_set_shard(self._h, int(rank), int(world)))
+
     def comm_info(self):
         r, w = C.c_int(), C.c_int()
         check(lib.gt_comm_info(self._h, C.byref(r), C.byref(w)))
@@ -463,6 +468,9 @@ class HipStepBackend(object):
 
     def set_option(self, name, value):
         self.engine.set_option(name, value)
+
+    def set_shard(self, rank, world):
+        self.engine.set_shard(rank, world)
 
     device_normalizer = True      # set_loss_normalizer accepts a CUDA float64 tensor (no host sync)
 

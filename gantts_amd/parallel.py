@@ -28,6 +28,10 @@ class DataParallelStep(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always_reduce = always_reduce and dist.is_initialized()   # exercise the collectives with one rank
         self._pending = None
+        # the backend's dropout streams are keyed by GLOBAL sequence (round-robin dealing: local sequence b of rank r is
+        # sequence r + world * b of the minibatch), so a world-k run draws the masks of the one-process run
+        if self.world > 1 and hasattr(backend, "set_shard"):
+            backend.set_shard(dist.get_rank(process_group), self.world)
         self._coalesce = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and \
             hasattr(dist, "_coalescing_manager")
 

@@ -227,6 +227,13 @@ int gt_comm_unique_id(void* id_out);
 int gt_comm_init(gt_engine* e, int rank, int world, const void* id);
 int gt_comm_destroy(gt_engine* e);
 int gt_comm_info(gt_engine* e, int* rank, int* world);
+/* The shard this engine holds, for hosts that all-reduce themselves between the split-phase calls (no communicator):
+ * sequence b of this engine is sequence rank + world * b of the whole minibatch (round-robin dealing).
+ * gt_comm_init implies it.  It keys the dropout streams by GLOBAL frame / sequence: with T % 16 == 0 a world-k run draws, for
+ * its rows, exactly the bits a one-process run draws for the whole minibatch (the reference draws one mask over the whole
+ * minibatch: gantts/models.py:139 inside train.py:538-585), so data-parallel runs reproduce the single-GPU run; for other T
+ * the MLP sites fall back to independent per-rank streams (the SRU's per-sequence masks are global for every T). */
+int gt_set_shard(gt_engine* e, int rank, int world);
 
 int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                   const float* mask, int B, int T, int train, float eps, void* stream);

@@ -307,6 +307,11 @@ ORACLE_ONLY_CASES = {
         windows=3, steps=2, adv_w=1.0, mse_w=0.5, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
 }
+# gate pre-activations of +-100 (fast_exp must saturate, not produce inf * 0): the persistent LSTM forward
+# kernel's fast gate functions and the SRU scans' fast sigmoids against the oracle's torch.sigmoid / tanh
+ORACLE_ONLY_CASES["acoustic_lstm_saturated"] = dict(CASES["acoustic_lstm"], saturate_gates=True)
+ORACLE_ONLY_CASES["acoustic_sru_saturated"] = dict(ORACLE_ONLY_CASES["acoustic_sru_uni_k3"], saturate_gates=True)
+ORACLE_ONLY_CASES["acoustic_sru_bi_saturated"] = dict(ORACLE_ONLY_CASES["acoustic_sru_dropout"], saturate_gates=True)
 
 
 def param_shapes(spec):
@@ -354,8 +359,10 @@ def param_shapes(spec):
     return out
 
 
-def make_weights(spec, seed):
-    """U(+-1/sqrt(fan_in)) like nn.Linear's default init (U(+-1/sqrt(H)) for LSTM tensors), from numpy RandomState."""
+def make_weights(spec, seed, saturate_gates=False):
+    """U(+-1/sqrt(fan_in)) like nn.Linear's default init (U(+-1/sqrt(H)) for LSTM tensors), from numpy RandomState.
+    saturate_gates: every third element of the recurrent cells' gate biases becomes +-100, so gate pre-activations of
+    about +-100 occur on every layer (sigmoid / tanh must saturate to 0 / 1 / +-1 like torch's, not overflow)."""
     rs = np.random.RandomState(seed)
     sd = {}
     shapes = param_shapes(spec)
@@ -369,6 +376,9 @@ def make_weights(spec, seed):
         if "rnn_lst" in name:        # SRU: U(+-sqrt(3/n_in)) weights, small non-zero biases for the test
             k = math.sqrt(3.0 / shape[0]) if name.endswith("weight") else 0.5
         sd[name] = ((rs.rand(*shape) * 2 - 1) * k).astype(np.float32)
+        if saturate_gates and (".bias_ih" in name or ("rnn_lst" in name and name.endswith("bias"))):
+            idx = np.arange(0, shape[0], 3)
+            sd[name][idx] = np.where((idx // 3) % 2 == 0, -100.0, 100.0).astype(np.float32)
     return sd
 
 

@@ -20,25 +20,28 @@ def make_hp(case):
     return hp
 
 
-def build_model(spec, seed):
+def build_model(spec, seed, saturate_gates=False):
     from gantts_amd import models
     kw = {k: v for k, v in spec.items() if k != "kind"}
     m = getattr(models, spec["kind"])(**kw)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed).items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in C.make_weights(spec, seed, saturate_gates).items()})
     return m.cuda()
 
 
-def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False, shard=None, comm_id=None, extra=None):
+def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False, shard=None, comm_id=None, extra=None,
+                 philox=False):
     """shard = (rank, world): this process holds sequences rank, rank + world, ... of the case's batch (whole
     sequences dealt round-robin) and, with `comm_id`, attaches the engine's communicator (gt_comm_init) first -- the
-    fused step functions are then data-parallel by themselves and every rank must reproduce the WHOLE batch's result."""
+    fused step functions are then data-parallel by themselves and every rank must reproduce the WHOLE batch's result.
+    philox=True: a dropout case runs on the engine's own Philox streams (the production path) instead of injected masks;
+    `extra` then receives the keep masks of the NEXT step's first G site and first D-step site (gt_op_philox_mask)."""
     import gantts_amd.train as T
     from gantts_amd import optim, paramgen
     from gantts_amd.multistream import get_static_features
     from gantts_amd.seqloss import sequence_mask
     hp = make_hp(case)
     T.hp = hp
-    mg, md = build_model(case["g"], 11), build_model(case["d"], 22)
+    mg, md = build_model(case["g"], 11, case.get("saturate_gates", False)), build_model(case["d"], 22)
     if case["dropout_on"]:
         mg.train(), md.train()
     else:
@@ -63,8 +66,6 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
             from gantts_amd.engine import engine_for
             eng = engine_for(hp, mg)
             eng.comm_init(rank, world, comm_id)
-            if extra is not None:      # Philox masks of this rank's next step (data parallel: ranks must draw different ones)
-                extra["philox"] = eng.philox_mask(0, 0, 0, 0.5, 64, 48).cpu().numpy()
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
     Tn = case["T"]
     has_dyn = bool(np.any(case["has_dynamic_features"]))
@@ -73,7 +74,7 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
     cpu_lengths = list(lengths)
     out = {}
     for step in range(case["steps"]):
-        if case["dropout_on"]:
+        if case["dropout_on"] and not philox:
             gm, dm = C.make_dropout_masks(case, step)
             nh = case["d"]["num_hidden"]
             mg.set_dropout_masks(0, [torch.from_numpy(m[rows]) for m in gm])
@@ -97,6 +98,12 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
                                      cpu_lengths, mask, "train", mse_w=case["mse_w"], mge_w=case["mge_w"])
             out["g_scalars_%d" % step] = np.array(res, dtype=np.float64)
     torch.cuda.synchronize()
+    if extra is not None:      # the keep masks the engine would draw for this shard's rows in the next step
+        from gantts_amd.engine import engine_for
+        eng = engine_for(hp, mg)
+        rows = x.shape[0] * Tn
+        extra["philox_g"] = eng.philox_mask(0, 0, 0, 0.5, rows, 48).cpu().numpy()
+        extra["philox_d"] = eng.philox_mask(1, 0, 0, 0.5, 2 * rows, 40).cpu().numpy()
     for k, v in mg.state_dict().items():
         out["G." + k] = v.cpu().numpy()
     for k, v in md.state_dict().items():

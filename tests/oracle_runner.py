@@ -6,7 +6,7 @@ import cases as C
 import gantts_oracle as O
 
 
-def build_oracle_model(spec, seed):
+def build_oracle_model(spec, seed, saturate_gates=False):
     kw = {k: v for k, v in spec.items() if k != "kind"}
     cls = {"MLP": O.OracleMLP, "In2OutHighwayNet": O.OracleIn2OutHighwayNet,
            "LSTMRNN": O.OracleLSTMRNN, "GRURNN": O.OracleLSTMRNN, "SRURNN": O.OracleSRURNN,
@@ -14,7 +14,7 @@ def build_oracle_model(spec, seed):
     if spec["kind"] == "GRURNN":
         kw["prefix"] = "gru"
     m = cls(**kw)
-    m.load_state_dict(C.make_weights(spec, seed))
+    m.load_state_dict(C.make_weights(spec, seed, saturate_gates))
     return m
 
 
@@ -25,7 +25,7 @@ def stream_config(case):
 
 def run_oracle_case(case):
     cfg = stream_config(case)
-    mg, md = build_oracle_model(case["g"], 11), build_oracle_model(case["d"], 22)
+    mg, md = build_oracle_model(case["g"], 11, case.get("saturate_gates", False)), build_oracle_model(case["d"], 22)
     mg.training = md.training = bool(case["dropout_on"])
     og = O.make_optimizer(case["opt_g"][0], mg.params, **case["opt_g"][1])
     od = O.make_optimizer(case["opt_d"][0], md.params, **case["opt_d"][1])
