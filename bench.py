@@ -129,6 +129,11 @@ def main():
                          "weak: every rank gets its own --batch sequences")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2..4] behind the timed region")
+    ap.add_argument("--spinup-ms", type=float, default=400.0,
+                    help="GPU clock spin-up before the warm-up steps: a generic memory-streaming loop (NOT steps of the workload) keeps "
+                         "the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a training "
+                         "run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--dp-python", action="store_true", help="data parallelism orchestrated from Python (torch.distributed "
                     "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
@@ -237,6 +242,18 @@ def main():
         if world > 1 or args.force_dp:
             dist.barrier()
 
+    if args.spinup_ms > 0:
+        # an idle MI355X sits at its lowest DPM state; the driver's 25 steps are 40 ms of work in total, all of it inside the
+        # ramp.  A training run is never in that state, so the device is brought to its working clocks first -- by
+        # streaming over a scratch tensor, nothing of the workload (no engine call, no cache the step would find warm).
+        burn = torch.empty(64 << 20, device=dev, dtype=torch.float32).fill_(1.0)
+        torch.cuda.synchronize()
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(8):
+                burn.mul_(1.0000001)
+            torch.cuda.synchronize()
+        del burn
     profile = not args.no_roofline
     for w in range(args.warmup):
         # the last warm-up step runs instrumented once, so that the event pool of the launch profiler exists before the
@@ -330,6 +347,19 @@ def main():
                "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
                "roofline": roofline}
+        out["config"]["clock_spinup_ms"] = args.spinup_ms
+        if world == 1 and not args.no_other_configs and not args.force_dp:
+            # the other BASELINE.json configurations, a few steps each, BEHIND the headline's timed region
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            del x, y, y_static, mask, R
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for name in bench_configs.ALL:
+                try:
+                    out["other_configs"][name] = bench_configs.run_config(name)
+                except Exception as e:      # noqa: BLE001 -- a failing side measurement must not lose the headline line
+                    out["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Bglobal, Tn)
         print(json.dumps(out), flush=True)

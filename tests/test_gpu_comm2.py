@@ -136,8 +136,8 @@ PHILOX_CASES = {
     "mlp": dict(C.CASES["acoustic_mlp_dropout"], B=4, T=48),
     # 3-layer BiLSTM with nn.LSTM inter-layer dropout (a per-element dropout kernel) + dropout-free D
     "lstm": dict(C.ORACLE_ONLY_CASES["acoustic_lstm_dropout"], B=4, T=32),
-    # SRU with both variational dropouts: masks per (sequence, column) -- global for any T (here T % 16 != 0)
-    "sru": dict(C.ORACLE_ONLY_CASES["acoustic_sru_dropout"], B=4),
+    # SRU with both variational dropouts (masks per (sequence, column), counted globally) + an MLP D with row dropout (T % 16 == 0)
+    "sru": dict(C.ORACLE_ONLY_CASES["acoustic_sru_dropout"], B=4, T=32),
 }
 
 
