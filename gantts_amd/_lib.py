@@ -134,7 +134,7 @@ def _build_if_missing():
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not os.path.isfile(LIB_PATH):       # another rank may have built it while we waited
-                subprocess.call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
+                subprocess.call(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.DEVNULL)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 

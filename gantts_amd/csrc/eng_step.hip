@@ -1,0 +1,981 @@
+// libgantts_hip.so -- the G+D step: MLPG, MLP stacks, apply_generator / update_discriminator / update_generator (reference train.py:245-355), plain forward
+#include "engine_internal.hip.h"
+
+using namespace gt;
+// ------------------------------------------------------------------------------------------
+// MLPG band cache
+// ------------------------------------------------------------------------------------------
+int ensure_band(gt_engine* e, const float* R, int T, hipStream_t s) {
+  MlpgCache& m = e->mlpg;
+  ++m.tick;
+  for (auto* b : m.entries)
+    if (b->R == R && b->T == T) { b->last_use = m.tick; m.cur = b; return GT_OK; }
+  const int nW = e->cfg.num_windows;
+  // first sight of this (R, T): per-offset maxima -> host, pick the smallest half-width whose outside is negligible
+  CHK(m.tmp.ensure((size_t)(2 * T - 1) * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_offset_max_kernel, dim3(2 * T - 1), dim3(256), 0, s, R, T, nW, m.tmp.as<float>());
+  LAUNCH_CHECK();
+  std::vector<float> off(2 * T - 1);
+  HIPCHK(hipMemcpyAsync(off.data(), m.tmp.p, off.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  float peak = 0.f;
+  for (float v : off) peak = fmaxf(peak, v);
+  if (!(peak > 0.f) || !isfinite(peak)) return fail(GT_ERR_INVALID, "MLPG matrix R is empty or not finite");
+  int kb = 0;
+  for (int o = -(T - 1); o <= T - 1; ++o)
+    if (off[o + T - 1] > 1e-9f * peak) kb = std::max(kb, abs(o));
+  if (kb > 63 || (kb > 48 && kb > T / 4))
+    return fail(GT_ERR_INVALID, "MLPG matrix R is not banded (half-width %d of T=%d): only window sets whose "
+                "R = (W^T W)^-1 W^T decays (hparams.py:22-26) are supported", kb, T);
+  MlpgBand* b = nullptr;
+  if (m.entries.size() >= MlpgCache::MAX_ENTRIES) {      // recycle the least recently used entry
+    size_t lru = 0;
+    for (size_t i = 1; i < m.entries.size(); ++i) if (m.entries[i]->last_use < m.entries[lru]->last_use) lru = i;
+    b = m.entries[lru];
+    HIPCHK(hipStreamSynchronize(s));                      // its band may still be read by queued kernels
+  } else {
+    b = new MlpgBand();
+    m.entries.push_back(b);
+  }
+  const int nb = 2 * kb + 1;
+  b->R = nullptr;
+  CHK(b->band.ensure((size_t)T * nW * nb * sizeof(float)));
+  hipLaunchKernelGGL(mlpg_extract_band_kernel, dim3(cdiv((long)T * nW * nb, 256)), dim3(256), 0, s, R, T, nW, kb, b->band.as<float>());
+  LAUNCH_CHECK();
+  b->R = R; b->T = T; b->kb = kb; b->last_use = m.tick;
+  m.cur = b;
+  return GT_OK;
+}
+extern "C" int gt_invalidate_mlpg_cache(gt_engine* e) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  HIPCHK(hipDeviceSynchronize());
+  e->mlpg.clear();
+  return GT_OK;
+}
+
+int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
+                        float* ys, int ldys, int B, int T, hipStream_t s) {
+  const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
+  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
+  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+#define GT_MLPG_FWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F>, lds)); \
+    hipLaunchKernelGGL(mlpg_forward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
+  if (fpl == 1) GT_MLPG_FWD(1) else if (fpl == 2) GT_MLPG_FWD(2) else GT_MLPG_FWD(4)
+#undef GT_MLPG_FWD
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, const int* sstride, int Ds,
+                         float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
+                         const float* mask, hipStream_t s) {
+  const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
+  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
+  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
+  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+#define GT_MLPG_BWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F>, lds)); \
+    hipLaunchKernelGGL(mlpg_backward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
+                       gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
+  if (fpl == 1) GT_MLPG_BWD(1) else if (fpl == 2) GT_MLPG_BWD(2) else GT_MLPG_BWD(4)
+#undef GT_MLPG_BWD
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// network passes
+// ------------------------------------------------------------------------------------------
+// stacked injected-mask buffer for one layer of a D pass group (real rows then fake rows)
+static int stage_injected(gt_engine* e, int role, int layer, const int* passes, int npass, long rows_each, int width,
+                          const float** out, hipStream_t s) {
+  Net& n = e->net[role];
+  *out = nullptr;
+  if (!n.training || n.d.dropout <= 0.f) return GT_OK;
+  bool any = false, all = true;
+  for (int i = 0; i < npass; ++i) { any |= n.inj[passes[i]][layer] != nullptr; all &= n.inj[passes[i]][layer] != nullptr; }
+  if (!any) return GT_OK;
+  if (!all) return fail(GT_ERR_INVALID, "injected dropout masks must be given for every pass of a step or for none");
+  if (npass == 1) { *out = n.inj[passes[0]][layer]; return GT_OK; }
+  const size_t per_layer = (size_t)npass * rows_each * width * sizeof(float);
+  CHK(e->dmask.ensure(per_layer * n.d.num_hidden));
+  float* base = (float*)((char*)e->dmask.p + per_layer * layer);
+  for (int i = 0; i < npass; ++i)
+    HIPCHK(hipMemcpyAsync(base + (size_t)i * rows_each * width, n.inj[passes[i]][layer], (size_t)rows_each * width * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+  *out = base;
+  return GT_OK;
+}
+
+// hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
+static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
+                         const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s) {
+  Net& n = e->net[role];
+  specs.resize(n.hidden.size());
+  const float* cur = in;
+  int ld = ld_in;
+  for (size_t l = 0; l < n.hidden.size(); ++l) {
+    const Lin& L = n.hidden[l];
+    CHK(acts[l].ensure((size_t)rows * L.out * sizeof(float)));
+    const float* inj = nullptr;
+    CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
+    const float* W = L.W;
+    int ldw = L.in;
+    if (l == 0 && (L.in & 3) && gemm_vec_ok(cur, ld) && tl_gemm_prec == PREC_F32) {
+      // The input image takes 16-byte loads (the discriminator's [x | adv] image, pitch 484) but the weight rows (483
+      // floats) do not: multiply by a copy of W with its row pitch rounded up to 4 floats, re-made from the caller's
+      // parameter buffer before every pass (it may have been stepped, loaded or broadcast since).
+      ldw = (L.in + 3) & ~3;
+      CHK(e->w0pad[role].ensure((size_t)L.out * ldw * sizeof(float)));
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv((long)L.out * ldw, 256)), dim3(256), 0, s, L.W, L.in, L.out, e->w0pad[role].as<float>(), ldw);
+      LAUNCH_CHECK();
+      W = e->w0pad[role].as<float>();
+    }
+    CHK(linear_forward(cur, ld, W, ldw, L.b, acts[l].as<float>(), L.out, rows, L.in, L.out, ACT_LEAKY_DROPOUT, specs[l], s));
+    cur = acts[l].as<float>();
+    ld = L.out;
+  }
+  return GT_OK;
+}
+
+// Measured with one rank and forced collectives (bench.py --force-dp, plain step 1.465 ms): round-2 schedule 1.577 ms; the
+// discriminator's gradient as ONE message 1.561 (kept); additionally ncclGroupStart/End around a step's closing messages
+// 1.571 (off); generator loss sums sent with the closing messages instead of early 1.604 (off: the host then waits for the
+// whole step before it can enqueue the next one).
+
+// hidden stack backward.  dz_top: gradient w.r.t. the pre-activation of the TOP hidden layer
+// (already multiplied by f'), in buffer `cur` (rows x hidden).  Produces dW/db (if want_w) and,
+// optionally, dX[:, col0:col0+ncols] of the stack input for rows [row0, row0+nrows).
+static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
+                          const std::vector<DropoutSpec>& specs, float* cur, float* other, bool want_w,
+                          float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s) {
+  Net& n = e->net[role];
+  const int L = (int)n.hidden.size();
+  {
+    // per-layer launches: each layer's weight gradient right behind the product that made its dZ (still warm in L2 / MALL)
+    for (int l = L - 1; l >= 0; --l) {
+      const Lin& Lr = n.hidden[l];
+      const float* Xin = l > 0 ? acts[l - 1].as<float>() : in;
+      const int ldx = l > 0 ? n.hidden[l - 1].out : ld_in;
+      bool rode = false;
+      GemmArgs nn;
+      if (l > 0) nn = backward_data_args(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
+                                         acts[l - 1].as<float>(), Lr.in, specs[l - 1]);
+      if (want_w) {
+        CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role],
+                                   l > 0 ? &nn : nullptr, &rode));
+        CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+        // generator: all layers above the first leave as one message under the first layer's backward; the discriminator's
+        // whole gradient (1 MB) is ONE message at the end of its backward pass (a second launch costs more than it hides)
+        if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
+      }
+      if (l > 0) {
+        if (!rode) CHK(launch_gemm(GEMM_NN, nn, 1, s));
+        std::swap(cur, other);
+      } else if (dX) {
+        CHK(linear_backward_data(cur + row0 * Lr.out, Lr.out, Lr.W, Lr.in, col0, dX, lddx, nrows, Lr.out, ncols, ACT_NONE, nullptr, 0,
+                                 no_drop(), s));
+      }
+    }
+    return GT_OK;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16-storage MLP stacks (GT_OPT_MATMUL_BF16; gemm_bf16s.hip.h): activations, dZ, the input images and weight shadows
+// live in HBM as bf16, in both orientations; every product is the k-contiguous form.
+// ------------------------------------------------------------------------------------------
+static bool use_b16(const gt_engine* e, int role) {
+  const Net& n = e->net[role];
+  if (!e->matmul_bf16 || !n.bound || n.d.arch != GT_ARCH_MLP || (n.d.hidden_dim & 7)) return false;
+  return true;
+}
+// re-made from the caller's float32 parameters before every pass (they may have been stepped, loaded or broadcast since)
+static int refresh_shadows(gt_engine* e, int role, bool with_last, hipStream_t s) {
+  Net& n = e->net[role];
+  auto& sh = e->wsh[role];
+  sh.resize(n.hidden.size() + 1);
+  CastJobs jobs;
+  jobs.n = 0; jobs.pad_ = 0;
+  int blocks = 0;
+  auto flush = [&]() -> int {
+    if (jobs.n > 0) {
+      hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(blocks), dim3(256), 0, s, jobs);
+      LAUNCH_CHECK();
+    }
+    jobs.n = 0; blocks = 0;
+    return GT_OK;
+  };
+  for (size_t l = 0; l <= n.hidden.size(); ++l) {     // all layers of the network in ONE launch
+    if (l == n.hidden.size() && !with_last) break;
+    const Lin& L = l < n.hidden.size() ? n.hidden[l] : n.last;
+    LinShadow& w = sh[l];
+    w.ldw = pad8(L.in); w.ldwt = pad8(L.out);
+    CHK(w.w.ensure((size_t)L.out * w.ldw * 2 + 64));
+    CHK(w.wt.ensure((size_t)L.in * w.ldwt * 2 + 64));
+    if (jobs.n == CAST_MAX_JOBS) CHK(flush());
+    CastJob& J = jobs.j[jobs.n++];
+    J.in = L.W; J.ldi = L.in; J.rows = L.out; J.cols = L.in; J.out = w.w.as<__bf16>(); J.ldo = w.ldw; J.outT = w.wt.as<__bf16>(); J.ldt = w.ldwt;
+    J.gy = cdiv(L.in, 64); J.block0 = blocks; J.pad_ = 0;
+    blocks += cdiv(L.out, 64) * J.gy;
+  }
+  return flush();
+}
+// in_b [rows][ld_in] bf16 -> acts[l] (bf16, + transposed twin when want_t: the weight gradients read it)
+static int stack_forward_b16(gt_engine* e, int role, const __bf16* in_b, int ld_in, long rows, std::vector<B16Img>& acts,
+                             const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, bool want_t, hipStream_t s) {
+  Net& n = e->net[role];
+  specs.resize(n.hidden.size());
+  acts.resize(n.hidden.size());
+  const __bf16* cur = in_b;
+  int ld = ld_in;
+  for (size_t l = 0; l < n.hidden.size(); ++l) {
+    const Lin& L = n.hidden[l];
+    CHK(acts[l].ensure(rows, L.out, want_t));
+    const float* inj = nullptr;
+    CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
+    specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
+    GemmB16Args g = b16_args();
+    g.A = cur; g.lda = ld; g.B = e->wsh[role][l].w.as<__bf16>(); g.ldb = e->wsh[role][l].ldw;
+    g.M = (int)rows; g.N = L.out; g.K = L.in; g.bias = L.b; g.epi = B16_FWD; g.act = ACT_LEAKY_DROPOUT; g.drop = specs[l];
+    g.Cb = acts[l].r(); g.ldcb = acts[l].ld;
+    if (want_t) { g.CbT = acts[l].t(); g.ldcbt = (int)acts[l].ldt; }
+    CHK(launch_gemm_b16(g, 1, s));
+    cur = acts[l].r();
+    ld = acts[l].ld;
+  }
+  return GT_OK;
+}
+// dz[cur]: gradient w.r.t. the pre-activation of the TOP hidden layer (both orientations when want_w).  in_t: transposed
+// image of the stack input [in][rows8] (weight gradient of layer 0).  dX (float32, optional): d loss / d input columns
+// [col0, col0 + ncols) for rows [row0, row0 + nrows).
+static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long ld_int, long rows, std::vector<B16Img>& acts,
+                              const std::vector<DropoutSpec>& specs, int cur, bool want_w, float* dX, int lddx, int col0, int ncols,
+                              long row0, long nrows, hipStream_t s) {
+  Net& n = e->net[role];
+  const int L = (int)n.hidden.size();
+  for (int l = L - 1; l >= 0; --l) {
+    const Lin& Lr = n.hidden[l];
+    B16Img& dz = e->dz_b[cur];
+    if (want_w) {
+      const __bf16* XT = l > 0 ? acts[l - 1].t() : in_t;
+      const long ldxt = l > 0 ? acts[l - 1].ldt : ld_int;
+      CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
+      CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+      if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
+    }
+    if (l > 0) {
+      B16Img& nx = e->dz_b[cur ^ 1];
+      CHK(nx.ensure(rows, Lr.in, want_w));
+      GemmB16Args g = b16_args();
+      g.A = dz.r(); g.lda = dz.ld; g.B = e->wsh[role][l].wt.as<__bf16>(); g.ldb = e->wsh[role][l].ldwt;
+      g.M = (int)rows; g.N = Lr.in; g.K = Lr.out; g.epi = B16_BWD_DATA; g.act = ACT_LEAKY_DROPOUT;
+      g.H = acts[l - 1].r(); g.ldh = acts[l - 1].ld; g.drop = specs[l - 1];
+      g.Cb = nx.r(); g.ldcb = nx.ld;
+      if (want_w) { g.CbT = nx.t(); g.ldcbt = (int)nx.ldt; }
+      CHK(launch_gemm_b16(g, 1, s));
+      cur ^= 1;
+    } else if (dX) {
+      GemmB16Args g = b16_args();
+      g.A = dz.r() + row0 * dz.ld; g.lda = dz.ld;
+      g.B = e->wsh[role][0].wt.as<__bf16>() + (long)col0 * e->wsh[role][0].ldwt; g.ldb = e->wsh[role][0].ldwt;
+      g.M = (int)nrows; g.N = ncols; g.K = Lr.out; g.epi = B16_BWD_DATA; g.act = ACT_NONE;
+      g.C = dX; g.ldc = lddx;
+      CHK(launch_gemm_b16(g, 1, s));
+    }
+  }
+  return GT_OK;
+}
+
+
+static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
+                             bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = (long)B * T;
+  const int pass0[1] = {0};
+  const float* gsrc = y_hat;            // what MLPG is applied to
+  if (G.d.arch == GT_ARCH_LSTM) {
+    CHK(lstm_forward(e, x, B, T, y_hat, s));
+  } else if (G.d.arch == GT_ARCH_IN2OUT_RNN) {
+    // G(x) = hidden2out(LSTM(x)) stays internal; the model returns its INPUT as y_hat (models.py:118)
+    CHK(e->i2o_gout.ensure((size_t)N * G.d.out_dim * sizeof(float)));
+    CHK(lstm_forward(e, x, B, T, e->i2o_gout.as<float>(), s));
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * G.d.in_dim, 256)), dim3(256), 0, s, x, G.d.in_dim, 0, (const int*)nullptr,
+                       y_hat, G.d.in_dim, 0, (int)N, G.d.in_dim);
+    LAUNCH_CHECK();
+    gsrc = e->i2o_gout.as<float>();
+  } else if (G.d.arch == GT_ARCH_SRU) {
+    CHK(sru_forward(e, x, B, T, y_hat, s));
+  } else {
+    if (use_b16(e, GT_ROLE_G)) {
+      const bool want_t = stash && G.d.grads != nullptr;
+      CHK(e->xin_b.ensure(N, G.d.in_dim, want_t));
+      CHK(cast_transpose(x, G.d.in_dim, N, G.d.in_dim, e->xin_b.r(), e->xin_b.ld, want_t ? e->xin_b.t() : (__bf16*)nullptr, e->xin_b.ldt,
+                                nullptr, false, &e->colp, s));
+      CHK(refresh_shadows(e, GT_ROLE_G, true, s));
+      CHK(stack_forward_b16(e, GT_ROLE_G, e->xin_b.r(), e->xin_b.ld, N, e->g_actb, pass0, 1, N, specs, want_t, s));
+      const LinShadow& ws = e->wsh[GT_ROLE_G][G.hidden.size()];
+      GemmB16Args g = b16_args();
+      g.A = e->g_actb.back().r(); g.lda = e->g_actb.back().ld; g.B = ws.w.as<__bf16>(); g.ldb = ws.ldw;
+      g.M = (int)N; g.N = G.last.out; g.K = G.last.in; g.bias = G.last.b; g.epi = B16_FWD;
+      g.act = G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = y_hat; g.ldc = G.d.out_dim;
+      CHK(launch_gemm_b16(g, 1, s));
+    } else {
+      CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+      const Lin& Lh = G.hidden.back();
+      CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
+                         G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
+    }
+  }
+  if (is_i2o(G.d.arch)) {
+    if (!R) return fail(GT_ERR_INVALID, "In2OutHighwayNet needs the MLPG matrix R (models.py:54)");
+    const int sd = G.d.static_dim;
+    CHK(ensure_band(e, R, T, s));
+    CHK(e->tx.ensure((size_t)N * sd * sizeof(float)));
+    CHK(e->gx.ensure((size_t)N * sd * sizeof(float)));
+    // T(x) = sigmoid(T x_static), x_static = x[:, :, :static_dim]   (models.py:57-60)
+    CHK(linear_forward(x, G.d.in_dim, G.gate.W, sd, G.gate.b, e->tx.as<float>(), sd, N, sd, sd, ACT_SIGMOID, no_drop(), s));
+    CHK(mlpg_forward(e, gsrc, G.d.out_dim, e->d_scol_i2o, e->d_sstride_i2o, sd, e->gx.as<float>(), sd, B, T, s));
+    if (stash) e->g_used_mlpg = true;
+    hipLaunchKernelGGL(highway_forward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, x, G.d.in_dim, e->tx.as<float>(), sd,
+                       e->gx.as<float>(), sd, y_hat_static, sd, N, sd);
+    LAUNCH_CHECK();
+  } else {
+    if (G.d.out_dim != e->Dout_cfg)
+      return fail(GT_ERR_DIM, "You probably have specified wrong dimention params.");  // multistream.py:93-94
+    if (R) {
+      CHK(ensure_band(e, R, T, s));
+      CHK(mlpg_forward(e, y_hat, G.d.out_dim, e->d_scol, e->d_sstride, e->Ds, y_hat_static, e->Ds, B, T, s));
+      if (stash) e->g_used_mlpg = true;
+    } else {
+      if (e->Ds != G.d.out_dim) return fail(GT_ERR_INVALID, "R is None but the stream config has dynamic features");
+      if (stash) e->g_used_mlpg = false;
+      // R is None: num_windows = 1, every stream passes through (multistream.py:88-89,119-120)
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * G.d.out_dim, 256)), dim3(256), 0, s, y_hat, G.d.out_dim, 0,
+                         (const int*)nullptr, y_hat_static, G.d.out_dim, 0, (int)N, G.d.out_dim);
+      LAUNCH_CHECK();
+    }
+  }
+  return GT_OK;
+}
+
+extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat,
+                                  float* y_hat_static, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& G = e->net[GT_ROLE_G];
+  if (!G.bound) return fail(GT_ERR_STATE, "generator not bound");
+  if (!x || !y_hat || !y_hat_static) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  CHK(fault_seen(e));
+  e->step_counter++;
+  e->B = B; e->T = T; e->N = (long)B * T;
+  e->g_pass_valid = false;
+  e->fake_cat_valid = false; e->dcat_b_ok = false;
+  e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
+  CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
+  e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
+  e->g_pass_valid = true;
+  return GT_OK;
+}
+
+// width of the conditioning input x fed to D (train.py:254-256); derived from the bound D when not configured
+int cond_dim(gt_engine* e) {
+  if (!e->cfg.discriminator_linguistic_condition) return 0;
+  if (e->cfg.cond_dim > 0) return e->cfg.cond_dim;
+  return e->net[GT_ROLE_D].bound ? e->net[GT_ROLE_D].d.in_dim - e->Da : 0;
+}
+static int d_in_dim(gt_engine* e) { return e->Da + cond_dim(e); }
+
+// rows [row0, row0+N) of dcat <- [x | feats[:, adv_cols]]
+static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_feats, long row0, long N, int ldc, hipStream_t s) {
+  float* dst = e->dcat.as<float>() + row0 * ldc;
+  int off = 0;
+  if (e->cfg.discriminator_linguistic_condition) {
+    if (!x) return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+    const int cd = cond_dim(e);
+    if (cd <= 0) return fail(GT_ERR_DIM, "discriminator in_dim too small for linguistic conditioning");
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * cd, 256)), dim3(256), 0, s, x, cd, 0, (const int*)nullptr, dst, ldc, 0,
+                       (int)N, cd);
+    LAUNCH_CHECK();
+    off = cd;
+  }
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * e->Da, 256)), dim3(256), 0, s, feats, ld_feats, 0, e->d_adv_cols, dst, ldc,
+                     off, (int)N, e->Da);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// H: the top hidden activation, float32 [n_rows][K] or (h_ld > 0) its bf16 image with row pitch h_ld
+static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
+                    float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
+                    StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false) {
+  Net& D = e->net[GT_ROLE_D];
+  const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
+  CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
+  CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
+  CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
+  const size_t lds = (size_t)4 * K * sizeof(float);
+#define GT_HEAD_LAUNCH(KP_)                                                                                              \
+  if (h_ld > 0)                                                                                                          \
+    hipLaunchKernelGGL((d_head_kernel<KP_, __bf16, true>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
+                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L);                    \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>())
+  if (K <= 128) { GT_HEAD_LAUNCH(2); }
+  else if (K <= 256) { GT_HEAD_LAUNCH(4); }
+  else if (K <= 512) { GT_HEAD_LAUNCH(8); }
+  else if (K <= 1024) { GT_HEAD_LAUNCH(16); }
+  else return fail(GT_ERR_INVALID, "discriminator hidden_dim > 1024 is not supported by the fused head kernel");
+#undef GT_HEAD_LAUNCH
+  LAUNCH_CHECK();
+  const bool w = want_grad && want_w;
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
+                     early_res);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t s) {
+  Net& n = e->net[role];
+  if (!n.has_opt) return fail(GT_ERR_STATE, "phase == \"train\" but no optimizer is bound for role %d", role);
+  const long np = n.d.n_params;
+  const int nblk = (int)std::min<long>(512, cdiv(np, RED_THREADS * 4));
+  CHK(e->partial.ensure(4096 * sizeof(double)));
+  double* part = e->partial.as<double>() + 2048;
+  CHK(slab_defer_flush(e->sdefer[role], s));            // the fused step's recorded weight-gradient combines, one launch
+  e->sdefer[role].active = false;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, n.d.grads, np, part);
+  LAUNCH_CHECK();
+  n.step += 1;
+  OptimSpec o;
+  o.kind = n.od.kind; o.lr = n.od.lr; o.weight_decay = n.od.weight_decay; o.eps = n.od.eps; o.lr_decay = n.od.lr_decay;
+  o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step; o.max_norm = n.od.max_grad_norm;
+  const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
+  hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
+                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev,
+                     e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+static int fetch_results(gt_engine* e, hipStream_t s) {
+  HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return GT_OK;
+}
+static int post_deferred_results(gt_engine* e, int role, hipStream_t s) {
+  if (!e->h_def[role]) HIPCHK(hipHostMalloc((void**)&e->h_def[role], sizeof(StepResults)));
+  if (!e->ev_def[role]) HIPCHK(hipEventCreateWithFlags(&e->ev_def[role], hipEventDisableTiming));
+  HIPCHK(hipMemcpyAsync(e->h_def[role], e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(e->ev_def[role], s));
+  e->def_pending[role] = true;
+  return GT_OK;
+}
+static StepResults* early_res_target(gt_engine* e) { return e->h_res_dev ? e->h_res_dev : e->res(); }
+int post_early_results(gt_engine* e, hipStream_t s) {
+  if (!e->ev_res) HIPCHK(hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
+  if (!e->h_res_dev) HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(e->ev_res, s));
+  e->early_done = true;
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// update_discriminator
+// ------------------------------------------------------------------------------------------
+extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                                             const float* mask, int B, int T, int train, float eps, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& D = e->net[GT_ROLE_D];
+  if (!D.bound) return fail(GT_ERR_STATE, "discriminator not bound");
+  if (!y_static || !y_hat_static || !mask) return fail(GT_ERR_INVALID, "null tensor");
+  if (D.d.in_dim != d_in_dim(e))
+    return fail(GT_ERR_DIM, "discriminator in_dim %d != adversarial input width %d (train.py:760-768)", D.d.in_dim, d_in_dim(e));
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
+  const bool tr = train != 0;
+  if (comm_on(e) && tr && D.grads_dirty)
+    return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
+  { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && D.has_opt; }
+  CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
+  const int passes[2] = {0, 1};
+  // the [x | adv] image of both halves: real rows, then generated rows
+  const bool b16 = use_b16(e, GT_ROLE_D);
+  if (b16) {
+    // bf16 storage: the image is written ONCE, as bf16, in both orientations (no float32 image at all)
+    if (e->cfg.discriminator_linguistic_condition && (!x || cond_dim(e) <= 0))
+      return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+    CHK(e->dcat_b.ensure(2 * N, K0, tr));
+    CatSrc src;
+    src.x = x; src.cd = cond_dim(e); src.fa = y_static; src.fb = y_hat_static; src.ldf = e->Ds; src.idx = e->d_adv_cols; src.N = N; src.row_off = 0;
+    hipLaunchKernelGGL(cat_cast_transpose_kernel, dim3(cdiv(2 * N, 64), cdiv(K0, 64)), dim3(256), 0, s, src, 2 * N, K0, e->dcat_b.r(), e->dcat_b.ld,
+                       tr ? e->dcat_b.t() : (__bf16*)nullptr, e->dcat_b.ldt);
+    LAUNCH_CHECK();
+    e->dcat_b_ok = true;
+    e->fake_cat_valid = false;                 // the float32 image was not built
+  } else {
+  CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+  if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
+    hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
+                       e->d_adv_cols, e->Da, e->dcat.as<float>(), ldc, N);
+    LAUNCH_CHECK();
+  } else {
+    CHK(build_cat(e, x, y_static, e->Ds, 0, N, ldc, s));
+    CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
+  }
+  e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+  }
+  e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
+  if (b16) {
+    CHK(refresh_shadows(e, GT_ROLE_D, false, s));
+    CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
+  } else {
+    CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+  }
+  const int H = D.d.hidden_dim;
+  if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
+  CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
+  CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
+  // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
+  // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
+  const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
+  CHK(ensure_tv(e, mask, N, s));
+  if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
+  CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
+               e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
+               (b16 && tr) ? &e->dz_b[0] : nullptr, true));
+  e->early_done = false;
+  if (plain_early) CHK(post_early_results(e, s));
+  if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
+  if (tr) {
+    CHK(comm_grads_ready(e, GT_ROLE_D, D.last.dW, (long)D.last.in * D.last.out + D.last.out, s));
+    // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
+    // (the autograd graph in the reference, train.py:265) and a generator with grads exists
+    Net& G = e->net[GT_ROLE_G];
+    const bool want_leak = G.bound && G.d.grads && e->g_pass_valid && y_hat_static == e->last_yhs && e->N == N;
+    if (want_leak && e->leak_pending)
+      return fail(GT_ERR_STATE, "update_discriminator called twice without optimizer_g.zero_grad() (train.py:538)");
+    float* leak = nullptr;
+    if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
+    const int col0 = cond_dim(e);
+    if (b16) {   // the head wrote its seed gradient as the top dZ image, both orientations
+      CHK(stack_backward_b16(e, GT_ROLE_D, e->dcat_b.t(), e->dcat_b.ldt, 2 * N, e->d_actb, e->d_specs, 0, true, leak, e->Da, col0, e->Da, N, N, s));
+    } else {
+      CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
+                         e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
+    }
+    D.grads_dirty = true;
+    if (want_leak) e->leak_pending = true;
+  }
+  // data parallel: the rest of D's gradient + the four loss / count sums, then the step stream waits for the communicator
+  CHK(comm_finish_step(e, GT_ROLE_D, tr, &e->sc()->s_real, comm_early ? 0 : 4, s));
+  e->d_begin_done = true;
+  return GT_OK;
+}
+
+static void fill_d_result(const StepResults* h, gt_d_result* out) {
+  out->loss_d = h->loss_d; out->loss_fake_d = h->loss_fake_d; out->loss_real_d = h->loss_real_d;
+  out->real_correct_count = h->real_correct; out->fake_correct_count = h->fake_correct;
+  out->grad_norm = h->gnorm_d;
+}
+static void fill_g_result(const StepResults* h, gt_g_result* out) {
+  out->loss_mse = h->loss_mse; out->loss_mge = h->loss_mge; out->loss_adv = h->loss_adv;
+  out->loss_g = h->loss_g; out->grad_norm = h->gnorm_g;
+}
+
+extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result* out, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->d_begin_done) return fail(GT_ERR_STATE, "gt_update_discriminator_end without _begin");
+  hipStream_t s = (hipStream_t)stream;
+  e->d_begin_done = false;
+  if (!out) {   // deferred: enqueue everything, synchronise nothing; gt_update_discriminator_result collects
+    if (e->early_done) return fail(GT_ERR_STATE, "deferred results are a split-phase feature");
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), train ? 0 : 1);
+    LAUNCH_CHECK();
+    return post_deferred_results(e, GT_ROLE_D, s);
+  }
+  if (e->early_done) {
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    HIPCHK(hipEventSynchronize(e->ev_res));       // only the scalar copy; backward + step stay queued
+    e->early_done = false;
+  } else {
+    if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
+    hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), train ? 0 : 1);
+    LAUNCH_CHECK();
+    CHK(fetch_results(e, s));
+  }
+  fill_d_result(e->h_res, out);
+  return GT_OK;
+}
+extern "C" int gt_update_discriminator_result(gt_engine* e, gt_d_result* out) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->def_pending[GT_ROLE_D]) return fail(GT_ERR_STATE, "no deferred discriminator result pending");
+  HIPCHK(hipEventSynchronize(e->ev_def[GT_ROLE_D]));
+  e->def_pending[GT_ROLE_D] = false;
+  fill_d_result(e->h_def[GT_ROLE_D], out);
+  return GT_OK;
+}
+
+extern "C" int gt_update_discriminator(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
+                                       const float* mask, int B, int T, int train, float eps, gt_d_result* out, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->early = true;
+  int r = gt_update_discriminator_begin(e, x, y_static, y_hat_static, mask, B, T, train, eps, stream);
+  e->early = false;
+  if (r != GT_OK) { e->early_done = false; return r; }
+  return gt_update_discriminator_end(e, train, out, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// update_generator
+// ------------------------------------------------------------------------------------------
+// e->partial: [0, 1024) MGE partials, [1024, 2048) MSE partials, [2048, ...) the optimizer's squared-norm partials.
+// deferred_blocks != null: the per-block partial sums stay in the MSE region and *deferred_blocks says how many -- the
+// caller folds their reduction into a later launch (finalize_g_kernel) instead of paying a launch for it here.
+static int sum_sqerr(gt_engine* e, const float* a, int lda, const float* b, int ldb, const float* mask, long rows, int D,
+                     double* out, float* g, int ldg, float gscale, hipStream_t s, int* deferred_blocks = nullptr) {
+  const int nblk = (int)std::min<long>(1024, cdiv(rows * D, RED_THREADS * 4));
+  CHK(e->partial.ensure(4096 * sizeof(double)));
+  double* part = e->partial.as<double>() + 1024;
+  hipLaunchKernelGGL(masked_sqerr_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, a, lda, b, ldb, mask, rows, D, part, g, ldg, gscale, e->sc());
+  LAUNCH_CHECK();
+  if (deferred_blocks) { *deferred_blocks = nblk; return GT_OK; }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, part, nblk, out);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// backward of G from the gradient at y_hat_static (gs) [+ masked-MSE term at y_hat]
+static int generator_backward(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* mask,
+                              float mse_w, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  const long N = e->N;
+  const int B = e->B, T = e->T, Do = G.d.out_dim;
+  // dloss/dy_hat is an engine buffer: for the MLP stacks its row pitch is rounded up to 4 floats, so that the last layer's
+  // two backward products (K = out_dim = 187 for the acoustic model) take the 16-byte loader and the 64x64 tiles; the
+  // pad column is never read as data (K tail / row clamp of the GEMM loader)
+  const bool mlp_body = !(has_lstm_body(G.d.arch) || G.d.arch == GT_ARCH_SRU);
+  const int ldgy = mlp_body && (is_i2o(G.d.arch) || e->g_used_mlpg) ? (Do + 3) & ~3 : Do;
+  CHK(e->gy.ensure((size_t)N * ldgy * sizeof(float)));
+  float* gy = e->gy.as<float>();
+  const float* gs = e->gs.as<float>();
+  if (is_i2o(G.d.arch)) {
+    const int sd = G.d.static_dim;
+    if (G.d.arch == GT_ARCH_IN2OUT_RNN) mse_w = 0.f;   // y_hat is the input x there: the MSE term has no path into G
+    CHK(e->dgx.ensure((size_t)N * sd * sizeof(float)));
+    CHK(e->dtz.ensure((size_t)N * sd * sizeof(float)));
+    hipLaunchKernelGGL(highway_backward_kernel, dim3(cdiv(N * sd, 256)), dim3(256), 0, s, gs, sd, e->tx.as<float>(), sd,
+                       e->gx.as<float>(), sd, e->dgx.as<float>(), sd, e->dtz.as<float>(), sd, N, sd);
+    LAUNCH_CHECK();
+    CHK(linear_backward_weight(e->dtz.as<float>(), sd, x, G.d.in_dim, N, sd, sd, G.gate.dW, G.gate.db, G.grads_dirty, e->slabs,
+                               e->colp, s, &e->sdefer[GT_ROLE_G]));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.gate.dW, (long)sd * sd + sd, s));
+    CHK(mlpg_backward(e, e->dgx.as<float>(), sd, e->d_scol_i2o, e->d_sstride_i2o, sd, gy, ldgy, B, T, mse_w, y_hat, y, Do, mask, s));
+  } else if (e->g_used_mlpg) {
+    CHK(mlpg_backward(e, gs, e->Ds, e->d_scol, e->d_sstride, e->Ds, gy, ldgy, B, T, mse_w, y_hat, y, Do, mask, s));
+  } else {
+    // no parameter generation: y_hat_static == y_hat, the gradient passes straight through,
+    // plus the masked-MSE gradient (which also yields loss_mse's sum)
+    if (mse_w != 0.f) CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, gy, Do, mse_w, s));
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  if (has_lstm_body(G.d.arch) || G.d.arch == GT_ARCH_SRU) {
+    CHK(has_lstm_body(G.d.arch) ? lstm_backward(e, x, gy, B, T, s) : sru_backward(e, x, gy, B, T, s));
+    G.grads_dirty = true;
+    return GT_OK;
+  }
+  if (use_b16(e, GT_ROLE_G)) {
+    // dloss/dy_hat -> bf16 image (both orientations); last_linear: dW = gyT . H_topT^T, dZ_top = (gy . W_lastT^T) (.) f'(H_top)
+    const int H = G.d.hidden_dim;
+    CHK(e->gy_b.ensure(N, Do, true));
+    CHK(cast_transpose(gy, ldgy, N, Do, e->gy_b.r(), e->gy_b.ld, e->gy_b.t(), e->gy_b.ldt, nullptr, false, &e->colp, s));
+    B16Img& top = e->g_actb.back();
+    CHK(weight_grad_b16(e->gy_b.t(), e->gy_b.ldt, top.t(), top.ldt, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty, e->slabs, s,
+                        &e->sdefer[GT_ROLE_G]));
+    CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
+    const LinShadow& ws = e->wsh[GT_ROLE_G][G.hidden.size()];
+    CHK(e->dz_b[0].ensure(N, H, true));
+    GemmB16Args g = b16_args();
+    g.A = e->gy_b.r(); g.lda = e->gy_b.ld; g.B = ws.wt.as<__bf16>(); g.ldb = ws.ldwt; g.M = (int)N; g.N = H; g.K = Do;
+    g.epi = B16_BWD_DATA; g.act = ACT_LEAKY_DROPOUT; g.H = top.r(); g.ldh = top.ld; g.drop = e->g_specs.back();
+    g.Cb = e->dz_b[0].r(); g.ldcb = e->dz_b[0].ld; g.CbT = e->dz_b[0].t(); g.ldcbt = (int)e->dz_b[0].ldt;
+    CHK(launch_gemm_b16(g, 1, s));
+    CHK(stack_backward_b16(e, GT_ROLE_G, e->xin_b.t(), e->xin_b.ldt, N, e->g_actb, e->g_specs, 0, true, nullptr, 0, 0, 0, 0, 0, s));
+    G.grads_dirty = true;
+    return GT_OK;
+  }
+  // last_linear: dW = gy^T H_top, db ; dZ_top = (gy W_last) (.) f'(H_top)
+  const Lin& Lt = G.hidden.back();
+  const int H = G.d.hidden_dim;
+  CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
+  CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
+  const GemmArgs nn_last = backward_data_args(gy, ldgy, G.last.W, G.last.in, 0, e->dzA.as<float>(), H, N, Do, H, ACT_LEAKY_DROPOUT,
+                                              e->g_act.back().as<float>(), H, e->g_specs.back());
+  bool rode = false;
+  CHK(linear_backward_weight(gy, ldgy, e->g_act.back().as<float>(), Lt.out, N, Do, G.last.in, G.last.dW, G.last.db, G.grads_dirty,
+                             e->slabs, e->colp, s, &e->sdefer[GT_ROLE_G], &nn_last, &rode));
+  CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * G.last.in + Do, s));
+  if (!rode) CHK(launch_gemm(GEMM_NN, nn_last, 1, s));
+  // The first layer's weight gradient reads G's input as its frame operand.  When the discriminator's input image of
+  // this step holds the very same x (linguistic conditioning on the generator's own input, no noise channels), the x
+  // columns of its rows are a bit-exact copy with a 16-byte row pitch: use it, and the product takes the 16-byte loader.
+  const float* xin = x;
+  int ldxin = G.d.in_dim;
+  if (e->fake_cat_valid && e->fake_cat_x == x && e->cfg.discriminator_linguistic_condition && cond_dim(e) == G.d.in_dim &&
+      e->dcat.p && (G.d.in_dim & 3)) {
+    ldxin = (d_in_dim(e) + 3) & ~3;
+    xin = e->dcat.as<float>() + N * ldxin;      // the generated half: the one that is valid whenever fake_cat_valid is
+  }
+  CHK(stack_backward(e, GT_ROLE_G, xin, ldxin, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
+                     nullptr, 0, 0, 0, 0, 0, s));
+  G.grads_dirty = true;
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* y_static,
+                                         const float* y_hat_static, float adv_w, const float* mask, int B, int T, int train,
+                                         float mse_w, float mge_w, float eps, void* stream) {
+  CHK(check_common(e, B, T));
+  Net& G = e->net[GT_ROLE_G];
+  Net& D = e->net[GT_ROLE_D];
+  if (!G.bound) return fail(GT_ERR_STATE, "generator not bound");
+  if (!y || !y_hat || !y_static || !y_hat_static || !mask) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const long N = (long)B * T;
+  const bool tr = train != 0;
+  if (tr) {
+    if (!e->g_pass_valid || y_hat != e->last_yhat || y_hat_static != e->last_yhs || N != e->N)
+      return fail(GT_ERR_STATE, "update_generator(phase=\"train\") needs the y_hat / y_hat_static returned by the last apply_generator");
+    if (!G.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the generator was bound without grads");
+    if (G.d.last_sigmoid) return fail(GT_ERR_INVALID, "training a generator with last_sigmoid=True is not supported");
+  }
+  const int Do = G.d.out_dim;
+  const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
+  if (comm_on(e) && tr && G.grads_dirty)
+    return fail(GT_ERR_STATE, "data-parallel step: optimizer_g.zero_grad() must precede update_generator");
+  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && G.has_opt; }
+  CHK(ensure_tv(e, mask, N, s));
+  // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
+  const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
+  // (the fused single-GPU call reduces the MSE partials inside its finalisation launch: see early_now below)
+  const bool early_fold = e->early && !comm_on(e) && !(tr && direct && mse_w != 0.f);
+  int mse_blocks = 0;
+  if (!(tr && direct && mse_w != 0.f))
+    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s, early_fold ? &mse_blocks : nullptr));
+  // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
+  e->g_has_adv = adv_w > 0.f;
+  float* gadv = nullptr;
+  if (adv_w > 0.f) {
+    if (!D.bound) return fail(GT_ERR_STATE, "adv_w > 0 but no discriminator bound");
+    if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
+    const int K0 = D.d.in_dim, ldc = (K0 + 3) & ~3;
+    const int passes[1] = {2};
+    const bool b16 = use_b16(e, GT_ROLE_D);
+    const float* cat = nullptr;
+    if (!b16) {
+      CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
+      if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
+        CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
+        e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+      }
+      cat = e->dcat.as<float>() + N * ldc;
+    }
+    if (b16) {   // the generated half of the bf16 image: rows N .. 2N, kept from the D step of the same batch or built here
+      CHK(e->dcat_b.ensure(2 * N, K0, false));
+      if (!(e->dcat_b_ok && e->dcat_b_x == x && e->dcat_b_yhs == y_hat_static)) {
+        if (e->cfg.discriminator_linguistic_condition && (!x || cond_dim(e) <= 0))
+          return fail(GT_ERR_INVALID, "discriminator_linguistic_condition is set but x is null");
+        CatSrc src;
+        src.x = x; src.cd = cond_dim(e); src.fa = y_hat_static; src.fb = y_hat_static; src.ldf = Ds; src.idx = e->d_adv_cols; src.N = N; src.row_off = N;
+        hipLaunchKernelGGL(cat_cast_transpose_kernel, dim3(cdiv(N, 64), cdiv(K0, 64)), dim3(256), 0, s, src, N, K0,
+                           e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, (__bf16*)nullptr, 0L);
+        LAUNCH_CHECK();
+        e->dcat_b_ok = true; e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
+      }
+      CHK(refresh_shadows(e, GT_ROLE_D, false, s));        // D has just been stepped (train.py:276 before :307)
+      CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, N, e->d_actb, passes, 1, N, e->d_specs, false, s));
+    } else {
+      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+    }
+    const int H = D.d.hidden_dim;
+    CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
+    CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
+    if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
+    CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
+                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false));
+    if (tr) {
+      CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
+      gadv = e->gadv.as<float>();
+      const int col0 = cond_dim(e);
+      if (b16) {
+        CHK(stack_backward_b16(e, GT_ROLE_D, nullptr, 0, N, e->d_actb, e->d_specs, 0, false, gadv, e->Da, col0, e->Da, 0, N, s));
+      } else {
+        CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
+                           e->Da, col0, e->Da, 0, N, s));
+      }
+    }
+  }
+  // MGE loss + gradient assembly at y_hat_static
+  const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
+  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e) && comm_early_g();
+  int mge_blocks = 0;
+  {
+    const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
+    CHK(e->partial.ensure(4096 * sizeof(double)));
+    float* gs = nullptr;
+    if (tr) { CHK(e->gs.ensure((size_t)N * Ds * sizeof(float))); gs = e->gs.as<float>(); }
+    const float* leak = (tr && e->leak_pending) ? e->leak.as<float>() : nullptr;
+    hipLaunchKernelGGL(static_grad_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
+                       e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, e->partial.as<double>(), e->sc());
+    LAUNCH_CHECK();
+    mge_blocks = nblk;
+    if (!early_now) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
+      LAUNCH_CHECK();
+    }
+  }
+  e->early_done = false;
+  if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), early_res_target(e), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
+                       (const double*)e->partial.as<double>(), mge_blocks,
+                       mse_blocks ? (const double*)(e->partial.as<double>() + 1024) : (const double*)nullptr, mse_blocks);
+    LAUNCH_CHECK();
+    CHK(post_early_results(e, s));
+  }
+  if (comm_early) CHK(comm_early_results(e, GT_ROLE_G, &e->sc()->s_adv, 3, adv_w, mse_w, mge_w, s));
+  if (tr) {
+    CHK(generator_backward(e, e->last_x, y, y_hat, mask, mse_w, s));  // G's own input (cat(x, z), train.py:542)
+    e->leak_pending = false;
+  }
+  CHK(comm_finish_step(e, GT_ROLE_G, tr, &e->sc()->s_adv, comm_early ? 0 : 3, s));
+  e->g_begin_done = true;
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, float mse_w, float mge_w, gt_g_result* out,
+                                       void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->g_begin_done) return fail(GT_ERR_STATE, "gt_update_generator_end without _begin");
+  hipStream_t s = (hipStream_t)stream;
+  e->g_begin_done = false;
+  if (!out) {
+    if (e->early_done) return fail(GT_ERR_STATE, "deferred results are a split-phase feature");
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
+                       train ? 0 : 1, (const double*)nullptr, 0, (const double*)nullptr, 0);
+    LAUNCH_CHECK();
+    return post_deferred_results(e, GT_ROLE_G, s);
+  }
+  if (e->early_done) {
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    HIPCHK(hipEventSynchronize(e->ev_res));
+    e->early_done = false;
+  } else {
+    if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
+    hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, s, e->sc(), e->res(), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0,
+                       train ? 0 : 1, (const double*)nullptr, 0, (const double*)nullptr, 0);
+    LAUNCH_CHECK();
+    CHK(fetch_results(e, s));
+  }
+  fill_g_result(e->h_res, out);
+  return fault_seen(e);
+}
+extern "C" int gt_update_generator_result(gt_engine* e, gt_g_result* out) {
+  if (!e || !out) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->def_pending[GT_ROLE_G]) return fail(GT_ERR_STATE, "no deferred generator result pending");
+  HIPCHK(hipEventSynchronize(e->ev_def[GT_ROLE_G]));
+  e->def_pending[GT_ROLE_G] = false;
+  fill_g_result(e->h_def[GT_ROLE_G], out);
+  return GT_OK;
+}
+
+extern "C" int gt_update_generator(gt_engine* e, const float* x, const float* y, const float* y_hat, const float* y_static,
+                                   const float* y_hat_static, float adv_w, const float* mask, int B, int T, int train,
+                                   float mse_w, float mge_w, float eps, gt_g_result* out, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  e->early = true;
+  int r = gt_update_generator_begin(e, x, y, y_hat, y_static, y_hat_static, adv_w, mask, B, T, train, mse_w, mge_w, eps, stream);
+  e->early = false;
+  if (r != GT_OK) { e->early_done = false; return r; }
+  return gt_update_generator_end(e, train, adv_w, mse_w, mge_w, out, stream);
+}
+
+extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  Net& G = e->net[GT_ROLE_G];
+  if (!G.bound || !G.d.grads || !e->g_pass_valid) return fail(GT_ERR_STATE, "no generator pass to back-propagate");
+  hipStream_t s = (hipStream_t)stream;
+  tl_gemm_prec = e->matmul_bf16 ? PREC_BF16 : PREC_F32;      // this entry point launches GEMMs without check_common
+  CHK(fault_seen(e));
+  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.active = false; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; }   // combines run in place here
+  const long N = e->N;
+  const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
+  CHK(e->gs.ensure((size_t)N * Ds * sizeof(float)));
+  HIPCHK(hipMemsetAsync(e->gs.p, 0, (size_t)N * Ds * sizeof(float), s));
+  if (e->leak_pending) {
+    // scatter leak[:, j] -> gs[:, adv_cols[j]]  (gather with swapped roles: one column at a time is fine here)
+    std::vector<int>& cols = e->h_adv_cols;
+    for (int j = 0; j < e->Da; ++j) {
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, e->leak.as<float>(), e->Da, j, (const int*)nullptr,
+                         e->gs.as<float>(), Ds, cols[j], (int)N, 1);
+    }
+    LAUNCH_CHECK();
+  }
+  CHK(generator_backward(e, e->last_x, e->last_yhat, e->last_yhat, (const float*)nullptr, 0.f, s));
+  e->leak_pending = false;
+  HIPCHK(hipStreamSynchronize(s));
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// plain forward
+// ------------------------------------------------------------------------------------------
+extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const float* R, int B, int T, float* out, float* out2,
+                                void* stream) {
+  CHK(check_common(e, B, T));
+  if (role < 0 || role > 1 || !e->net[role].bound) return fail(GT_ERR_STATE, "model not bound");
+  if (!x || !out) return fail(GT_ERR_INVALID, "null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  Net& n = e->net[role];
+  const long N = (long)B * T;
+  e->step_counter++;
+  std::vector<DropoutSpec> specs;
+  if (role == GT_ROLE_G && is_i2o(n.d.arch)) {
+    if (!out2) return fail(GT_ERR_INVALID, "In2OutHighwayNet forward returns two tensors");
+    e->g_pass_valid = false;
+    return generator_forward(e, x, R, B, T, out, out2, false, s, specs);
+  }
+  if (n.d.arch == GT_ARCH_LSTM || n.d.arch == GT_ARCH_SRU) {
+    if (role != GT_ROLE_G) return fail(GT_ERR_INVALID, "recurrent networks are supported in the generator slot only");
+    e->g_pass_valid = false;
+    return n.d.arch == GT_ARCH_LSTM ? lstm_forward(e, x, B, T, out, s) : sru_forward(e, x, B, T, out, s);
+  }
+  const int pass0[1] = {0};
+  auto& acts = role == GT_ROLE_G ? e->g_act : e->d_act;
+  if (role == GT_ROLE_G) e->g_pass_valid = false;
+  if (use_b16(e, role)) {
+    auto& actb = role == GT_ROLE_G ? e->g_actb : e->d_actb;
+    CHK(e->fwd_b.ensure(N, n.d.in_dim, false));
+    CHK(cast_transpose(x, n.d.in_dim, N, n.d.in_dim, e->fwd_b.r(), e->fwd_b.ld, (__bf16*)nullptr, 0, nullptr, false, &e->colp, s));
+    CHK(refresh_shadows(e, role, true, s));
+    CHK(stack_forward_b16(e, role, e->fwd_b.r(), e->fwd_b.ld, N, actb, pass0, 1, N, specs, false, s));
+    const LinShadow& ws = e->wsh[role][n.hidden.size()];
+    GemmB16Args g = b16_args();
+    g.A = actb.back().r(); g.lda = actb.back().ld; g.B = ws.w.as<__bf16>(); g.ldb = ws.ldw;
+    g.M = (int)N; g.N = n.last.out; g.K = n.last.in; g.bias = n.last.b; g.epi = B16_FWD;
+    g.act = n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = out; g.ldc = n.d.out_dim;
+    return launch_gemm_b16(g, 1, s);
+  }
+  CHK(stack_forward(e, role, x, n.d.in_dim, N, acts, pass0, 1, N, specs, s));
+  return linear_forward(acts.back().as<float>(), n.hidden.back().out, n.last.W, n.last.in, n.last.b, out, n.d.out_dim, N, n.last.in,
+                        n.last.out, n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+}
+

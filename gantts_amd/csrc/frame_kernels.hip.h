@@ -53,7 +53,7 @@ __device__ __forceinline__ bool dropout_keep(const DropoutSpec& d, int row, int 
 
 // parity hook (gt_op_philox_mask): materialises the keep bits of one Philox dropout site from the layout-independent
 // definition philox_keep(row, col), one element per thread
-__global__ void philox_mask_kernel(const DropoutSpec d, long rows, int cols, float* __restrict__ mask) {
+static __global__ void philox_mask_kernel(const DropoutSpec d, long rows, int cols, float* __restrict__ mask) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
   const int r = (int)(e / cols), c = (int)(e - (long)r * cols);
@@ -82,7 +82,7 @@ struct StepResults {
 };
 
 // tv = sum(mask[0..n)) ; single workgroup (n = B*T is small)
-__global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
+static __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
                                 StepScalars* sc) {
   __shared__ double sh[16];
   double v = 0.0;
@@ -102,7 +102,7 @@ __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_
 }
 
 // out[0] = sum(mask[0..n)) as a double (data parallel: the local term of the global valid-frame count)
-__global__ void mask_total_kernel(const float* __restrict__ mask, int n, double* __restrict__ out) {
+static __global__ void mask_total_kernel(const float* __restrict__ mask, int n, double* __restrict__ out) {
   __shared__ double sh[16];
   double v = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)mask[i];
@@ -111,7 +111,7 @@ __global__ void mask_total_kernel(const float* __restrict__ mask, int n, double*
 }
 
 // mask[b][t] = t < len[b]   (reference gantts/seqloss.py:9-20)
-__global__ void sequence_mask_kernel(const long* __restrict__ lengths, int B, int T, float* __restrict__ mask) {
+static __global__ void sequence_mask_kernel(const long* __restrict__ lengths, int B, int T, float* __restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * T) return;
   const int b = i / T, t = i - b * T;
@@ -120,7 +120,7 @@ __global__ void sequence_mask_kernel(const long* __restrict__ lengths, int B, in
 
 // out[r*ldo + ooff + j] = in[r*ldi + (idx ? idx[j] : ioff + j)]   -- bit-exact column gather
 // (reference gantts/multistream.py:33-79, train.py:232-242,254-256)
-__global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int ioff, const int* __restrict__ idx,
+static __global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int ioff, const int* __restrict__ idx,
                                    float* __restrict__ out, int ldo, int ooff, int rows, int nj) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)rows * nj) return;
@@ -133,7 +133,7 @@ __global__ void gather_cols_kernel(const float* __restrict__ in, int ldi, int io
 
 // D-step input image in one pass: rows [0,N) = [x | fa[:, idx]], rows [N,2N) = [x | fb[:, idx]] (train.py:254-256 for
 // the real and the generated half).  x is read once and written twice; one launch instead of four gathers.
-__global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const float* __restrict__ fa, const float* __restrict__ fb,
+static __global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const float* __restrict__ fa, const float* __restrict__ fb,
                                   int ldf, const int* __restrict__ idx, int na, float* __restrict__ out, int ldo, long N) {
   const int w = cd + na;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +153,7 @@ __global__ void build_cat2_kernel(const float* __restrict__ x, int cd, const flo
 }
 
 // out[c][r] = in[r][c]  (float32, rows x cols -> cols x rows), 32 x 32 tiles through LDS.  grid = (ceil(cols/32), ceil(rows/32)), 256 threads
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int rows, int cols, int ldi, float* __restrict__ out, int ldo) {
+static __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int rows, int cols, int ldi, float* __restrict__ out, int ldo) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 }
 
 // out[r][0..ldo) = in[r][0..cols), zero in the pad columns (row pitch rounded up for 16-byte loads)
-__global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows, float* __restrict__ out, int ldo) {
+static __global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows, float* __restrict__ out, int ldo) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * ldo) return;
   const int r = (int)(i / ldo), c = (int)(i - (long)r * ldo);
@@ -185,7 +185,7 @@ __global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows
 // and verifies that everything outside the band is negligible before using the O(T*kb) form.
 // ---------------------------------------------------------------------------------------
 // per-offset max |R[t][w*T + t + o]| , o in [-(T-1), T-1]  ->  offmax[o + T - 1]
-__global__ void mlpg_offset_max_kernel(const float* __restrict__ R, int T, int nW, float* __restrict__ offmax) {
+static __global__ void mlpg_offset_max_kernel(const float* __restrict__ R, int T, int nW, float* __restrict__ offmax) {
   const int o = blockIdx.x - (T - 1);
   __shared__ float sh[16];
   float mx = 0.f;
@@ -205,7 +205,7 @@ __global__ void mlpg_offset_max_kernel(const float* __restrict__ R, int T, int n
   }
 }
 
-__global__ void mlpg_extract_band_kernel(const float* __restrict__ R, int T, int nW, int kb, float* __restrict__ band) {
+static __global__ void mlpg_extract_band_kernel(const float* __restrict__ R, int T, int nW, int kb, float* __restrict__ band) {
   const int nb = 2 * kb + 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= T * nW * nb) return;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
 // masked squared error: partial[blk] = sum_{rows of blk} sum_d (a*m - b*m)^2   (double)
 // optional gradient out: g[r][d] = gscale * 2 * (a*m - b*m) * m * inv_tv
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
+static __global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
     const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
     const float* __restrict__ mask, long rows, int D, double* __restrict__ partial,
     float* __restrict__ g, int ldg, float gscale, const StepScalars* __restrict__ sc) {
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 // finalize head: sums HeadPartials in a fixed order into StepScalars, writes dw/db of last_linear.
 // grid = ceil(K/64) workgroups of 1024 threads (16 row-parts x 64 columns); workgroup 0 also
 // reduces the scalar partials.
-__global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
+static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
                                                                int nblk, int K, int mode, StepScalars* sc,
                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                StepResults* early_res /* D step: also finalize_d (gnorm 0) */) {
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartial
 //            + adv_w * gadv[n][j]  (dloss_adv/dy_hat_static, NEW D weights; train.py:307-308,314)
 // for c = adv_cols[j]; also produces the MGE loss partials.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
+static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     const float* __restrict__ yhs, int ld1, const float* __restrict__ ys, int ld2,
     const float* __restrict__ mask, long rows, int Ds, float mge_w,
     const int* __restrict__ adv_inv /* [Ds] -> j or -1 */, const float* __restrict__ leak, int ldl,
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
   __shared__ double sh[16];
   double v = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 // column sums of a frame matrix (bias gradient when no weight gradient is requested):
 // workgroup = 64 columns x rows_per_blk rows, 4 row lanes; partial[blk_r][c] then a fixed-order finalize
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, long rows, int cols,
+static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, long rows, int cols,
                                                              int rows_per_blk, float* __restrict__ partial) {
   __shared__ float sh[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (rl == 0 && c < cols) partial[(long)blockIdx.x * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int cols, float* __restrict__ out, int accumulate) {
+static __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int cols, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
@@ -822,19 +822,19 @@ struct SlabJob {
   int nslab, accumulate, nb, main_blocks, block0, pad_;
 };
 struct SlabJobs { int n, pad_; SlabJob j[SLAB_MAX_JOBS]; };
-__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabJobs jobs) {
+static __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabJobs jobs) {
   int q = 0;
   while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].block0) ++q;
   const SlabJob& J = jobs.j[q];
   slab_reduce4_body((int)blockIdx.x - J.block0, J.slabs, J.slab_stride, J.nslab, J.n4, J.out, J.accumulate, J.bslabs, J.nb, J.bout, J.main_blocks);
 }
-__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
+static __global__ __launch_bounds__(256) void slab_reduce4_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n4,
                                                            float* __restrict__ out, int accumulate,
                                                            const float* __restrict__ bslabs, int nb, float* __restrict__ bout, int main_blocks) {
   slab_reduce4_body((int)blockIdx.x, slabs, slab_stride, nslab, n4, out, accumulate, bslabs, nb, bout, main_blocks);
 }
 // small-n variant (bias gradients): 64 columns x 16 slab lanes per workgroup, fixed-order combine
-__global__ __launch_bounds__(1024) void slab_reduce_small_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, int n,
+static __global__ __launch_bounds__(1024) void slab_reduce_small_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, int n,
                                                                  float* __restrict__ out, int accumulate) {
   __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_small_kernel(const float* __
     out[c] = accumulate ? out[c] + tot : tot;
   }
 }
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n,
+static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, long n,
                                    float* __restrict__ out, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -867,7 +867,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_st
 // clip_grad_norm_(params, 1.0) + optimizer step, fused over the flat parameter buffer
 // (reference train.py:275-276, 317-318; torch.optim.Adagrad / Adam update rules)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RED_THREADS) void sqnorm_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+static __global__ __launch_bounds__(RED_THREADS) void sqnorm_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
   __shared__ double sh[16];
   double acc = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -887,7 +887,7 @@ struct OptimSpec {
   float max_norm;      // clip threshold (1.0 in the reference); <= 0 disables clipping
 };
 
-__global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
+static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
     const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o,
     const unsigned int* __restrict__ fault_dev, unsigned int* fault_host /* pinned, or null */,
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
 }
 
 // out[r][c] = in[r][c] * keep(r, c) / (1 - p)   (nn.LSTM inter-layer dropout and its backward; in == out allowed)
-__global__ void dropout_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, DropoutSpec d) {
+static __global__ void dropout_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, DropoutSpec d) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
   const long r = e / cols;
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void distortion_kernel(const float* __restrict
 }
 
 // out[i] = sum over blocks of partials[blk][i], fixed order; grid 1 x 64*DIST_NSUM threads (one wave per sum)
-__global__ void distortion_finalize_kernel(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+static __global__ void distortion_finalize_kernel(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
   const int lane = threadIdx.x & 63, i = threadIdx.x >> 6;
   double r = 0.0;
   for (int k = lane; k < nblk; k += 64) r += partials[(long)k * DIST_NSUM + i];
@@ -1043,7 +1043,7 @@ __global__ void distortion_finalize_kernel(const double* __restrict__ partials, 
 // In2OutHighwayNet combine (reference gantts/models.py:57-69):
 //   y_hat_static = x_static + Tx * Gx      ;  backward: dGx = g*Tx, dTz = g*Gx*Tx*(1-Tx)
 // ---------------------------------------------------------------------------------------
-__global__ void highway_forward_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Tx, int ldt,
+static __global__ void highway_forward_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Tx, int ldt,
                                        const float* __restrict__ Gx, int ldg, float* __restrict__ out, int ldo,
                                        long rows, int sd) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1051,7 +1051,7 @@ __global__ void highway_forward_kernel(const float* __restrict__ x, int ldx, con
   const long r = e / sd; const int c = (int)(e - r * sd);
   out[r * ldo + c] = x[r * ldx + c] + Tx[r * ldt + c] * Gx[r * ldg + c];
 }
-__global__ void highway_backward_kernel(const float* __restrict__ g, int ldgr, const float* __restrict__ Tx, int ldt,
+static __global__ void highway_backward_kernel(const float* __restrict__ g, int ldgr, const float* __restrict__ Tx, int ldt,
                                         const float* __restrict__ Gx, int ldg, float* __restrict__ dGx, int ld1,
                                         float* __restrict__ dTz, int ld2, long rows, int sd) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1066,7 +1066,7 @@ __global__ void highway_backward_kernel(const float* __restrict__ g, int ldgr, c
 // results of one update_* call, written by a single thread and copied D2H once
 // ---------------------------------------------------------------------------------------
 // zero_gnorm: the gradient norm is not known / not applicable at this point (early results, phase != "train"): report 0
-__global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int zero_gnorm) {
+static __global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int zero_gnorm) {
   if (threadIdx.x || blockIdx.x) return;
   const float T = sc->tv;
   const float lr = -((float)sc->s_real) / T, lf = -((float)sc->s_fake) / T;
@@ -1076,7 +1076,7 @@ __global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int z
 }
 // part_mge / part_mse (optional): per-block partial sums that have not been reduced into sc yet -- the fused
 // (single-GPU) call folds sum_partials_kernel into this launch; launch with 256 threads then, else 1.
-__global__ void finalize_g_kernel(StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
+static __global__ void finalize_g_kernel(StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
                                   int zero_gnorm, const double* __restrict__ part_mge, int n_mge,
                                   const double* __restrict__ part_mse, int n_mse) {
   if (blockIdx.x) return;

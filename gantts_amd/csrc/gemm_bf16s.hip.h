@@ -625,7 +625,7 @@ struct SeqDropSrc {
   const float* in; int ldi; const float* mul; int T, n;
   __device__ __forceinline__ float operator()(long r, int c) const { return in[r * ldi + c] * mul[(r / T) * n + c]; }
 };
-__global__ __launch_bounds__(256) void seqdrop_cast_transpose_kernel(const SeqDropSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
+static __global__ __launch_bounds__(256) void seqdrop_cast_transpose_kernel(const SeqDropSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
                                                                      __bf16* __restrict__ outT, long ldt) {
   __shared__ float tile[64][65];
   cast_transpose_tile(tile, src, nullptr, 0, rows, cols, out, ldo, outT, ldt, nullptr, (int)blockIdx.x, (int)blockIdx.y);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void seqdrop_cast_transpose_kernel(const SeqDr
 constexpr int CAST_MAX_JOBS = 8;
 struct CastJob { const float* in; __bf16* out; __bf16* outT; long rows, ldt; int ldi, cols, ldo, gy, block0, pad_; };
 struct CastJobs { int n, pad_; CastJob j[CAST_MAX_JOBS]; };
-__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastJobs jobs) {
+static __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastJobs jobs) {
   __shared__ float tile[64][65];
   int q = 0;
   while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].block0) ++q;
@@ -656,14 +656,14 @@ struct CatSrc {
     return (g >= N ? fb : fa)[rr * ldf + idx[c - cd]];
   }
 };
-__global__ __launch_bounds__(256) void cat_cast_transpose_kernel(const CatSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
+static __global__ __launch_bounds__(256) void cat_cast_transpose_kernel(const CatSrc src, long rows, int cols, __bf16* __restrict__ out, int ldo,
                                                                  __bf16* __restrict__ outT, long ldt) {
   __shared__ float tile[64][65];
   cast_transpose_tile(tile, src, nullptr, 0, rows, cols, out, ldo, outT, ldt, nullptr, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // out[r][c] (contiguous float32) = in[r][c] of a bf16 image with row pitch ld (inspection / parity hooks)
-__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ in, long ld, long rows, int cols, float* __restrict__ out) {
+static __global__ void bf16_to_f32_kernel(const __bf16* __restrict__ in, long ld, long rows, int cols, float* __restrict__ out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
   const long r = e / cols;

@@ -10,7 +10,7 @@
 //
 // Tile: BM x BN (64 or 128 each) per 256-thread workgroup (4 waves, 2x2), each wave (BM/2)x(BN/2) in
 // 32x32 MFMA tiles; K step 32.  The engine runs 64x64 tiles (4 workgroups per CU) whenever both operands take
-// 16-byte loads and 128-wide tiles (2 per CU) otherwise (engine.hip: launch_gemm; measurements in DESIGN.md 3.1).
+// 16-byte loads and 128-wide tiles (2 per CU) otherwise (eng_gemm_f32.hip: launch_gemm; measurements in DESIGN.md 3.1).
 // gemm_tile() is the tile body, gemm_store_tile() its epilogue; gemm_f32_kernel launches one product,
 // gemm_pair_kernel a layer's backward-data product + weight gradient, gemm_chain.hip.h a stack of layers.
 // LDS image is k-major  As[k][m] / Bs[k][n]; the MFMA
@@ -786,7 +786,7 @@ __device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
 // first n1 workgroups run g1's tiles, the rest g2's: one launch edge (ramp, first-tile latency, drain) instead of two,
 // and the second product's tiles start while the first one's last tiles finish.
 // tn_first: the weight-gradient workgroups (K = frames / slabs: several times the work of a backward-data tile) take the
-// FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (engine.hip).
+// FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (eng_gemm_f32_pair.hip).
 template <int PREC, int AMODE = GEMM_A_RUNTIME>
 __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

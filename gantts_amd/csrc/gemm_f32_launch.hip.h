@@ -1,0 +1,80 @@
+// Launchers of the float32 MFMA GEMM family (gemm_f32.hip.h), included by the translation units that instantiate its kernels
+// (eng_gemm_f32_nt / _nn / _tn / _pair.hip: one operand orientation each, so that they compile in parallel).
+#pragma once
+#include "engine_internal.hip.h"
+
+static double gemm_algorithmic_bytes(int kind, const GemmArgs& g) {
+  double b = 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N);
+  if (kind == GEMM_NN && g.act != ACT_NONE && g.H) b += 4.0 * (double)g.M * g.N;     // the producer's stored activation
+  return b;
+}
+// per-device ticket counters of the start stagger (mode 3): the two workgroups of a CU draw consecutive tickets
+static unsigned int* gemm_stagger_tickets() {
+  static std::map<int, unsigned int*> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = bufs.find(dev);
+  if (it != bufs.end()) return it->second;
+  unsigned int* p = nullptr;
+  if (hipMalloc((void**)&p, 2048 * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, 2048 * sizeof(unsigned int)) != hipSuccess) p = nullptr;
+  bufs[dev] = p;
+  return p;
+}
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC, int AM>
+static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
+  const size_t lds = gemm_lds_bytes<KIND, BM, BN, PREC>();
+  CHK(ensure_dyn_lds((const void*)gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>, lds));
+  g.n_tiles_m = cdiv(g.M, BM);
+  g.n_tiles_n = cdiv(g.N, BN);
+  const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
+  if (grid <= 0) return GT_OK;
+  // Start stagger (gemm_f32.hip.h), OFF by default: in isolation (tools/gemm_stagger_bench.hip, dense random operands,
+  // the five big launches of a step back to back) letting one of the two workgroups of a CU start 0.5 .. 2 us late is
+  // worth 10-15 % (372 -> 325 us per sequence); inside the training step it measured 0.0 % in every mode,
+  // so it stays a measurement switch: GT_GEMM_STAGGER_TICKS (10 ns units), GT_GEMM_STAGGER_MODE.
+  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 0;
+  static const int stagger_mode = getenv("GT_GEMM_STAGGER_MODE") ? atoi(getenv("GT_GEMM_STAGGER_MODE")) : 3;
+  if (stagger_ticks > 0 && grid > gemm_cu_count()) {
+    g.stagger_ticks = stagger_ticks; g.stagger_mode = stagger_mode;
+    if (stagger_mode == 3 && !(g.stagger_ticket = gemm_stagger_tickets())) g.stagger_ticks = 0;
+  }
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
+}
+template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>
+static int launch_gemm_t(const GemmArgs& g, int nslab, hipStream_t s) {
+  // the hot shape of the float32 step (64 x 64 tiles, 16-byte loadable operands) has its two common epilogue flavours
+  // compiled in: no activation, LeakyReLU + Philox dropout (gemm_f32.hip.h: GemmAmode); everything else decides at run time
+  if constexpr (KIND != GEMM_TN && BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) {
+    if (g.act == ACT_NONE) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_NONE>(g, nslab, s);
+    if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX>(g, nslab, s);
+  }
+  return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_RUNTIME>(g, nslab, s);
+}
+template <int KIND, int BM, int BN>
+static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
+  GemmArgs g = g_in;
+  g.wide_store = KIND != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
+                 (KIND != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
+  const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
+  const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
+  if (tl_gemm_prec == PREC_BF16) {
+    if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true, PREC_BF16>(g, nslab, s);
+    if (va) return launch_gemm_t<KIND, BM, BN, true, false, PREC_BF16>(g, nslab, s);
+    if (vb) return launch_gemm_t<KIND, BM, BN, false, true, PREC_BF16>(g, nslab, s);
+    return launch_gemm_t<KIND, BM, BN, false, false, PREC_BF16>(g, nslab, s);
+  }
+  if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true, PREC_F32>(g, nslab, s);
+  if (va) return launch_gemm_t<KIND, BM, BN, true, false, PREC_F32>(g, nslab, s);
+  if (vb) return launch_gemm_t<KIND, BM, BN, false, true, PREC_F32>(g, nslab, s);
+  return launch_gemm_t<KIND, BM, BN, false, false, PREC_F32>(g, nslab, s);
+}
+

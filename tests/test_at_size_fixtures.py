@@ -73,7 +73,7 @@ def test_oracle_reproduces_the_reference_fixture_at_full_size():
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.isfile("/opt/rocm/bin/hipcc"), reason="no HIP compiler")
 def test_rccl_test_double_exports_what_the_engine_binds():
-    """tests/fake_rccl.cpp must export exactly the seven nccl* symbols engine.hip resolves (rccl_api())."""
+    """tests/fake_rccl.cpp must export exactly the seven nccl* symbols eng_comm.hip resolves (rccl_api())."""
     so = os.path.join(HERE, "libfake_rccl.so")
     src = os.path.join(HERE, "fake_rccl.cpp")
     if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
@@ -82,7 +82,7 @@ def test_rccl_test_double_exports_what_the_engine_binds():
     lib = ctypes.CDLL(so)
     for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
         assert hasattr(lib, sym), sym
-    eng = open(os.path.join(os.path.dirname(HERE), "gantts_amd", "csrc", "engine.hip")).read()
+    eng = open(os.path.join(os.path.dirname(HERE), "gantts_amd", "csrc", "eng_comm.hip")).read()
     for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
         assert '"%s"' % sym in eng
     buf = ctypes.create_string_buffer(128)

@@ -1,4 +1,4 @@
-"""-m gpu: the engine's OWN data-parallel communicator (gt_comm_*, engine.hip) with TWO ranks.
+"""-m gpu: the engine's OWN data-parallel communicator (gt_comm_*, gantts_amd/csrc/eng_comm.hip) with TWO ranks.
 
 RCCL refuses two ranks on one device and the test boxes have one MI355X, so the two processes bind a test double
 (tests/fake_rccl.cpp through GT_RCCL_LIB: all-reduce over POSIX shared memory, stream-ordered, summed in rank order).
