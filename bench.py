@@ -31,9 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
-VARIANTS = ["fwd X.W^T BN64", "fwd X.W^T BN128", "bwd-data dZ.W BN64", "bwd-data dZ.W BN128",
-            "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128", "layer chain fwd X.W^T BN64", "layer chain bwd-data dZ.W BN64",
-            "pair bwd-data dZ.W + bwd-weight dZ^T.X BN64"]
+# one entry per kernel (template instantiation family): include/gantts_hip.h, GT_PROFILE_SLOTS
+VARIANTS = ["fwd X.W^T BN64 (run-time epilogue)", "fwd X.W^T BN128", "bwd-data dZ.W BN64 (run-time epilogue)", "bwd-data dZ.W BN128",
+            "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128", "fwd X.W^T 64x64 <no activation>", "fwd X.W^T 64x64 <LeakyReLU + Philox>",
+            "pair bwd-data dZ.W + bwd-weight dZ^T.X BN64", "fwd X.W^T 64x64 <LeakyReLU + Philox, added matrix>",
+            "bwd-data dZ.W 64x64 <no activation>", "bwd-data dZ.W 64x64 <LeakyReLU + Philox>",
+            "bwd-weight pair of the split first layer (x block + adversarial block)", "-", "-", "-"]
 
 G_SPEC = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
 D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
@@ -50,7 +53,7 @@ def pmc_traffic(variant):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        key = ("pair" if variant == 8 else "chain,%d" % (variant - 6)) if variant >= 6 else "%d,%d" % (variant // 2, 64 if variant % 2 == 0 else 128)
+        key = "pair" if variant == 8 else ("slot%d" % variant if variant >= 6 else "%d,%d" % (variant // 2, 64 if variant % 2 == 0 else 128))
         return d["gemm_variants"][key]["hbm_bytes_per_launch"], os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))) + ": " + d["source"]
     except Exception:
         return None, None

@@ -8,12 +8,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgantts_hip.so")
+LIB_PATH = os.environ.get("GT_HIP_LIB") or os.path.join(_HERE, "libgantts_hip.so")      # GT_HIP_LIB: A/B of two builds (tools/)
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
 OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16 = 2, 3, 4, 5
-PROFILE_SLOTS = 9
+PROFILE_SLOTS = 16
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
 MAX_STREAMS = 8

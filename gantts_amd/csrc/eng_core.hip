@@ -42,9 +42,7 @@ extern "C" int gt_profile_enable(int on) {
   g_prof.on = on != 0;
   return GT_OK;
 }
-// Drains the recorded launches into per-variant totals.  variant = kind*2 + (bn==128): 6 slots, then slot 6 = layer-chain
-// launches of forward products, slot 7 = layer-chain launches of backward-data products (gemm_chain.hip.h), slot 8 = pair
-// launches (backward-data + weight gradient of one layer, gemm_pair_kernel).
+// Drains the recorded launches into per-kernel totals (slot layout: include/gantts_hip.h).
 // out_ms[v] = summed kernel time, out_flops[v] = summed algorithmic 2*M*N*K, out_count[v] = launches.
 extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_count) {
   for (int v = 0; v < GT_PROFILE_SLOTS; ++v) { out_ms[v] = 0; out_flops[v] = 0; out_count[v] = 0; g_prof.last_bytes[v] = 0; }
@@ -52,7 +50,15 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
     if (hipEventSynchronize(r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventSynchronize failed");
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(GT_ERR_HIP, "hipEventElapsedTime failed");
-    const int v = r.kind >= 3 ? 3 + r.kind : r.kind * 2 + (r.bn == 128 ? 1 : 0);     // kind 3 / 4: chain of NT / NN products, 5: pair
+    int v = r.kind * 2 + (r.bn == 128 ? 1 : 0);
+    if (r.kind == 5) v = 8;                                   // pair launch
+    else if (r.kind == 6) v = 12;                             // weight-gradient pair of a split first layer
+    else if (r.kind == GEMM_NT && r.am == GEMM_A_NONE) v = 6;
+    else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX) v = 7;
+    else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX_ADDM) v = 9;
+    else if (r.kind == GEMM_NN && r.am == GEMM_A_NONE) v = 10;
+    else if (r.kind == GEMM_NN && r.am == GEMM_A_LEAKY_PHILOX) v = 11;
+    if (v < 0 || v >= GT_PROFILE_SLOTS) v = GT_PROFILE_SLOTS - 1;
     out_ms[v] += ms; out_flops[v] += r.flops; out_count[v] += 1; g_prof.last_bytes[v] += r.bytes;
     g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1);
   }
@@ -151,6 +157,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
   e->w0pad[0].release(); e->w0pad[1].release();
+  e->d_pre.release(); e->adv2.release(); e->pitched[0].buf.release(); e->pitched[1].buf.release();
   for (auto* v : {&e->g_actb, &e->d_actb}) for (auto& b : *v) b.release();
   e->xin_b.release(); e->dcat_b.release(); e->gy_b.release(); e->dz_b[0].release(); e->dz_b[1].release(); e->fwd_b.release();
   for (int r = 0; r < 2; ++r) for (auto& w : e->wsh[r]) { w.w.release(); w.wt.release(); }
@@ -339,7 +346,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       // interchangeable, so a change drops whatever is stashed -- the next update_* then asks for a fresh apply_generator
       // instead of back-propagating through buffers the forward never filled
       if (e->matmul_bf16 != (value != 0)) {
-        e->g_pass_valid = false; e->fake_cat_valid = false; e->dcat_b_ok = false; e->leak_pending = false;
+        e->g_pass_valid = false; e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false; e->leak_pending = false;
         e->d_begin_done = false; e->g_begin_done = false;
       }
       e->matmul_bf16 = value != 0;
@@ -494,7 +501,7 @@ extern "C" int gt_clear_faults(gt_engine* e, void* stream) {
   HIPCHK(hipMemset(e->d_fault, 0, 64));
   for (int r = 0; r < 2; ++r) { e->net[r].step -= (long)e->h_fault[2 + r]; if (e->net[r].step < 0) e->net[r].step = 0; }
   for (int i = 0; i < 4; ++i) e->h_fault[i] = 0;
-  e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false;
+  e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false; e->adv2_fake_ok = false;
   e->d_begin_done = e->g_begin_done = false; e->early_done = false;
   return GT_OK;
 }

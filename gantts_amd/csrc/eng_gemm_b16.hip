@@ -15,7 +15,7 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   if (grid <= 0) return GT_OK;
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = g.epi; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.kind = g.epi; rec.bn = BN; rec.am = -1; rec.flops = 2.0 * g.M * g.N * g.K;
     rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
                 (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
@@ -41,7 +41,7 @@ static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
   if (grid <= 0) return GT_OK;
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = g.epi; rec.bn = T; rec.flops = 2.0 * g.M * g.N * g.K;
+    rec.kind = g.epi; rec.bn = T; rec.am = -1; rec.flops = 2.0 * g.M * g.N * g.K;
     rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
                 (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();

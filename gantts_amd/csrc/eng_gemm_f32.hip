@@ -7,6 +7,7 @@ int launch_gemm_nt(const GemmArgs& g, int bm, int bn, hipStream_t s);
 int launch_gemm_nn(const GemmArgs& g, int bm, int bn, hipStream_t s);
 int launch_gemm_tn(const GemmArgs& g, int bm, int bn, int nslab, hipStream_t s);
 int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hipStream_t s);
+int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------
@@ -36,19 +37,28 @@ static int gemm_tile_mode() {   // measurement switch: GT_GEMM_TILES=big restore
   static const int m = [] { const char* v = getenv("GT_GEMM_TILES"); return v && !strcmp(v, "big") ? 1 : 0; }();
   return m;
 }
-bool gemm_vec_ok(const float* p, int ld) { return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
+static bool gemm_unaligned_ok() {   // measurement switch
+  static const bool on = [] { const char* v = getenv("GT_GEMM_UNALIGNED"); return !(v && v[0] == '0'); }();
+  return on;
+}
+bool gemm_vec_ok(const float* p, int ld, bool k_contiguous) {
+  if (k_contiguous && gemm_unaligned_ok()) return true;
+  return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0);
+}
+// NT / NN results (and the producer's activation the NN epilogue reads) leave / arrive row-wise, 16 bytes per lane
+bool gemm_wide_store_ok(int kind, const GemmArgs& g) {
+  if (kind == GEMM_TN) return false;
+  if (gemm_unaligned_ok()) return true;
+  return (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
+         (kind != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
+}
 bool gemm_small_tiles_ok() { return gemm_tile_mode() == 0; }   // f32 and bf16 products alike (bf16: cfg2 1.30 -> 1.21 ms, SRU 32.0 -> 28.2 ms)
 
 
-static void gemm_set_wide_store(int kind, GemmArgs& g) {
-  // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
-  g.wide_store = kind != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
-                 (kind != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
-}
 int launch_gemm(int kind, const GemmArgs& g, int nslab, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(GT_ERR_INVALID, "empty GEMM");
   const int bn = pick_bn(g.N);
-  const bool vec = gemm_vec_ok(g.A, g.lda) && gemm_vec_ok(g.B, g.ldb);
+  const bool vec = gemm_vec_ok(g.A, g.lda, kind != GEMM_TN) && gemm_vec_ok(g.B, g.ldb, kind == GEMM_NT);
   if (kind != GEMM_TN && vec && g.M > 64 && gemm_small_tiles_ok())
     return kind == GEMM_NT ? launch_gemm_nt(g, 64, 64, s) : launch_gemm_nn(g, 64, 64, s);
   // Otherwise tile height by a residency model: 128-row tiles keep 2 workgroups per CU resident (512 at once),
@@ -112,7 +122,7 @@ static bool gemm_pair_enabled() {
   return on;
 }
 static bool gemm_pair_ok(const GemmArgs& nn) {
-  return gemm_pair_enabled() && gemm_small_tiles_ok() && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda) && gemm_vec_ok(nn.B, nn.ldb);
+  return gemm_pair_enabled() && gemm_small_tiles_ok() && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda, true) && gemm_vec_ok(nn.B, nn.ldb);
 }
 
 
@@ -216,3 +226,85 @@ int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, l
   return GT_OK;
 }
 
+
+// Weight gradient of a SPLIT first layer (conditioned discriminator: input [x | adv], the same x under the real and the
+// generated rows):  dW[:, :cd] = (dZ[:wrap] + dZ[wrap:])^T . x   over `wrap` frames (the loader sums the two halves),
+//                   dW[:, cd:] = dZ^T . adv                         over all `rows` frames,      db = column sums of dZ.
+// Both products write column blocks of one slab set [nslab][out][cd + Da] in ONE launch; the combine is the usual one.
+// xp: x with a 16-byte row pitch (n-contiguous operand), adv: [rows][ld_adv] with a 16-byte pitch.
+int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap, const float* xp, int ldxp, int cd,
+                                 const float* adv, int ld_adv, int Da, int out, float* dW, float* db, bool accumulate,
+                                 Scratch& slabs, hipStream_t s, SlabDefer* defer) {
+  if (rows != wrap && rows != 2 * wrap) return fail(GT_ERR_INVALID, "split weight gradient: rows must be one or two halves");
+  if (!gemm_vec_ok(dZ, lddz) || !gemm_vec_ok(xp, ldxp) || !gemm_vec_ok(adv, ld_adv) || tl_gemm_prec != PREC_F32)
+    return fail(GT_ERR_INVALID, "split weight gradient: operands must be 16-byte loadable (float32 products)");
+  const int in = cd + Da;
+  // Slab count: the adversarial block has cdiv(Da, 64) tile columns against cdiv(cd, 64) of the x block but twice the frames, so
+  // its workgroups are the long ones (rows / nslab frames each): enough slabs that one of them is about as long as a quarter of
+  // the launch (4 workgroups per CU), dispatched FIRST (gemm_tn_pair_kernel), the x block's workgroups back-fill behind them.
+  const int tiles = cdiv(out, 64) * cdiv(cd, 64);
+  int nslab = std::max(1, 1024 / tiles);
+  nslab = std::min<long>(nslab, std::max<long>(1, wrap / 256));
+  const int kc1 = cdiv(cdiv(wrap, nslab), GEMM_BK) * GEMM_BK;
+  const int ns1 = cdiv(wrap, kc1);
+  const int kc2 = cdiv(cdiv(rows, ns1), GEMM_BK) * GEMM_BK;
+  const int ns2 = cdiv(rows, kc2);                      // <= ns1
+  nslab = ns1;
+  const long slab_stride = (long)out * in;
+  const size_t need = (((size_t)nslab * slab_stride + (size_t)nslab * out) * sizeof(float) + 255) & ~(size_t)255;
+  const bool can4 = slab_stride % 4 == 0 && ((uintptr_t)dW) % 16 == 0;
+  float* slab_base = nullptr;
+  if (defer && defer->active && accumulate) { CHK(slab_defer_flush(*defer, s)); defer = nullptr; }
+  if (defer && defer->active && can4) {
+    if (defer->jobs.n == SLAB_MAX_JOBS || defer->used + need > defer->pool.bytes) {
+      CHK(slab_defer_flush(*defer, s));
+      if (need > defer->pool.bytes) CHK(defer->pool.ensure(std::max(need * 4, (size_t)64 << 20)));
+    }
+    slab_base = (float*)((char*)defer->pool.p + defer->used);
+    defer->used += need;
+  } else {
+    defer = nullptr;
+    CHK(slabs.ensure(need));
+    slab_base = slabs.as<float>();
+  }
+  float* bias_slabs = slab_base + (size_t)nslab * slab_stride;
+  if (ns2 < ns1)      // (tiny batches) the adversarial block and the bias sums of the trailing slabs are not written by any workgroup
+    HIPCHK(hipMemsetAsync(slab_base, 0, need, s));
+  GemmArgs g1, g2;
+  memset(&g1, 0, sizeof(g1));
+  g1.A = dZ; g1.lda = lddz; g1.A2 = rows == 2 * wrap ? dZ + wrap * (long)lddz : nullptr;
+  g1.B = xp; g1.ldb = ldxp; g1.C = slab_base; g1.ldc = in;
+  g1.M = out; g1.N = cd; g1.K = (int)wrap; g1.k_chunk = kc1; g1.slab_stride = slab_stride; g1.drop = no_drop();
+  g2 = g1;
+  g2.A2 = nullptr; g2.B = adv; g2.ldb = ld_adv; g2.C = slab_base + cd; g2.N = Da; g2.K = (int)rows; g2.k_chunk = kc2;
+  g2.colsum_slab = db ? bias_slabs : nullptr;
+  if (g1.A2) {
+    CHK(launch_gemm_tn_pair(g1, g2, ns1, ns2, s));
+  } else {             // one half only: two plain weight-gradient launches
+    g1.n_tiles_m = 64; g2.n_tiles_m = 64;
+    CHK(launch_gemm(GEMM_TN, g1, ns1, s));
+    CHK(launch_gemm(GEMM_TN, g2, ns2, s));
+  }
+  if (can4) {
+    const int main_blocks = cdiv(slab_stride / 4, 256), bias_blocks = db ? cdiv(out, 256) : 0;
+    if (defer) {
+      SlabJob& J = defer->jobs.j[defer->jobs.n++];
+      J.slabs = slab_base; J.slab_stride = slab_stride; J.n4 = slab_stride / 4; J.out = dW; J.bslabs = bias_slabs; J.bout = db;
+      J.nslab = nslab; J.accumulate = accumulate ? 1 : 0; J.nb = out; J.main_blocks = main_blocks; J.block0 = defer->blocks; J.pad_ = 0;
+      defer->blocks += main_blocks + bias_blocks;
+      return GT_OK;
+    }
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, s, slab_base, slab_stride, nslab,
+                       slab_stride / 4, dW, accumulate ? 1 : 0, (const float*)bias_slabs, out, db, main_blocks);
+    LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(slab_stride, 256)), dim3(256), 0, s, slab_base, slab_stride, nslab, slab_stride, dW,
+                       accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+    if (db) {
+      hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(out, 64)), dim3(1024), 0, s, bias_slabs, (long)out, nslab, out, db, accumulate ? 1 : 0);
+      LAUNCH_CHECK();
+    }
+  }
+  return GT_OK;
+}

@@ -1,14 +1,9 @@
 // libgantts_hip.so -- float32 MFMA family, pair launches (a layer's backward-data product + weight gradient in one launch, gemm_pair_kernel)
 #include "gemm_f32_launch.hip.h"
 
-static void gemm_set_wide_store(int kind, GemmArgs& g) {
-  // 16-byte accesses need a 16-byte aligned base and a row pitch that is a multiple of 4 floats
-  g.wide_store = kind != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
-                 (kind != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
-}
 int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hipStream_t s) {
   GemmArgs nn = nn_in, tn = tn_in;
-  gemm_set_wide_store(GEMM_NN, nn);
+  nn.wide_store = gemm_wide_store_ok(GEMM_NN, nn) ? 1 : 0;
   tn.wide_store = 0;
   nn.n_tiles_m = cdiv(nn.M, 64); nn.n_tiles_n = cdiv(nn.N, 64);
   tn.n_tiles_m = cdiv(tn.M, 64); tn.n_tiles_n = cdiv(tn.N, 64);
@@ -22,7 +17,7 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
   CHK(ensure_dyn_lds(kern, lds));
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = 5; rec.bn = 64; rec.flops = 2.0 * nn.M * nn.N * nn.K + 2.0 * tn.M * tn.N * tn.K;
+    rec.kind = 5; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * nn.M * nn.N * nn.K + 2.0 * tn.M * tn.N * tn.K;
     rec.bytes = gemm_algorithmic_bytes(GEMM_NN, nn) + gemm_algorithmic_bytes(GEMM_TN, tn);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
@@ -33,6 +28,28 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
   else if (am == GEMM_A_NONE) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_NONE>), dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   else if (am == GEMM_A_LEAKY_PHILOX) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX>), dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  LAUNCH_CHECK();
+  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  return GT_OK;
+}
+
+// the two weight-gradient products of a split first layer in one launch (gemm_tn_pair_kernel); float32, 64 x 64 tiles
+int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s) {
+  GemmArgs g1 = g1_in, g2 = g2_in;
+  g1.wide_store = g2.wide_store = 0;
+  g1.n_tiles_m = cdiv(g1.M, 64); g1.n_tiles_n = cdiv(g1.N, 64);
+  g2.n_tiles_m = cdiv(g2.M, 64); g2.n_tiles_n = cdiv(g2.N, 64);
+  const int n1 = g1.n_tiles_m * g1.n_tiles_n * nslab1, n2 = g2.n_tiles_m * g2.n_tiles_n * nslab2;
+  const size_t lds = gemm_lds_bytes<GEMM_TN, 64, 64>();
+  CHK(ensure_dyn_lds((const void*)gemm_tn_pair_kernel<PREC_F32>, lds));
+  GemmProfiler::Rec rec;
+  if (g_prof.on) {
+    rec.kind = 6; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * g1.M * g1.N * g1.K + 2.0 * g2.M * g2.N * g2.K;
+    rec.bytes = gemm_algorithmic_bytes(GEMM_TN, g1) + 4.0 * (double)g1.M * g1.K + gemm_algorithmic_bytes(GEMM_TN, g2);
+    rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
+    HIPCHK(hipEventRecord(rec.e0, s));
+  }
+  hipLaunchKernelGGL(gemm_tn_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, g1, g2, n1);
   LAUNCH_CHECK();
   if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;

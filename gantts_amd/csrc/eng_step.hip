@@ -106,9 +106,38 @@ static int stage_injected(gt_engine* e, int role, int layer, const int* passes, 
   return GT_OK;
 }
 
+// SPLIT first layer of the conditioned discriminator (float32 path).  D sees [x | adv] (train.py:254-256) for the real AND the
+// generated rows of a D step with the SAME x, so layer 0 is evaluated as
+//     P = x . W[:, :cd]^T + b                      once, over the `wrap` rows of x             (no activation)
+//     H = act(adv . W[:, cd:]^T + P[r mod wrap])   over all rows of the pass                   (K = Da = 58 columns)
+// instead of one product over a concatenated [2N][cd + Da] image: no image of x is built (109 MB / step at cfg2), the
+// x product of a D step is done once instead of twice (- 44 % of the layer's flops), and the weight gradient contracts
+// (dZ_real + dZ_generated) with x over N frames (linear_backward_weight_split).  Same sums up to float32 association.
+struct FirstSplit {
+  const float* x; int ldx; int cd;     // conditioning input: `wrap` rows, any pitch (k-contiguous operand)
+  const float* xp; int ldxp;           // the same rows with a 16-byte pitch (weight gradient), or null (forward only)
+  const float* adv; int ld_adv;        // [rows][ld_adv]: the pass's adversarial columns, 16-byte pitch
+  long wrap;
+};
+// a caller tensor's rows with a 16-byte pitch: the tensor itself when it already has one, else a copy made once per step
+static int pitched_rows(gt_engine* e, int slot, const float* p, int ld, int cols, long rows, const float** out, int* ldo, hipStream_t s) {
+  if (gemm_vec_ok(p, ld)) { *out = p; *ldo = ld; return GT_OK; }
+  gt_engine::Pitched& P = e->pitched[slot];
+  const int ldp = (cols + 3) & ~3;
+  if (!(P.src == p && P.ld == ld && P.cols == cols && P.rows == rows && P.step == e->step_counter)) {
+    CHK(P.buf.ensure((size_t)rows * ldp * sizeof(float)));
+    hipLaunchKernelGGL(repitch_kernel, dim3(cdiv(rows * (ldp / 4), 256)), dim3(256), 0, s, p, ld, cols, rows, P.buf.as<float>(), ldp);
+    LAUNCH_CHECK();
+    P.src = p; P.ld = ld; P.cols = cols; P.rows = rows; P.step = e->step_counter;
+  }
+  *out = P.buf.as<float>(); *ldo = ldp;
+  return GT_OK;
+}
+
 // hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
 static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
-                         const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s) {
+                         const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s,
+                         const FirstSplit* fs = nullptr) {
   Net& n = e->net[role];
   specs.resize(n.hidden.size());
   const float* cur = in;
@@ -119,9 +148,23 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
     specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
+    if (l == 0 && fs) {
+      const int Da = L.in - fs->cd;
+      CHK(e->d_pre.ensure((size_t)fs->wrap * L.out * sizeof(float)));
+      CHK(linear_forward(fs->x, fs->ldx, L.W, L.in, L.b, e->d_pre.as<float>(), L.out, fs->wrap, fs->cd, L.out, ACT_NONE, no_drop(), s));
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = fs->adv; g.lda = fs->ld_adv; g.B = L.W + fs->cd; g.ldb = L.in; g.C = acts[l].as<float>(); g.ldc = L.out;
+      g.M = (int)rows; g.N = L.out; g.K = Da; g.act = ACT_LEAKY_DROPOUT; g.drop = specs[l];
+      g.addm = e->d_pre.as<float>(); g.ld_addm = L.out; g.addm_wrap = (int)fs->wrap;
+      CHK(launch_gemm(GEMM_NT, g, 1, s));
+      cur = acts[l].as<float>();
+      ld = L.out;
+      continue;
+    }
     const float* W = L.W;
     int ldw = L.in;
-    if (l == 0 && (L.in & 3) && gemm_vec_ok(cur, ld) && tl_gemm_prec == PREC_F32) {
+    if (l == 0 && (L.in & 3) && gemm_vec_ok(cur, ld) && !gemm_vec_ok(L.W, L.in, true) && tl_gemm_prec == PREC_F32) {
       // The input image takes 16-byte loads (the discriminator's [x | adv] image, pitch 484) but the weight rows (483
       // floats) do not: multiply by a copy of W with its row pitch rounded up to 4 floats, re-made from the caller's
       // parameter buffer before every pass (it may have been stepped, loaded or broadcast since).
@@ -148,7 +191,7 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
 // optionally, dX[:, col0:col0+ncols] of the stack input for rows [row0, row0+nrows).
 static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
                           const std::vector<DropoutSpec>& specs, float* cur, float* other, bool want_w,
-                          float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s) {
+                          float* dX, int lddx, int col0, int ncols, long row0, long nrows, hipStream_t s, const FirstSplit* fs = nullptr) {
   Net& n = e->net[role];
   const int L = (int)n.hidden.size();
   {
@@ -161,7 +204,11 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       GemmArgs nn;
       if (l > 0) nn = backward_data_args(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
                                          acts[l - 1].as<float>(), Lr.in, specs[l - 1]);
-      if (want_w) {
+      if (want_w && l == 0 && fs) {
+        CHK(linear_backward_weight_split(cur, Lr.out, rows, fs->wrap, fs->xp, fs->ldxp, fs->cd, fs->adv, fs->ld_adv, Lr.in - fs->cd, Lr.out,
+                                         Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
+        CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
+      } else if (want_w) {
         CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role],
                                    l > 0 ? &nn : nullptr, &rode));
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
@@ -370,7 +417,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->step_counter++;
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
-  e->fake_cat_valid = false; e->dcat_b_ok = false;
+  e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false;
   e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
   e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
@@ -488,6 +535,16 @@ int post_early_results(gt_engine* e, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // update_discriminator
 // ------------------------------------------------------------------------------------------
+// the split first layer (FirstSplit) applies to the conditioned discriminator on the float32 path
+static bool d_split_enabled() {   // measurement switch: GT_D_SPLIT=0 keeps the concatenated [x | adv] image
+  static const bool on = [] { const char* v = getenv("GT_D_SPLIT"); return !(v && v[0] == '0'); }();
+  return on;
+}
+static bool d_split_ok(gt_engine* e, const float* x, bool b16) {
+  return d_split_enabled() && !b16 && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
+         e->Da > 0 && gemm_small_tiles_ok() && (e->net[GT_ROLE_D].d.hidden_dim & 3) == 0;     // (dZ as a 16-byte loadable operand)
+}
+
 extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const float* y_static, const float* y_hat_static,
                                              const float* mask, int B, int T, int train, float eps, void* stream) {
   CHK(check_common(e, B, T));
@@ -507,6 +564,9 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
   const bool b16 = use_b16(e, GT_ROLE_D);
+  const bool split = d_split_ok(e, x, b16);
+  FirstSplit fs;
+  memset(&fs, 0, sizeof(fs));
   if (b16) {
     // bf16 storage: the image is written ONCE, as bf16, in both orientations (no float32 image at all)
     if (e->cfg.discriminator_linguistic_condition && (!x || cond_dim(e) <= 0))
@@ -520,6 +580,19 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     e->dcat_b_ok = true;
     e->fake_cat_valid = false;                 // the float32 image was not built
   } else {
+  if (split) {
+    // split first layer (FirstSplit): only the adversarial columns of the two halves are gathered (58 of 483 columns at cfg2)
+    e->ld_adv2 = (e->Da + 3) & ~3;
+    CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
+    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256)), dim3(256), 0, s, y_static, y_hat_static, e->Ds, e->d_adv_cols, e->Da,
+                       e->adv2.as<float>(), e->ld_adv2, N, 2 * N);
+    LAUNCH_CHECK();
+    e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
+    e->fake_cat_valid = false;
+    fs.x = x; fs.ldx = cond_dim(e); fs.cd = cond_dim(e); fs.adv = e->adv2.as<float>(); fs.ld_adv = e->ld_adv2; fs.wrap = N;
+    fs.xp = nullptr; fs.ldxp = 0;
+    if (tr) CHK(pitched_rows(e, 0, x, fs.ldx, fs.cd, N, &fs.xp, &fs.ldxp, s));
+  } else {
   CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
   if (e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0) {
     hipLaunchKernelGGL(build_cat2_kernel, dim3(cdiv(N * K0, 256)), dim3(256), 0, s, x, cond_dim(e), y_static, y_hat_static, e->Ds,
@@ -530,13 +603,15 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(build_cat(e, x, y_hat_static, e->Ds, N, N, ldc, s));
   }
   e->fake_cat_valid = true; e->fake_cat_x = x; e->fake_cat_yhs = y_hat_static;
+  e->adv2_fake_ok = false;
+  }
   }
   e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
   if (b16) {
     CHK(refresh_shadows(e, GT_ROLE_D, false, s));
     CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
   } else {
-    CHK(stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s));
+    CHK(stack_forward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s, split ? &fs : nullptr));
   }
   const int H = D.d.hidden_dim;
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
@@ -567,8 +642,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     if (b16) {   // the head wrote its seed gradient as the top dZ image, both orientations
       CHK(stack_backward_b16(e, GT_ROLE_D, e->dcat_b.t(), e->dcat_b.ldt, 2 * N, e->d_actb, e->d_specs, 0, true, leak, e->Da, col0, e->Da, N, N, s));
     } else {
-      CHK(stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
-                         e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s));
+      CHK(stack_backward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
+                         e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s, split ? &fs : nullptr));
     }
     D.grads_dirty = true;
     if (want_leak) e->leak_pending = true;
@@ -727,12 +802,20 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   // The first layer's weight gradient reads G's input as its frame operand.  When the discriminator's input image of
   // this step holds the very same x (linguistic conditioning on the generator's own input, no noise channels), the x
   // columns of its rows are a bit-exact copy with a 16-byte row pitch: use it, and the product takes the 16-byte loader.
+  // The first layer's weight gradient reads G's input as its n-contiguous frame operand: with a 16-byte pitch it takes the
+  // 16-byte loader and the 64 x 64 tiles.  The caller's tensor when it has one, else the discriminator's input image of this step
+  // when that holds the very same x (bit-exact copy), else a pitched copy made once per step (shared with the split first layer
+  // of D when it conditions on the same tensor).
   const float* xin = x;
   int ldxin = G.d.in_dim;
-  if (e->fake_cat_valid && e->fake_cat_x == x && e->cfg.discriminator_linguistic_condition && cond_dim(e) == G.d.in_dim &&
-      e->dcat.p && (G.d.in_dim & 3)) {
-    ldxin = (d_in_dim(e) + 3) & ~3;
-    xin = e->dcat.as<float>() + N * ldxin;      // the generated half: the one that is valid whenever fake_cat_valid is
+  if (!gemm_vec_ok(x, G.d.in_dim) && tl_gemm_prec == PREC_F32) {
+    if (e->fake_cat_valid && e->fake_cat_x == x && e->cfg.discriminator_linguistic_condition && cond_dim(e) == G.d.in_dim && e->dcat.p) {
+      ldxin = (d_in_dim(e) + 3) & ~3;
+      xin = e->dcat.as<float>() + N * ldxin;      // the generated half: the one that is valid whenever fake_cat_valid is
+    } else {
+      const int slot = (e->pitched[0].src == x && e->pitched[0].cols == G.d.in_dim && e->pitched[0].step == e->step_counter) ? 0 : 1;
+      CHK(pitched_rows(e, slot, x, G.d.in_dim, G.d.in_dim, N, &xin, &ldxin, s));
+    }
   }
   CHK(stack_backward(e, GT_ROLE_G, xin, ldxin, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
                      nullptr, 0, 0, 0, 0, 0, s));
@@ -780,7 +863,21 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     const int passes[1] = {2};
     const bool b16 = use_b16(e, GT_ROLE_D);
     const float* cat = nullptr;
-    if (!b16) {
+    const bool split = d_split_ok(e, x, b16);
+    FirstSplit fs;
+    memset(&fs, 0, sizeof(fs));
+    if (split) {     // the generated rows' adversarial columns: kept from the D step of the same batch, or gathered here
+      e->ld_adv2 = (e->Da + 3) & ~3;
+      CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
+      float* fake = e->adv2.as<float>() + N * e->ld_adv2;
+      if (!(e->adv2_fake_ok && e->adv2_yhs == y_hat_static)) {
+        hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(N * e->ld_adv2, 256)), dim3(256), 0, s, y_hat_static, y_hat_static, Ds, e->d_adv_cols, e->Da,
+                           fake, e->ld_adv2, N, N);
+        LAUNCH_CHECK();
+        e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
+      }
+      fs.x = x; fs.ldx = cond_dim(e); fs.cd = cond_dim(e); fs.adv = fake; fs.ld_adv = e->ld_adv2; fs.wrap = N;
+    } else if (!b16) {
       CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
       if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
         CHK(build_cat(e, x, y_hat_static, Ds, N, N, ldc, s));
@@ -803,7 +900,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       CHK(refresh_shadows(e, GT_ROLE_D, false, s));        // D has just been stepped (train.py:276 before :307)
       CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, N, e->d_actb, passes, 1, N, e->d_specs, false, s));
     } else {
-      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s));
+      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s, split ? &fs : nullptr));
     }
     const int H = D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));

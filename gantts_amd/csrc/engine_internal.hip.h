@@ -64,8 +64,8 @@ int gemm_cu_count();
 // optional per-launch timing of the product families (HIP events on the launch stream); bench.py's live roofline figure
 struct GemmProfiler {
   bool on = false;
-  struct Rec { int kind, bn; double flops, bytes; hipEvent_t e0, e1; };
-  double last_bytes[GT_PROFILE_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic bytes per slot of the last gt_profile_read
+  struct Rec { int kind, bn, am; double flops, bytes; hipEvent_t e0, e1; };   // am: GemmAmode of a float32 kernel (-1: run-time flavour)
+  double last_bytes[GT_PROFILE_SLOTS] = {};   // algorithmic bytes per slot of the last gt_profile_read
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
@@ -229,6 +229,11 @@ struct gt_engine {
   const float* dcat_b_x = nullptr; const float* dcat_b_yhs = nullptr;
   std::vector<LinShadow> wsh[2];                   // per role: bf16 shadows of the hidden layers' weights, then of the last layer's
   SlabDefer sdefer[2];                             // per role: deferred weight-gradient combines of the fused step
+  Scratch d_pre;                                   // split first layer of the conditioned D: P = x . W[:, :cd]^T + b  (eng_step.hip: FirstSplit)
+  Scratch adv2; int ld_adv2 = 0;                   // ... and the adversarial columns of a pass's rows, [real | generated], 16-byte pitch
+  bool adv2_fake_ok = false; const float* adv2_yhs = nullptr;   // its generated half holds adv(y_hat_static) of this tensor
+  struct Pitched { Scratch buf; const float* src = nullptr; int ld = 0, cols = 0; long rows = 0; uint64_t step = ~0ULL; };
+  Pitched pitched[2];                              // 16-byte-pitch copies of caller tensors (slot 0: D's x, 1: G's input), once per step
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
@@ -267,7 +272,11 @@ gt::DropoutSpec drop_spec(gt_engine* e, int role, int pass, int layer, const flo
 // engine entry point for the launches it issues on this thread
 // ------------------------------------------------------------------------------------------
 extern thread_local int tl_gemm_prec;
-bool gemm_vec_ok(const float* p, int ld);
+// may this operand be loaded 16 bytes per lane?  k-contiguous operands (rows of X / W in the forward product, rows of dZ in
+// backward-data): any float pointer and pitch (unaligned 16-byte loads, gemm_f32.hip.h: ld4u); operands whose contiguous
+// direction is m / n: 16-byte aligned base and a pitch that is a multiple of 4 floats (GT_GEMM_UNALIGNED=0: that rule for all)
+bool gemm_vec_ok(const float* p, int ld, bool k_contiguous = false);
+bool gemm_wide_store_ok(int kind, const gt::GemmArgs& g);
 bool gemm_small_tiles_ok();
 gt::DropoutSpec no_drop();
 int launch_gemm(int kind, const gt::GemmArgs& g, int nslab, hipStream_t s);
@@ -281,6 +290,10 @@ int slab_defer_flush(SlabDefer& d, hipStream_t s);
 int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, long rows, int out, int in,
                            float* dW, float* db, bool accumulate, Scratch& slabs, Scratch& colp, hipStream_t s,
                            SlabDefer* defer = nullptr, const gt::GemmArgs* ride_along = nullptr, bool* rode = nullptr);
+
+int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap, const float* xp, int ldxp, int cd,
+                                 const float* adv, int ld_adv, int Da, int out, float* dW, float* db, bool accumulate,
+                                 Scratch& slabs, hipStream_t s, SlabDefer* defer);
 
 // ------------------------------------------------------------------------------------------
 // eng_gemm_b16.hip

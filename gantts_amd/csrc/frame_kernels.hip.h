@@ -171,6 +171,33 @@ static __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* 
 }
 
 // out[r][0..ldo) = in[r][0..cols), zero in the pad columns (row pitch rounded up for 16-byte loads)
+// The adversarial columns of a pass's rows as one image with a 16-byte row pitch (the split first layer of the conditioned
+// discriminator, eng_step.hip): out[r][j] = fa[r][idx[j]] for r < split, fb[r - split][idx[j]] otherwise; pad columns are 0.
+// Bit-exact copies (train.py:232-242 select_streams on the static features).
+static __global__ void build_adv_kernel(const float* __restrict__ fa, const float* __restrict__ fb, int ldf, const int* __restrict__ idx,
+                                        int na, float* __restrict__ out, int ldo, long split, long rows) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * ldo) return;
+  const long r = e / ldo;
+  const int c = (int)(e - r * ldo);
+  float v = 0.f;
+  if (c < na) v = r < split ? fa[r * ldf + idx[c]] : fb[(r - split) * ldf + idx[c]];
+  out[e] = v;
+}
+// [rows][cols] with row pitch ld_in -> the same rows with row pitch ldo (multiple of 4 floats, pad columns 0): the operand image of
+// products that read a caller tensor along its rows' direction (n-contiguous operand of a weight gradient)
+static __global__ void repitch_kernel(const float* __restrict__ in, int ld_in, int cols, long rows, float* __restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one 4-float group per thread
+  const int g4 = ldo >> 2;
+  if (i >= rows * g4) return;
+  const long r = i / g4;
+  const int c = (int)(i - r * g4) * 4;
+  const float* src = in + r * ld_in + c;
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = c + k < cols ? src[k] : 0.f;
+  *reinterpret_cast<f32x4*>(out + r * ldo + c) = v;
+}
 static __global__ void pad_rows_kernel(const float* __restrict__ in, int cols, int rows, float* __restrict__ out, int ldo) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * ldo) return;

@@ -39,6 +39,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// 16-byte global accesses at addresses that are only 4-byte aligned (row pitches 425 / 483 / 187 of the reference's tensors):
+// legal on gfx950 (the compiler emits global_load_dwordx4 / global_store_dwordx4 for an align-4 aggregate; measured with
+// tools/unaligned_probe.hip), so k-contiguous operands and result rows take the vector path whatever their pitch.
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };
+__device__ __forceinline__ f32x4 ld4u(const float* p) {
+  const F4U t = *reinterpret_cast<const F4U*>(p);
+  f32x4 r; r[0] = t.v[0]; r[1] = t.v[1]; r[2] = t.v[2]; r[3] = t.v[3];
+  return r;
+}
+__device__ __forceinline__ void st4u(float* p, const f32x4& r) {
+  F4U t; t.v[0] = r[0]; t.v[1] = r[1]; t.v[2] = r[2]; t.v[3] = r[3];
+  *reinterpret_cast<F4U*>(p) = t;
+}
+
 // PREC: arithmetic of the products.  PREC_F32: v_mfma_f32_32x32x2_f32 on f32 operands (exact f32, the default).
 // PREC_BF16 (mixed precision, BASELINE.json configs[2]): operands are rounded to bf16 (RNE) on their way into LDS and
 // multiplied by v_mfma_f32_32x32x16_bf16 with f32 accumulation -- 16x the matrix rate; memory layout, epilogues and
@@ -135,6 +149,12 @@ struct GemmArgs {
   int act;                   // Act
   const float* H; int ldh;   // NN: producer's stored activation (for f'), or null
   int accumulate;            // NT/NN: C += result (sum over LSTM directions / SRU highway term)
+  // NT: a matrix added to the product before the activation: z = A.B^T + bias + addm[m mod addm_wrap][n].  The conditioned
+  // discriminator's first layer sees [x | adv] for the real AND the generated rows with the same x: x . W_x^T is computed once
+  // (N rows) and added to adv . W_adv^T of both halves (2N rows, addm_wrap = N).   (reference train.py:254-256)
+  const float* addm; int ld_addm; int addm_wrap;
+  // TN: the A operand is the element-wise sum A + A2 (same pitch): dW_x = (dZ_real + dZ_generated)^T . x over N frames
+  const float* A2;
   int wide_store;            // NT/NN: C (and H) 16-byte aligned with pitch % 4 == 0 -> full tiles are written
                              // row-wise with 16 B stores through an LDS transpose (set by the launcher)
   DropoutSpec drop;
@@ -208,7 +228,7 @@ __device__ __forceinline__ void epi_store4(float* dst, const f32x4& v) {
 #elif GT_EPI_STORE == 2
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
 #else
-  *reinterpret_cast<f32x4*>(dst) = v;
+  st4u(dst, v);
 #endif
 }
 __device__ __forceinline__ void epi_store1(float* dst, float v) {
@@ -227,12 +247,16 @@ __device__ __forceinline__ void epi_store1(float* dst, float v) {
 // AMODE: epilogue flavour restated at COMPILE time for the hot instantiations (-1 = decided at run time from g.act /
 // g.drop.mode).  The epilogue is unrolled over the tile's accumulators; with run-time flavours every element carries the
 // branches of all of them (the 64 x 64 forward kernel: ~2500 of its 3100 instructions are prologue + epilogue).
-enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1 };
+enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1,
+                 GEMM_A_LEAKY_PHILOX_ADDM = 2,   // NT: LeakyReLU + Philox dropout on (product + bias + addm)
+                 GEMM_A_TN_SUM2 = 3 };           // TN: loader sums A + A2
 template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
                                                 f32x16 (&acc)[BM / 64][BN / 64], float* smem) {
-  const int g_act = AMODE == GEMM_A_RUNTIME ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
-  const int g_dmode = AMODE == GEMM_A_RUNTIME ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
+  constexpr bool RT = AMODE == GEMM_A_RUNTIME || AMODE == GEMM_A_TN_SUM2;
+  const int g_act = RT ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
+  const int g_dmode = RT ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
+  const bool has_addm = KIND == GEMM_NT && (AMODE == GEMM_A_LEAKY_PHILOX_ADDM || (RT && g.addm != nullptr));
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN_ = WN / 32;
   const int tid = threadIdx.x;
@@ -275,6 +299,10 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
             float v = acc[i][j][q * 4 + s4];
             if (KIND == GEMM_NT) {
               v += bias;
+              if (has_addm) {
+                const int mr = mrow + s4;
+                v += g.addm[(long)(mr >= g.addm_wrap ? mr - g.addm_wrap : mr) * g.ld_addm + n];
+              }
               if (g_act == ACT_LEAKY_DROPOUT) {
                 v = leaky(v);
                 if (g_dmode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
@@ -301,14 +329,14 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
         const long m = m0 + wm * WM + i * 32 + row;
         const int n = n0 + wn * WN + sc4;
         if (KIND == GEMM_NN && g_act != ACT_NONE) {
-          const f32x4 h = *reinterpret_cast<const f32x4*>(g.H + m * g.ldh + n);
+          const f32x4 h = ld4u(g.H + m * g.ldh + n);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             v[c] *= g_act == ACT_SIGMOID ? h[c] * (1.f - h[c]) : (h[c] > 0.f ? 1.f : 0.01f);
         }
         float* dst = C + m * g.ldc + n;
         if (g.accumulate) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+          const f32x4 o = ld4u(dst);
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] += o[c];
         }
@@ -341,6 +369,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
             v += bias;
+            if (has_addm) v += g.addm[(long)(m >= g.addm_wrap ? m - g.addm_wrap : m) * g.ld_addm + n];
             if (g_act == ACT_LEAKY_DROPOUT) {
               v = leaky(v);
               if (g_dmode == DROP_PHILOX) v = keep_px ? v * g.drop.scale : 0.f;
@@ -442,6 +471,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   const long stepA = A_KC ? (long)GEMM_BK : (long)GEMM_BK * g.lda;
   const long stepB = B_KC ? (long)GEMM_BK : (long)GEMM_BK * g.ldb;
   const float* pA = g.A + (A_KC ? (long)k_begin : (long)k_begin * g.lda);
+  const long a2_delta = (KIND == GEMM_TN && AMODE == GEMM_A_TN_SUM2) ? (long)(g.A2 - g.A) : 0L;     // A2 as an offset from the moving A pointer
   const float* pB = g.B + (B_KC ? (long)k_begin : (long)k_begin * g.ldb);
 
   float ra[UA * VWA], rb[UB * VWB];
@@ -450,17 +480,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   auto load_a = [&](auto& ra, int u, bool tail, int krem) {
     int kk, mm; a_pos(u, kk, mm);
     uint32_t off = offA[u];
-    if (tail) {  // keep the address inside the matrix: step back to the last valid k (vector start)
-      const int klast = A_KC ? ((krem - 1) / VWA) * VWA : krem - 1;
-      const int back = max(0, kk - klast);
+    if (tail && A_KC && VA) {
+      // k-contiguous vector unit in the K tail: element-wise, clamped to the last valid k -- nothing is read beyond the row's
+      // K elements (the pitch need not leave room behind them), the rest of the unit is zero
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = kk + c;
+        const float v = pA[(long)off + (min(k, krem - 1) - kk)];
+        ra[u * 4 + c] = k < krem ? v : 0.f;
+      }
+      return;
+    }
+    if (tail) {  // keep the address inside the matrix: step back to the last valid k
+      const int back = max(0, kk - (krem - 1));
       off -= (uint32_t)back * (A_KC ? 1u : (uint32_t)g.lda);
     }
     if (VA) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(pA + off);
+      f32x4 v = A_KC ? ld4u(pA + off) : *reinterpret_cast<const f32x4*>(pA + off);
+      if (KIND == GEMM_TN && AMODE == GEMM_A_TN_SUM2) v += *reinterpret_cast<const f32x4*>(pA + a2_delta + off);
 #pragma unroll
       for (int c = 0; c < 4; ++c) ra[u * 4 + c] = v[c];
     } else {
       ra[u] = pA[off];
+      if (KIND == GEMM_TN && AMODE == GEMM_A_TN_SUM2) ra[u] += pA[a2_delta + off];
     }
     if (tail) {
 #pragma unroll
@@ -473,13 +515,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   auto load_b = [&](auto& rb, int u, bool tail, int krem) {
     int kk, nn; b_pos(u, kk, nn);
     uint32_t off = offB[u];
+    if (tail && B_KC && VB) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = kk + c;
+        const float v = pB[(long)off + (min(k, krem - 1) - kk)];
+        rb[u * 4 + c] = k < krem ? v : 0.f;
+      }
+      return;
+    }
     if (tail) {
-      const int klast = B_KC ? ((krem - 1) / VWB) * VWB : krem - 1;
-      const int back = max(0, kk - klast);
+      const int back = max(0, kk - (krem - 1));
       off -= (uint32_t)back * (B_KC ? 1u : (uint32_t)g.ldb);
     }
     if (VB) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(pB + off);
+      const f32x4 v = B_KC ? ld4u(pB + off) : *reinterpret_cast<const f32x4*>(pB + off);
 #pragma unroll
       for (int c = 0; c < 4; ++c) rb[u * 4 + c] = v[c];
     } else {
@@ -803,6 +853,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmAr
     const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
     const int tile_m = t / g2.n_tiles_n, tile_n = t - tile_m * g2.n_tiles_n;
     gemm_tile<GEMM_TN, 64, 64, true, true, PREC>(g2, slab, tile_m, tile_n, smem);
+  }
+}
+
+// One launch = the two weight-gradient products of a SPLIT first layer (eng_step.hip: FirstSplit): g1 = the x columns, A operand
+// summed over the two halves of the pass (GEMM_A_TN_SUM2), g2 = the adversarial columns over all rows; both write column blocks
+// of the same slab set.  g2's workgroups (twice the frames each) take the FIRST block ids: longest work first.
+template <int PREC>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int bid = blockIdx.x;
+  const int n2 = (int)gridDim.x - n1;
+  if (bid >= n2) {      // g2's (long) workgroups take the first block ids
+    bid = gemm_xcd_order(bid - n2, n1);
+    const int tiles_mn = g1.n_tiles_m * g1.n_tiles_n;
+    const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
+    gemm_tile<GEMM_TN, 64, 64, true, true, PREC, 32, GEMM_A_TN_SUM2>(g1, slab, t / g1.n_tiles_n, t % g1.n_tiles_n, smem);
+  } else {
+    bid = gemm_xcd_order(bid, n2);
+    const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
+    const int slab = bid / tiles_mn, t = bid - slab * tiles_mn;
+    gemm_tile<GEMM_TN, 64, 64, true, true, PREC>(g2, slab, t / g2.n_tiles_n, t % g2.n_tiles_n, smem);
   }
 }
 

@@ -40,7 +40,7 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   }
   GemmProfiler::Rec rec;
   if (g_prof.on) {
-    rec.kind = KIND; rec.bn = BN; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
+    rec.kind = KIND; rec.bn = BN; rec.am = AM; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
@@ -54,18 +54,30 @@ static int launch_gemm_t(const GemmArgs& g, int nslab, hipStream_t s) {
   // the hot shape of the float32 step (64 x 64 tiles, 16-byte loadable operands) has its two common epilogue flavours
   // compiled in: no activation, LeakyReLU + Philox dropout (gemm_f32.hip.h: GemmAmode); everything else decides at run time
   if constexpr (KIND != GEMM_TN && BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) {
-    if (g.act == ACT_NONE) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_NONE>(g, nslab, s);
-    if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX>(g, nslab, s);
+    if (g.addm == nullptr) {
+      if (g.act == ACT_NONE) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_NONE>(g, nslab, s);
+      if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX>(g, nslab, s);
+    } else if constexpr (KIND == GEMM_NT) {
+      if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX_ADDM>(g, nslab, s);
+    }
   }
+  if constexpr (KIND == GEMM_TN) {
+    if (g.A2 != nullptr) {      // summed A operand: the 64 x 64 float32 form with 16-byte loadable operands only
+      if constexpr (BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_TN_SUM2>(g, nslab, s);
+      else return fail(GT_ERR_INVALID, "weight gradient with a summed operand needs 64 x 64 tiles and 16-byte loadable operands");
+    }
+  } else if (g.A2 != nullptr) {
+    return fail(GT_ERR_INVALID, "summed A operand: weight gradients only");
+  }
+  if (g.addm != nullptr && KIND != GEMM_NT) return fail(GT_ERR_INVALID, "added matrix: forward products only");
   return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_RUNTIME>(g, nslab, s);
 }
 template <int KIND, int BM, int BN>
 static int launch_gemm_v(const GemmArgs& g_in, int nslab, hipStream_t s) {
   GemmArgs g = g_in;
-  g.wide_store = KIND != GEMM_TN && (g.ldc % 4 == 0) && (((uintptr_t)g.C) % 16 == 0) &&
-                 (KIND != GEMM_NN || g.act == ACT_NONE || ((g.ldh % 4 == 0) && (((uintptr_t)g.H) % 16 == 0)));
-  const bool va = (g.lda % 4 == 0) && (((uintptr_t)g.A) % 16 == 0);
-  const bool vb = (g.ldb % 4 == 0) && (((uintptr_t)g.B) % 16 == 0);
+  g.wide_store = gemm_wide_store_ok(KIND, g) ? 1 : 0;
+  const bool va = gemm_vec_ok(g.A, g.lda, KIND != GEMM_TN);
+  const bool vb = gemm_vec_ok(g.B, g.ldb, KIND == GEMM_NT);
   if (tl_gemm_prec == PREC_BF16) {
     if (va && vb) return launch_gemm_t<KIND, BM, BN, true, true, PREC_BF16>(g, nslab, s);
     if (va) return launch_gemm_t<KIND, BM, BN, true, false, PREC_BF16>(g, nslab, s);

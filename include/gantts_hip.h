@@ -320,10 +320,16 @@ int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t
                       float* Y_image, float* YT_image, void* stream);
 
 /* ---- measurement (bench.py): HIP-event timing of every GEMM launch on its own stream --------
- * slot = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W), 2 backward-weight (dZ^T X);
- * slots 6, 7 unused; slot 8 = pair launches (one layer's backward-data product and weight gradient in one launch).
+ * One slot per KERNEL (template instantiation family), so that the figures line up with a rocprofv3 kernel trace:
+ *   0..5  = kind*2 + (tile N == 128), kind: 0 forward (X W^T), 1 backward-data (dZ W), 2 backward-weight (dZ^T X) -- the
+ *           instantiations whose epilogue flavour is decided at run time, and every bf16-storage product;
+ *   6, 7  = 64x64 forward kernels with a compiled-in epilogue: none / LeakyReLU + Philox dropout;
+ *   8     = pair launches (one layer's backward-data product and weight gradient in one launch);
+ *   9     = 64x64 forward, LeakyReLU + Philox dropout on (product + added matrix): the split first layer of the conditioned D;
+ *   10,11 = 64x64 backward-data kernels with a compiled-in epilogue: none / LeakyReLU + Philox;
+ *   12    = the two weight-gradient products of a split first layer in one launch;  13..15 unused.
  * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries. */
-#define GT_PROFILE_SLOTS 9
+#define GT_PROFILE_SLOTS 16
 int gt_profile_enable(int on);
 int gt_profile_read(double* ms_per_slot, double* flops_per_slot, int64_t* launches_per_slot);
 /* algorithmic HBM bytes (each operand once + the result once, fp32) of the launches the last gt_profile_read summed */

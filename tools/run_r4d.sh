@@ -1,0 +1,20 @@
+mkdir -p gpurun_out/r4d; O=gpurun_out/r4d
+b() { # name, env...
+  n=$1; shift
+  env "$@" timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $O/bench_$n.json 2> $O/bench_$n.err
+  python - <<PY
+import json
+try:
+    d=[json.loads(l) for l in open("$O/bench_$n.json") if l.startswith("{")][-1]
+    r=d["roofline"]
+    print("$n ms/step %.4f frac %.3f family %.3f"%(d["ms_per_step"], r["frac"], r["gemm_family"]["frac"]), [(x["kernel"][16:36], round(x["avg_us"],1), x["launches_per_step"]) for x in r["variants"]])
+except Exception as e: print("$n failed", e)
+PY
+}
+b mono GT_HIP_LIB=$PWD/tools/bin/libgantts_mono.so
+b unity GT_HIP_LIB=$PWD/tools/bin/libgantts_unity.so
+b split A=1
+b mono2 GT_HIP_LIB=$PWD/tools/bin/libgantts_mono.so
+b unity2 GT_HIP_LIB=$PWD/tools/bin/libgantts_unity.so
+b split2 A=1
+b unity_al GT_HIP_LIB=$PWD/tools/bin/libgantts_unity.so GT_GEMM_UNALIGNED=0
