@@ -137,6 +137,8 @@ def main():
                     help="GPU clock spin-up before the warm-up steps: a generic memory-streaming loop (NOT steps of the workload) keeps "
                          "the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a training "
                          "run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
+    ap.add_argument("--dense-x", action="store_true", help="x resident with dense 425-float rows (the engine then makes the 16-byte-pitch "
+                    "copy its weight-gradient products read, once per step) instead of the pitched rows the batch pipeline stages")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--dp-python", action="store_true", help="data parallelism orchestrated from Python (torch.distributed "
                     "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
@@ -200,6 +202,13 @@ def main():
         del xg, yg
     else:                              # every rank its own shard
         x, y = synthetic_batch(B, Tn, 1000 + rank, dev)
+    if not args.dense_x:
+        # x resident as gantts_amd.data.DevicePrefetcher(pitch_x=True) stages it: rows of 425 floats on a 428-float pitch
+        # (include/gantts_hip.h: gt_set_x_pitch -- the lda of the step functions' x)
+        from gantts_amd.engine import pitched_empty
+        xp = pitched_empty(B, Tn, 425, dev)
+        xp.copy_(x)
+        x = xp
     R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn, dev)
     lengths = torch.full((B,), Tn, dtype=torch.long, device=dev)
     cpu_lengths = [Tn] * B
@@ -341,7 +350,8 @@ def main():
         out = {"metric": "acoustic frames/sec per G+D GAN step (B=32,T=512)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "cfg2: TTS acoustic MLP G 425-512x3-187 + conditioned MLP D 483-256x3-1, "
+               "config": {"x_layout": "dense rows (425 floats)" if args.dense_x else "rows of 425 floats on a 428-float pitch (gt_set_x_pitch; DevicePrefetcher(pitch_x=True))",
+                          "workload": "cfg2: TTS acoustic MLP G 425-512x3-187 + conditioned MLP D 483-256x3-1, "
                                       "Adagrad, MGE+ADV loss, global B=%d T=%d (%d sequences per GPU, %s scaling), fp32, "
                                       "dropout 0.5 (Philox)" % (Bglobal, Tn, B, args.scaling),
                           "global_batch": Bglobal, "per_gpu_batch": B, "frames_per_step": Bglobal * Tn,

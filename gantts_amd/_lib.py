@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GT_HIP_LIB") or os.path.join(_HERE, "libgantts_hip.so
 
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
-OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16 = 2, 3, 4, 5
+OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_SPLIT_FIRST_LAYER, OPT_FUSED_OPTIMIZER = 2, 3, 4, 5, 6, 7
 PROFILE_SLOTS = 16
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
@@ -87,6 +87,7 @@ SIGNATURES = {
     "gt_set_loss_normalizer": (_I, [_P, _F]),
     "gt_set_loss_normalizer_device": (_I, [_P, _P]),
     "gt_set_option": (_I, [_P, _I, _I]),
+    "gt_set_x_pitch": (_I, [_P, _I, _I]),
     "gt_check_faults": (_I, [_P, _P]),
     "gt_clear_faults": (_I, [_P, _P]),
     "gt_comm_unique_id": (_I, [_P]),

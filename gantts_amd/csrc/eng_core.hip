@@ -157,7 +157,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
                     &e->headp, &e->headw, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
   e->w0pad[0].release(); e->w0pad[1].release();
-  e->d_pre.release(); e->adv2.release(); e->pitched[0].buf.release(); e->pitched[1].buf.release();
+  e->opt_bar.release(); e->d_pre.release(); e->adv2.release(); e->pitched[0].buf.release(); e->pitched[1].buf.release();
   for (auto* v : {&e->g_actb, &e->d_actb}) for (auto& b : *v) b.release();
   e->xin_b.release(); e->dcat_b.release(); e->gy_b.release(); e->dz_b[0].release(); e->dz_b[1].release(); e->fwd_b.release();
   for (int r = 0; r < 2; ++r) for (auto& w : e->wsh[r]) { w.w.release(); w.wt.release(); }
@@ -341,6 +341,11 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_LSTM_PERSISTENT: e->lstm_persistent = value != 0; return GT_OK;
     case GT_OPT_LSTM_FWD_UNITS: e->lstm_fwd_upc = value; return GT_OK;
     case GT_OPT_LSTM_XCD_LOCAL: e->lstm_xcd_local = value != 0; return GT_OK;
+    case GT_OPT_SPLIT_FIRST_LAYER:
+      if (e->opt_split_first != (value != 0)) { e->fake_cat_valid = false; e->adv2_fake_ok = false; }
+      e->opt_split_first = value != 0;
+      return GT_OK;
+    case GT_OPT_FUSED_OPTIMIZER: e->opt_fused_optimizer = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16:
       // the storage precision belongs to a PASS: buffers of a stashed forward pass (bf16 images vs float32 stashes) are not
       // interchangeable, so a change drops whatever is stashed -- the next update_* then asks for a fresh apply_generator
@@ -353,6 +358,11 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
+}
+extern "C" int gt_set_x_pitch(gt_engine* e, int ld_generator_input, int ld_condition) {
+  if (!e || ld_generator_input < 0 || ld_condition < 0) return fail(GT_ERR_INVALID, "bad argument");
+  e->ld_gx = ld_generator_input; e->ld_cx = ld_condition;
+  return GT_OK;
 }
 extern "C" int gt_set_loss_normalizer(gt_engine* e, float tv) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
@@ -499,6 +509,7 @@ extern "C" int gt_clear_faults(gt_engine* e, void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemset(e->d_fault, 0, 64));
+  if (e->opt_bar.p) { HIPCHK(hipMemset(e->opt_bar.p, 0, 64)); e->opt_bar_count = 0; }      // the barrier counter restarts with the re-armed engine
   for (int r = 0; r < 2; ++r) { e->net[r].step -= (long)e->h_fault[2 + r]; if (e->net[r].step < 0) e->net[r].step = 0; }
   for (int i = 0; i < 4; ++i) e->h_fault[i] = 0;
   e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false; e->adv2_fake_ok = false;

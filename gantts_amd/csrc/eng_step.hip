@@ -335,9 +335,16 @@ static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long l
 }
 
 
+// row pitch of the generator's input / of the conditioning x (gt_set_x_pitch; dense by default)
+static int gx_pitch(const gt_engine* e) { return e->ld_gx > 0 ? e->ld_gx : e->net[GT_ROLE_G].d.in_dim; }
+static int cx_pitch(gt_engine* e) { return e->ld_cx > 0 ? e->ld_cx : cond_dim(e); }
+
 static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
                              bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
   Net& G = e->net[GT_ROLE_G];
+  if (gx_pitch(e) != G.d.in_dim && (G.d.arch != GT_ARCH_MLP || use_b16(e, GT_ROLE_G) || gx_pitch(e) < G.d.in_dim))
+    return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense generator input (pitch %d for %d columns) is supported by the float32 MLP generator only",
+                gx_pitch(e), G.d.in_dim);
   const long N = (long)B * T;
   const int pass0[1] = {0};
   const float* gsrc = y_hat;            // what MLPG is applied to
@@ -368,7 +375,7 @@ static int generator_forward(gt_engine* e, const float* x, const float* R, int B
       g.act = G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = y_hat; g.ldc = G.d.out_dim;
       CHK(launch_gemm_b16(g, 1, s));
     } else {
-      CHK(stack_forward(e, GT_ROLE_G, x, G.d.in_dim, N, e->g_act, pass0, 1, N, specs, s));
+      CHK(stack_forward(e, GT_ROLE_G, x, gx_pitch(e), N, e->g_act, pass0, 1, N, specs, s));
       const Lin& Lh = G.hidden.back();
       CHK(linear_forward(e->g_act.back().as<float>(), Lh.out, G.last.W, G.last.in, G.last.b, y_hat, G.d.out_dim, N, G.last.in,
                          G.last.out, G.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s));
@@ -491,21 +498,65 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   Net& n = e->net[role];
   if (!n.has_opt) return fail(GT_ERR_STATE, "phase == \"train\" but no optimizer is bound for role %d", role);
   const long np = n.d.n_params;
-  const int nblk = (int)std::min<long>(512, cdiv(np, RED_THREADS * 4));
   CHK(e->partial.ensure(4096 * sizeof(double)));
   double* part = e->partial.as<double>() + 2048;
+  OptimSpec o;
+  o.kind = n.od.kind; o.lr = n.od.lr; o.weight_decay = n.od.weight_decay; o.eps = n.od.eps; o.lr_decay = n.od.lr_decay;
+  o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step + 1; o.max_norm = n.od.max_grad_norm;
+  unsigned int* skipped = e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr;
+  SlabDefer& sd = e->sdefer[role];
+  if (sd.active && sd.jobs.n > 0 && e->opt_fused_optimizer) {
+    // The fused step recorded this network's weight-gradient combines: combines + squared norm + clip + step in ONE launch
+    // (optim_fused_kernel).  The recorded jobs write disjoint ranges of the flat gradient; whatever they do not cover (the
+    // discriminator's last layer, written by the head's reduction) still counts for the norm and is stepped: `rest`.
+    std::vector<std::pair<long, long>> cov;
+    bool ok = true;
+    for (int q = 0; q < sd.jobs.n && ok; ++q) {
+      const SlabJob& J = sd.jobs.j[q];
+      const long o0 = J.out - n.d.grads;
+      if (o0 < 0 || o0 + J.n4 * 4 > np) ok = false;
+      cov.push_back(std::make_pair(o0, J.n4 * 4));
+      if (J.bout && J.main_blocks < (q + 1 < sd.jobs.n ? sd.jobs.j[q + 1].block0 : sd.blocks) - J.block0) {
+        const long b0 = J.bout - n.d.grads;
+        if (b0 < 0 || b0 + J.nb > np) ok = false;
+        cov.push_back(std::make_pair(b0, (long)J.nb));
+      }
+    }
+    std::sort(cov.begin(), cov.end());
+    OptimRest rest;
+    memset(&rest, 0, sizeof(rest));
+    long pos = 0;
+    for (size_t i = 0; i <= cov.size() && ok; ++i) {
+      const long next = i < cov.size() ? cov[i].first : np;
+      if (next < pos) { ok = false; break; }                       // overlapping jobs: not this path
+      if (next > pos) {
+        if (rest.n_rest == 4) { ok = false; break; }
+        rest.off[rest.n_rest] = pos; rest.n[rest.n_rest] = next - pos; ++rest.n_rest;
+      }
+      if (i < cov.size()) pos = cov[i].first + cov[i].second;
+    }
+    if (ok) {
+      if (!e->opt_bar.p) { CHK(e->opt_bar.ensure(64)); HIPCHK(hipMemsetAsync(e->opt_bar.p, 0, 64, s)); e->opt_bar_count = 0; }
+      const int grid = std::min(4 * gemm_cu_count(), std::max(sd.blocks, 64));
+      e->opt_bar_count += (unsigned long long)grid;
+      n.step += 1;
+      hipLaunchKernelGGL(optim_fused_kernel, dim3(grid), dim3(256), 0, s, sd.jobs, sd.blocks, rest, n.d.params, n.d.grads, n.od.state0, n.od.state1,
+                         part, e->opt_bar.as<unsigned long long>(), e->opt_bar_count, 200000000ULL /* 2 s of 100 MHz ticks */, norm2_out, o,
+                         e->d_fault, e->h_fault_dev, skipped);
+      LAUNCH_CHECK();
+      sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = false;
+      return GT_OK;
+    }
+  }
+  const int nblk = (int)std::min<long>(512, cdiv(np, RED_THREADS * 4));
   CHK(slab_defer_flush(e->sdefer[role], s));            // the fused step's recorded weight-gradient combines, one launch
   e->sdefer[role].active = false;
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, n.d.grads, np, part);
   LAUNCH_CHECK();
   n.step += 1;
-  OptimSpec o;
-  o.kind = n.od.kind; o.lr = n.od.lr; o.weight_decay = n.od.weight_decay; o.eps = n.od.eps; o.lr_decay = n.od.lr_decay;
-  o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step; o.max_norm = n.od.max_grad_norm;
   const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
   hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
-                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev,
-                     e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr);
+                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -536,12 +587,8 @@ int post_early_results(gt_engine* e, hipStream_t s) {
 // update_discriminator
 // ------------------------------------------------------------------------------------------
 // the split first layer (FirstSplit) applies to the conditioned discriminator on the float32 path
-static bool d_split_enabled() {   // measurement switch: GT_D_SPLIT=0 keeps the concatenated [x | adv] image
-  static const bool on = [] { const char* v = getenv("GT_D_SPLIT"); return !(v && v[0] == '0'); }();
-  return on;
-}
 static bool d_split_ok(gt_engine* e, const float* x, bool b16) {
-  return d_split_enabled() && !b16 && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
+  return e->opt_split_first && !b16 && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
          e->Da > 0 && gemm_small_tiles_ok() && (e->net[GT_ROLE_D].d.hidden_dim & 3) == 0;     // (dZ as a 16-byte loadable operand)
 }
 
@@ -565,6 +612,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // the [x | adv] image of both halves: real rows, then generated rows
   const bool b16 = use_b16(e, GT_ROLE_D);
   const bool split = d_split_ok(e, x, b16);
+  if (!split && x && e->cfg.discriminator_linguistic_condition && cx_pitch(e) != cond_dim(e))
+    return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense conditioning x is supported by the conditioned float32 discriminator's split first layer only");
   FirstSplit fs;
   memset(&fs, 0, sizeof(fs));
   if (b16) {
@@ -589,7 +638,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     LAUNCH_CHECK();
     e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
     e->fake_cat_valid = false;
-    fs.x = x; fs.ldx = cond_dim(e); fs.cd = cond_dim(e); fs.adv = e->adv2.as<float>(); fs.ld_adv = e->ld_adv2; fs.wrap = N;
+    fs.x = x; fs.ldx = cx_pitch(e); fs.cd = cond_dim(e); fs.adv = e->adv2.as<float>(); fs.ld_adv = e->ld_adv2; fs.wrap = N;
     fs.xp = nullptr; fs.ldxp = 0;
     if (tr) CHK(pitched_rows(e, 0, x, fs.ldx, fs.cd, N, &fs.xp, &fs.ldxp, s));
   } else {
@@ -807,14 +856,14 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
   // when that holds the very same x (bit-exact copy), else a pitched copy made once per step (shared with the split first layer
   // of D when it conditions on the same tensor).
   const float* xin = x;
-  int ldxin = G.d.in_dim;
-  if (!gemm_vec_ok(x, G.d.in_dim) && tl_gemm_prec == PREC_F32) {
+  int ldxin = gx_pitch(e);
+  if (!gemm_vec_ok(x, ldxin) && tl_gemm_prec == PREC_F32) {
     if (e->fake_cat_valid && e->fake_cat_x == x && e->cfg.discriminator_linguistic_condition && cond_dim(e) == G.d.in_dim && e->dcat.p) {
       ldxin = (d_in_dim(e) + 3) & ~3;
       xin = e->dcat.as<float>() + N * ldxin;      // the generated half: the one that is valid whenever fake_cat_valid is
     } else {
-      const int slot = (e->pitched[0].src == x && e->pitched[0].cols == G.d.in_dim && e->pitched[0].step == e->step_counter) ? 0 : 1;
-      CHK(pitched_rows(e, slot, x, G.d.in_dim, G.d.in_dim, N, &xin, &ldxin, s));
+      const int slot = (e->pitched[0].src == x && e->pitched[0].ld == gx_pitch(e) && e->pitched[0].cols == G.d.in_dim && e->pitched[0].step == e->step_counter) ? 0 : 1;
+      CHK(pitched_rows(e, slot, x, gx_pitch(e), G.d.in_dim, N, &xin, &ldxin, s));
     }
   }
   CHK(stack_backward(e, GT_ROLE_G, xin, ldxin, N, e->g_act, e->g_specs, e->dzA.as<float>(), e->dzB.as<float>(), true,
@@ -864,6 +913,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     const bool b16 = use_b16(e, GT_ROLE_D);
     const float* cat = nullptr;
     const bool split = d_split_ok(e, x, b16);
+    if (!split && x && e->cfg.discriminator_linguistic_condition && cx_pitch(e) != cond_dim(e))
+      return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense conditioning x is supported by the conditioned float32 discriminator's split first layer only");
     FirstSplit fs;
     memset(&fs, 0, sizeof(fs));
     if (split) {     // the generated rows' adversarial columns: kept from the D step of the same batch, or gathered here
@@ -876,7 +927,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
         LAUNCH_CHECK();
         e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
       }
-      fs.x = x; fs.ldx = cond_dim(e); fs.cd = cond_dim(e); fs.adv = fake; fs.ld_adv = e->ld_adv2; fs.wrap = N;
+      fs.x = x; fs.ldx = cx_pitch(e); fs.cd = cond_dim(e); fs.adv = fake; fs.ld_adv = e->ld_adv2; fs.wrap = N;
     } else if (!b16) {
       CHK(e->dcat.ensure((size_t)2 * N * ldc * sizeof(float)));
       if (!(e->fake_cat_valid && e->fake_cat_x == x && e->fake_cat_yhs == y_hat_static)) {
@@ -1071,7 +1122,7 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
     g.act = n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE; g.C = out; g.ldc = n.d.out_dim;
     return launch_gemm_b16(g, 1, s);
   }
-  CHK(stack_forward(e, role, x, n.d.in_dim, N, acts, pass0, 1, N, specs, s));
+  CHK(stack_forward(e, role, x, n.d.in_dim, N, acts, pass0, 1, N, specs, s));      // (plain forward: dense rows)
   return linear_forward(acts.back().as<float>(), n.hidden.back().out, n.last.W, n.last.in, n.last.b, out, n.d.out_dim, N, n.last.in,
                         n.last.out, n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
 }

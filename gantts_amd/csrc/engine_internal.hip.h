@@ -234,6 +234,11 @@ struct gt_engine {
   bool adv2_fake_ok = false; const float* adv2_yhs = nullptr;   // its generated half holds adv(y_hat_static) of this tensor
   struct Pitched { Scratch buf; const float* src = nullptr; int ld = 0, cols = 0; long rows = 0; uint64_t step = ~0ULL; };
   Pitched pitched[2];                              // 16-byte-pitch copies of caller tensors (slot 0: D's x, 1: G's input), once per step
+  // GT_OPT_SPLIT_FIRST_LAYER / GT_OPT_FUSED_OPTIMIZER (per engine; the environment only provides the default at creation)
+  bool opt_split_first = !(getenv("GT_D_SPLIT") && getenv("GT_D_SPLIT")[0] == '0');
+  bool opt_fused_optimizer = getenv("GT_OPT_FUSED") && getenv("GT_OPT_FUSED")[0] == '1';       // measured slower: off
+  int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
+  Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)

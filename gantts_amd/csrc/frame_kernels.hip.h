@@ -914,6 +914,27 @@ struct OptimSpec {
   float max_norm;      // clip threshold (1.0 in the reference); <= 0 disables clipping
 };
 
+// one element of clip_grad_norm_ + Adagrad / Adam (torch's update rules; `coef` = the clip coefficient, clr / step_size / bc2_sqrt
+// the step's scalar factors).  The clipped gradient is written back (clip_grad_norm_ scales .grad in place).
+__device__ __forceinline__ void optim_update(float& p, float& g, float& s0, float* s1, float coef, const OptimSpec& o, float clr, float step_size,
+                                             float bc2_sqrt) {
+  float gi = g * coef;
+  g = gi;
+  const float pi = p;
+  if (o.weight_decay != 0.f) gi = fmaf(o.weight_decay, pi, gi);
+  if (o.kind == 0) {
+    const float s = fmaf(gi, gi, s0);
+    s0 = s;
+    p = pi - clr * (gi / (sqrtf(s) + o.eps));
+  } else {
+    const float m = o.beta1 * s0 + (1.f - o.beta1) * gi;
+    const float v = o.beta2 * *s1 + (1.f - o.beta2) * gi * gi;
+    s0 = m; *s1 = v;
+    const float denom = sqrtf(v) / bc2_sqrt + o.eps;
+    p = pi - step_size * (m / denom);
+  }
+}
+
 static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
     const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o,
@@ -955,22 +976,145 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     step_size = (float)((double)o.lr / bc1);
     bc2_sqrt = (float)sqrt(bc2);
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float gi = g[i] * coef;
-    g[i] = gi;                                  // clip_grad_norm_ scales .grad in place
-    float pi = p[i];
-    if (o.weight_decay != 0.f) gi = fmaf(o.weight_decay, pi, gi);
-    if (o.kind == 0) {
-      const float s = fmaf(gi, gi, s0[i]);
-      s0[i] = s;
-      p[i] = pi - clr * (gi / (sqrtf(s) + o.eps));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    optim_update(p[i], g[i], s0[i], s1 ? s1 + i : nullptr, coef, o, clr, step_size, bc2_sqrt);
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused single-GPU step's closing launch of a network: weight-gradient combines (the recorded slab jobs) + squared norm +
+// clip + optimizer step in ONE launch instead of three (slab_reduce_multi, sqnorm_partial, optim_step).  Every workgroup
+// owns the same elements in both phases -- it sums their slabs, writes the gradient and keeps its share of the squared norm;
+// a device-wide barrier (one arrival counter, monotonically increasing across launches; every wait bounded by a wall-clock
+// timeout that raises the engine's fault word and skips the update) makes the total known to all; then it clips and steps
+// what it owns.  Only the per-workgroup norm partials cross workgroups -- written, counted and read with RELAXED agent-scope
+// atomics, which act at the device's coherence point; no release / acquire fence is needed (and none is used: a release at
+// agent scope writes back the XCD's whole dirty L2, measured at +50 us per launch), because no gradient is read through
+// another workgroup's cache: a workgroup's own stores precede its own atomic store in program order.  Same arithmetic per element as the three kernels; the norm is the same fixed-order double sum.
+// Requires gridDim.x workgroups to be co-resident (<= 4 per CU: the launcher's choice).
+// ---------------------------------------------------------------------------------------
+struct OptimRest { long off[4]; long n[4]; int n_rest, pad_; };   // ranges of the flat gradient that no slab job writes
+constexpr unsigned OPT_FAULT_BARRIER = 0x100u;
+__device__ __forceinline__ double slab_own_block(int pass, int blk, const SlabJob& J, float* __restrict__ p, float* __restrict__ g,
+                                                 float* __restrict__ s0, float* __restrict__ s1, float coef, const OptimSpec& o,
+                                                 float clr, float step_size, float bc2_sqrt) {
+  double sq = 0.0;
+  if (blk >= J.main_blocks) {      // bias-gradient slabs
+    const int c = (blk - J.main_blocks) * blockDim.x + threadIdx.x;
+    if (c >= J.nb) return 0.0;
+    const long e = (J.bout - g) + c;
+    if (pass == 0) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int k = 0;
+      for (; k + 4 <= J.nslab; k += 4) {
+        a0 += J.bslabs[(long)k * J.nb + c];       a1 += J.bslabs[(long)(k + 1) * J.nb + c];
+        a2 += J.bslabs[(long)(k + 2) * J.nb + c]; a3 += J.bslabs[(long)(k + 3) * J.nb + c];
+      }
+      for (; k < J.nslab; ++k) a0 += J.bslabs[(long)k * J.nb + c];
+      const float tot = (a0 + a1) + (a2 + a3);
+      const float v = J.accumulate ? g[e] + tot : tot;
+      g[e] = v;
+      sq = (double)v * (double)v;
     } else {
-      const float m = o.beta1 * s0[i] + (1.f - o.beta1) * gi;
-      const float v = o.beta2 * s1[i] + (1.f - o.beta2) * gi * gi;
-      s0[i] = m; s1[i] = v;
-      const float denom = sqrtf(v) / bc2_sqrt + o.eps;
-      p[i] = pi - step_size * (m / denom);
+      optim_update(p[e], g[e], s0[e], s1 ? s1 + e : nullptr, coef, o, clr, step_size, bc2_sqrt);
     }
+    return sq;
+  }
+  const long i = (long)blk * blockDim.x + threadIdx.x;
+  if (i >= J.n4) return 0.0;
+  const long e = (J.out - g) + 4 * i;
+  if (pass == 0) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(J.slabs) + i;
+    const long st4 = J.slab_stride / 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= J.nslab; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q[(long)(k + u) * st4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; k < J.nslab; ++k) a += q[(long)k * st4];
+    f32x4* og = reinterpret_cast<f32x4*>(g + e);
+    if (J.accumulate) a += *og;
+    *og = a;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sq += (double)a[c] * (double)a[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) optim_update(p[e + c], g[e + c], s0[e + c], s1 ? s1 + e + c : nullptr, coef, o, clr, step_size, bc2_sqrt);
+  }
+  return sq;
+}
+static __global__ __launch_bounds__(256) void optim_fused_kernel(
+    const SlabJobs jobs, const int n_job_blocks, const OptimRest rest, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
+    float* __restrict__ s1, double* norm_part /* [gridDim.x] */, unsigned long long* bar, const unsigned long long bar_target,
+    const unsigned long long timeout_ticks, double* __restrict__ norm2_out, OptimSpec o, unsigned int* fault_dev, unsigned int* fault_host,
+    unsigned int* skipped_host) {
+  __shared__ double shn[16];
+  __shared__ float coef_sh;
+  __shared__ int ok_sh;
+  if (*fault_dev) {       // a persistent launch of this step gave up: no combine, no update (optim_step_kernel's rule); uniform over the grid
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the counter advances by the grid per launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (fault_host) *fault_host = *fault_dev;
+      if (skipped_host) *skipped_host += 1u;
+      if (norm2_out) *norm2_out = __longlong_as_double(0x7ff8000000000000LL);
+    }
+    return;
+  }
+  float clr = o.lr, bc2_sqrt = 1.f, step_size = o.lr;
+  if (o.kind == 0) {
+    clr = o.lr / (1.f + (float)(o.step - 1) * o.lr_decay);
+  } else {
+    const double bc1 = 1.0 - pow((double)o.beta1, (double)o.step);
+    const double bc2 = 1.0 - pow((double)o.beta2, (double)o.step);
+    step_size = (float)((double)o.lr / bc1);
+    bc2_sqrt = (float)sqrt(bc2);
+  }
+  float coef = 1.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    double acc = 0.0;
+    int q = 0;
+    for (int vb = blockIdx.x; vb < n_job_blocks; vb += gridDim.x) {
+      while (q + 1 < jobs.n && vb >= jobs.j[q + 1].block0) ++q;
+      acc += slab_own_block(pass, vb - jobs.j[q].block0, jobs.j[q], p, g, s0, s1, coef, o, clr, step_size, bc2_sqrt);
+    }
+    for (int r = 0; r < rest.n_rest; ++r)
+      for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rest.n[r]; i += (long)gridDim.x * blockDim.x) {
+        const long e = rest.off[r] + i;
+        if (pass == 0) { const double v = (double)g[e]; acc += v * v; }
+        else optim_update(p[e], g[e], s0[e], s1 ? s1 + e : nullptr, coef, o, clr, step_size, bc2_sqrt);
+      }
+    if (pass == 1) break;
+    const double part = block_sum_d(acc, shn);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(norm_part + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt: the partial is acknowledged before the arrival is counted (no L2 write-back)
+      __hip_atomic_fetch_add(bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+      }
+      if (!ok) atomicOr(fault_dev, OPT_FAULT_BARRIER);
+      ok_sh = ok;
+    }
+    __syncthreads();
+    if (!ok_sh) return;           // nobody steps: a workgroup that never arrived keeps everyone below the target
+    double tot = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+      tot += __hip_atomic_load(norm_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot = block_sum_d(tot, shn);     // the same fixed order in every workgroup
+    if (threadIdx.x == 0) {
+      if (blockIdx.x == 0 && norm2_out) *norm2_out = tot;
+      float c = 1.f;
+      if (o.max_norm > 0.f) c = fminf(o.max_norm / ((float)sqrt(tot) + 1e-6f), 1.f);
+      coef_sh = c;
+    }
+    __syncthreads();
+    coef = coef_sh;
   }
 }
 

@@ -258,8 +258,12 @@ class DevicePrefetcher(object):
     batch in pinned host buffers and copies it on a dedicated stream; ``__next__`` makes the compute
     stream wait on that copy's event (no host sync)."""
 
-    def __init__(self, loader, device="cuda", depth=2):
+    def __init__(self, loader, device="cuda", depth=2, pitch_x=False):
+        """pitch_x: stage x with a row pitch that is a multiple of 4 floats (a (B, T, D) view over a (B, T, P) device buffer,
+        ``gantts_amd.engine.pitched_empty``): the engine then reads the batch's rows with 16-byte loads in every product
+        (gt_set_x_pitch) instead of making that copy itself once per step.  Free here -- the batch is being copied anyway."""
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.pitch_x = bool(pitch_x)
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pinned, self._slot_copied = {}, {}
 
@@ -287,9 +291,17 @@ class DevicePrefetcher(object):
         prev = self._slot_copied.get(slot)
         if prev is not None:
             prev.synchronize()          # the slot's previous H2D must have drained before the host overwrites it
-        hx, hy = self._pin((slot, "x"), x.contiguous()), self._pin((slot, "y"), y.contiguous())
+        if self.pitch_x and x.size(-1) % 4:
+            xp = x.new_zeros(x.size(0), x.size(1), (x.size(-1) + 3) // 4 * 4)
+            xp[:, :, :x.size(-1)] = x
+            x_host, width = xp, x.size(-1)
+        else:
+            x_host, width = x.contiguous(), None
+        hx, hy = self._pin((slot, "x"), x_host), self._pin((slot, "y"), y.contiguous())
         with torch.cuda.stream(self.copy_stream):
             dx = hx.to(self.device, non_blocking=True)
+            if width is not None:
+                dx = dx[:, :, :width]             # the pitched view the engine takes as it is
             dy = hy.to(self.device, non_blocking=True)
             dl = sorted_lengths.to(self.device)
             ev = torch.cuda.Event()

@@ -65,6 +65,23 @@ def _check_frames(t, name, last_dim=None):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def pitched_empty(B, T, D, device="cuda", align=4):
+    """A (B, T, D) float32 view whose rows have a pitch that is a multiple of ``align`` floats (16 bytes): the layout
+    ``gt_set_x_pitch`` lets the engine read with 16-byte loads in every product (``DevicePrefetcher(pitch_x=True)`` stages x so)."""
+    P = (D + align - 1) // align * align
+    return torch.zeros(B, T, P, device=device, dtype=torch.float32)[:, :, :D]
+
+
+def _check_x(t, name, last_dim):
+    """x of the step functions: (tensor to pass, row pitch in floats or 0 for dense rows).  A (B, T, D) view over a (B, T, P)
+    buffer (``pitched_empty``) is taken as it is; anything else goes through ``_check_frames`` (dense, contiguous)."""
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and not t.is_contiguous() \
+            and t.size(-1) == last_dim and t.stride(2) == 1 and t.stride(1) >= last_dim and t.stride(1) % 4 == 0 \
+            and t.stride(0) == t.size(1) * t.stride(1) and t.data_ptr() % 16 == 0:
+        return t, int(t.stride(1))
+    return _check_frames(t, name, last_dim), 0
+
+
 class _SingleStreamHP(object):
     """hp stand-in for forward-only engines: one stream, no dynamic features."""
 
@@ -88,6 +105,9 @@ class StepEngine(object):
         self._bound = {L.ROLE_G: (None, -1, False), L.ROLE_D: (None, -1, False)}   # (model ref, version, with_grads)
         self._bound_opt = {L.ROLE_G: (None, -1, None), L.ROLE_D: (None, -1, None)}
         self._keep = {}
+        self._ld_gx = self._ld_cx = 0            # row pitches last announced through gt_set_x_pitch (0 = dense)
+        self._pitch_sent = (0, 0)
+        self._opt_bf16 = False
         nW = len(hp.windows)
         ss = [s // nW if d else s for s, d in zip(hp.stream_sizes, hp.has_dynamic_features)]
         self.static_dim = int(sum(ss))
@@ -193,13 +213,18 @@ class StepEngine(object):
 
     def set_option(self, name, value):
         """Engine switches (results unchanged up to fp32 summation order): ``"lstm_persistent"``,
-        ``"lstm_fwd_units"``, ``"lstm_xcd_local"``; ``"matmul_bf16"`` switches the GEMMs to bf16 products with float32 accumulation."""
+        ``"lstm_fwd_units"``, ``"lstm_xcd_local"``, ``"split_first_layer"`` (conditioned D: x product once per D step),
+        ``"fused_optimizer"`` (combines + norm + clip + step in one launch); ``"matmul_bf16"`` switches the GEMMs to bf16 products
+        with float32 accumulation."""
         opts = {"lstm_persistent": L.OPT_LSTM_PERSISTENT,
                 "lstm_fwd_units": L.OPT_LSTM_FWD_UNITS, "lstm_xcd_local": L.OPT_LSTM_XCD_LOCAL,
-                "matmul_bf16": L.OPT_MATMUL_BF16}
+                "matmul_bf16": L.OPT_MATMUL_BF16, "split_first_layer": L.OPT_SPLIT_FIRST_LAYER,
+                "fused_optimizer": L.OPT_FUSED_OPTIMIZER}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))
+        if name == "matmul_bf16":
+            self._opt_bf16 = bool(value)
 
     def set_loss_normalizer(self, tv):
         """``tv``: python number, or a 1-element CUDA float64 tensor (kept alive here; read in stream order --
@@ -228,7 +253,10 @@ class StepEngine(object):
         check(lib.gt_set_lengths(self._h, arr, B, L.current_stream()))
 
     def apply_generator(self, model_g, x, R, lengths=None):
-        x = _check_frames(x, "x", model_g.in_dim)
+        x, ld = _check_x(x, "x", model_g.in_dim)
+        if ld and (type(model_g).__name__ != "MLP" or self._opt_bf16):
+            x, ld = x.contiguous(), 0            # pitched rows: float32 MLP generators only (gt_set_x_pitch)
+        self._set_pitch(gx=ld)
         B, T, _ = x.shape
         model_g._check_masks(B, T)
         self.bind_model(L.ROLE_G, model_g, with_grads=True)
@@ -245,6 +273,23 @@ class StepEngine(object):
         self._keep["g"] = (x, R, y_hat, y_hat_static)
         y_hat._gt_engine = y_hat_static._gt_engine = self
         return y_hat, y_hat_static
+
+    def _set_pitch(self, gx=None, cx=None):
+        if gx is not None:
+            self._ld_gx = gx
+        if cx is not None:
+            self._ld_cx = cx
+        if (self._ld_gx, self._ld_cx) != self._pitch_sent:
+            check(lib.gt_set_x_pitch(self._h, self._ld_gx, self._ld_cx))
+            self._pitch_sent = (self._ld_gx, self._ld_cx)
+
+    def _cond_x(self, x, model_d):
+        """The conditioning x of D (train.py:254-256): dense, or pitched rows where the engine takes them (float32 D)."""
+        x, ld = _check_x(x, "x", model_d.in_dim - self._adv_width())
+        if ld and self._opt_bf16:
+            x, ld = x.contiguous(), 0
+        self._set_pitch(cx=ld)
+        return x
 
     def _mask2d(self, mask, B, T):
         mask = _check_frames(mask, "mask")
@@ -263,7 +308,7 @@ class StepEngine(object):
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
         if self.signature[5]:
-            x = _check_frames(x, "x", model_d.in_dim - self._adv_width())
+            x = self._cond_x(x, model_d)
         else:
             x = None
         res = L.DResult()
@@ -288,7 +333,7 @@ class StepEngine(object):
         if adv_w > 0:
             model_d._check_masks(B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
-            x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+            x = self._cond_x(x, model_d) if self.signature[5] else None
         else:
             x = None
         res = L.GResult()
@@ -321,7 +366,7 @@ class StepEngine(object):
         self.bind_model(L.ROLE_D, model_d, with_grads=True)
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
-        x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+        x = self._cond_x(x, model_d) if self.signature[5] else None
         check(lib.gt_update_discriminator_begin(self._h, ptr(x), ptr(y_static), ptr(y_hat_static_c), ptr(mask), B, T,
                                                 int(train), float(eps), L.current_stream()))
 
@@ -357,7 +402,7 @@ class StepEngine(object):
         if adv_w > 0:
             model_d._check_masks(B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
-            x = _check_frames(x, "x", model_d.in_dim - self._adv_width()) if self.signature[5] else None
+            x = self._cond_x(x, model_d) if self.signature[5] else None
         else:
             x = None
         check(lib.gt_update_generator_begin(self._h, ptr(x), ptr(y), ptr(y_hat_c), ptr(y_static), ptr(y_hat_static_c),

@@ -202,7 +202,23 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * accumulation; parameters ("master weights"), optimizer state, activations in memory, the recurrent state and every
  * reduction stay float32.  Results differ from the float32 path at the 1e-2 relative level (tests/test_gpu_parity.py). */
 #define GT_OPT_MATMUL_BF16 5
+/* GT_OPT_SPLIT_FIRST_LAYER (default 1): the conditioned float32 discriminator evaluates its first layer as x . W_x^T (once per
+ * D step, shared by the real and the generated rows) + adv . W_adv^T instead of one product over a concatenated [x | adv] image
+ * (train.py:254-256); 0 = the concatenated image.  Same sums up to float32 association. */
+#define GT_OPT_SPLIT_FIRST_LAYER 6
+/* GT_OPT_FUSED_OPTIMIZER (default 0): the fused single-GPU step closes a network's update with ONE launch (weight-gradient
+ * combines + squared norm + clip + optimizer step behind a device-wide barrier) instead of three.  Same arithmetic; measured
+ * SLOWER on MI355X (the barrier's wait costs more than two launch edges: cfg2 1.453 vs 1.411 ms), so it is off by default. */
+#define GT_OPT_FUSED_OPTIMIZER 7
 int gt_set_option(gt_engine* e, int option, int value);
+/* Row pitch (in floats) of the input tensors `x` of the step functions, like the `lda` of a BLAS call: ld_generator_input for the
+ * x of gt_apply_generator (train.py:542: cat(x, z) or x), ld_condition for the conditioning x of gt_update_discriminator /
+ * gt_update_generator (train.py:254-256).  0 (default) = dense rows (pitch = width).  A pitch that is a multiple of 4 floats on a
+ * 16-byte aligned tensor lets every product read the caller's rows with 16-byte loads -- a batch pipeline that stages batches
+ * anyway (gantts_amd.data.DevicePrefetcher(pitch_x=True)) provides it for free; with dense 425-wide rows the engine makes the
+ * 16-byte-pitch copy its weight-gradient products need itself, once per step.  Supported where it pays: float32 MLP generators
+ * and the conditioned float32 discriminator; other paths reject a non-dense pitch. */
+int gt_set_x_pitch(gt_engine* e, int ld_generator_input, int ld_condition);
 /* The persistent recurrence kernels bound every inter-workgroup wait by a wall-clock timeout and raise a device fault
  * word instead of hanging.  The step functions report a fault they have seen (GT_ERR_HIP) at their next entry;
  * this call synchronises `stream` and reports the current state. */

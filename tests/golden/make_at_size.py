@@ -172,7 +172,7 @@ def main():
             runs[dtype] = runner(case, dtype)
             secs[dtype] = time.time() - t0
             print("%-14s %-8s %s: %.1f s" % (name, case["source"], str(dtype).split(".")[1], secs[dtype]), flush=True)
-        fx = A.digest(runs[torch.float32], runs[torch.float64])
+        fx = A.digest(runs[torch.float32], runs[torch.float64], cold=bool(case.get("cold")))
         fx["meta.source"] = np.array(case["source"])
         fx["meta.seconds_f32"], fx["meta.seconds_f64"] = np.float64(secs[torch.float32]), np.float64(secs[torch.float64])
         path = os.path.join(os.environ.get("AT_SIZE_OUT", HERE), "at_size_%s.npz" % name)

@@ -29,7 +29,7 @@ def build_model(spec, seed, saturate_gates=False):
 
 
 def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=False, shard=None, comm_id=None, extra=None,
-                 philox=False):
+                 philox=False, pitch_x=False):
     """shard = (rank, world): this process holds sequences rank, rank + world, ... of the case's batch (whole
     sequences dealt round-robin) and, with `comm_id`, attaches the engine's communicator (gt_comm_init) first -- the
     fused step functions are then data-parallel by themselves and every rank must reproduce the WHOLE batch's result.
@@ -67,6 +67,11 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
             eng = engine_for(hp, mg)
             eng.comm_init(rank, world, comm_id)
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
+    if pitch_x:       # rows on a 16-byte pitch, as DevicePrefetcher(pitch_x=True) stages them (gt_set_x_pitch)
+        from gantts_amd.engine import pitched_empty
+        xp = pitched_empty(x.size(0), x.size(1), x.size(2))
+        xp.copy_(x)
+        x = xp
     Tn = case["T"]
     has_dyn = bool(np.any(case["has_dynamic_features"]))
     R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, Tn) if has_dyn else None

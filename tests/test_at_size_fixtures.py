@@ -33,12 +33,14 @@ def test_fixture_is_complete_and_self_consistent(name):
     for k in tensors:
         assert np.isfinite(fx[k + ".sample"]).all() and float(fx[k + ".norm"]) > 0
         # the reference's own float32 run is close to its float64 run (1e-2 at the very worst: sign-like first Adam steps)
-        assert 0 <= float(fx[k + ".err32"]) < 1e-2, (k, float(fx[k + ".err32"]))
+        # (a cold Adagrad accumulator makes the first update lr * sign(g): the reference's own two runs disagree on the sign of
+        # gradient elements that are zero within rounding, each a 2 * lr difference -- those tensors are judged element-wise)
+        assert 0 <= float(fx[k + ".err32"]) < (0.3 if case.get("cold") and k[1:5] == "upd." else 1e-2), (k, float(fx[k + ".err32"]))
         # the sample's norm cannot exceed the whole tensor's
         assert float(np.sqrt((fx[k + ".sample"].astype(np.float64) ** 2).sum())) <= float(fx[k + ".norm"]) * (1 + 1e-6)
     for st in range(case["steps"]):
         for k in ("d_scalars_%d" % st, "g_scalars_%d" % st):
-            np.testing.assert_allclose(fx[k + ".f32"], fx[k + ".f64"], rtol=2e-5)
+            np.testing.assert_allclose(fx[k + ".f32"], fx[k + ".f64"], rtol=2e-5, atol=1e-7)      # (atol: a saturated loss_adv of 2e-6)
     # the sample positions are a function of the key alone
     a = np.arange(100000, dtype=np.float32)
     assert np.array_equal(A.sample_of("Ggrad.x", a), A.sample_of("Ggrad.x", a)) and A.sample_of("Ggrad.x", a).size == A.SAMPLE

@@ -318,6 +318,44 @@ def test_model_forward_eval_matches_oracle_and_errors():
     assert list(m.state_dict().keys()) == o.names
 
 
+@pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_chain_d"])
+def test_pitched_x_is_bit_identical_to_dense_x(name):
+    """gt_set_x_pitch (include/gantts_hip.h): x handed over with rows on a 16-byte pitch -- what DevicePrefetcher(pitch_x=True)
+    stages -- must give the very same step as dense rows: the forward products read the same values in the same order, and
+    the weight gradients read the caller's rows instead of the engine's own pitched copy of them."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    dense, pitched = run_hip_case(case), run_hip_case(case, pitch_x=True)
+    assert set(dense) == set(pitched)
+    for k in dense:
+        assert np.array_equal(dense[k], pitched[k]), k
+
+
+@pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm"])
+def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
+    """GT_OPT_SPLIT_FIRST_LAYER (x . W_x^T once per D step + adv . W_adv^T, weight gradient with the two halves summed in the
+    loader) and GT_OPT_FUSED_OPTIMIZER (combines + norm + clip + step behind a device-wide barrier) against the concatenated
+    [x | adv] image and the three-launch optimizer: the reference golden holds for BOTH settings (test_step_matches_reference_golden
+    runs the defaults); here the two settings are compared with each other at the same 1e-4, counts exactly, and the fused
+    optimizer alone must agree with the three launches to rounding (same arithmetic per element; the squared norm is the
+    same double-precision sum over a different partition, so the clip coefficient may differ in its last bit)."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    on = run_hip_case(case, engine_options={"split_first_layer": 1, "fused_optimizer": 1})
+    off = run_hip_case(case, engine_options={"split_first_layer": 0, "fused_optimizer": 0})
+    fused_only = run_hip_case(case, engine_options={"split_first_layer": 0, "fused_optimizer": 1})
+    for k in off:
+        if "scalars" in k:
+            _close(on[k], off[k], msg=k)
+            if k.startswith("d_scalars"):
+                assert on[k][3] == off[k][3] and on[k][4] == off[k][4], k
+        elif ".opt." in k:
+            _close(on[k], off[k], rtol=5e-4, atol=1e-9, msg=k)
+        else:
+            _close(on[k], off[k], msg=k)
+        _close(fused_only[k], off[k], rtol=2e-6, atol=1e-9, msg="fused optimizer " + k)
+
+
 def test_philox_dropout_statistics_and_determinism():
     from gantts_amd import models
     m = models.MLP(in_dim=16, out_dim=8, num_hidden=1, hidden_dim=2048, dropout=0.5, last_sigmoid=False).cuda().train()
