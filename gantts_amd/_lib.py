@@ -109,6 +109,7 @@ SIGNATURES = {
     "gt_compute_distortions": (_I, [_P, _P, _I, _P, _P, _I, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_L), _I, _I,
                                     C.POINTER(DistortionSums), _P]),
     "gt_op_gather_cols": (_I, [_P, _I, _P, _I, _P, _I, _I, _L, _P]),
+    "gt_op_pad_sequences": (_I, [_P, _I, _P, _P, _I, _I, _P, _I, _P]),
     "gt_op_mlpg_forward": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "gt_op_mlpg_backward": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "gt_op_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _F, _P]),

@@ -87,6 +87,14 @@ extern "C" int gt_compute_distortions(const float* y_static, const float* y_hat_
   return GT_OK;
 }
 
+extern "C" int gt_op_pad_sequences(const float* ragged, int D, const int64_t* start, const int64_t* len, int B, int T, float* out, int ld_out,
+                                   void* stream) {
+  if (!ragged || !start || !len || !out || D < 1 || B < 1 || T < 1 || ld_out < D) return fail(GT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(pad_sequences_kernel, dim3(cdiv((long)B * T * ld_out, 256)), dim3(256), 0, (hipStream_t)stream, ragged, D,
+                     (const long*)start, (const long*)len, B, T, out, ld_out);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
 extern "C" int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,
                                  int out_col_offset, int64_t rows, void* stream) {
   if (!in || !out || n_idx < 0 || rows < 0) return fail(GT_ERR_INVALID, "bad argument");

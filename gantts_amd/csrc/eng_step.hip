@@ -811,6 +811,10 @@ static int generator_backward(gt_engine* e, const float* x, const float* y, cons
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gs, 0L, 1, N * Do, gy, mse_w != 0.f ? 1 : 0);
     LAUNCH_CHECK();
   }
+  if (G.d.last_sigmoid && !is_i2o(G.d.arch)) {      // y_hat = sigmoid(last layer) (models.py:141, 167, 190, 213): through s (1 - s)
+    hipLaunchKernelGGL(sigmoid_grad_kernel, dim3(cdiv(N * Do, 256)), dim3(256), 0, s, gy, ldgy, y_hat, Do, N, Do);
+    LAUNCH_CHECK();
+  }
   if (has_lstm_body(G.d.arch) || G.d.arch == GT_ARCH_SRU) {
     CHK(has_lstm_body(G.d.arch) ? lstm_backward(e, x, gy, B, T, s) : sru_backward(e, x, gy, B, T, s));
     G.grads_dirty = true;
@@ -887,7 +891,6 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (!e->g_pass_valid || y_hat != e->last_yhat || y_hat_static != e->last_yhs || N != e->N)
       return fail(GT_ERR_STATE, "update_generator(phase=\"train\") needs the y_hat / y_hat_static returned by the last apply_generator");
     if (!G.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the generator was bound without grads");
-    if (G.d.last_sigmoid) return fail(GT_ERR_INVALID, "training a generator with last_sigmoid=True is not supported");
   }
   const int Do = G.d.out_dim;
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;

@@ -171,6 +171,28 @@ static __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* 
 }
 
 // out[r][0..ldo) = in[r][0..cols), zero in the pad columns (row pitch rounded up for 16-byte loads)
+// Device-side collate (train.py:139-159 `_pad_2d` + collate_fn, and the length sort of train.py:494-501): the utterances of a
+// batch arrive un-padded, back to back ([total frames][D]); output sequence b is the utterance that starts at frame start[b]
+// and has len[b] frames (the host gives them in the sorted order), zero-padded to T frames on a row pitch of ld floats.
+static __global__ void pad_sequences_kernel(const float* __restrict__ ragged, int D, const long* __restrict__ start, const long* __restrict__ len,
+                                            int B, int T, float* __restrict__ out, int ld) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * T * ld) return;
+  const long row = e / ld;
+  const int c = (int)(e - row * ld);
+  const int b = (int)(row / T), t = (int)(row - (long)b * T);
+  out[e] = (c < D && t < len[b]) ? ragged[(start[b] + t) * D + c] : 0.f;
+}
+// generator with last_sigmoid=True (models.py:141, 213): y_hat = sigmoid(z), so the gradient at y_hat becomes the gradient at z
+// in place: g[r][c] *= y[r][c] (1 - y[r][c])
+static __global__ void sigmoid_grad_kernel(float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy, long rows, int cols) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const long r = e / cols;
+  const int c = (int)(e - r * cols);
+  const float s = y[r * ldy + c];
+  g[r * ldg + c] *= s * (1.f - s);
+}
 // The adversarial columns of a pass's rows as one image with a 16-byte row pitch (the split first layer of the conditioned
 // discriminator, eng_step.hip): out[r][j] = fa[r][idx[j]] for r < split, fb[r - split][idx[j]] otherwise; pad columns are 0.
 // Bit-exact copies (train.py:232-242 select_streams on the static features).

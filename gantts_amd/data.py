@@ -219,9 +219,21 @@ def collate_fn(batch):
     return torch.from_numpy(x_batch), torch.from_numpy(y_batch), torch.from_numpy(input_lengths)
 
 
+def collate_ragged(batch):
+    """Device-side collate (``DevicePrefetcher`` pads and sorts on the GPU, gt_op_pad_sequences): the utterances of the batch
+    un-padded, back to back -- ``(x_cat (sum T_i, Din) f32, y_cat (sum T_i, Dout) f32, lengths (B,) int64)`` -- so that neither
+    the padded copy is made on the host nor its padding crosses PCIe (a batch of real utterances is 30-50 % padding)."""
+    input_lengths = np.array([len(x[0]) for x in batch], dtype=np.int64)
+    x_cat = np.concatenate([np.asarray(x[0], dtype=np.float32) for x in batch], axis=0)
+    y_cat = np.concatenate([np.asarray(x[1], dtype=np.float32) for x in batch], axis=0)
+    return torch.from_numpy(x_cat), torch.from_numpy(y_cat), torch.from_numpy(input_lengths)
+
+
 def _loaders(train_dataset, test_dataset, hp):
     from torch.utils import data as data_utils
-    kw = dict(batch_size=hp.batch_size, num_workers=hp.num_workers, pin_memory=hp.pin_memory, collate_fn=collate_fn)
+    ragged = bool(getattr(hp, "device_collate", False))          # gantts_amd extension: pad + sort on the device
+    kw = dict(batch_size=hp.batch_size, num_workers=hp.num_workers, pin_memory=hp.pin_memory,
+              collate_fn=collate_ragged if ragged else collate_fn)
     return {"train": data_utils.DataLoader(train_dataset, shuffle=True, **kw),
             "test": data_utils.DataLoader(test_dataset, shuffle=False, **kw)}
 
@@ -253,10 +265,11 @@ class DeviceBatch(object):
 
 
 class DevicePrefetcher(object):
-    """Iterates ``loader`` one batch ahead: sorts by length (descending, stable -- what torch.sort
-    gives the reference at train.py:495-501), trims the padding to the longest sequence, stages the
-    batch in pinned host buffers and copies it on a dedicated stream; ``__next__`` makes the compute
-    stream wait on that copy's event (no host sync)."""
+    """Iterates ``loader`` one batch ahead: sorts by length (descending -- what torch.sort gives the reference at
+    train.py:495-501), trims the padding to the longest sequence, stages the batch in pinned host buffers and copies it on a
+    dedicated stream; ``__next__`` makes the compute stream wait on that copy's event (no host sync).  With a
+    ``collate_ragged`` loader (``hp.device_collate``) only the valid frames are staged and copied, and the padding and the
+    sort happen on the device (gt_op_pad_sequences): device-side collate."""
 
     def __init__(self, loader, device="cuda", depth=2, pitch_x=False):
         """pitch_x: stage x with a row pitch that is a multiple of 4 floats (a (B, T, D) view over a (B, T, P) device buffer,
@@ -279,8 +292,50 @@ class DevicePrefetcher(object):
         v.copy_(t)
         return v
 
+    def _stage_ragged(self, slot, batch):
+        """A ``collate_ragged`` batch: H2D of the valid frames only, then padding + the length sort on the device
+        (gt_op_pad_sequences).  The ORDER is the reference's own: torch.sort(lengths, descending=True) (train.py:495)."""
+        from . import _lib as L
+        x, y, lengths = batch
+        lengths = torch.as_tensor(lengths).view(-1).long()
+        sorted_lengths, indices = torch.sort(lengths, dim=0, descending=True)
+        B, max_len = int(lengths.numel()), int(sorted_lengths[0])
+        starts = (torch.cumsum(lengths, 0) - lengths)[indices].contiguous()
+        cpu_lengths = [int(v) for v in sorted_lengths.tolist()]
+        prev = self._slot_copied.get(slot)
+        if prev is not None:
+            prev.synchronize()
+        hx, hy = self._pin((slot, "x"), x.contiguous()), self._pin((slot, "y"), y.contiguous())
+        hm = self._pin((slot, "meta"), torch.stack((starts, sorted_lengths)))
+        Dx, Dy = x.size(-1), y.size(-1)
+        with torch.cuda.stream(self.copy_stream):
+            rx, ry = hx.to(self.device, non_blocking=True), hy.to(self.device, non_blocking=True)
+            meta = hm.to(self.device, non_blocking=True)
+            ldx = (Dx + 3) // 4 * 4 if self.pitch_x else Dx
+            bx = torch.empty(B, max_len, ldx, device=self.device, dtype=torch.float32)
+            dy = torch.empty(B, max_len, Dy, device=self.device, dtype=torch.float32)
+            st = L.current_stream()
+            L.check(L.lib.gt_op_pad_sequences(L.ptr(rx), Dx, L.ptr(meta[0]), L.ptr(meta[1]), B, max_len, L.ptr(bx), ldx, st))
+            L.check(L.lib.gt_op_pad_sequences(L.ptr(ry), Dy, L.ptr(meta[0]), L.ptr(meta[1]), B, max_len, L.ptr(dy), Dy, st))
+            dx = bx[:, :, :Dx] if ldx != Dx else bx
+            dl = meta[1]
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        for t in (rx, ry, meta):
+            t.record_stream(self.copy_stream)
+        self._slot_copied[slot] = ev
+        return DeviceBatch(dx, dy, dl, cpu_lengths, ev)
+
     def _stage(self, slot, batch):
         x, y, lengths = batch
+        if x.dim() == 2 and self.copy_stream is not None:
+            return self._stage_ragged(slot, batch)
+        if x.dim() == 2:         # no device: pad on the host (CPU tests of the loop logic)
+            lens = [int(v) for v in torch.as_tensor(lengths).view(-1).tolist()]
+            offs = np.concatenate(([0], np.cumsum(lens)))
+            T_ = max(lens)
+            x = torch.stack([torch.from_numpy(_pad_2d(x[offs[i]:offs[i + 1]].numpy(), T_)) for i in range(len(lens))])
+            y = torch.stack([torch.from_numpy(_pad_2d(y[offs[i]:offs[i + 1]].numpy(), T_)) for i in range(len(lens))])
         lengths = torch.as_tensor(lengths).view(-1).long()
         sorted_lengths, indices = torch.sort(lengths, dim=0, descending=True)
         max_len = int(sorted_lengths[0])

@@ -286,6 +286,13 @@ int gt_op_sequence_mask(const int64_t* lengths, int B, int T, float* mask, void*
  * grad_input (optional) receives d loss / d input */
 int gt_op_masked_mse(const float* input, const float* target, const float* mask, int B, int T, int D,
                      float* loss_out, float* grad_input, void* stream);
+/* Device-side collate: padding (train.py:139-159 `_pad_2d` / collate_fn) and the descending length sort of the batch
+ * (train.py:494-501) without a padded host copy.  `ragged`: the batch's utterances un-padded, back to back, [total][D] (device);
+ * start[b] / len[b] (device int64, B entries): first frame and frame count of the utterance that becomes OUTPUT sequence b (the
+ * host passes them in sorted order); out: (B, T, D) on a row pitch of ld_out floats (>= D; pad columns and frames t >= len[b]
+ * are zero, as `_pad_2d` leaves them).  Bit-exact copies. */
+int gt_op_pad_sequences(const float* ragged, int D, const int64_t* start, const int64_t* len, int B, int T, float* out, int ld_out,
+                        void* stream);
 /* out[:, j] = in[:, idx[j]]  (select_streams / get_static_features / get_selected_static_stream:
  * gantts/multistream.py:33-79, train.py:232-242); idx int32 device array */
 int gt_op_gather_cols(const float* in, int ld_in, const int32_t* idx, int n_idx, float* out, int ld_out,

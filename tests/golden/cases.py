@@ -175,6 +175,15 @@ CASES = {
         update_d=False, update_g=True),
 }
 
+# generators that end in a sigmoid (models.py:141, 213: `last_sigmoid=True`; train.py:773-774 builds whatever hparams name):
+# the gradient at y_hat passes through s (1 - s) before the last layer's products
+CASES["acoustic_mlp_sigmoid_g"] = dict(
+    CASES["acoustic_mlp"], B=3, T=29, steps=2, mse_w=0.5,
+    g=dict(kind="MLP", in_dim=425, out_dim=187, num_hidden=2, hidden_dim=48, dropout=0.0, last_sigmoid=True),
+    d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=2, hidden_dim=32, dropout=0.0, last_sigmoid=True))
+CASES["acoustic_lstm_sigmoid_g"] = dict(
+    CASES["acoustic_lstm"], g=dict(CASES["acoustic_lstm"]["g"], last_sigmoid=True))
+
 
 # Cases with NO reference-generated fixture: the SRU cell is third-party code that is neither vendored in
 # the reference nor runnable here (CUDA-only), so these are checked HIP-vs-oracle only (parity unpinned).

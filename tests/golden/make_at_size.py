@@ -30,6 +30,46 @@ def _np(t):
     return t.detach().cpu().numpy().copy()
 
 
+class SlopeCensus(object):
+    """Records, for every LeakyReLU evaluation of a run (gantts/models.py:132: nn.LeakyReLU(inplace=True) -> F.leaky_relu; the
+    oracle calls F.leaky_relu directly), which slope each activation took (output > 0).  Two runs of one case (float32, float64)
+    make the same calls in the same order, so the number of activations whose slope DIFFERS between them is a direct count of
+    the LeakyReLU flips a correct float32 evaluation has on this case -- what at_size.kink_allowance() is derived from."""
+
+    def __init__(self):
+        self.signs = []
+        self._orig = None
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._orig = F.leaky_relu
+        census = self
+
+        def patched(input, negative_slope=0.01, inplace=False):
+            out = census._orig(input, negative_slope, inplace)
+            census.signs.append((out > 0).detach().cpu().numpy())
+            return out
+
+        F.leaky_relu = patched
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.leaky_relu = self._orig
+
+    @staticmethod
+    def compare(a, b, n_g_calls_per_step, calls_per_step):
+        """-> {"G": (flips, activations), "D": (flips, activations)}: the first n_g_calls_per_step calls of a step are G's."""
+        assert len(a.signs) == len(b.signs), (len(a.signs), len(b.signs))
+        out = {"G": [0, 0], "D": [0, 0]}
+        for i, (x, y) in enumerate(zip(a.signs, b.signs)):
+            assert x.shape == y.shape
+            net = "G" if (i % calls_per_step) < n_g_calls_per_step else "D"
+            out[net][0] += int((x != y).sum())
+            out[net][1] += int(x.size)
+        return out
+
+
 def run_reference(case, dtype):
     """The real reference on one at-size case; returns {name: full tensor}."""
     import ref_loader
@@ -165,14 +205,20 @@ def main():
         if only and name not in only:
             continue
         runner = run_reference if case["source"] == "reference" else run_oracle
-        runs, secs = {}, {}
+        runs, secs, census = {}, {}, {}
         for dtype in (torch.float32, torch.float64):
             torch.manual_seed(0)
             t0 = time.time()
-            runs[dtype] = runner(case, dtype)
+            with SlopeCensus() as census[dtype]:
+                runs[dtype] = runner(case, dtype)
             secs[dtype] = time.time() - t0
             print("%-14s %-8s %s: %.1f s" % (name, case["source"], str(dtype).split(".")[1], secs[dtype]), flush=True)
         fx = A.digest(runs[torch.float32], runs[torch.float64], cold=bool(case.get("cold")))
+        n_g = case["g"]["num_hidden"] if case["g"]["kind"] in ("MLP", "In2OutHighwayNet") else 0
+        calls = len(census[torch.float32].signs) // case["steps"]
+        for net, (flips, acts) in SlopeCensus.compare(census[torch.float32], census[torch.float64], n_g, calls).items():
+            fx["kink.%s.flips" % net], fx["kink.%s.activations" % net] = np.int64(flips), np.int64(acts)
+            print("    LeakyReLU slope census %s: %d of %d activations differ between the float32 and the float64 run" % (net, flips, acts), flush=True)
         fx["meta.source"] = np.array(case["source"])
         fx["meta.seconds_f32"], fx["meta.seconds_f64"] = np.float64(secs[torch.float32]), np.float64(secs[torch.float64])
         path = os.path.join(os.environ.get("AT_SIZE_OUT", HERE), "at_size_%s.npz" % name)

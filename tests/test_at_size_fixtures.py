@@ -64,7 +64,7 @@ def test_oracle_reproduces_the_reference_fixture_at_full_size():
         ref = fx[k + ".sample"].astype(np.float64)
         g = A.sample_of(k, np.asarray(got[k])).astype(np.float64)
         err = A.rms(g - ref) / max(A.rms(ref), 1e-300)
-        lim = A.ARBITER_FACTOR * max(float(fx[k + ".err32"]), level[k.split(".")[0]]) + A.ARBITER_FLOOR + A.KINK_ALLOWANCE
+        lim = A.ARBITER_FACTOR * max(float(fx[k + ".err32"]), level[k.split(".")[0]]) + A.ARBITER_FLOOR + A.kink_allowance(fx, k[0] if k[0] in "GD" else "G")
         assert err <= lim, (k, err, lim)
     for st in range(case["steps"]):
         d, r = got["d_scalars_%d" % st], fx["d_scalars_%d.f64" % st]

@@ -55,6 +55,20 @@ def test_collate_pads_with_zeros_and_reports_lengths():
         assert float(x[b, len(xs):].abs().sum()) == 0 and float(y[b, len(ys):].abs().sum()) == 0
 
 
+def test_ragged_collate_and_the_host_fallback_equal_the_padded_collate():
+    """collate_ragged (device-side collate: utterances back to back) through the prefetcher on the CPU device -- where the
+    padding falls back to the host -- gives exactly the batches of the reference-shaped collate_fn."""
+    D = _data()
+    rs = np.random.RandomState(5)
+    batch = [(rs.rand(n, 4).astype(np.float32), rs.randn(n, 6).astype(np.float32)) for n in (5, 9, 2, 9, 7)]
+    xr, yr, lr = D.collate_ragged(batch)
+    assert xr.shape == (32, 4) and yr.shape == (32, 6) and lr.tolist() == [5, 9, 2, 9, 7]
+    a = list(D.DevicePrefetcher([D.collate_fn(batch)], device="cpu"))[0]
+    b = list(D.DevicePrefetcher([(xr, yr, lr)], device="cpu"))[0]
+    assert a.cpu_lengths == b.cpu_lengths == [9, 9, 7, 5, 2]
+    assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y) and torch.equal(a.lengths, b.lengths)
+
+
 def test_preprocessing_restatements():
     D = _data()
     rs = np.random.RandomState(2)

@@ -136,12 +136,14 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
             continue                                       # judged below, once every gradient's error is known
         exposed = kind in ("Dgrad", "Ggrad", "Dupd", "Gupd") and not k.startswith("Dgrad.last_linear")
         e32 = max(e32_of[k], level[kind]) if exposed else e32_of[k]
-        lim = factor * e32 + floor + (A.KINK_ALLOWANCE if exposed else 0.0)
+        kink = A.kink_allowance(fx, "G" if kind[0] == "G" else "D") if exposed else 0.0
+        lim = factor * e32 + floor + kink
         # the whole tensor, through its norm: nothing outside the sample can be far off without moving it
         norm_ref = float(fx[k + ".norm"])
         norm_err = abs(float(np.sqrt((g_full * g_full).sum())) - norm_ref) / max(norm_ref, 1e-300)
         worst = float(np.abs(g - ref).max()) / max(float(np.abs(ref).max()), 1e-300)
-        lines.append("%-14s %-44s rel-rms %.2e  limit %.2e (ref32 %.2e)  |norm| %.2e  worst elem %.2e" % (name, k, err, lim, e32, norm_err, worst))
+        lines.append("%-14s %-44s rel-rms %.2e  limit %.2e (ref32 %.2e, kink %.1e)  margin x%.1f  |norm| %.2e  worst elem %.2e"
+                     % (name, k, err, lim, e32, kink, lim / max(err, 1e-300), norm_err, worst))
         if measure is not None:
             measure[k] = (err, norm_err, e32)
         elif not (err <= lim and norm_err <= max(lim, 10 * floor) and worst <= 10 * lim):
@@ -187,8 +189,26 @@ def test_at_size_step_matches_fixture(name):
     compare_with_fixture(name, got, fx, cold=bool(case.get("cold")))
 
 
-# measured on MI355X (GT_PARITY_REPORT run of this test): relative rms distance to the float64 reference with bf16 operands
-BF16_LIMITS = {"y_hat": 2e-2, "y_hat_static": 2e-2, "scalars": 2e-2, "grad": 8e-2, "upd": 8e-2}
+# Relative rms distance to the float64 reference with bf16 storage, per case, network and kind: MEASURED on MI355X (round 4,
+# GT_PARITY_REPORT run of these tests, committed as profiles/r04_parity_report.txt) and limited at <= 2x the measurement:
+#                      measured:  y_hat    y_hat_static  Ggrad    Gupd     Dgrad    Dupd     losses
+#   cfg3_lstm (T = 1024)          2.3e-3   2.2e-3        3.8e-3   4.3e-3   2.1e-2   2.0e-2   < 1e-3
+#   cfg5_acoustic (B = 64)        4.3e-3   3.4e-3        2.1e-2   3.8e-2   1.9e-2   1.5e-2   < 1e-3
+BF16_LIMITS = {
+    "cfg3_lstm": {"y_hat": 4.6e-3, "y_hat_static": 4.4e-3, "Ggrad": 7.6e-3, "Gupd": 8.6e-3, "Dgrad": 4.2e-2, "Dupd": 4.0e-2, "scalars": 5e-3},
+    "cfg5_acoustic": {"y_hat": 8.6e-3, "y_hat_static": 6.8e-3, "Ggrad": 4.2e-2, "Gupd": 7.6e-2, "Dgrad": 3.9e-2, "Dupd": 3.1e-2, "scalars": 5e-3},
+}
+
+
+def _judge_bf16(case_name, seen):
+    worst = {}
+    lim = BF16_LIMITS[case_name]
+    for k, (err, norm_err, _) in seen.items():
+        kind = "scalars" if "scalars" in k else k.split(".")[0]
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        assert err <= lim[kind], "bf16 %s %s: distance %.3e > %.1e" % (case_name, k, err, lim[kind])
+    assert worst["y_hat"] > 1e-5, "suspiciously exact: the bf16 path did not run"
+    return worst
 
 
 def test_cfg3_full_length_bf16_tracks_the_reference():
@@ -200,12 +220,7 @@ def test_cfg3_full_length_bf16_tracks_the_reference():
     got = run_hip_at_size(case, engine_options={"matmul_bf16": 1})
     seen = {}
     compare_with_fixture("cfg3_lstm/bf16", got, fx, measure=seen)
-    worst = {}
-    for k, (err, norm_err, _) in seen.items():
-        kind = "scalars" if "scalars" in k else ("grad" if "grad." in k else ("upd" if "upd." in k else k))
-        worst[kind] = max(worst.get(kind, 0.0), err)
-        assert err <= BF16_LIMITS[kind], "bf16 %s: distance %.3e > %.1e" % (k, err, BF16_LIMITS[kind])
-    assert worst["y_hat"] > 1e-5, "suspiciously exact: the bf16 path did not run"
+    _judge_bf16("cfg3_lstm", seen)
 
 
 def test_cfg5_acoustic_bf16_storage_tracks_the_reference():
@@ -217,9 +232,4 @@ def test_cfg5_acoustic_bf16_storage_tracks_the_reference():
     got = run_hip_at_size(case, engine_options={"matmul_bf16": 1})
     seen = {}
     compare_with_fixture("cfg5_acoustic/bf16", got, fx, measure=seen)
-    worst = {}
-    for k, (err, norm_err, _) in seen.items():
-        kind = "scalars" if "scalars" in k else ("grad" if "grad." in k else ("upd" if "upd." in k else k))
-        worst[kind] = max(worst.get(kind, 0.0), err)
-        assert err <= BF16_LIMITS[kind], "bf16 %s: distance %.3e > %.1e" % (k, err, BF16_LIMITS[kind])
-    assert worst["y_hat"] > 1e-5, "suspiciously exact: the bf16 path did not run"
+    _judge_bf16("cfg5_acoustic", seen)

@@ -22,7 +22,7 @@ def _scale_of(b, msg):
     are not hidden behind mgc), weight matrices additionally per row (output unit): scale[i,j] = min(row_i, col_j).
     Vectors and scalars use their own max."""
     ab = np.abs(b)
-    if b.ndim < 2 or b.shape[-1] == 1:
+    if b.ndim < 2 or b.shape[-1] == 1 or (b.ndim == 2 and b.shape[0] == 1):      # (a (1, K) weight -- out_dim 1 -- is a vector)
         return np.full(b.shape, max(1e-30, float(ab.max()) if b.size else 1e-30))
     col = ab.reshape(-1, b.shape[-1]).max(0)
     scale = np.broadcast_to(col, b.shape).copy()
@@ -54,6 +54,17 @@ def _close(a, b, rtol=RTOL, atol=1e-6, msg="", frac_ok=0.0):
         msg, bad, worst, rtol, atol)
 
 
+def _close_state(got, ref, msg):
+    """Optimizer state at the suite's 1e-4: first moments (Adam exp_avg) directly; second moments (Adagrad `sum`, Adam
+    `exp_avg_sq`) are sums of SQUARED gradients -- a gradient that is right to 1e-4 gives a second moment that is right to
+    2e-4 -- so they are compared on the scale the update uses them on, their square root (p -= lr * g / (sqrt(sum) + eps))."""
+    if ".opt.sum." in msg or ".opt.exp_avg_sq." in msg:
+        _close(np.sqrt(np.maximum(np.asarray(got, dtype=np.float64), 0.0)), np.sqrt(np.maximum(np.asarray(ref, dtype=np.float64), 0.0)),
+               rtol=RTOL, atol=1e-9, msg=msg + " (sqrt)")
+    else:
+        _close(got, ref, rtol=RTOL, atol=1e-9, msg=msg)
+
+
 def test_library_loaded_is_the_hip_one():
     import gantts_amd._lib as L
     assert os.path.isfile(L.LIB_PATH)
@@ -76,7 +87,7 @@ def test_step_matches_reference_golden(name):
             if k.startswith("d_scalars"):
                 assert o[3] == g[3] and o[4] == g[4], (k, o, g)   # classification counts exact
         elif ".opt." in k:
-            _close(o, g, rtol=5e-4, atol=1e-9, msg=k)
+            _close_state(o, g, k)
         else:
             _close(o, g, rtol=RTOL, atol=1e-6, msg=k)
     # vuv stream is a pass-through copy: bit-exact
@@ -318,6 +329,26 @@ def test_model_forward_eval_matches_oracle_and_errors():
     assert list(m.state_dict().keys()) == o.names
 
 
+@pytest.mark.parametrize("pitch_x", [False, True])
+def test_device_side_collate_equals_host_collate(pitch_x):
+    """SURVEY 8(f)2 / VERDICT r3 missing #7: padding (train.py:139-159) and the length sort (train.py:494-501) on the device.
+    A collate_ragged batch (un-padded utterances back to back) through DevicePrefetcher -> gt_op_pad_sequences must be the
+    bit-identical (B, T, D) batch, in the same order, that the reference-shaped host collate + sort + trim produces."""
+    from gantts_amd import data as D
+    rs = np.random.RandomState(9)
+    lens = [37, 120, 5, 120, 64, 1, 99]
+    batch = [(rs.rand(n, 425).astype(np.float32), rs.randn(n, 187).astype(np.float32)) for n in lens]
+    host = list(D.DevicePrefetcher([D.collate_fn(batch)], pitch_x=pitch_x))[0]
+    dev = list(D.DevicePrefetcher([D.collate_ragged(batch)], pitch_x=pitch_x))[0]
+    torch.cuda.synchronize()
+    assert host.cpu_lengths == dev.cpu_lengths == sorted(lens, reverse=True)
+    assert torch.equal(host.lengths.cpu(), dev.lengths.cpu())
+    assert dev.x.shape == host.x.shape == (7, 120, 425) and dev.y.shape == (7, 120, 187)
+    assert torch.equal(host.x.contiguous(), dev.x.contiguous()) and torch.equal(host.y, dev.y)
+    if pitch_x:
+        assert dev.x.stride(1) == 428 and not dev.x.is_contiguous()
+
+
 @pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_chain_d"])
 def test_pitched_x_is_bit_identical_to_dense_x(name):
     """gt_set_x_pitch (include/gantts_hip.h): x handed over with rows on a 16-byte pitch -- what DevicePrefetcher(pitch_x=True)
@@ -350,7 +381,7 @@ def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
             if k.startswith("d_scalars"):
                 assert on[k][3] == off[k][3] and on[k][4] == off[k][4], k
         elif ".opt." in k:
-            _close(on[k], off[k], rtol=5e-4, atol=1e-9, msg=k)
+            _close_state(on[k], off[k], k)
         else:
             _close(on[k], off[k], msg=k)
         _close(fused_only[k], off[k], rtol=2e-6, atol=1e-9, msg="fused optimizer " + k)
@@ -542,7 +573,7 @@ def _rms(a):
     return float(np.sqrt((a * a).mean())) if a.size else 0.0
 
 
-ARBITER_FACTOR, ARBITER_FLOOR, KINK_ALLOWANCE = 3.0, 2e-6, 1e-3      # derivation of the last one: tests/golden/at_size.py
+ARBITER_FACTOR, ARBITER_FLOOR = 3.0, 2e-6
 
 
 def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_FLOOR, kink=0.0):
@@ -555,10 +586,11 @@ def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_
     No hand-set per-layer tolerance: where float32 itself is ill-conditioned -- a pre-activation within rounding of 0 picks
     LeakyReLU slope 1 or 0.01 (in-place LeakyReLU, gantts/models.py:132: the derivative follows the sign of the stored output)
     and moves a rank-one piece of every lower weight gradient -- rms(ref32 - ref64) shows it, tensor by tensor, and where it is
-    well-conditioned the limit is a few float32 ulps.  `kink` (KINK_ALLOWANCE, for gradient tensors downstream of a LeakyReLU
-    layer only): whether a given run HAS such a flip on a given tensor is a Poisson draw with a mean of order one per network,
-    so the reference's single float32 run may show none where the engine shows one (about 3e-4 relative rms each;
-    tests/golden/at_size.py has the derivation and the evidence).  A wrong keep bit or tile shows at 1e-1..1.  The worst
+    well-conditioned the limit is a few float32 ulps.  `kink` (for gradient tensors downstream of a LeakyReLU layer only): whether
+    a given run HAS such a flip on a given tensor is a Poisson draw with a mean of order one per network, so the reference's
+    single float32 run may show none where the engine shows one.  The allowance is MEASURED per case: the oracle's float32 and
+    float64 runs are compared activation by activation (make_at_size.SlopeCensus) and n = flips + 3 sqrt(flips) + 5 flips -- the
+    upper end of that Poisson draw -- are allowed, i.e. sqrt(n / activations) relative rms (tests/golden/at_size.py).  A wrong keep bit or tile shows at 1e-1..1.  The worst
     single element must stay within 10x the limit (relative to the tensor's largest magnitude)."""
     g, r32, r64 = (np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64))
     den = max(_rms(r64), 1e-300)
@@ -663,8 +695,27 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
                             ggrad=[q.grad.numpy().copy() for q in omg.params]))
         return rec, [q.detach().numpy() - i for q, i in zip(omg.params, init_g)], [q.detach().numpy() - i for q, i in zip(omd.params, init_d)], omg.names, omd.names
 
-    ref, ref_gu, ref_du, gnames, dnames = oracle_run(torch.float32)     # records of both steps, total parameter updates
-    alt, alt_gu, alt_du, _, _ = oracle_run(torch.float64)               # the arbiter: same inputs and masks, float64
+    from make_at_size import SlopeCensus
+    with SlopeCensus() as c32:
+        ref, ref_gu, ref_du, gnames, dnames = oracle_run(torch.float32)     # records of both steps, total parameter updates
+    with SlopeCensus() as c64:
+        alt, alt_gu, alt_du, _, _ = oracle_run(torch.float64)               # the arbiter: same inputs and masks, float64
+    calls = len(c32.signs) // steps
+
+    def kink_of(first_call, last_call):      # measured allowance from the flips among calls [first, last)
+        a, b = SlopeCensus(), SlopeCensus()
+        a.signs, b.signs = c32.signs[first_call:last_call], c64.signs[first_call:last_call]
+        cen = SlopeCensus.compare(a, b, 3, calls)
+        flips, acts = cen["G"][0] + cen["D"][0], cen["G"][1] + cen["D"][1]
+        return float(np.sqrt((flips + 3.0 * np.sqrt(flips) + 5.0) / acts)), cen
+
+    # the first step's gradients see the first step's flips only; whatever follows the first update sees many more (the two
+    # precisions' parameters differ after it, so every pre-activation within that difference of 0 flips)
+    kink_by_step = [kink_of(0, calls)[0]] + [kink_of(0, calls * (st + 1))[0] for st in range(1, steps)]
+    KINK_ALLOWANCE = kink_by_step[-1]
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write("%s: LeakyReLU slope census, all steps: %s -> kink allowance by step %s\n" % (tag, kink_of(0, calls * steps)[1], kink_by_step))
 
     def split(flat, like):
         out, off = [], 0
@@ -686,9 +737,9 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
             _close_arbiter(h["yh"], r["yh"], a["yh"], t + "y_hat", kink=KINK_ALLOWANCE)
             _close_arbiter(h["yhs"], r["yhs"], a["yhs"], t + "y_hat_static", kink=KINK_ALLOWANCE)
         for nm, got, rr, aa in zip(dnames, split(h["dgrad"], r["dgrad"]), r["dgrad"], a["dgrad"]):
-            _close_arbiter(got, rr, aa, t + "D.grad " + nm, kink=0.0 if nm.startswith("last_linear") and st == 0 else KINK_ALLOWANCE)
+            _close_arbiter(got, rr, aa, t + "D.grad " + nm, kink=0.0 if nm.startswith("last_linear") and st == 0 else kink_by_step[st])
         for nm, got, rr, aa in zip(gnames, split(h["ggrad"], r["ggrad"]), r["ggrad"], a["ggrad"]):
-            _close_arbiter(got, rr, aa, t + "G.grad " + nm, kink=KINK_ALLOWANCE)
+            _close_arbiter(got, rr, aa, t + "G.grad " + nm, kink=kink_by_step[st])
     # parameters after both steps: the UPDATE each tensor received
     for tagm, m, ru, au, w0 in (("G", mg, ref_gu, alt_gu, wg0), ("D", md, ref_du, alt_du, wd0)):
         for (k, v), r_, a_ in zip(m.state_dict().items(), ru, au):
@@ -741,7 +792,7 @@ def test_oracle_only_step_matches_oracle(name):
         if "scalars" in k:
             _close(got[k], r, msg=k)
         elif ".opt." in k:
-            _close(got[k], r, rtol=5e-4, atol=1e-9, msg=k)
+            _close_state(got[k], r, k)
         else:
             _close(got[k], r, msg=k)
 
@@ -1155,7 +1206,7 @@ def test_engine_communicator_world_1_matches_reference_golden(name):
             if k.startswith("d_scalars"):
                 assert got[k][3] == gold[k][3] and got[k][4] == gold[k][4]
         elif ".opt." in k:
-            _close(got[k], gold[k], rtol=5e-4, atol=1e-9, msg=k)
+            _close_state(got[k], gold[k], k)
         else:
             _close(got[k], gold[k], msg=k)
 
@@ -1401,7 +1452,7 @@ def test_tiny_batches_match_oracle(B, T):
             continue
         a, b = np.asarray(got[k], dtype=np.float64), np.asarray(r, dtype=np.float64)
         if ".opt." in k:
-            _close(a, b, rtol=5e-4, atol=1e-9, msg=k)
+            _close_state(a, b, k)
         elif k.startswith(("G.", "D.")):
             bad = np.abs(a - b) > 1e-4 * max(1e-30, float(np.abs(b).max())) + 1e-6
             assert bad.sum() <= max(1, a.size // 2000), (k, int(bad.sum()), a.size)
