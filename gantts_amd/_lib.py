@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("GT_HIP_LIB") or os.path.join(_HERE, "libgantts_hip.so
 GT_OK, GT_ERR_INVALID, GT_ERR_HIP, GT_ERR_STATE, GT_ERR_DIM = 0, 1, 2, 3, 4
 ROLE_G, ROLE_D = 0, 1
 OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_SPLIT_FIRST_LAYER, OPT_FUSED_OPTIMIZER = 2, 3, 4, 5, 6, 7
+OPT_SIDE_OVERLAP, OPT_LSTM_SIDE, OPT_COMM_D_ONE_MSG, OPT_COMM_EARLY_G, OPT_COMM_GROUP, OPT_COMM_FORCE = 8, 9, 10, 11, 12, 13
 PROFILE_SLOTS = 16
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
@@ -88,6 +89,7 @@ SIGNATURES = {
     "gt_set_loss_normalizer_device": (_I, [_P, _P]),
     "gt_set_option": (_I, [_P, _I, _I]),
     "gt_set_x_pitch": (_I, [_P, _I, _I]),
+    "gt_set_tuning": (_I, [C.c_char_p, _I]),
     "gt_check_faults": (_I, [_P, _P]),
     "gt_clear_faults": (_I, [_P, _P]),
     "gt_comm_unique_id": (_I, [_P]),

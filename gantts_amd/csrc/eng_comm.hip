@@ -121,8 +121,7 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
 }
 
 bool comm_on(const gt_engine* e) {
-  static const bool force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
-  return e->comm != nullptr && (e->comm->world > 1 || force);
+  return e->comm != nullptr && (e->comm->world > 1 || e->opt_comm_force);
 }
 // all-reduce(sum) of buf[0..count) in place on the communicator's stream, ordered after everything queued on `compute`
 static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute) {
@@ -175,7 +174,7 @@ int comm_flush(gt_engine* e, int role, hipStream_t compute) {
 int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute) {
   if (!comm_on(e)) return GT_OK;
   Net& n = e->net[role];
-  const bool grp = comm_group() && rccl_api();
+  const bool grp = e->opt_comm_group && rccl_api();
   if (grp) NCCLCHK(rccl_api()->GroupStart());       // the closing messages of a step (rest of the gradient + loss sums): one launch
   if (grads) {
     CHK(comm_flush(e, role, compute));

@@ -346,6 +346,12 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       e->opt_split_first = value != 0;
       return GT_OK;
     case GT_OPT_FUSED_OPTIMIZER: e->opt_fused_optimizer = value != 0; return GT_OK;
+    case GT_OPT_SIDE_OVERLAP: e->opt_side_overlap = value != 0; return GT_OK;
+    case GT_OPT_LSTM_SIDE: e->opt_lstm_side = value != 0; return GT_OK;
+    case GT_OPT_COMM_D_ONE_MSG: e->opt_comm_d_one_msg = value != 0; return GT_OK;
+    case GT_OPT_COMM_EARLY_G: e->opt_comm_early_g = value != 0; return GT_OK;
+    case GT_OPT_COMM_GROUP: e->opt_comm_group = value != 0; return GT_OK;
+    case GT_OPT_COMM_FORCE: e->opt_comm_force = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16:
       // the storage precision belongs to a PASS: buffers of a stashed forward pass (bf16 images vs float32 stashes) are not
       // interchangeable, so a change drops whatever is stashed -- the next update_* then asks for a fresh apply_generator
@@ -358,6 +364,30 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       return GT_OK;
   }
   return fail(GT_ERR_INVALID, "unknown option %d", option);
+}
+GtTuning& gt_tuning() {
+  static GtTuning t = [] {
+    GtTuning v;
+    auto geti = [](const char* n, int d) { const char* s = getenv(n); return s && s[0] ? atoi(s) : d; };
+    v.gemm_pair = geti("GT_GEMM_PAIR", v.gemm_pair); v.pair_order = geti("GT_PAIR_ORDER", v.pair_order);
+    { const char* s = getenv("GT_GEMM_TILES"); v.gemm_tiles_big = s && !strcmp(s, "big") ? 1 : 0; }
+    v.gemm_unaligned = geti("GT_GEMM_UNALIGNED", v.gemm_unaligned); v.tn_wgs = geti("GT_TN_WGS", v.tn_wgs);
+    v.stagger_ticks = geti("GT_GEMM_STAGGER_TICKS", v.stagger_ticks); v.stagger_mode = geti("GT_GEMM_STAGGER_MODE", v.stagger_mode);
+    v.b16_tiles = geti("GT_B16_TILES", v.b16_tiles); v.b16_wg_tile = geti("GT_B16_WG_TILE", v.b16_wg_tile); v.b16_dma = geti("GT_B16_DMA", v.b16_dma);
+    v.mlpg_fpl = geti("GT_MLPG_FPL", v.mlpg_fpl); v.sru_lw = geti("GT_SRU_LW", v.sru_lw);
+    return v;
+  }();
+  return t;
+}
+extern "C" int gt_set_tuning(const char* name, int value) {
+  if (!name) return fail(GT_ERR_INVALID, "null name");
+  GtTuning& t = gt_tuning();
+  struct { const char* n; int* p; } tab[] = {
+      {"gemm_pair", &t.gemm_pair}, {"pair_order", &t.pair_order}, {"gemm_tiles_big", &t.gemm_tiles_big}, {"gemm_unaligned", &t.gemm_unaligned},
+      {"tn_wgs", &t.tn_wgs}, {"stagger_ticks", &t.stagger_ticks}, {"stagger_mode", &t.stagger_mode}, {"b16_tiles", &t.b16_tiles},
+      {"b16_wg_tile", &t.b16_wg_tile}, {"b16_dma", &t.b16_dma}, {"mlpg_fpl", &t.mlpg_fpl}, {"sru_lw", &t.sru_lw}};
+  for (auto& e : tab) if (!strcmp(e.n, name)) { *e.p = value; return GT_OK; }
+  return fail(GT_ERR_INVALID, "unknown tuning knob '%s'", name);
 }
 extern "C" int gt_set_x_pitch(gt_engine* e, int ld_generator_input, int ld_condition) {
   if (!e || ld_generator_input < 0 || ld_condition < 0) return fail(GT_ERR_INVALID, "bad argument");

@@ -60,11 +60,11 @@ int launch_gemm_b16(const GemmB16Args& g, int nslab, hipStream_t s, int tile) {
   if (g.CbT && ((g.ldcbt & 3) || (((uintptr_t)g.CbT) & 7))) return fail(GT_ERR_INVALID, "bf16 product: transposed result must be 8-byte aligned");
   // 128 x 128 tiles once they still give every CU two workgroups (one resident round), else 64 x 64 (four per CU)
   const long t128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nslab;
-  static const int force_tiles = getenv("GT_B16_TILES") ? atoi(getenv("GT_B16_TILES")) : 0;      // measurement switch: 64 / 128
+  const int force_tiles = gt_tuning().b16_tiles;      // measurement knob: 64 / 128 / 256
   const bool big = tile ? tile >= 128
                         : (force_tiles == 64 ? false : (g.epi != B16_SLAB && g.M >= 128 && g.N >= 128 && (force_tiles == 128 || t128 >= 2L * gemm_cu_count())));
   // operand stages by LDS-DMA when no element of a stage needs masking and no row sums ride in the loader
-  static const bool dma_on = !(getenv("GT_B16_DMA") && getenv("GT_B16_DMA")[0] == '0');
+  const bool dma_on = gt_tuning().b16_dma != 0;
   const bool dma = dma_on && big && g.K % 64 == 0 && (g.epi != B16_SLAB || (g.k_chunk % 64 == 0 && !g.rowsum_slab));
   // 256 x 256 tiles when they fill whole rounds of CUs (one workgroup per CU) to within 15 %
   const long t256 = (long)cdiv(g.M, 256) * cdiv(g.N, 256) * nslab, cus = gemm_cu_count();
@@ -129,7 +129,7 @@ int weight_grad_b16(const __bf16* dZT, long lddzt, const __bf16* XT, long ldxt, 
   // 128 x 128 tiles (two workgroups per CU) once the matrix has at least 16 of them, with the slab count that fills whole
   // rounds of 2 x CUs workgroups best (r = 1 .. 3 rounds; tools/gemm_b16_sweep: 1024 x 3072 over 32 768 frames 450 us with
   // 64 x 64 tiles -> 246 us with 8 slabs of 128 x 128; 512 x 2048: 124 -> 76 us); 64 x 64 (four per CU) below that
-  static const int force_wg_tile = getenv("GT_B16_WG_TILE") ? atoi(getenv("GT_B16_WG_TILE")) : 0;     // measurement switch: 64 / 128
+  const int force_wg_tile = gt_tuning().b16_wg_tile;     // measurement knob: 64 / 128 / 256
   const int t128 = cdiv(out, 128) * cdiv(in, 128), t256 = cdiv(out, 256) * cdiv(in, 256);
   const bool big = force_wg_tile ? force_wg_tile >= 128 : (out >= 128 && in >= 128 && t128 >= 16);
   // 256 x 256 tiles (one 8-wave workgroup per CU, LDS-DMA only: no bias gradient, whole 64-frame stages) for the largest matrices

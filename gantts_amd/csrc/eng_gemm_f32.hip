@@ -33,14 +33,8 @@ static int pick_bn(int N) { return (cdiv(N, 64) * 64 < cdiv(N, 128) * 128) ? 64 
 // 44.7 vs 47.9; 16384x256x256: 25.1 vs 27.4 / 31.5) -- four tiles per CU drain their epilogues under each other's K loops,
 // and the 2x operand re-reads come out of the XCD's L2.  Operands that need the 4-byte loader keep the larger tiles
 // (their loader is the bottleneck, and a tile re-read costs 4x the instructions).
-static int gemm_tile_mode() {   // measurement switch: GT_GEMM_TILES=big restores the residency model for every launch
-  static const int m = [] { const char* v = getenv("GT_GEMM_TILES"); return v && !strcmp(v, "big") ? 1 : 0; }();
-  return m;
-}
-static bool gemm_unaligned_ok() {   // measurement switch
-  static const bool on = [] { const char* v = getenv("GT_GEMM_UNALIGNED"); return !(v && v[0] == '0'); }();
-  return on;
-}
+static int gemm_tile_mode() { return gt_tuning().gemm_tiles_big; }   // measurement knob: GT_GEMM_TILES=big restores the residency model for every launch
+static bool gemm_unaligned_ok() { return gt_tuning().gemm_unaligned != 0; }   // measurement knob
 bool gemm_vec_ok(const float* p, int ld, bool k_contiguous) {
   if (k_contiguous && gemm_unaligned_ok()) return true;
   return (ld % 4 == 0) && (((uintptr_t)p) % 16 == 0);
@@ -117,10 +111,7 @@ int linear_backward_data(const float* dZ, int lddz, const float* W, int ldw, int
 }
 // Pair launch (gemm_pair_kernel): the same layer's backward-data product rides in the weight gradient's launch when both
 // run on 64x64 tiles with 16-byte loadable operands.  GT_GEMM_PAIR=0 keeps them apart (measurement switch).
-static bool gemm_pair_enabled() {
-  static const bool on = [] { const char* v = getenv("GT_GEMM_PAIR"); return !(v && v[0] == '0'); }();
-  return on;
-}
+static bool gemm_pair_enabled() { return gt_tuning().gemm_pair != 0; }
 static bool gemm_pair_ok(const GemmArgs& nn) {
   return gemm_pair_enabled() && gemm_small_tiles_ok() && nn.M > 64 && gemm_vec_ok(nn.A, nn.lda, true) && gemm_vec_ok(nn.B, nn.ldb);
 }
@@ -151,7 +142,7 @@ int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, l
     const bool t64 = gemm_vec_ok(dZ, lddz) && gemm_vec_ok(X, ldx) && gemm_small_tiles_ok();
     const int bn = t64 ? 64 : pick_bn(in);
     const int tiles = cdiv(out, t64 ? 64 : 128) * cdiv(in, bn);
-    static const int slab_wgs = getenv("GT_TN_WGS") ? atoi(getenv("GT_TN_WGS")) : 512;   // measurement switch
+    const int slab_wgs = gt_tuning().tn_wgs;   // measurement knob
     int nslab = std::max(1, slab_wgs / tiles);   // <= 2 workgroups per CU x 256 CUs: one resident round
     const int max_slab = (int)((rows + 255) / 256);
     if (nslab > max_slab) nslab = max_slab;

@@ -268,7 +268,7 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
   // Built, correct (the at-size cfg3 parity test passes with it) and MEASURED NOT TO PAY: cfg3 fp32 25.74 ms with it vs
   // 25.68 ms without, bf16 19.04 vs 18.14 ms -- the recurrence is bound by its L2 hand-offs, and the products' operand
   // traffic through the same L2s slows every one of its 1024 steps by about what the overlap hides.
-  static const bool side_on = getenv("GT_LSTM_SIDE") && getenv("GT_LSTM_SIDE")[0] == '1';
+  const bool side_on = e->opt_lstm_side;
   hipStream_t ws = s;
   if (side_on) {
     if (!e->side) {

@@ -38,7 +38,10 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
 
 // the scans with loader waves (sru_kernels.hip.h); GT_SRU_LW=0 selects the one-wave kernels (A/B reference, bit-identical results)
 // (read at every launch: the A/B test flips it between two steps of one process)
-static bool sru_loader_waves() { const char* v = getenv("GT_SRU_LW"); return !(v && v[0] == '0'); }
+static bool sru_loader_waves() { return gt_tuning().sru_lw != 0; }
+// Measured and dropped (round 4, gpurun_out/r4k): 32 columns per workgroup (twice the recurrence waves per CU, half of every wave
+// idle) for the shapes that give fewer than three 64-column workgroups per CU -- cfg4 (B = 16, T = 2048) 11.36 vs 10.84 ms, the
+// hparams-default generator at B = 32 9.49 vs 9.32 ms: the scan is not bound by one wave's per-frame latency.
 static bool sru_b16(const gt_engine* e) { return e->matmul_bf16 && (e->net[GT_ROLE_G].d.hidden_dim & 7) == 0; }
 int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
   Net& G = e->net[GT_ROLE_G];

@@ -58,7 +58,7 @@ int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const i
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+  const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
 #define GT_MLPG_FWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F>, lds)); \
     hipLaunchKernelGGL(mlpg_forward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
   if (fpl == 1) GT_MLPG_FWD(1) else if (fpl == 2) GT_MLPG_FWD(2) else GT_MLPG_FWD(4)
@@ -72,7 +72,7 @@ int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, cons
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
   dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  static const int fpl = getenv("GT_MLPG_FPL") ? atoi(getenv("GT_MLPG_FPL")) : 2;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+  const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
 #define GT_MLPG_BWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F>, lds)); \
     hipLaunchKernelGGL(mlpg_backward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
                        gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
@@ -214,7 +214,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
         // generator: all layers above the first leave as one message under the first layer's backward; the discriminator's
         // whole gradient (1 MB) is ONE message at the end of its backward pass (a second launch costs more than it hides)
-        if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
+        if (l == 1 && (role == GT_ROLE_G || !e->opt_comm_d_one_msg)) CHK(comm_flush(e, role, s));
       }
       if (l > 0) {
         if (!rode) CHK(launch_gemm(GEMM_NN, nn, 1, s));
@@ -309,7 +309,7 @@ static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long l
       const long ldxt = l > 0 ? acts[l - 1].ldt : ld_int;
       CHK(weight_grad_b16(dz.t(), dz.ldt, XT, ldxt, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
       CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
-      if (l == 1 && (role == GT_ROLE_G || !comm_d_one_message())) CHK(comm_flush(e, role, s));
+      if (l == 1 && (role == GT_ROLE_G || !e->opt_comm_d_one_msg)) CHK(comm_flush(e, role, s));
     }
     if (l > 0) {
       B16Img& nx = e->dz_b[cur ^ 1];
@@ -586,6 +586,28 @@ int post_early_results(gt_engine* e, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // update_discriminator
 // ------------------------------------------------------------------------------------------
+// Small HBM-bound kernels that nothing in front of them depends on run on the engine's side stream, UNDER the matrix
+// products of the step stream (which leave the memory system mostly idle): the valid-frame count of the D step (needed
+// only by the head, a whole forward pass later) and the reported MSE loss of the G step (train.py:294; needed only by the
+// step's finalisation).  side_fork: the side stream starts behind everything queued on `s` so far; side_join: `s` continues
+// behind the side stream.  Fused single-GPU calls only.  MEASURED SLOWER (cfg2 1.426 vs 1.413 ms: two event hand-offs per use cost
+// more than the 17 us of kernels they hide), so GT_OPT_SIDE_OVERLAP is off by default.
+static int side_fork(gt_engine* e, hipStream_t s) {
+  if (!e->side) {
+    HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(e->ev_side_go, s));
+  HIPCHK(hipStreamWaitEvent(e->side, e->ev_side_go, 0));
+  return GT_OK;
+}
+static int side_join(gt_engine* e, hipStream_t s) {
+  HIPCHK(hipEventRecord(e->ev_side_done, e->side));
+  HIPCHK(hipStreamWaitEvent(s, e->ev_side_done, 0));
+  return GT_OK;
+}
+
 // the split first layer (FirstSplit) applies to the conditioned discriminator on the float32 path
 static bool d_split_ok(gt_engine* e, const float* x, bool b16) {
   return e->opt_split_first && !b16 && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
@@ -608,6 +630,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
   { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && D.has_opt; }
   CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
+  const bool tv_side = e->early && !comm_on(e) && e->opt_side_overlap && !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
+  if (tv_side) { CHK(side_fork(e, s)); CHK(ensure_tv(e, mask, N, e->side)); }      // single GPU: the count is summed under the D forward pass
   const int passes[2] = {0, 1};
   // the [x | adv] image of both halves: real rows, then generated rows
   const bool b16 = use_b16(e, GT_ROLE_D);
@@ -669,6 +693,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // fused call: losses and counts are final after the head (the gradient norm is not: reported as 0), so the head's
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
+  if (tv_side) CHK(side_join(e, s));
   CHK(ensure_tv(e, mask, N, s));
   if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
@@ -903,8 +928,11 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   // (the fused single-GPU call reduces the MSE partials inside its finalisation launch: see early_now below)
   const bool early_fold = e->early && !comm_on(e) && !(tr && direct && mse_w != 0.f);
   int mse_blocks = 0;
-  if (!(tr && direct && mse_w != 0.f))
-    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, s, early_fold ? &mse_blocks : nullptr));
+  const bool mse_side = early_fold && e->opt_side_overlap && adv_w > 0.f;      // (under the D pass of the adversarial term)
+  if (!(tr && direct && mse_w != 0.f)) {
+    if (mse_side) CHK(side_fork(e, s));
+    CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, mse_side ? e->side : s, early_fold ? &mse_blocks : nullptr));
+  }
   // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
   e->g_has_adv = adv_w > 0.f;
   float* gadv = nullptr;
@@ -976,7 +1004,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   }
   // MGE loss + gradient assembly at y_hat_static
   const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
-  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e) && comm_early_g();
+  const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e) && e->opt_comm_early_g;
   int mge_blocks = 0;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
@@ -994,6 +1022,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     }
   }
   e->early_done = false;
+  if (mse_side && mse_blocks) CHK(side_join(e, s));
   if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
     hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), early_res_target(e), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
                        (const double*)e->partial.as<double>(), mge_blocks,

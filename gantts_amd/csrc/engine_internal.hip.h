@@ -54,12 +54,35 @@ int fail(int code, const char* fmt, ...);
   } while (0)
 #define LAUNCH_CHECK() HIPCHK(hipGetLastError())
 
+static inline bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v && v[0] ? v[0] != '0' : dflt; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int pad8(long n) { return (int)((n + 7) & ~7L); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: remembered per (kernel, device)
 int ensure_dyn_lds(const void* kernel, size_t bytes);
 int gemm_cu_count();
+
+// ------------------------------------------------------------------------------------------
+// Dispatch knobs of the product families and frame kernels: ONE process-wide table, read once from the environment when the
+// library is first used and settable afterwards by name (gt_set_tuning; tools/ harnesses and A/B runs).  Every default is the
+// measured best; none selects different arithmetic.  What changes a STEP's schedule or a network's path is
+// per-engine state instead (gt_engine::opt_*, gt_set_option): two engines of one process may differ.
+// ------------------------------------------------------------------------------------------
+struct GtTuning {
+  int gemm_pair = 1;          // GT_GEMM_PAIR      backward-data + weight gradient of a layer in one launch
+  int pair_order = 1;         // GT_PAIR_ORDER     pair launch: weight-gradient workgroups first
+  int gemm_tiles_big = 0;     // GT_GEMM_TILES=big residency model (128-wide tiles) for every float32 launch
+  int gemm_unaligned = 1;     // GT_GEMM_UNALIGNED 16-byte loads of k-contiguous operands at 4-byte aligned addresses
+  int tn_wgs = 512;           // GT_TN_WGS         workgroups of a weight-gradient launch
+  int stagger_ticks = 0;      // GT_GEMM_STAGGER_TICKS / _MODE   start stagger (off)
+  int stagger_mode = 3;
+  int b16_tiles = 0;          // GT_B16_TILES      bf16-storage products: force 64 / 128 / 256 tiles (0 = by shape)
+  int b16_wg_tile = 0;        // GT_B16_WG_TILE    ... their weight gradients
+  int b16_dma = 1;            // GT_B16_DMA        LDS-DMA operand stages
+  int mlpg_fpl = 2;           // GT_MLPG_FPL       frames per lane of the MLPG compute phase
+  int sru_lw = 1;             // GT_SRU_LW         loader-wave SRU scans (0: one-wave kernels, bit-identical results)
+};
+GtTuning& gt_tuning();
 
 // optional per-launch timing of the product families (HIP events on the launch stream); bench.py's live roofline figure
 struct GemmProfiler {
@@ -235,15 +258,21 @@ struct gt_engine {
   struct Pitched { Scratch buf; const float* src = nullptr; int ld = 0, cols = 0; long rows = 0; uint64_t step = ~0ULL; };
   Pitched pitched[2];                              // 16-byte-pitch copies of caller tensors (slot 0: D's x, 1: G's input), once per step
   // GT_OPT_SPLIT_FIRST_LAYER / GT_OPT_FUSED_OPTIMIZER (per engine; the environment only provides the default at creation)
-  bool opt_split_first = !(getenv("GT_D_SPLIT") && getenv("GT_D_SPLIT")[0] == '0');
-  bool opt_fused_optimizer = getenv("GT_OPT_FUSED") && getenv("GT_OPT_FUSED")[0] == '1';       // measured slower: off
+  bool opt_split_first = env_flag("GT_D_SPLIT", true);
+  bool opt_fused_optimizer = env_flag("GT_OPT_FUSED", false);      // measured slower: off
+  bool opt_side_overlap = env_flag("GT_SIDE_OVERLAP", false);      // GT_OPT_SIDE_OVERLAP: tv / MSE kernels on the side stream (measured slower: off)
+  bool opt_lstm_side = env_flag("GT_LSTM_SIDE", false);            // GT_OPT_LSTM_SIDE: LSTM weight gradients beside the next layer's recurrence (measured: no gain)
+  // data-parallel schedule (GT_OPT_COMM_*): D's gradient as one message, G's loss sums early, grouped closing messages,
+  // collectives issued even with one rank (bench.py --force-dp, tests)
+  bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
+       opt_comm_group = env_flag("GT_COMM_GROUP", false), opt_comm_force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
   unsigned int* d_fault = nullptr;                 // device fault word of the persistent kernels (0 = ok)
   unsigned int* h_fault = nullptr;                 // pinned mirror, refreshed behind every persistent launch
-  bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT
+  bool lstm_persistent = getenv("GT_LSTM_STEPS") == nullptr;   // GT_OPT_LSTM_PERSISTENT (the environment only provides the default at creation)
   int lstm_fwd_upc = 0;                            // 0 = automatic
   bool lstm_xcd_local = getenv("GT_LSTM_NO_XCD_LOCAL") == nullptr;   // GT_OPT_LSTM_XCD_LOCAL
   bool matmul_bf16 = false;                                          // GT_OPT_MATMUL_BF16
@@ -343,10 +372,7 @@ int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sum
 int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float adv_w, float mse_w, float mge_w, hipStream_t compute);
 int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t s);
 int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s);
-// measurement switches of the data-parallel schedule
-static inline bool comm_d_one_message() { static const bool v = !(getenv("GT_COMM_D_ONE_MSG") && getenv("GT_COMM_D_ONE_MSG")[0] == '0'); return v; }
-static inline bool comm_early_g() { static const bool v = !(getenv("GT_COMM_EARLY_G") && getenv("GT_COMM_EARLY_G")[0] == '0'); return v; }
-static inline bool comm_group() { static const bool v = getenv("GT_COMM_GROUP") && getenv("GT_COMM_GROUP")[0] == '1'; return v; }
+// (the data-parallel schedule switches are per-engine state: gt_engine::opt_comm_*)
 
 // ------------------------------------------------------------------------------------------
 // eng_lstm.hip / eng_sru.hip

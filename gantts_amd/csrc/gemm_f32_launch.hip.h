@@ -32,8 +32,7 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   // the five big launches of a step back to back) letting one of the two workgroups of a CU start 0.5 .. 2 us late is
   // worth 10-15 % (372 -> 325 us per sequence); inside the training step it measured 0.0 % in every mode,
   // so it stays a measurement switch: GT_GEMM_STAGGER_TICKS (10 ns units), GT_GEMM_STAGGER_MODE.
-  static const int stagger_ticks = getenv("GT_GEMM_STAGGER_TICKS") ? atoi(getenv("GT_GEMM_STAGGER_TICKS")) : 0;
-  static const int stagger_mode = getenv("GT_GEMM_STAGGER_MODE") ? atoi(getenv("GT_GEMM_STAGGER_MODE")) : 3;
+  const int stagger_ticks = gt_tuning().stagger_ticks, stagger_mode = gt_tuning().stagger_mode;
   if (stagger_ticks > 0 && grid > gemm_cu_count()) {
     g.stagger_ticks = stagger_ticks; g.stagger_mode = stagger_mode;
     if (stagger_mode == 3 && !(g.stagger_ticket = gemm_stagger_tickets())) g.stagger_ticks = 0;

@@ -210,7 +210,22 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * combines + squared norm + clip + optimizer step behind a device-wide barrier) instead of three.  Same arithmetic; measured
  * SLOWER on MI355X (the barrier's wait costs more than two launch edges: cfg2 1.453 vs 1.411 ms), so it is off by default. */
 #define GT_OPT_FUSED_OPTIMIZER 7
+/* Schedule switches (defaults are the measured best; the GT_* environment variables of the same names only provide the default at
+ * engine creation): GT_OPT_SIDE_OVERLAP (0; measured slower) small memory-bound kernels on a side stream under the products; GT_OPT_LSTM_SIDE (0)
+ * LSTM weight gradients beside the next layer's recurrence; GT_OPT_COMM_D_ONE_MSG (1) / _EARLY_G (1) / _GROUP (0) data-parallel
+ * message schedule; GT_OPT_COMM_FORCE (0) issue the collectives with one rank as well (bench.py --force-dp, tests). */
+#define GT_OPT_SIDE_OVERLAP 8
+#define GT_OPT_LSTM_SIDE 9
+#define GT_OPT_COMM_D_ONE_MSG 10
+#define GT_OPT_COMM_EARLY_G 11
+#define GT_OPT_COMM_GROUP 12
+#define GT_OPT_COMM_FORCE 13
 int gt_set_option(gt_engine* e, int option, int value);
+/* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
+ * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs,
+ * stagger_ticks, stagger_mode, b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, sru_lw; the environment variables GT_<NAME>
+ * provide the initial values. */
+int gt_set_tuning(const char* name, int value);
 /* Row pitch (in floats) of the input tensors `x` of the step functions, like the `lda` of a BLAS call: ld_generator_input for the
  * x of gt_apply_generator (train.py:542: cat(x, z) or x), ld_condition for the conditioning x of gt_update_discriminator /
  * gt_update_generator (train.py:254-256).  0 (default) = dense rows (pitch = width).  A pitch that is a multiple of 4 floats on a

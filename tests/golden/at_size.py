@@ -37,18 +37,20 @@ ARBITER_FLOOR = 2e-6          # relative rms: a few float32 ulps, for tensors th
 KINK_ALLOWANCE = 1e-3          # legacy flat value: used only for a fixture without a slope census
 
 
-def kink_allowance(fx, net):
+def kink_allowance(fx, net, first_step=False):
     """MEASURED LeakyReLU-flip allowance of a network's gradient / update tensors (relative rms), from the slope census the fixture
     carries (make_at_size.SlopeCensus): `flips` activations took a different slope in the reference's own float32 run than in its
     float64 run, out of `activations`.  The engine's float32 evaluation draws its flips from the same distribution (Poisson with
     about that mean), each moves one element of a dZ tensor by its whole size, so n of them move the tensors downstream by about
     sqrt(n / activations): allowed is the upper end of that draw, n = flips + 3 sqrt(flips) + 5.  Tensors of G see the flips of
-    both networks (the adversarial gradient passes through D), tensors of D those of D."""
+    both networks (the adversarial gradient passes through D), tensors of D those of D.  first_step: the census of the first
+    step alone (the gradients the fixtures record are the first step's; updates are those of all steps)."""
     nets = ("G", "D") if net == "G" else ("D",)
     if not all(("kink.%s.flips" % n) in fx.files for n in nets):
         return KINK_ALLOWANCE
-    flips = sum(int(fx["kink.%s.flips" % n]) for n in nets)
-    acts = sum(int(fx["kink.%s.activations" % n]) for n in nets)
+    sfx = "_step0" if first_step and all(("kink.%s.flips_step0" % n) in fx.files for n in nets) else ""
+    flips = sum(int(fx["kink.%s.flips%s" % (n, sfx)]) for n in nets)
+    acts = sum(int(fx["kink.%s.activations%s" % (n, sfx)]) for n in nets)
     if acts == 0:
         return 0.0
     return float(np.sqrt((flips + 3.0 * np.sqrt(flips) + 5.0) / acts))

@@ -58,11 +58,13 @@ class SlopeCensus(object):
         F.leaky_relu = self._orig
 
     @staticmethod
-    def compare(a, b, n_g_calls_per_step, calls_per_step):
+    def compare(a, b, n_g_calls_per_step, calls_per_step, first_step_only=False):
         """-> {"G": (flips, activations), "D": (flips, activations)}: the first n_g_calls_per_step calls of a step are G's."""
         assert len(a.signs) == len(b.signs), (len(a.signs), len(b.signs))
         out = {"G": [0, 0], "D": [0, 0]}
         for i, (x, y) in enumerate(zip(a.signs, b.signs)):
+            if first_step_only and i >= calls_per_step:
+                break
             assert x.shape == y.shape
             net = "G" if (i % calls_per_step) < n_g_calls_per_step else "D"
             out[net][0] += int((x != y).sum())
@@ -219,6 +221,10 @@ def main():
         for net, (flips, acts) in SlopeCensus.compare(census[torch.float32], census[torch.float64], n_g, calls).items():
             fx["kink.%s.flips" % net], fx["kink.%s.activations" % net] = np.int64(flips), np.int64(acts)
             print("    LeakyReLU slope census %s: %d of %d activations differ between the float32 and the float64 run" % (net, flips, acts), flush=True)
+        # the first step alone (its gradients see only its own flips; after the first update the two precisions' parameters differ
+        # and every pre-activation within that difference of 0 flips)
+        for net, (flips, acts) in SlopeCensus.compare(census[torch.float32], census[torch.float64], n_g, calls, first_step_only=True).items():
+            fx["kink.%s.flips_step0" % net], fx["kink.%s.activations_step0" % net] = np.int64(flips), np.int64(acts)
         fx["meta.source"] = np.array(case["source"])
         fx["meta.seconds_f32"], fx["meta.seconds_f64"] = np.float64(secs[torch.float32]), np.float64(secs[torch.float64])
         path = os.path.join(os.environ.get("AT_SIZE_OUT", HERE), "at_size_%s.npz" % name)

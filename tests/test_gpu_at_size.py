@@ -136,7 +136,7 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
             continue                                       # judged below, once every gradient's error is known
         exposed = kind in ("Dgrad", "Ggrad", "Dupd", "Gupd") and not k.startswith("Dgrad.last_linear")
         e32 = max(e32_of[k], level[kind]) if exposed else e32_of[k]
-        kink = A.kink_allowance(fx, "G" if kind[0] == "G" else "D") if exposed else 0.0
+        kink = A.kink_allowance(fx, "G" if kind[0] == "G" else "D", first_step=kind.endswith("grad")) if exposed else 0.0
         lim = factor * e32 + floor + kink
         # the whole tensor, through its norm: nothing outside the sample can be far off without moving it
         norm_ref = float(fx[k + ".norm"])

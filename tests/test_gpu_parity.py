@@ -900,18 +900,21 @@ def test_bf16_storage_sru_step_tracks_the_float32_oracle():
 
 @pytest.mark.parametrize("name,bf16", [("acoustic_sru_at_size", 0), ("acoustic_sru_uni_k3_dropout", 0), ("vc_sru_multistream", 0),
                                        ("acoustic_sru_at_size", 1), ("acoustic_sru_dropout", 1)])
-def test_sru_loader_wave_scans_equal_the_one_wave_scans_bit_for_bit(name, bf16, monkeypatch):
+def test_sru_loader_wave_scans_equal_the_one_wave_scans_bit_for_bit(name, bf16):
     """The SRU scans with loader waves (three frame blocks per column in flight through an LDS ring, sru_kernels.hip.h)
-    against the one-wave scans (GT_SRU_LW=0): same arithmetic in the same order, so a whole G+D step -- outputs, scalars,
+    against the one-wave scans (gt_set_tuning("sru_lw", 0)): same arithmetic in the same order, so a whole G+D step -- outputs, scalars,
     parameters after the update, optimizer state -- must agree bit for bit (widths 6 x 512 bidirectional with both
     dropouts, a unidirectional tanh k = 3 net, a 3-stream net with ragged T = 19: partial blocks, partial workgroups).
     Also with bf16 storage (the scans are float32 there too; the products around them read bf16 images of their results)."""
     from hip_runner import run_hip_case
     case = C.ORACLE_ONLY_CASES[name]
+    from gantts_amd import _lib as L
     opts = {"matmul_bf16": 1} if bf16 else None
-    monkeypatch.setenv("GT_SRU_LW", "0")
-    ref = run_hip_case(case, engine_options=opts)
-    monkeypatch.setenv("GT_SRU_LW", "1")
+    try:
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 0))
+        ref = run_hip_case(case, engine_options=opts)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 1))
     got = run_hip_case(case, engine_options=opts)
     assert set(got) == set(ref)
     for k in ref:
