@@ -233,8 +233,8 @@ int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap
   // Slab count: the adversarial block has cdiv(Da, 64) tile columns against cdiv(cd, 64) of the x block but twice the frames, so
   // its workgroups are the long ones (rows / nslab frames each): enough slabs that one of them is about as long as a quarter of
   // the launch (4 workgroups per CU), dispatched FIRST (gemm_tn_pair_kernel), the x block's workgroups back-fill behind them.
-  const int tiles = cdiv(out, 64) * cdiv(cd, 64);
-  int nslab = std::max(1, 1024 / tiles);
+  const int tiles = cdiv(out, 64) * (cdiv(cd, 64) + cdiv(Da, 64));      // both blocks' tiles: one resident round of 4 workgroups per CU
+  int nslab = std::max(1, gt_tuning().tn_split_wgs / tiles);
   nslab = std::min<long>(nslab, std::max<long>(1, wrap / 256));
   const int kc1 = cdiv(cdiv(wrap, nslab), GEMM_BK) * GEMM_BK;
   const int ns1 = cdiv(wrap, kc1);

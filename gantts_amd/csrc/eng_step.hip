@@ -505,10 +505,11 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step + 1; o.max_norm = n.od.max_grad_norm;
   unsigned int* skipped = e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr;
   SlabDefer& sd = e->sdefer[role];
-  if (sd.active && sd.jobs.n > 0 && e->opt_fused_optimizer) {
-    // The fused step recorded this network's weight-gradient combines: combines + squared norm + clip + step in ONE launch
-    // (optim_fused_kernel).  The recorded jobs write disjoint ranges of the flat gradient; whatever they do not cover (the
-    // discriminator's last layer, written by the head's reduction) still counts for the norm and is stepped: `rest`.
+  if (sd.active && sd.jobs.n > 0) {
+    // The fused step recorded this network's weight-gradient combines.  They write disjoint ranges of the flat gradient; whatever
+    // they do not cover (the discriminator's last layer, written by the head's reduction) still counts for the norm and is
+    // stepped: `rest`.  Default: combines + squared norm in ONE launch (slab_reduce_norm_kernel), then clip + step;
+    // GT_OPT_FUSED_OPTIMIZER: all of it in one launch behind a device-wide barrier (measured slower).
     std::vector<std::pair<long, long>> cov;
     bool ok = true;
     for (int q = 0; q < sd.jobs.n && ok; ++q) {
@@ -525,17 +526,18 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
     std::sort(cov.begin(), cov.end());
     OptimRest rest;
     memset(&rest, 0, sizeof(rest));
-    long pos = 0;
+    long pos = 0, rest_total = 0;
     for (size_t i = 0; i <= cov.size() && ok; ++i) {
       const long next = i < cov.size() ? cov[i].first : np;
       if (next < pos) { ok = false; break; }                       // overlapping jobs: not this path
       if (next > pos) {
         if (rest.n_rest == 4) { ok = false; break; }
         rest.off[rest.n_rest] = pos; rest.n[rest.n_rest] = next - pos; ++rest.n_rest;
+        rest_total += next - pos;
       }
       if (i < cov.size()) pos = cov[i].first + cov[i].second;
     }
-    if (ok) {
+    if (ok && e->opt_fused_optimizer) {
       if (!e->opt_bar.p) { CHK(e->opt_bar.ensure(64)); HIPCHK(hipMemsetAsync(e->opt_bar.p, 0, 64, s)); e->opt_bar_count = 0; }
       const int grid = std::min(4 * gemm_cu_count(), std::max(sd.blocks, 64));
       e->opt_bar_count += (unsigned long long)grid;
@@ -545,6 +547,19 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
                          e->d_fault, e->h_fault_dev, skipped);
       LAUNCH_CHECK();
       sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = false;
+      return GT_OK;
+    }
+    const int rest_blocks = rest_total > 0 ? (int)std::min<long>(64, cdiv(rest_total, 256)) : 0;
+    if (ok && sd.blocks + rest_blocks <= 2048) {
+      hipLaunchKernelGGL(slab_reduce_norm_kernel, dim3(sd.blocks + rest_blocks), dim3(256), 0, s, sd.jobs, sd.blocks, rest, n.d.grads, part);
+      LAUNCH_CHECK();
+      const int n_partial = sd.blocks + rest_blocks;
+      sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = false;
+      n.step += 1;
+      const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
+      hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
+                         part, n_partial, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped);
+      LAUNCH_CHECK();
       return GT_OK;
     }
   }

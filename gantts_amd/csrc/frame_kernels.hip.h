@@ -1068,6 +1068,32 @@ __device__ __forceinline__ double slab_own_block(int pass, int blk, const SlabJo
   }
   return sq;
 }
+// The fused single-GPU step's combine launch of a network: the recorded weight-gradient combines (slab_reduce_multi_kernel's work)
+// AND the squared norm of the whole flat gradient (sqnorm_partial_kernel's work) in one launch -- every workgroup squares what it
+// has just written (or, for the trailing `rest_blocks` workgroups, what no job writes: OptimRest) and leaves one double per
+// workgroup for optim_step_kernel's fixed-order sum.  One launch and one pass over the gradient less per network and step.
+static __global__ __launch_bounds__(256) void slab_reduce_norm_kernel(const SlabJobs jobs, const int n_job_blocks, const OptimRest rest,
+                                                                      float* __restrict__ g, double* __restrict__ norm_part) {
+  __shared__ double shn[16];
+  double acc = 0.0;
+  if ((int)blockIdx.x < n_job_blocks) {
+    int q = 0;
+    while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].block0) ++q;
+    OptimSpec none;
+    none.kind = 0; none.lr = none.weight_decay = none.eps = none.lr_decay = none.beta1 = none.beta2 = 0.f; none.step = 1; none.max_norm = 0.f;
+    acc = slab_own_block(0, (int)blockIdx.x - jobs.j[q].block0, jobs.j[q], nullptr, g, nullptr, nullptr, 1.f, none, 0.f, 0.f, 1.f);
+  } else {
+    const long nrb = (long)gridDim.x - n_job_blocks, rb = (long)blockIdx.x - n_job_blocks;
+    for (int r = 0; r < rest.n_rest; ++r)
+      for (long i = rb * blockDim.x + threadIdx.x; i < rest.n[r]; i += nrb * blockDim.x) {
+        const double v = (double)g[rest.off[r] + i];
+        acc += v * v;
+      }
+  }
+  const double part = block_sum_d(acc, shn);
+  if (threadIdx.x == 0) norm_part[blockIdx.x] = part;
+}
+
 static __global__ __launch_bounds__(256) void optim_fused_kernel(
     const SlabJobs jobs, const int n_job_blocks, const OptimRest rest, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0,
     float* __restrict__ s1, double* norm_part /* [gridDim.x] */, unsigned long long* bar, const unsigned long long bar_target,

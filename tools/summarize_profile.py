@@ -34,7 +34,11 @@ shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, 
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 
-stats = list(csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv"))))
+stats = [r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))
+         if "at::native" not in r["Name"] and not r["Name"].startswith("__amd_rocclr")]      # torch's own fills / copies of the set-up are not the step
+_tot_ns = sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
+for r in stats:
+    r["Percentage"] = "%.4f" % (100.0 * float(r["TotalDurationNs"]) / _tot_ns)
 steps = 25.0  # bench.py --steps 20 --warmup 5 under the kernel trace
 fetch, nf = agg(os.path.join(src, "pmc_fetch", "k_counter_collection.csv"))
 write, nw = agg(os.path.join(src, "pmc_write", "k_counter_collection.csv"))
@@ -89,11 +93,15 @@ for k in sorted(mfma, key=lambda k: -mfma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) 
 import re
 pmc = {}
 for k in mfma:
-    mm = re.match(r"gemm_f32_kernel<(\d), (\d+), (\d+)", k)
+    mm = re.match(r"gemm_f32_kernel<(\d), (\d+), (\d+), (\w+), (\w+), (\d), (\d+), (-?\d+)", k)
     if mm:
-        key = "%s,%s" % (mm.group(1), mm.group(3))
+        kind, am = int(mm.group(1)), int(mm.group(8))
+        slot = {(0, 0): 6, (0, 1): 7, (0, 2): 9, (1, 0): 10, (1, 1): 11}.get((kind, am))      # include/gantts_hip.h: GT_PROFILE_SLOTS layout
+        key = "slot%d" % slot if slot is not None else "%s,%s" % (mm.group(1), mm.group(3))
     elif k.startswith("gemm_pair_kernel"):
         key = "pair"
+    elif k.startswith("gemm_tn_pair_kernel"):
+        key = "slot12"
     else:
         continue
     d = pmc.setdefault(key, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
