@@ -134,9 +134,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2..4] behind the timed region")
     ap.add_argument("--spinup-ms", type=float, default=400.0,
-                    help="GPU clock spin-up before the warm-up steps: a generic memory-streaming loop (NOT steps of the workload) keeps "
-                         "the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a training "
-                         "run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
+                    help="GPU clock spin-up before the warm-up steps: a generic matrix product on scratch operands (NOT steps of the "
+                         "workload) keeps the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a "
+                         "training run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
     ap.add_argument("--dense-x", action="store_true", help="x resident with dense 425-float rows (the engine then makes the 16-byte-pitch "
                     "copy its weight-gradient products read, once per step) instead of the pitched rows the batch pipeline stages")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
@@ -256,16 +256,21 @@ def main():
 
     if args.spinup_ms > 0:
         # an idle MI355X sits at its lowest DPM state; the driver's 25 steps are 40 ms of work in total, all of it inside the
-        # ramp.  A training run is never in that state, so the device is brought to its working clocks first -- by
-        # streaming over a scratch tensor, nothing of the workload (no engine call, no cache the step would find warm).
-        burn = torch.empty(64 << 20, device=dev, dtype=torch.float32).fill_(1.0)
+        # ramp.  A training run is never in that state, so the device is brought to its working clocks first -- by a
+        # generic matrix product on scratch operands (the library's stand-alone gt_op_linear_forward: matrix-pipe load, like the
+        # step's), nothing of the workload: no step function, no model parameter, no tensor the step would find warm.
+        import ctypes as C1
+        ba = torch.rand(8192, 512, device=dev)
+        bw = torch.rand(512, 512, device=dev)
+        bo = torch.empty(8192, 512, device=dev)
         torch.cuda.synchronize()
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            for _ in range(8):
-                burn.mul_(1.0000001)
+            for _ in range(32):
+                L.check(L.lib.gt_op_linear_forward(L.ptr(ba), 512, L.ptr(bw), None, L.ptr(bo), 512, 8192, 512, 512, 0, None, C1.c_float(0.0),
+                                                   L.current_stream()))
             torch.cuda.synchronize()
-        del burn
+        del ba, bw, bo
     profile = not args.no_roofline
     for w in range(args.warmup):
         # the last warm-up step runs instrumented once, so that the event pool of the launch profiler exists before the
