@@ -36,7 +36,8 @@ VARIANTS = ["fwd X.W^T BN64 (run-time epilogue)", "fwd X.W^T BN128", "bwd-data d
             "bwd-weight dZ^T.X BN64", "bwd-weight dZ^T.X BN128", "fwd X.W^T 64x64 <no activation>", "fwd X.W^T 64x64 <LeakyReLU + Philox>",
             "pair bwd-data dZ.W + bwd-weight dZ^T.X BN64", "fwd X.W^T 64x64 <LeakyReLU + Philox, added matrix>",
             "bwd-data dZ.W 64x64 <no activation>", "bwd-data dZ.W 64x64 <LeakyReLU + Philox>",
-            "bwd-weight pair of the split first layer (x block + adversarial block)", "-", "-", "-"]
+            "bwd-weight pair of the split first layer (x block + adversarial block)",
+            "fwd split first layer 64x64 <two K segments, LeakyReLU + Philox>", "-", "-"]
 
 G_SPEC = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
 D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)

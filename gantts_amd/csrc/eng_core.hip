@@ -56,6 +56,7 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
     else if (r.kind == GEMM_NT && r.am == GEMM_A_NONE) v = 6;
     else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX) v = 7;
     else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX_ADDM) v = 9;
+    else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX_SEG) v = 13;
     else if (r.kind == GEMM_NN && r.am == GEMM_A_NONE) v = 10;
     else if (r.kind == GEMM_NN && r.am == GEMM_A_LEAKY_PHILOX) v = 11;
     if (v < 0 || v >= GT_PROFILE_SLOTS) v = GT_PROFILE_SLOTS - 1;
@@ -371,7 +372,7 @@ GtTuning& gt_tuning() {
     auto geti = [](const char* n, int d) { const char* s = getenv(n); return s && s[0] ? atoi(s) : d; };
     v.gemm_pair = geti("GT_GEMM_PAIR", v.gemm_pair); v.pair_order = geti("GT_PAIR_ORDER", v.pair_order);
     { const char* s = getenv("GT_GEMM_TILES"); v.gemm_tiles_big = s && !strcmp(s, "big") ? 1 : 0; }
-    v.gemm_unaligned = geti("GT_GEMM_UNALIGNED", v.gemm_unaligned); v.tn_wgs = geti("GT_TN_WGS", v.tn_wgs); v.tn_split_wgs = geti("GT_TN_SPLIT_WGS", v.tn_split_wgs);
+    v.gemm_unaligned = geti("GT_GEMM_UNALIGNED", v.gemm_unaligned); v.tn_wgs = geti("GT_TN_WGS", v.tn_wgs); v.tn_split_wgs = geti("GT_TN_SPLIT_WGS", v.tn_split_wgs); v.split_fused = geti("GT_SPLIT_FUSED", v.split_fused);
     v.stagger_ticks = geti("GT_GEMM_STAGGER_TICKS", v.stagger_ticks); v.stagger_mode = geti("GT_GEMM_STAGGER_MODE", v.stagger_mode);
     v.b16_tiles = geti("GT_B16_TILES", v.b16_tiles); v.b16_wg_tile = geti("GT_B16_WG_TILE", v.b16_wg_tile); v.b16_dma = geti("GT_B16_DMA", v.b16_dma);
     v.mlpg_fpl = geti("GT_MLPG_FPL", v.mlpg_fpl); v.sru_lw = geti("GT_SRU_LW", v.sru_lw);
@@ -384,7 +385,7 @@ extern "C" int gt_set_tuning(const char* name, int value) {
   GtTuning& t = gt_tuning();
   struct { const char* n; int* p; } tab[] = {
       {"gemm_pair", &t.gemm_pair}, {"pair_order", &t.pair_order}, {"gemm_tiles_big", &t.gemm_tiles_big}, {"gemm_unaligned", &t.gemm_unaligned},
-      {"tn_wgs", &t.tn_wgs}, {"tn_split_wgs", &t.tn_split_wgs}, {"stagger_ticks", &t.stagger_ticks}, {"stagger_mode", &t.stagger_mode}, {"b16_tiles", &t.b16_tiles},
+      {"tn_wgs", &t.tn_wgs}, {"tn_split_wgs", &t.tn_split_wgs}, {"split_fused", &t.split_fused}, {"stagger_ticks", &t.stagger_ticks}, {"stagger_mode", &t.stagger_mode}, {"b16_tiles", &t.b16_tiles},
       {"b16_wg_tile", &t.b16_wg_tile}, {"b16_dma", &t.b16_dma}, {"mlpg_fpl", &t.mlpg_fpl}, {"sru_lw", &t.sru_lw}};
   for (auto& e : tab) if (!strcmp(e.n, name)) { *e.p = value; return GT_OK; }
   return fail(GT_ERR_INVALID, "unknown tuning knob '%s'", name);

@@ -148,6 +148,22 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
     specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
+    if (l == 0 && fs && specs[l].mode == DROP_PHILOX && gt_tuning().split_fused && gemm_vec_ok(fs->x, fs->ldx, true) &&
+        gemm_vec_ok(L.W, L.in, true) && gemm_vec_ok(fs->adv, fs->ld_adv, true) && fs->wrap > 64 && gemm_small_tiles_ok() &&
+        tl_gemm_prec == PREC_F32 && (rows == fs->wrap || rows == 2 * fs->wrap)) {
+      // ONE launch (GEMM_A_LEAKY_PHILOX_SEG): every tile multiplies its rows of x by W[:, :cd]^T once, then -- per half of the
+      // pass -- continues the same accumulators over the adversarial columns and runs that half's epilogue: no P buffer
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = fs->x; g.lda = fs->ldx; g.B = L.W; g.ldb = L.in; g.C = acts[l].as<float>(); g.ldc = L.out;
+      g.M = (int)fs->wrap; g.N = L.out; g.K = fs->cd; g.bias = L.b; g.act = ACT_LEAKY_DROPOUT; g.drop = specs[l];
+      g.A_seg = fs->adv; g.lda_seg = fs->ld_adv; g.B_seg = L.W + fs->cd; g.K_seg = L.in - fs->cd;
+      g.dual_rows = rows == 2 * fs->wrap ? (int)fs->wrap : 0;
+      CHK(launch_gemm(GEMM_NT, g, 1, s));
+      cur = acts[l].as<float>();
+      ld = L.out;
+      continue;
+    }
     if (l == 0 && fs) {
       const int Da = L.in - fs->cd;
       CHK(e->d_pre.ensure((size_t)fs->wrap * L.out * sizeof(float)));

@@ -74,6 +74,7 @@ struct GtTuning {
   int gemm_tiles_big = 0;     // GT_GEMM_TILES=big residency model (128-wide tiles) for every float32 launch
   int gemm_unaligned = 1;     // GT_GEMM_UNALIGNED 16-byte loads of k-contiguous operands at 4-byte aligned addresses
   int tn_wgs = 512;           // GT_TN_WGS         workgroups of a weight-gradient launch
+  int split_fused = 1;        // GT_SPLIT_FUSED    split first layer's forward as one two-segment launch (0: x product + K = 58 pass)
   int tn_split_wgs = 1024;    // GT_TN_SPLIT_WGS   ... of the split first layer's two-block launch
   int stagger_ticks = 0;      // GT_GEMM_STAGGER_TICKS / _MODE   start stagger (off)
   int stagger_mode = 3;

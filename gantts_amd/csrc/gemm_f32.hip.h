@@ -155,6 +155,12 @@ struct GemmArgs {
   const float* addm; int ld_addm; int addm_wrap;
   // TN: the A operand is the element-wise sum A + A2 (same pitch): dW_x = (dZ_real + dZ_generated)^T . x over N frames
   const float* A2;
+  // NT, GEMM_A_LEAKY_PHILOX_SEG: a SECOND K segment on top of the first (K_seg > 0): z = A . B^T + A_seg . B_seg^T + bias, both
+  // operands k-contiguous, B_seg on B's pitch (the columns of W behind the first K).  dual_rows > 0: the first segment's rows
+  // (M = dual_rows of them) serve TWO halves of the result -- rows [0, dual_rows) and [dual_rows, 2 dual_rows), each with its
+  // own rows of A_seg: the first segment is multiplied once, the second segment and the epilogue run once per half.
+  // (The split first layer of the conditioned discriminator in one launch: x . W_x^T + adv . W_adv^T, eng_step.hip: FirstSplit.)
+  const float* A_seg; int lda_seg; const float* B_seg; int K_seg; int dual_rows;
   int wide_store;            // NT/NN: C (and H) 16-byte aligned with pitch % 4 == 0 -> full tiles are written
                              // row-wise with 16 B stores through an LDS transpose (set by the launcher)
   DropoutSpec drop;
@@ -249,10 +255,11 @@ __device__ __forceinline__ void epi_store1(float* dst, float v) {
 // branches of all of them (the 64 x 64 forward kernel: ~2500 of its 3100 instructions are prologue + epilogue).
 enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1,
                  GEMM_A_LEAKY_PHILOX_ADDM = 2,   // NT: LeakyReLU + Philox dropout on (product + bias + addm)
-                 GEMM_A_TN_SUM2 = 3 };           // TN: loader sums A + A2
+                 GEMM_A_TN_SUM2 = 3,             // TN: loader sums A + A2
+                 GEMM_A_LEAKY_PHILOX_SEG = 4 };  // NT: LeakyReLU + Philox dropout behind a two-segment K loop (A_seg / B_seg)
 template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
-                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem) {
+                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem, const int m_lim) {
   constexpr bool RT = AMODE == GEMM_A_RUNTIME || AMODE == GEMM_A_TN_SUM2;
   const int g_act = RT ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
   const int g_dmode = RT ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
@@ -265,7 +272,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
   const int wm = wave >> 1, wn = wave & 1;
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* C = g.C + (KIND == GEMM_TN ? (long)slab * g.slab_stride : 0L);
-  const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards
+  const bool full_tile = m0 + BM <= m_lim && n0 + BN <= g.N;   // workgroup-uniform: no per-element guards (m_lim: row limit of this result block)
   const bool philox = (KIND != GEMM_TN) && g_act == ACT_LEAKY_DROPOUT && g_dmode == DROP_PHILOX;
 
   if (KIND != GEMM_TN && full_tile && g.wide_store) {
@@ -365,7 +372,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;
           const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
-          if (!full_tile && (!n_ok || m >= g.M)) continue;
+          if (!full_tile && (!n_ok || m >= m_lim)) continue;
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
             v += bias;
@@ -625,8 +632,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
-  const bool has_tail = ((k_end - k_begin) % GEMM_BK) != 0;
+  // (mutable: the segmented forward product runs prologue + K loop once per segment)
+  int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+  bool has_tail = ((k_end - k_begin) % GEMM_BK) != 0;
+  auto prologue = [&]() {
   if (nk > 0) {   // prologue: tile 0 -> LDS buffer 0
     const bool tail0 = has_tail && nk == 1;
     const int krem0 = k_end - k_begin;
@@ -641,6 +650,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     for (int u = 0; u < UB; ++u) store_b(rb, u, PREC == PREC_BF16 ? reinterpret_cast<float*>(Bh) : Bs);
   }
   __syncthreads();
+  };
 
   // K loop.  A K-tile is NG = 16 MFMA groups (one k-pair each, TM*TN_ MFMAs of 64 cycles).  The
   // matrix pipe is the bottleneck resource, so everything else is slotted into its shadow:
@@ -731,6 +741,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
 #ifdef GT_GEMM_CLK_DBG   // harness only: shader cycles / wall ticks of this workgroup's K loop -> stagger_dbg[4*block ..]
   const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
 #endif
+  auto k_loop = [&]() {
   if (PREC == PREC_BF16) {
     // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace (the launch is bound by the
     // f32 operands it streams and converts).  Per tile: request tile t+1 (global -> registers), multiply tile t, deposit
@@ -784,6 +795,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   }
   if (kt + 1 == nk) k_tile(kt, F_{}, F_{});                         // last tile: nothing to prefetch
   }
+  };
+  prologue();
+  k_loop();
 
 #ifdef GT_GEMM_CLK_DBG
   if (g.stagger_dbg && tid == 0) {
@@ -821,7 +835,41 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     return;
   }
 #endif
-  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0, n0, acc, smem);
+  if constexpr (KIND == GEMM_NT && AMODE == GEMM_A_LEAKY_PHILOX_SEG) {
+    // second K segment (per half), then the epilogue of that half
+    const int nh = g.dual_rows > 0 ? 2 : 1;
+    f32x16 acc0[TM][TN_];
+    if (nh > 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) acc0[i][j] = acc[i][j];
+    }
+    for (int h = 0; h < nh; ++h) {
+      if (h > 0) {
+        __syncthreads();                       // the first half's epilogue staging is dead before the next prologue writes LDS
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN_; ++j) acc[i][j] = acc0[i][j];
+      }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        int kk, mm; a_pos(u, kk, mm);
+        offA[u] = (uint32_t)min(m0 + mm, mclamp) * (uint32_t)g.lda_seg + (uint32_t)kk;
+      }
+      pA = g.A_seg + (long)h * g.dual_rows * g.lda_seg;
+      pB = g.B_seg;                            // same rows n0.. and pitch as B: offB stands
+      k_begin = 0; k_end = g.K_seg;
+      nk = (k_end + GEMM_BK - 1) / GEMM_BK;
+      has_tail = (k_end % GEMM_BK) != 0;
+      prologue();
+      k_loop();
+      gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0 + h * g.dual_rows, n0, acc, smem, nh > 1 ? (h + 1) * g.dual_rows : g.M);
+    }
+    return;
+  }
+  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0, n0, acc, smem, g.M);
 }
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous run of

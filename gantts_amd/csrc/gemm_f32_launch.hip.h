@@ -40,6 +40,11 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   GemmProfiler::Rec rec;
   if (g_prof.on) {
     rec.kind = KIND; rec.bn = BN; rec.am = AM; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
+    if (g.K_seg > 0) {      // + the second segment over all result rows; the result (and the second segment's A rows) once per half
+      const double halves = g.dual_rows > 0 ? 2.0 : 1.0;
+      rec.flops += 2.0 * halves * g.M * g.N * g.K_seg;
+      rec.bytes += 4.0 * (halves * g.M * g.K_seg + (double)g.K_seg * g.N + (halves - 1.0) * g.M * g.N);
+    }
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
@@ -52,6 +57,13 @@ template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>
 static int launch_gemm_t(const GemmArgs& g, int nslab, hipStream_t s) {
   // the hot shape of the float32 step (64 x 64 tiles, 16-byte loadable operands) has its two common epilogue flavours
   // compiled in: no activation, LeakyReLU + Philox dropout (gemm_f32.hip.h: GemmAmode); everything else decides at run time
+  if (g.K_seg > 0) {      // two-segment forward product (+ two halves): the compiled LeakyReLU + Philox flavour on 64 x 64 tiles only
+    if constexpr (KIND == GEMM_NT && BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) {
+      if (g.act == ACT_LEAKY_DROPOUT && g.drop.mode == DROP_PHILOX && g.addm == nullptr)
+        return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_LEAKY_PHILOX_SEG>(g, nslab, s);
+    }
+    return fail(GT_ERR_INVALID, "segmented forward product: float32, 64 x 64 tiles, 16-byte loadable operands, LeakyReLU + Philox only");
+  }
   if constexpr (KIND != GEMM_TN && BM == 64 && BN == 64 && VA && VB && PREC == PREC_F32) {
     if (g.addm == nullptr) {
       if (g.act == ACT_NONE) return launch_gemm_impl<KIND, BM, BN, VA, VB, PREC, GEMM_A_NONE>(g, nslab, s);

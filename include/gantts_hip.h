@@ -222,7 +222,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_COMM_FORCE 13
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
- * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs,
+ * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,
  * stagger_ticks, stagger_mode, b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, sru_lw; the environment variables GT_<NAME>
  * provide the initial values. */
 int gt_set_tuning(const char* name, int value);
@@ -365,7 +365,8 @@ int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t
  *   8     = pair launches (one layer's backward-data product and weight gradient in one launch);
  *   9     = 64x64 forward, LeakyReLU + Philox dropout on (product + added matrix): the split first layer of the conditioned D;
  *   10,11 = 64x64 backward-data kernels with a compiled-in epilogue: none / LeakyReLU + Philox;
- *   12    = the two weight-gradient products of a split first layer in one launch;  13..15 unused.
+ *   12    = the two weight-gradient products of a split first layer in one launch;
+ *   13    = the split first layer's forward in one launch (two K segments, two result halves);  14, 15 unused.
  * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries. */
 #define GT_PROFILE_SLOTS 16
 int gt_profile_enable(int on);

@@ -88,6 +88,16 @@ AT_SIZE_CASES = {
         d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True),
         opt_g=("Adagrad", _WARM), opt_d=("Adagrad", _WARM),
         steps=1, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
+    # The same configuration run for TEN steps (error growth of the bf16 path over several steps at T = 1024):
+    # the digest holds the scalars of all ten steps and the parameter updates after the tenth.  Source: the REAL reference
+    # (nn.LSTM; ~25 min float32 + ~55 min float64 in the build container).
+    "cfg3_lstm_10": dict(
+        _ACOUSTIC, hp="tts_acoustic", B=32, T=1024, din=425, dout=187, noise_dim=0, source="reference",
+        g=dict(kind="LSTMRNN", in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True, dropout=0.0,
+               last_sigmoid=False),
+        d=dict(kind="MLP", in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", _WARM), opt_d=("Adagrad", _WARM),
+        steps=10, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
     # BASELINE.json configs[3]: SRU generator on VC mgc / lf0 / bap streams, B = 16, T = 2048 (gantts/models.py:144-167; the
     # hparams-default SRU widths, hparams.py:211-222; the VC discriminator, hparams.py:56-64).  Source: the oracle's
     # restated SRU cell (un-vendored third-party code: PARITY UNPINNED).  Both variational dropouts + D dropout injected.

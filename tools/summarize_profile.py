@@ -96,7 +96,7 @@ for k in mfma:
     mm = re.match(r"gemm_f32_kernel<(\d), (\d+), (\d+), (\w+), (\w+), (\d), (\d+), (-?\d+)", k)
     if mm:
         kind, am = int(mm.group(1)), int(mm.group(8))
-        slot = {(0, 0): 6, (0, 1): 7, (0, 2): 9, (1, 0): 10, (1, 1): 11}.get((kind, am))      # include/gantts_hip.h: GT_PROFILE_SLOTS layout
+        slot = {(0, 0): 6, (0, 1): 7, (0, 2): 9, (0, 4): 13, (1, 0): 10, (1, 1): 11}.get((kind, am))      # include/gantts_hip.h: GT_PROFILE_SLOTS layout
         key = "slot%d" % slot if slot is not None else "%s,%s" % (mm.group(1), mm.group(3))
     elif k.startswith("gemm_pair_kernel"):
         key = "pair"
