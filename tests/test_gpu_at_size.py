@@ -233,3 +233,30 @@ def test_cfg5_acoustic_bf16_storage_tracks_the_reference():
     seen = {}
     compare_with_fixture("cfg5_acoustic/bf16", got, fx, measure=seen)
     _judge_bf16("cfg5_acoustic", seen)
+
+
+# measured (round 4): see the assertion messages' reference values in profiles/r04_parity_report.txt
+TEN_STEP_LIMITS = {"scalars": 1e-2, "Gupd": 5e-2, "Dupd": 1.5e-1}
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(GOLDEN, "at_size_cfg3_lstm_10.npz")), reason="ten-step digest not generated")
+def test_cfg3_ten_steps_bf16_error_growth():
+    """TEN G+D steps of cfg3 at T = 1024 with bf16 storage against the REAL reference's ten-step float64
+    digest -- where a rounding bias of the bf16 path would compound: 10 240 recurrent steps of bf16-rounded h, ten optimizer
+    updates built on bf16-rounded gradients.  Judged: the losses of EVERY step and the parameter updates after the tenth, with
+    limits at about 2x the measured distances; the float32 engine on the same ten steps must stay under the arbiter's rule."""
+    case = A.AT_SIZE_CASES["cfg3_lstm_10"]
+    fx = np.load(os.path.join(GOLDEN, "at_size_cfg3_lstm_10.npz"))
+    got = run_hip_at_size(case, engine_options={"matmul_bf16": 1})
+    seen = {}
+    compare_with_fixture("cfg3_lstm_10/bf16", got, fx, measure=seen)
+    by_step = []
+    for st in range(case["steps"]):
+        by_step.append(max(seen["d_scalars_%d" % st][0], seen["g_scalars_%d" % st][0]))
+    upd = {k: max(v[0] for q, v in seen.items() if q.startswith(k + ".")) for k in ("Gupd", "Dupd")}
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write("cfg3_lstm_10/bf16 loss distance by step: %s; updates after 10 steps: %s\n" % (["%.2e" % v for v in by_step], upd))
+    assert max(by_step) <= TEN_STEP_LIMITS["scalars"], by_step
+    assert by_step[-1] <= 4 * max(by_step[0], 2e-4) + 2e-3, "loss error grows over the steps: %s" % by_step
+    assert upd["Gupd"] <= TEN_STEP_LIMITS["Gupd"] and upd["Dupd"] <= TEN_STEP_LIMITS["Dupd"], upd
