@@ -286,13 +286,12 @@ def main():
             _a, _b, _c = (C0.c_double * L.PROFILE_SLOTS)(), (C0.c_double * L.PROFILE_SLOTS)(), (C0.c_int64 * L.PROFILE_SLOTS)()
             L.check(L.lib.gt_profile_read(_a, _b, _c))
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides --------------------
-    # The dominant kernel's HIP-event timing is taken LIVE inside the timed region, on a sample of
-    # its steps: two hipEventRecord per GEMM launch are not free (~3 us each), so instrumenting every launch of every
-    # step would itself cost several % of `value` (measured: 1.515 ms/step un-instrumented, 1.535-1.547 with every 5th
-    # step instrumented).  Every 10th step is sampled, starting with the 6th: two steps of the driver's 20-step run,
-    # five of the default 50 -- none of them the first steps after a short warm-up, which still run at ramping clocks
-    # (20 steps after 5 warm-up steps: 1.56 ms/step; after 40: 1.52).
-    PROFILE_EVERY, PROFILE_PHASE = 10, 5
+    # The dominant kernel's HIP-event timing is taken LIVE inside the timed region, on a sample of its steps: two
+    # hipEventRecord per product launch are not free (~3 us each, ~25 launches), so instrumenting every launch of every step
+    # would itself cost several % of `value` (measured: 1.515 ms/step un-instrumented, 1.535-1.547 with every 5th step
+    # instrumented).  Every 20th step is sampled, starting with the 11th: one step of the driver's 20-step run, two of the
+    # default 50 -- never the first steps after the warm-up.
+    PROFILE_EVERY, PROFILE_PHASE = 20, 10
     profiled_steps = 0
     barrier()
     torch.cuda.synchronize()

@@ -242,7 +242,11 @@ int gt_check_faults(gt_engine* e, void* stream);
  * faulted step stay as they were; optimizer.step() of train.py:276,318 is simply not taken).  This call synchronises,
  * takes the skipped steps back out of the step counters, clears the word and resets the per-step call state, so the
  * engine can be used again -- e.g. after gt_set_option(e, GT_OPT_LSTM_PERSISTENT, 0).  The next call must be
- * gt_apply_generator. */
+ * gt_apply_generator.  The gradient norm of a skipped update is reported as NaN.
+ * DATA PARALLEL: the fault word is local to a rank -- a timeout on one rank makes only that rank skip its update while its peers
+ * apply the all-reduced gradient, and the faulted rank stops posting collectives at its next step entry.  Under a communicator a
+ * fault is therefore FATAL for the job: tear the ranks down and restart from the last checkpoint (gt_clear_faults re-arms one
+ * engine, it does not re-synchronise replicas). */
 int gt_clear_faults(gt_engine* e, void* stream);
 /* ---- data-parallel communicator (one process per GPU; RCCL == NCCL on ROCm, bound at run time) ----
  * The reference has no multi-device code; the step being sharded is train.py:538-585.  Every rank holds the
