@@ -153,6 +153,9 @@ int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStr
 }
 int comm_flush(gt_engine* e, int role, hipStream_t compute) {
   if (!comm_on(e)) return GT_OK;
+  // the fused step only RECORDS its weight-gradient combines (SlabDefer): the ranges about to leave must be final, so the recorded
+  // combines run now, as ONE launch per message instead of one per layer
+  CHK(slab_defer_flush(e->sdefer[role], compute));
   auto& pend = e->comm_pending[role];
   if (pend.empty()) return GT_OK;
   Net& n = e->net[role];

@@ -659,7 +659,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   const bool tr = train != 0;
   if (comm_on(e) && tr && D.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
-  { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && D.has_opt; }
+  { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && tr && D.has_opt; }
   CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
   const bool tv_side = e->early && !comm_on(e) && e->opt_side_overlap && !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
   if (tv_side) { CHK(side_fork(e, s)); CHK(ensure_tv(e, mask, N, e->side)); }      // single GPU: the count is summed under the D forward pass
@@ -952,7 +952,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const int Ds = is_i2o(G.d.arch) ? G.d.static_dim : e->Ds;
   if (comm_on(e) && tr && G.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_g.zero_grad() must precede update_generator");
-  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && !comm_on(e) && tr && G.has_opt; }
+  { SlabDefer& sd = e->sdefer[GT_ROLE_G]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && tr && G.has_opt; }
   CHK(ensure_tv(e, mask, N, s));
   // loss_mse (always reported, train.py:294); its gradient is fused into the MLPG^T kernel
   const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
