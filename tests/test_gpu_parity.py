@@ -387,6 +387,32 @@ def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
         _close(fused_only[k], off[k], rtol=2e-6, atol=1e-9, msg="fused optimizer " + k)
 
 
+def test_split_first_layer_one_launch_equals_two_launches():
+    """The split first layer's forward as ONE two-segment launch with two result halves (GEMM_A_LEAKY_PHILOX_SEG: the production
+    path with Philox dropout) against its two-launch form (x product, then the K = 58 pass that adds it: GEMM_A_LEAKY_PHILOX_ADDM):
+    same Philox bits (keyed by site and row, not by launch), same sums up to float32 association -- a whole two-step run with the
+    engine's own dropout must agree at 1e-4, counts exactly."""
+    from gantts_amd import _lib as L
+    from hip_runner import run_hip_case
+    case = dict(C.CASES["acoustic_mlp_dropout"], B=4, T=80)       # 320 rows: five 64-row tiles per half
+    try:
+        L.check(L.lib.gt_set_tuning(b"split_fused", 0))
+        two = run_hip_case(case, philox=True)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"split_fused", 1))
+    one = run_hip_case(case, philox=True)
+    for k in two:
+        if "scalars" in k:
+            _close(one[k], two[k], msg=k)
+            if k.startswith("d_scalars"):
+                assert one[k][3] == two[k][3] and one[k][4] == two[k][4], k
+        elif ".opt." in k:
+            _close_state(one[k], two[k], k)
+        else:
+            _close(one[k], two[k], msg=k)
+    assert not np.array_equal(one["D.layers.0.weight"], C.make_weights(case["d"], 22)["layers.0.weight"])     # (the steps did run)
+
+
 def test_philox_dropout_statistics_and_determinism():
     from gantts_amd import models
     m = models.MLP(in_dim=16, out_dim=8, num_hidden=1, hidden_dim=2048, dropout=0.5, last_sigmoid=False).cuda().train()
