@@ -53,30 +53,43 @@ extern "C" int gt_invalidate_mlpg_cache(gt_engine* e) {
   return GT_OK;
 }
 
+// output frames per workgroup of the MLPG kernels: 32, or 64 (gt_set_tuning("mlpg_tt", 64): half the halo re-reads -- (64 + 2 kb) / 64
+// instead of (32 + 2 kb) / 32 staged rows per output frame -- but one workgroup per CU instead of two).  Measured at cfg2
+// (gpurun_out/r4o, one lease): 1.404 / 1.398 ms with 64 vs 1.393 / 1.398 with 32 -- no gain, 32 stays.
+static int mlpg_tile_frames(gt_engine* e, int B, int T, size_t lds64) {
+  (void)e; (void)B; (void)T;
+  return gt_tuning().mlpg_tt == 64 && lds64 <= 150 * 1024 ? 64 : 32;
+}
 int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
-                        float* ys, int ldys, int B, int T, hipStream_t s) {
+                 float* ys, int ldys, int B, int T, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
-  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * nW * MLPG_CC + (size_t)MLPG_TT * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
+  auto lds_of = [&](int tt) { return ((size_t)(tt + 2 * kb) * nW * MLPG_CC + (size_t)tt * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float); };
+  const int tt = mlpg_tile_frames(e, B, T, lds_of(64));
+  const size_t lds = lds_of(tt);
+  dim3 grid(B * cdiv(T, tt), cdiv(Ds, MLPG_CC));
   const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
-#define GT_MLPG_FWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F>, lds)); \
-    hipLaunchKernelGGL(mlpg_forward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
-  if (fpl == 1) GT_MLPG_FWD(1) else if (fpl == 2) GT_MLPG_FWD(2) else GT_MLPG_FWD(4)
+#define GT_MLPG_FWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F, TTV>, lds)); \
+    hipLaunchKernelGGL((mlpg_forward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
+  if (tt == 64) { if (fpl == 1) GT_MLPG_FWD(1, 64) else if (fpl == 4) GT_MLPG_FWD(4, 64) else GT_MLPG_FWD(2, 64) }
+  else { if (fpl == 1) GT_MLPG_FWD(1, 32) else if (fpl == 2) GT_MLPG_FWD(2, 32) else GT_MLPG_FWD(4, 32) }
 #undef GT_MLPG_FWD
   LAUNCH_CHECK();
   return GT_OK;
 }
 int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, const int* sstride, int Ds,
-                         float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
-                         const float* mask, hipStream_t s) {
+                  float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
+                  const float* mask, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
-  const size_t lds = ((size_t)(MLPG_TT + 2 * kb) * MLPG_CC + (size_t)(MLPG_TT + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float);
-  dim3 grid(B * cdiv(T, MLPG_TT), cdiv(Ds, MLPG_CC));
-  const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
-#define GT_MLPG_BWD(F) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F>, lds)); \
-    hipLaunchKernelGGL(mlpg_backward_kernel<F>, grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
+  auto lds_of = [&](int tt) { return ((size_t)(tt + 2 * kb) * MLPG_CC + (size_t)(tt + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float); };
+  const int tt = mlpg_tile_frames(e, B, T, lds_of(64));
+  const size_t lds = lds_of(tt);
+  dim3 grid(B * cdiv(T, tt), cdiv(Ds, MLPG_CC));
+  const int fpl = gt_tuning().mlpg_fpl;
+#define GT_MLPG_BWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F, TTV>, lds)); \
+    hipLaunchKernelGGL((mlpg_backward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
                        gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
-  if (fpl == 1) GT_MLPG_BWD(1) else if (fpl == 2) GT_MLPG_BWD(2) else GT_MLPG_BWD(4)
+  if (tt == 64) { if (fpl == 1) GT_MLPG_BWD(1, 64) else if (fpl == 4) GT_MLPG_BWD(4, 64) else GT_MLPG_BWD(2, 64) }
+  else { if (fpl == 1) GT_MLPG_BWD(1, 32) else if (fpl == 2) GT_MLPG_BWD(2, 32) else GT_MLPG_BWD(4, 32) }
 #undef GT_MLPG_BWD
   LAUNCH_CHECK();
   return GT_OK;

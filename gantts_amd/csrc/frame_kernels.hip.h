@@ -280,18 +280,19 @@ constexpr int MLPG_PAD = 3;      // = frames per lane - 1
 constexpr int MLPG_MAXW = 4;
 constexpr int MLPG_THREADS = 1024; // all 16 waves stage the tile and band rows, waves 0-3 compute
 
-template <int FPL>   // frames per lane of the compute phase: 32 / FPL frame groups x 32 column pairs = 1024 / FPL compute threads
+template <int FPL, int TT = MLPG_TT>   // FPL: frames per lane of the compute phase: TT / FPL frame groups x 32 column pairs = TT * 32 / FPL compute threads;
+                                       // TT: output frames per workgroup (32, or 64: half the halo re-reads, one workgroup per CU)
 __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     const float* __restrict__ y, int ldy, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ ys, int ldys, int B, int T) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int nb = 2 * kb + 1, nbp = nb + 2 * MLPG_PAD;
-  const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
-  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
+  const int tiles_t = (T + TT - 1) / TT;
+  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
-  const int rows = MLPG_TT + 2 * kb;
+  const int rows = TT + 2 * kb;
   float* sb = sm + rows * nW * MLPG_CC;            // [TT][nW][nbp]
   const float* yb = y + (long)b * T * ldy;
   // Staging is one wave per LDS row (64 lanes = the 64 columns of a data row / the taps of a band row), rows strided over
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
     }
   }
   {  // band rows: LDS row tw = tl * nW + w  <-  band row t0 * nW + tw (the band is [t][w][nb], so rows are consecutive)
-    const int nrow = MLPG_TT * nW;
+    const int nrow = TT * nW;
     const long src_rows = (long)T * nW;
     for (int jp = lane; jp < nbp; jp += 64) {      // one pass for half-widths up to 28 (nbp <= 64 taps)
       const int j = jp - MLPG_PAD;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
   }
   __syncthreads();
   static_assert(FPL >= 1 && FPL <= MLPG_PAD + 1, "the band rows are padded for at most MLPG_PAD + 1 frames per lane");
-  if (threadIdx.x >= 1024 / FPL) return;  // every wave stages (memory-level parallelism); 16 / FPL of them compute
+  if (threadIdx.x >= TT * 32 / FPL) return;  // every wave stages (memory-level parallelism); 16 / FPL of them compute
   const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;     // column pair, frame group (FPL frames)
   const int tl0 = fg * FPL;
   float acc[FPL][2];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
 //   gy += mse_w * 2 * (yhat*m - y*m) * m / Tv        (reference gantts/seqloss.py:41-43)
 // LDS: gs tile [(TT+2kb)][CC] + the band rows of the same frames, padded, [(TT+2kb)][nW][nb+2*PAD].
 // Lane = 2 columns x 4 frames x all windows: one ds_read_b64 of gs feeds 8*nW FMAs.
-template <int FPL>
+template <int FPL, int TT = MLPG_TT>
 __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
@@ -395,11 +396,11 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
     const float* __restrict__ mask, const StepScalars* __restrict__ sc) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int nb = 2 * kb + 1, nbp = nb + 2 * MLPG_PAD;
-  const int tiles_t = (T + MLPG_TT - 1) / MLPG_TT;
-  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * MLPG_TT;
+  const int tiles_t = (T + TT - 1) / TT;
+  const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * TT;
   const int c0 = blockIdx.y * MLPG_CC;
   const int nc = min(MLPG_CC, Ds - c0);
-  const int rows = MLPG_TT + 2 * kb;
+  const int rows = TT + 2 * kb;
   float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nbp]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
   }
   __syncthreads();
   static_assert(FPL >= 1 && FPL <= MLPG_PAD + 1, "the band rows are padded for at most MLPG_PAD + 1 frames per lane");
-  if (threadIdx.x >= 1024 / FPL) return;
+  if (threadIdx.x >= TT * 32 / FPL) return;
   const int cp = threadIdx.x & 31, fg = threadIdx.x >> 5;
   const int tl0 = fg * FPL;
   float acc[MLPG_MAXW][FPL][2];
