@@ -491,7 +491,8 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 // H: the top hidden activation, float32 [n_rows][K] or (h_ld > 0) its bf16 image with row pitch h_ld
 static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
-                    StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false) {
+                    StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false,
+                    int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -516,6 +517,7 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
 #undef GT_HEAD_LAUNCH
   LAUNCH_CHECK();
   const bool w = want_grad && want_w;
+  if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
                      early_res);
@@ -701,9 +703,14 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     // split first layer (FirstSplit): only the adversarial columns of the two halves are gathered (58 of 483 columns at cfg2)
     e->ld_adv2 = (e->Da + 3) & ~3;
     CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
-    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256)), dim3(256), 0, s, y_static, y_hat_static, e->Ds, e->d_adv_cols, e->Da,
-                       e->adv2.as<float>(), e->ld_adv2, N, 2 * N);
+    // (the valid-frame count rides in this launch when it is not known yet: fused single-GPU call)
+    const bool tv_ride = e->early && e->opt_launch_riders && !comm_on(e) && !tv_side &&
+                         !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
+    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (tv_ride ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static, e->Ds,
+                       e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, tv_ride ? mask : (const float*)nullptr, (int)N,
+                       e->tv_override, e->sc());
     LAUNCH_CHECK();
+    if (tv_ride) { e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override; }
     e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
     e->fake_cat_valid = false;
     fs.x = x; fs.ldx = cx_pitch(e); fs.cd = cond_dim(e); fs.adv = e->adv2.as<float>(); fs.ld_adv = e->ld_adv2; fs.wrap = N;
@@ -971,15 +978,26 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const bool direct = !is_i2o(G.d.arch) && !e->g_used_mlpg;
   // (the fused single-GPU call reduces the MSE partials inside its finalisation launch: see early_now below)
   const bool early_fold = e->early && !comm_on(e) && !(tr && direct && mse_w != 0.f);
-  int mse_blocks = 0;
+  int mse_blocks = 0, mge_pre_blocks = 0;
   const bool mse_side = early_fold && e->opt_side_overlap && adv_w > 0.f;      // (under the D pass of the adversarial term)
-  if (!(tr && direct && mse_w != 0.f)) {
+  // launch riders (fused single-GPU call): both reported sums of squares in one launch here; the head's scalar reduction and the
+  // step's finalisation as one extra workgroup of the gradient-assembly launch -- four launches become two
+  const bool riders = early_fold && e->opt_launch_riders && !mse_side;
+  if (riders) {
+    mse_blocks = (int)std::min<long>(1024, cdiv(N * Do, RED_THREADS * 4));
+    mge_pre_blocks = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
+    CHK(e->partial.ensure(4096 * sizeof(double)));
+    hipLaunchKernelGGL(g_losses_kernel, dim3(mse_blocks + mge_pre_blocks), dim3(RED_THREADS), 0, s, y_hat, Do, y, Do, Do, mse_blocks,
+                       e->partial.as<double>() + 1024, y_hat_static, Ds, y_static, Ds, Ds, e->partial.as<double>(), mask, N);
+    LAUNCH_CHECK();
+  } else if (!(tr && direct && mse_w != 0.f)) {
     if (mse_side) CHK(side_fork(e, s));
     CHK(sum_sqerr(e, y_hat, Do, y, Do, mask, N, Do, &e->sc()->s_mse, nullptr, 0, 0.f, mse_side ? e->side : s, early_fold ? &mse_blocks : nullptr));
   }
   // adversarial term with the CURRENT (already updated) D weights and a fresh dropout mask (train.py:297-308)
   e->g_has_adv = adv_w > 0.f;
   float* gadv = nullptr;
+  int head_blocks = 0;
   if (adv_w > 0.f) {
     if (!D.bound) return fail(GT_ERR_STATE, "adv_w > 0 but no discriminator bound");
     if (D.d.in_dim != d_in_dim(e)) return fail(GT_ERR_DIM, "discriminator in_dim mismatch");
@@ -998,7 +1016,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       float* fake = e->adv2.as<float>() + N * e->ld_adv2;
       if (!(e->adv2_fake_ok && e->adv2_yhs == y_hat_static)) {
         hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(N * e->ld_adv2, 256)), dim3(256), 0, s, y_hat_static, y_hat_static, Ds, e->d_adv_cols, e->Da,
-                           fake, e->ld_adv2, N, N);
+                           fake, e->ld_adv2, N, N, (const float*)nullptr, 0, 0.f, (StepScalars*)nullptr);
         LAUNCH_CHECK();
         e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
       }
@@ -1033,7 +1051,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
     if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
     CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
-                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false));
+                 e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false,
+                 riders ? &head_blocks : nullptr));
     if (tr) {
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
@@ -1050,24 +1069,37 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const bool early_ok = e->early && !(tr && direct && mse_w != 0.f);
   const bool early_now = early_ok && !comm_on(e), comm_early = early_ok && comm_on(e) && e->opt_comm_early_g;
   int mge_blocks = 0;
+  e->early_done = false;
   {
     const int nblk = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
     CHK(e->partial.ensure(4096 * sizeof(double)));
     float* gs = nullptr;
     if (tr) { CHK(e->gs.ensure((size_t)N * Ds * sizeof(float))); gs = e->gs.as<float>(); }
     const float* leak = (tr && e->leak_pending) ? e->leak.as<float>() : nullptr;
-    hipLaunchKernelGGL(static_grad_kernel, dim3(nblk), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
-                       e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, e->partial.as<double>(), e->sc());
+    GFinalize fin;
+    memset(&fin, 0, sizeof(fin));
+    if (riders) {       // (early_now holds: riders implies the fused single-GPU call)
+      fin.on = 1; fin.sc = e->sc(); fin.out = early_res_target(e); fin.adv_w = adv_w; fin.mse_w = mse_w; fin.mge_w = mge_w;
+      fin.has_adv = e->g_has_adv ? 1 : 0;
+      fin.part_mge = e->partial.as<double>(); fin.n_mge = mge_pre_blocks;
+      fin.part_mse = e->partial.as<double>() + 1024; fin.n_mse = mse_blocks;
+      fin.hp = head_blocks ? e->headp.as<HeadPartials>() : (const HeadPartials*)nullptr; fin.n_hp = head_blocks;
+    }
+    if (tr || !riders)
+      hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (riders ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
+                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, riders ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin);
+    else      // phase != "train": no gradient to assemble, the finalisation alone
+      hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();
     mge_blocks = nblk;
-    if (!early_now) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
+    if (riders) CHK(post_early_results(e, s));
+    else if (!early_now) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
       hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
       LAUNCH_CHECK();
     }
   }
-  e->early_done = false;
   if (mse_side && mse_blocks) CHK(side_join(e, s));
-  if (early_now) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
+  if (early_now && !riders) {   // all four losses are final here; the MGE partials are reduced inside the finalisation launch
     hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(256), 0, s, e->sc(), early_res_target(e), adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
                        (const double*)e->partial.as<double>(), mge_blocks,
                        mse_blocks ? (const double*)(e->partial.as<double>() + 1024) : (const double*)nullptr, mse_blocks);

@@ -269,6 +269,7 @@ struct gt_engine {
   // collectives issued even with one rank (bench.py --force-dp, tests)
   bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
        opt_comm_group = env_flag("GT_COMM_GROUP", false), opt_comm_force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
+  bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)

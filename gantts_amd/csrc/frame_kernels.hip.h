@@ -81,12 +81,11 @@ struct StepResults {
   float gnorm_d, gnorm_g, tv;
 };
 
-// tv = sum(mask[0..n)) ; single workgroup (n = B*T is small)
-static __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
-                                StepScalars* sc) {
-  __shared__ double sh[16];
+// tv = sum(mask[0..n)) ; single workgroup (n = B*T is small); any workgroup size that is a multiple of 64
+__device__ __forceinline__ void mask_sum_body(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
+                                              StepScalars* sc, double* sh /* [16] */) {
   double v = 0.0;
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // 0/1 values: float partial sums of <= n/4096 terms are exact
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // 0/1 values: float partial sums of <= 2^24 terms are exact
   int i = threadIdx.x;
   for (; i + 3 * (int)blockDim.x < n; i += 4 * blockDim.x) {
     p0 += mask[i]; p1 += mask[i + blockDim.x]; p2 += mask[i + 2 * blockDim.x]; p3 += mask[i + 3 * blockDim.x];
@@ -99,6 +98,11 @@ static __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, fl
     sc->tv = tv;
     sc->inv_tv = 1.0f / tv;
   }
+}
+static __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
+                                StepScalars* sc) {
+  __shared__ double sh[16];
+  mask_sum_body(mask, n, tv_override, tv_dev, sc, sh);
 }
 
 // out[0] = sum(mask[0..n)) as a double (data parallel: the local term of the global valid-frame count)
@@ -196,8 +200,16 @@ static __global__ void sigmoid_grad_kernel(float* __restrict__ g, int ldg, const
 // The adversarial columns of a pass's rows as one image with a 16-byte row pitch (the split first layer of the conditioned
 // discriminator, eng_step.hip): out[r][j] = fa[r][idx[j]] for r < split, fb[r - split][idx[j]] otherwise; pad columns are 0.
 // Bit-exact copies (train.py:232-242 select_streams on the static features).
+// Rider (tv_mask != null): one extra workgroup at the end of the grid sums the frame mask into the step's normaliser
+// (mask_sum_kernel's work: nothing in this launch reads it, the head a whole forward pass later does) -- one launch less per step.
 static __global__ void build_adv_kernel(const float* __restrict__ fa, const float* __restrict__ fb, int ldf, const int* __restrict__ idx,
-                                        int na, float* __restrict__ out, int ldo, long split, long rows) {
+                                        int na, float* __restrict__ out, int ldo, long split, long rows,
+                                        const float* __restrict__ tv_mask, int tv_n, float tv_override, StepScalars* sc) {
+  if (tv_mask && blockIdx.x == gridDim.x - 1) {
+    __shared__ double sh[16];
+    mask_sum_body(tv_mask, tv_n, tv_override, nullptr, sc, sh);
+    return;
+  }
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * ldo) return;
   const long r = e / ldo;
@@ -500,19 +512,16 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
 // masked squared error: partial[blk] = sum_{rows of blk} sum_d (a*m - b*m)^2   (double)
 // optional gradient out: g[r][d] = gscale * 2 * (a*m - b*m) * m * inv_tv
 // ---------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
+__device__ __forceinline__ double masked_sqerr_body(
     const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
-    const float* __restrict__ mask, long rows, int D, double* __restrict__ partial,
-    float* __restrict__ g, int ldg, float gscale, const StepScalars* __restrict__ sc) {
-  __shared__ double sh[16];
+    const float* __restrict__ mask, long rows, int D, float* __restrict__ g, int ldg, float gs, int blk, int nblk) {
   double acc = 0.0;
   const long total = rows * D;
-  const float gs = g ? 2.f * gscale * sc->inv_tv : 0.f;
   // (row, column) advance incrementally with the grid stride: no 64-bit division per element
-  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride = (long)nblk * blockDim.x;
   const long sr = stride / D;
   const int sd = (int)(stride - sr * D);
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long e = (long)blk * blockDim.x + threadIdx.x;
   long r = e / D;
   int d = (int)(e - r * D);
   for (; e < total; e += stride) {
@@ -523,8 +532,32 @@ static __global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
     r += sr; d += sd;
     if (d >= D) { d -= D; ++r; }
   }
+  return acc;
+}
+static __global__ __launch_bounds__(RED_THREADS) void masked_sqerr_kernel(
+    const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+    const float* __restrict__ mask, long rows, int D, double* __restrict__ partial,
+    float* __restrict__ g, int ldg, float gscale, const StepScalars* __restrict__ sc) {
+  __shared__ double sh[16];
+  const float gs = g ? 2.f * gscale * sc->inv_tv : 0.f;
+  const double acc = masked_sqerr_body(a, lda, b, ldb, mask, rows, D, g, ldg, gs, blockIdx.x, gridDim.x);
   const double tot = block_sum_d(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+// The two reported sums of squares of a generator step in ONE launch (train.py:291-294): workgroups [0, n1) the masked squared error
+// of (a1, b1) -> partial1 (loss_mse over y_hat), workgroups [n1, gridDim) that of (a2, b2) -> partial2 (loss_mge over the static
+// features).  Both only need the batch, so the launch goes first in the step and nothing waits for it.
+static __global__ __launch_bounds__(RED_THREADS) void g_losses_kernel(
+    const float* __restrict__ a1, int lda1, const float* __restrict__ b1, int ldb1, int D1, int n1, double* __restrict__ partial1,
+    const float* __restrict__ a2, int lda2, const float* __restrict__ b2, int ldb2, int D2, double* __restrict__ partial2,
+    const float* __restrict__ mask, long rows) {
+  __shared__ double sh[16];
+  const bool first = (int)blockIdx.x < n1;
+  const int blk = first ? blockIdx.x : blockIdx.x - n1, nblk = first ? n1 : gridDim.x - n1;
+  const double acc = first ? masked_sqerr_body(a1, lda1, b1, ldb1, mask, rows, D1, nullptr, 0, 0.f, blk, nblk)
+                           : masked_sqerr_body(a2, lda2, b2, ldb2, mask, rows, D2, nullptr, 0, 0.f, blk, nblk);
+  const double tot = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) (first ? partial1 : partial2)[blk] = tot;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -759,17 +792,74 @@ static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const Head
 //            + adv_w * gadv[n][j]  (dloss_adv/dy_hat_static, NEW D weights; train.py:307-308,314)
 // for c = adv_cols[j]; also produces the MGE loss partials.
 // ---------------------------------------------------------------------------------------
+// Rider of static_grad_kernel (fused single-GPU generator step): the step's scalar finalisation -- what d_head_finalize_kernel and
+// finalize_g_kernel would do in two more launches -- runs as one extra workgroup at the end of the grid.  Everything it reads
+// was produced by EARLIER launches (the head's per-workgroup partials, g_losses_kernel's partial sums), nothing by this one.
+struct GFinalize {
+  int on;
+  StepScalars* sc;
+  StepResults* out;
+  float adv_w, mse_w, mge_w;
+  int has_adv;
+  const double* part_mge; int n_mge;
+  const double* part_mse; int n_mse;
+  const HeadPartials* hp; int n_hp;
+};
+__device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
+                                                int zero_gnorm, const double* __restrict__ part_mge, int n_mge,
+                                                const double* __restrict__ part_mse, int n_mse,
+                                                const HeadPartials* __restrict__ hp, int n_hp, double* shp /* [16] */) {
+  if (part_mge || part_mse || hp) {
+    if (part_mge) {
+      double v = 0.0;
+      for (int i = threadIdx.x; i < n_mge; i += blockDim.x) v += part_mge[i];
+      const double t = block_sum_d(v, shp);
+      if (threadIdx.x == 0) sc->s_mge = t;
+    }
+    if (part_mse) {
+      double v = 0.0;
+      for (int i = threadIdx.x; i < n_mse; i += blockDim.x) v += part_mse[i];
+      const double t = block_sum_d(v, shp);
+      if (threadIdx.x == 0) sc->s_mse = t;
+    }
+    if (hp) {          // the adversarial term's sum of log D(G(x)) over the head's workgroups (d_head_finalize_kernel, HEAD_G_ADV)
+      double v = 0.0;
+      for (int i = threadIdx.x; i < n_hp; i += blockDim.x) v += hp[i].s_real;
+      const double t = block_sum_d(v, shp);
+      if (threadIdx.x == 0) sc->s_adv = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  const float T = sc->tv;
+  const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
+  const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;
+  out->loss_mse = mse; out->loss_mge = mge; out->loss_adv = adv;
+  out->loss_g = (mse_w * mse + mge_w * mge) + adv_w * adv;
+  out->gnorm_g = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_g); out->tv = T;
+}
+
+// partial == null: no sum of squares (g_losses_kernel produced it)
 static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     const float* __restrict__ yhs, int ld1, const float* __restrict__ ys, int ld2,
     const float* __restrict__ mask, long rows, int Ds, float mge_w,
     const int* __restrict__ adv_inv /* [Ds] -> j or -1 */, const float* __restrict__ leak, int ldl,
     const float* __restrict__ gadv, int lda, float adv_w,
-    float* __restrict__ gs, int ldg, double* __restrict__ partial, const StepScalars* __restrict__ sc) {
+    float* __restrict__ gs, int ldg, double* __restrict__ partial, StepScalars* __restrict__ sc, const GFinalize fin) {
   __shared__ double sh[16];
+  int nblk = gridDim.x;
+  if (fin.on) {
+    if (blockIdx.x == gridDim.x - 1) {
+      finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
+                      fin.hp, fin.n_hp, sh);
+      return;
+    }
+    --nblk;
+  }
   double acc = 0.0;
   const long total = rows * Ds;
   const float sc2 = 2.f * mge_w * sc->inv_tv;
-  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride = (long)nblk * blockDim.x;
   const long sr = stride / Ds;
   const int sd = (int)(stride - sr * Ds);
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -779,7 +869,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     if (c >= Ds) { c -= Ds; ++r; }
     const float m = mask[r];
     const float diff = yhs[r * ld1 + c] * m - ys[r * ld2 + c] * m;
-    acc += (double)diff * (double)diff;
+    if (partial) acc += (double)diff * (double)diff;
     if (gs) {
       float v = sc2 * diff * m;
       const int j = adv_inv ? adv_inv[c] : -1;
@@ -790,8 +880,16 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
       gs[r * ldg + c] = v;
     }
   }
-  const double tot = block_sum_d(acc, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  if (partial) {
+    const double tot = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  }
+}
+
+static __global__ __launch_bounds__(RED_THREADS) void finalize_g_rider_kernel(const GFinalize fin) {
+  __shared__ double sh[16];
+  finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
+                  fin.hp, fin.n_hp, sh);
 }
 
 static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
@@ -1300,29 +1398,8 @@ static __global__ void finalize_g_kernel(StepScalars* sc, StepResults* out, floa
                                   int zero_gnorm, const double* __restrict__ part_mge, int n_mge,
                                   const double* __restrict__ part_mse, int n_mse) {
   if (blockIdx.x) return;
-  if (part_mge || part_mse) {
-    __shared__ double shp[16];
-    if (part_mge) {
-      double v = 0.0;
-      for (int i = threadIdx.x; i < n_mge; i += blockDim.x) v += part_mge[i];
-      const double t = block_sum_d(v, shp);
-      if (threadIdx.x == 0) sc->s_mge = t;
-    }
-    if (part_mse) {
-      double v = 0.0;
-      for (int i = threadIdx.x; i < n_mse; i += blockDim.x) v += part_mse[i];
-      const double t = block_sum_d(v, shp);
-      if (threadIdx.x == 0) sc->s_mse = t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x) return;
-  const float T = sc->tv;
-  const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
-  const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;
-  out->loss_mse = mse; out->loss_mge = mge; out->loss_adv = adv;
-  out->loss_g = (mse_w * mse + mge_w * mge) + adv_w * adv;
-  out->gnorm_g = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_g); out->tv = T;
+  __shared__ double shp[16];
+  finalize_g_body(sc, out, adv_w, mse_w, mge_w, has_adv, zero_gnorm, part_mge, n_mge, part_mse, n_mse, nullptr, 0, shp);
 }
 
 }  // namespace gt

@@ -213,13 +213,16 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 /* Schedule switches (defaults are the measured best; the GT_* environment variables of the same names only provide the default at
  * engine creation): GT_OPT_SIDE_OVERLAP (0; measured slower) small memory-bound kernels on a side stream under the products; GT_OPT_LSTM_SIDE (0)
  * LSTM weight gradients beside the next layer's recurrence; GT_OPT_COMM_D_ONE_MSG (1) / _EARLY_G (1) / _GROUP (0) data-parallel
- * message schedule; GT_OPT_COMM_FORCE (0) issue the collectives with one rank as well (bench.py --force-dp, tests). */
+ * message schedule; GT_OPT_COMM_FORCE (0) issue the collectives with one rank as well (bench.py --force-dp, tests);
+ * GT_OPT_LAUNCH_RIDERS (1) the fused single-GPU step's small reductions (valid-frame count, the head's scalars in the generator
+ * step, the generator step's finalisation) ride as an extra workgroup of a neighbouring launch instead of launches of their own. */
 #define GT_OPT_SIDE_OVERLAP 8
 #define GT_OPT_LSTM_SIDE 9
 #define GT_OPT_COMM_D_ONE_MSG 10
 #define GT_OPT_COMM_EARLY_G 11
 #define GT_OPT_COMM_GROUP 12
 #define GT_OPT_COMM_FORCE 13
+#define GT_OPT_LAUNCH_RIDERS 14
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,

@@ -398,6 +398,26 @@ def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
         _close(fused_only[k], off[k], rtol=2e-6, atol=1e-9, msg="fused optimizer " + k)
 
 
+@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm", "duration_mlp", "vc_in2out"])
+def test_launch_riders_match_the_separate_launches(name):
+    """GT_OPT_LAUNCH_RIDERS: the valid-frame count as an extra workgroup of the adversarial-column gather, the generator step's two
+    sums of squares in one launch, the head's scalar reduction and the step's finalisation as an extra workgroup of the
+    gradient-assembly launch.  No gradient depends on where those sums are formed: parameters and optimizer state must be
+    BIT-IDENTICAL to the separate launches, the reported scalars equal to double-precision summation order (counts exactly)."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    on = run_hip_case(case, engine_options={"launch_riders": 1})
+    off = run_hip_case(case, engine_options={"launch_riders": 0})
+    assert set(on) == set(off)
+    for k in off:
+        if "scalars" in k:
+            _close(on[k], off[k], rtol=1e-6, atol=1e-9, msg=k)
+            if k.startswith("d_scalars"):
+                assert on[k][3] == off[k][3] and on[k][4] == off[k][4], k
+        else:
+            assert np.array_equal(on[k], off[k]), k
+
+
 def test_split_first_layer_one_launch_equals_two_launches():
     """The split first layer's forward as ONE two-segment launch with two result halves (GEMM_A_LEAKY_PHILOX_SEG: the production
     path with Philox dropout) against its two-launch form (x product, then the K = 58 pass that adds it: GEMM_A_LEAKY_PHILOX_ADDM):
