@@ -124,8 +124,14 @@ bool comm_on(const gt_engine* e) {
   return e->comm != nullptr && (e->comm->world > 1 || e->opt_comm_force);
 }
 // all-reduce(sum) of buf[0..count) in place on the communicator's stream, ordered after everything queued on `compute`
-static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute) {
+// on_compute: the collective is issued on `compute` itself -- for a step's CLOSING messages, which nothing can overlap: no event
+// hand-off to the communicator's stream and back on the critical path (RCCL orders successive calls on one communicator)
+static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute, bool on_compute = false) {
   GtComm* c = e->comm;
+  if (on_compute) {
+    NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, compute));
+    return GT_OK;
+  }
   hipEvent_t ev = c->ev[c->next_ev];
   c->next_ev = (c->next_ev + 1) % 8;
   HIPCHK(hipEventRecord(ev, compute));
@@ -151,7 +157,7 @@ int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStr
   e->comm_pending[role].push_back(std::make_pair(off, count));
   return GT_OK;
 }
-int comm_flush(gt_engine* e, int role, hipStream_t compute) {
+int comm_flush(gt_engine* e, int role, hipStream_t compute, bool closing) {
   if (!comm_on(e)) return GT_OK;
   // the fused step only RECORDS its weight-gradient combines (SlabDefer): the ranges about to leave must be final, so the recorded
   // combines run now, as ONE launch per message instead of one per layer
@@ -165,7 +171,7 @@ int comm_flush(gt_engine* e, int role, hipStream_t compute) {
     long lo = pend[i].first, hi = lo + pend[i].second;
     size_t j = i + 1;
     while (j < pend.size() && pend[j].first <= hi) { hi = std::max(hi, pend[j].first + pend[j].second); ++j; }
-    CHK(comm_allreduce_after(e, n.d.grads + lo, (size_t)(hi - lo), GT_NCCL_FLOAT, compute));
+    CHK(comm_allreduce_after(e, n.d.grads + lo, (size_t)(hi - lo), GT_NCCL_FLOAT, compute, closing));
     e->comm_done[role].push_back(std::make_pair(lo, hi - lo));
     i = j;
   }
@@ -178,23 +184,28 @@ int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sum
   if (!comm_on(e)) return GT_OK;
   Net& n = e->net[role];
   const bool grp = e->opt_comm_group && rccl_api();
+  const bool inl = e->opt_comm_close_inline;
+  // closing messages on the step's own stream: whatever the communicator's stream still carries (earlier buckets of this step)
+  // must be ordered in front of them for the final join below to cover everything; RCCL serialises the calls of a communicator
+  // in issue order, and the step stream also waits for the communicator's stream explicitly before the first inline call
+  if (inl) CHK(comm_join(e, compute));
   if (grp) NCCLCHK(rccl_api()->GroupStart());       // the closing messages of a step (rest of the gradient + loss sums): one launch
   if (grads) {
-    CHK(comm_flush(e, role, compute));
+    CHK(comm_flush(e, role, compute, inl));
     auto& done = e->comm_done[role];
     std::sort(done.begin(), done.end());
     long pos = 0;
     for (size_t i = 0; i <= done.size(); ++i) {
       const long next = i < done.size() ? done[i].first : (long)n.d.n_params;
-      if (next > pos) CHK(comm_allreduce_after(e, n.d.grads + pos, (size_t)(next - pos), GT_NCCL_FLOAT, compute));
+      if (next > pos) CHK(comm_allreduce_after(e, n.d.grads + pos, (size_t)(next - pos), GT_NCCL_FLOAT, compute, inl));
       if (i < done.size()) pos = std::max(pos, done[i].first + done[i].second);
     }
   }
   e->comm_done[role].clear();
   e->comm_pending[role].clear();
-  if (sums && n_sums > 0) CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
+  if (sums && n_sums > 0) CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute, inl));
   if (grp) NCCLCHK(rccl_api()->GroupEnd());
-  return comm_join(e, compute);
+  return inl ? GT_OK : comm_join(e, compute);
 }
 
 // Data-parallel early results: the step's loss sums are final on `compute` here, long before its backward pass is.
@@ -223,6 +234,17 @@ int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t s) {
     CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
     e->tv_inflight = true;
   }
+  return GT_OK;
+}
+// riders (eng_step.hip): the local count was written to comm_tv by a rider of another launch / is consumed by the head directly
+int comm_tv_sent(gt_engine* e, hipStream_t s) {
+  CHK(comm_allreduce_after(e, e->comm_tv.p, 1, GT_NCCL_DOUBLE, s));
+  e->tv_inflight = true;
+  return GT_OK;
+}
+int comm_tv_join(gt_engine* e, hipStream_t s) {
+  CHK(comm_join(e, s));
+  e->tv_inflight = false;
   return GT_OK;
 }
 int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s) {

@@ -353,6 +353,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_COMM_EARLY_G: e->opt_comm_early_g = value != 0; return GT_OK;
     case GT_OPT_COMM_GROUP: e->opt_comm_group = value != 0; return GT_OK;
     case GT_OPT_COMM_FORCE: e->opt_comm_force = value != 0; return GT_OK;
+    case GT_OPT_COMM_CLOSE_INLINE: e->opt_comm_close_inline = value != 0; return GT_OK;
     case GT_OPT_LAUNCH_RIDERS: e->opt_launch_riders = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16:
       // the storage precision belongs to a PASS: buffers of a stashed forward pass (bf16 images vs float32 stashes) are not

@@ -492,7 +492,8 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
                     StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false,
-                    int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */) {
+                    int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */,
+                    const double* tv_dev = nullptr /* the valid-frame count when it is not in the step's scalars yet */) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -504,11 +505,11 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
     hipLaunchKernelGGL((d_head_kernel<KP_, __bf16, true>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
-                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L);                    \
+                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L, tv_dev);            \
   else                                                                                                                   \
     hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
-                       e->headp.as<HeadPartials>(), e->headw.as<float>())
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev)
   if (K <= 128) { GT_HEAD_LAUNCH(2); }
   else if (K <= 256) { GT_HEAD_LAUNCH(4); }
   else if (K <= 512) { GT_HEAD_LAUNCH(8); }
@@ -675,7 +676,12 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (comm_on(e) && tr && D.grads_dirty)
     return fail(GT_ERR_STATE, "data-parallel step: optimizer_d.zero_grad() must precede update_discriminator (the gradient buckets are summed over the ranks in place)");
   { SlabDefer& sd = e->sdefer[GT_ROLE_D]; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; sd.active = e->early && tr && D.has_opt; }
-  CHK(ensure_tv_begin(e, mask, N, s));        // data parallel: the global count travels under the D forward pass
+  // data parallel: the global count travels under the D forward pass.  With the split first layer its local term is summed by a
+  // rider of the gather launch below (tv_ride_dp), else by a launch of its own right here.
+  const bool tv_known = e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override;
+  const bool tv_ride_dp = e->early && e->opt_launch_riders && comm_on(e) && !tv_known && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight &&
+                          !use_b16(e, GT_ROLE_D) && d_split_ok(e, x, false);
+  if (!tv_ride_dp) CHK(ensure_tv_begin(e, mask, N, s));
   const bool tv_side = e->early && !comm_on(e) && e->opt_side_overlap && !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
   if (tv_side) { CHK(side_fork(e, s)); CHK(ensure_tv(e, mask, N, e->side)); }      // single GPU: the count is summed under the D forward pass
   const int passes[2] = {0, 1};
@@ -704,13 +710,13 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     e->ld_adv2 = (e->Da + 3) & ~3;
     CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
     // (the valid-frame count rides in this launch when it is not known yet: fused single-GPU call)
-    const bool tv_ride = e->early && e->opt_launch_riders && !comm_on(e) && !tv_side &&
-                         !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
-    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (tv_ride ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static, e->Ds,
-                       e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, tv_ride ? mask : (const float*)nullptr, (int)N,
-                       e->tv_override, e->sc());
+    const bool tv_ride = e->early && e->opt_launch_riders && !comm_on(e) && !tv_side && !tv_known;
+    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (tv_ride || tv_ride_dp ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static,
+                       e->Ds, e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, tv_ride || tv_ride_dp ? mask : (const float*)nullptr,
+                       (int)N, e->tv_override, e->sc(), tv_ride_dp ? e->comm_tv.as<double>() : (double*)nullptr);
     LAUNCH_CHECK();
     if (tv_ride) { e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override; }
+    if (tv_ride_dp) CHK(comm_tv_sent(e, s));          // all-reduce of the count on the communicator's stream, joined in front of the head
     e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
     e->fake_cat_valid = false;
     fs.x = x; fs.ldx = cx_pitch(e); fs.cd = cond_dim(e); fs.adv = e->adv2.as<float>(); fs.ld_adv = e->ld_adv2; fs.wrap = N;
@@ -745,11 +751,18 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // reduction kernel also writes the result struct and the scalars start their way to the host right behind it
   const bool plain_early = e->early && !comm_on(e), comm_early = e->early && comm_on(e);
   if (tv_side) CHK(side_join(e, s));
-  CHK(ensure_tv(e, mask, N, s));
+  // data parallel + riders: the head reads the all-reduced count where the collective left it (and files it in the step's scalars):
+  // no conversion launch between the join and the head
+  const double* head_tv = nullptr;
+  if (comm_on(e) && e->opt_launch_riders && e->tv_inflight && !tv_known) {
+    CHK(comm_tv_join(e, s));
+    head_tv = e->comm_tv.as<double>();
+    e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
+  } else CHK(ensure_tv(e, mask, N, s));
   if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
                e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
-               (b16 && tr) ? &e->dz_b[0] : nullptr, true));
+               (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv));
   e->early_done = false;
   if (plain_early) CHK(post_early_results(e, s));
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
@@ -983,7 +996,9 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   // launch riders (fused single-GPU call): both reported sums of squares in one launch here; the head's scalar reduction and the
   // step's finalisation as one extra workgroup of the gradient-assembly launch -- four launches become two
   const bool riders = early_fold && e->opt_launch_riders && !mse_side;
-  if (riders) {
+  // data parallel: the same launches, the rider then only files the three sums for the collective (nothing is reported from it)
+  const bool riders_dp = e->early && comm_on(e) && e->opt_launch_riders && !(tr && direct && mse_w != 0.f);
+  if (riders || riders_dp) {
     mse_blocks = (int)std::min<long>(1024, cdiv(N * Do, RED_THREADS * 4));
     mge_pre_blocks = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
     CHK(e->partial.ensure(4096 * sizeof(double)));
@@ -1016,7 +1031,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       float* fake = e->adv2.as<float>() + N * e->ld_adv2;
       if (!(e->adv2_fake_ok && e->adv2_yhs == y_hat_static)) {
         hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(N * e->ld_adv2, 256)), dim3(256), 0, s, y_hat_static, y_hat_static, Ds, e->d_adv_cols, e->Da,
-                           fake, e->ld_adv2, N, N, (const float*)nullptr, 0, 0.f, (StepScalars*)nullptr);
+                           fake, e->ld_adv2, N, N, (const float*)nullptr, 0, 0.f, (StepScalars*)nullptr, (double*)nullptr);
         LAUNCH_CHECK();
         e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;
       }
@@ -1052,7 +1067,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
     CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
                  e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false,
-                 riders ? &head_blocks : nullptr));
+                 riders || riders_dp ? &head_blocks : nullptr));
     if (tr) {
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
@@ -1078,22 +1093,23 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     const float* leak = (tr && e->leak_pending) ? e->leak.as<float>() : nullptr;
     GFinalize fin;
     memset(&fin, 0, sizeof(fin));
-    if (riders) {       // (early_now holds: riders implies the fused single-GPU call)
-      fin.on = 1; fin.sc = e->sc(); fin.out = early_res_target(e); fin.adv_w = adv_w; fin.mse_w = mse_w; fin.mge_w = mge_w;
+    const bool rid = riders || riders_dp;
+    if (rid) {       // (riders implies early_now: the fused single-GPU call; riders_dp: sums only)
+      fin.on = 1; fin.sc = e->sc(); fin.out = riders ? early_res_target(e) : (StepResults*)nullptr; fin.adv_w = adv_w; fin.mse_w = mse_w; fin.mge_w = mge_w;
       fin.has_adv = e->g_has_adv ? 1 : 0;
       fin.part_mge = e->partial.as<double>(); fin.n_mge = mge_pre_blocks;
       fin.part_mse = e->partial.as<double>() + 1024; fin.n_mse = mse_blocks;
       fin.hp = head_blocks ? e->headp.as<HeadPartials>() : (const HeadPartials*)nullptr; fin.n_hp = head_blocks;
     }
-    if (tr || !riders)
-      hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (riders ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
-                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, riders ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin);
+    if (tr || !rid)
+      hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
+                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, rid ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin);
     else      // phase != "train": no gradient to assemble, the finalisation alone
       hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();
     mge_blocks = nblk;
     if (riders) CHK(post_early_results(e, s));
-    else if (!early_now) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
+    else if (!early_now && !riders_dp) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
       hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
       LAUNCH_CHECK();
     }

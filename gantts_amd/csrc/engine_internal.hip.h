@@ -269,6 +269,7 @@ struct gt_engine {
   // collectives issued even with one rank (bench.py --force-dp, tests)
   bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
        opt_comm_group = env_flag("GT_COMM_GROUP", false), opt_comm_force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
+  bool opt_comm_close_inline = env_flag("GT_COMM_CLOSE_INLINE", true);   // GT_OPT_COMM_CLOSE_INLINE: a step's closing messages on the step stream itself
   bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
@@ -371,7 +372,9 @@ struct GtComm {
 };
 bool comm_on(const gt_engine* e);
 int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
-int comm_flush(gt_engine* e, int role, hipStream_t compute);
+int comm_flush(gt_engine* e, int role, hipStream_t compute, bool closing = false);
+int comm_tv_sent(gt_engine* e, hipStream_t s);
+int comm_tv_join(gt_engine* e, hipStream_t s);
 int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute);
 int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float adv_w, float mse_w, float mge_w, hipStream_t compute);
 int ensure_tv_begin(gt_engine* e, const float* mask, long N, hipStream_t s);

@@ -204,10 +204,16 @@ static __global__ void sigmoid_grad_kernel(float* __restrict__ g, int ldg, const
 // (mask_sum_kernel's work: nothing in this launch reads it, the head a whole forward pass later does) -- one launch less per step.
 static __global__ void build_adv_kernel(const float* __restrict__ fa, const float* __restrict__ fb, int ldf, const int* __restrict__ idx,
                                         int na, float* __restrict__ out, int ldo, long split, long rows,
-                                        const float* __restrict__ tv_mask, int tv_n, float tv_override, StepScalars* sc) {
+                                        const float* __restrict__ tv_mask, int tv_n, float tv_override, StepScalars* sc,
+                                        double* __restrict__ tv_total /* data parallel: the local term of the global count instead */) {
   if (tv_mask && blockIdx.x == gridDim.x - 1) {
     __shared__ double sh[16];
-    mask_sum_body(tv_mask, tv_n, tv_override, nullptr, sc, sh);
+    if (tv_total) {
+      double v = 0.0;
+      for (int i = threadIdx.x; i < tv_n; i += blockDim.x) v += (double)tv_mask[i];
+      const double tot = block_sum_d(v, sh);
+      if (threadIdx.x == 0) tv_total[0] = tot;
+    } else mask_sum_body(tv_mask, tv_n, tv_override, nullptr, sc, sh);
     return;
   }
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -588,11 +594,16 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     int has_act, const StepScalars* __restrict__ sc,
     HeadPartials* __restrict__ hp, float* __restrict__ dw_partial /* [grid][K] */,
     __bf16* __restrict__ dHb = nullptr, int lddhb = 0,        // bf16 image of dH (GT_OPT_MATMUL_BF16), instead of / beside dH
-    __bf16* __restrict__ dHbT = nullptr, long lddhbt = 0) {   // and its transposed twin [K][rows]: 4 consecutive rows per 8-byte store
+    __bf16* __restrict__ dHbT = nullptr, long lddhbt = 0,     // and its transposed twin [K][rows]: 4 consecutive rows per 8-byte store
+    const double* __restrict__ tv_dev = nullptr) {            // data parallel: the all-reduced valid-frame count, not yet in *sc (workgroup 0 puts it there)
   extern __shared__ __attribute__((aligned(16))) float smf[];   // [4][K] dw staging
   __shared__ double shd[5][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float inv_tv = sc->inv_tv;
+  const float inv_tv = tv_dev ? 1.0f / (float)*tv_dev : sc->inv_tv;
+  if (tv_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+    StepScalars* scw = const_cast<StepScalars*>(sc);
+    scw->tv = (float)*tv_dev; scw->inv_tv = 1.0f / (float)*tv_dev;
+  }
   const float b0 = bias[0];
   double s_real = 0, s_fake = 0, n_rok = 0, n_fok = 0, dbs = 0;
   float wreg[KP], dwacc[KP];
@@ -830,7 +841,7 @@ __device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* ou
     }
     __syncthreads();
   }
-  if (threadIdx.x) return;
+  if (threadIdx.x || !out) return;       // out == null (data parallel): the sums only -- they are all-reduced before anything is reported
   const float T = sc->tv;
   const float mse = (float)sc->s_mse / T, mge = (float)sc->s_mge / T;
   const float adv = has_adv ? -((float)sc->s_adv) / T : 0.f;

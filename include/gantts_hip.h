@@ -223,6 +223,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_COMM_GROUP 12
 #define GT_OPT_COMM_FORCE 13
 #define GT_OPT_LAUNCH_RIDERS 14
+#define GT_OPT_COMM_CLOSE_INLINE 15
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,
