@@ -138,6 +138,7 @@ def main():
                     help="GPU clock spin-up before the warm-up steps: a generic matrix product on scratch operands (NOT steps of the "
                          "workload) keeps the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a "
                          "training run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
+    ap.add_argument("--trace-steps", action="store_true", help="diagnostic: host time of every timed step to stderr")
     ap.add_argument("--dense-x", action="store_true", help="x resident with dense 425-float rows (the engine then makes the 16-byte-pitch "
                     "copy its weight-gradient products read, once per step) instead of the pitched rows the batch pipeline stages")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
@@ -293,6 +294,7 @@ def main():
     # default 50 -- never the first steps after the warm-up.
     PROFILE_EVERY, PROFILE_PHASE = 20, 10
     profiled_steps = 0
+    step_marks = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -304,9 +306,15 @@ def main():
         last = step()
         if on:
             L.lib.gt_profile_enable(0)
+        if args.trace_steps:
+            step_marks.append(time.perf_counter())
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.trace_steps and rank == 0:
+        marks = [t0] + step_marks
+        print("host ms per step: " + " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])) +
+              " | drain %.3f" % (1e3 * (t0 + elapsed - marks[-1])), file=sys.stderr)
     L.check(L.lib.gt_profile_enable(0))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -98,8 +98,11 @@ extern "C" int gt_comm_init(gt_engine* e, int rank, int world, const void* id) {
   int r = api->CommInitRank(&c->comm, world, nid, rank);
   if (r != 0) { c->comm = nullptr; (void)gt_comm_destroy(e); return fail(GT_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(r) : "?"); }
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (auto& ev : c->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  // stream-to-stream hand-offs on ONE device: a device-scope release is enough (the collective's own kernels fence what leaves the
+  // device), and a record then does not flush to system scope in the middle of the step
+  const unsigned evf = hipEventDisableTiming | (env_flag("GT_COMM_EVENT_DEVICE_SCOPE", true) ? hipEventReleaseToDevice : 0u);
+  for (auto& ev : c->ev) HIPCHK(hipEventCreateWithFlags(&ev, evf));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_done, evf));
   CHK(e->comm_tv.ensure(64));
   return GT_OK;
 }

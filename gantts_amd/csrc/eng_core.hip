@@ -124,7 +124,9 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
       (r = upload_ints(e->h_adv_cols, &e->d_adv_cols)) || (r = upload_ints(e->h_adv_inv, &e->d_adv_inv))) { delete e; return r; }
   if ((r = e->scal.ensure(1024))) { delete e; return r; }
   if (hipMemset(e->scal.p, 0, 1024) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMemset failed"); }
-  if (hipHostMalloc((void**)&e->h_res, sizeof(StepResults)) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  static_assert(sizeof(StepResults) <= 64, "the result ticket sits 64 bytes behind the results");
+  if (hipHostMalloc((void**)&e->h_res, 128) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
+  memset(e->h_res, 0, 128);
   if (hipHostGetDevicePointer((void**)&e->h_res_dev, e->h_res, 0) != hipSuccess) { (void)hipGetLastError(); e->h_res_dev = nullptr; }
   if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
   if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
@@ -354,6 +356,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_COMM_GROUP: e->opt_comm_group = value != 0; return GT_OK;
     case GT_OPT_COMM_FORCE: e->opt_comm_force = value != 0; return GT_OK;
     case GT_OPT_COMM_CLOSE_INLINE: e->opt_comm_close_inline = value != 0; return GT_OK;
+    case GT_OPT_POLL_RESULTS: e->opt_poll_results = value != 0; return GT_OK;
     case GT_OPT_LAUNCH_RIDERS: e->opt_launch_riders = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16:
       // the storage precision belongs to a PASS: buffers of a stashed forward pass (bf16 images vs float32 stashes) are not

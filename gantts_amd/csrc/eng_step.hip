@@ -493,7 +493,8 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
                     StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false,
                     int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */,
-                    const double* tv_dev = nullptr /* the valid-frame count when it is not in the step's scalars yet */) {
+                    const double* tv_dev = nullptr /* the valid-frame count when it is not in the step's scalars yet */,
+                    unsigned ticket = 0 /* early_res in host memory: the ticket that announces it */) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -521,7 +522,7 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
   if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
-                     early_res);
+                     early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -622,7 +623,37 @@ static int post_deferred_results(gt_engine* e, int role, hipStream_t s) {
   return GT_OK;
 }
 static StepResults* early_res_target(gt_engine* e) { return e->h_res_dev ? e->h_res_dev : e->res(); }
-int post_early_results(gt_engine* e, hipStream_t s) {
+// a ticket for results that the NEXT finalising launch writes into the host page (0: not available -- the event is used)
+static unsigned take_ticket(gt_engine* e) {
+  if (!e->opt_poll_results || !e->h_res_dev) return 0;
+  if (++e->ticket_next == 0) ++e->ticket_next;
+  return e->ticket_next;
+}
+static int wait_early_results(gt_engine* e) {
+  if (e->ticket_wait) {
+    volatile unsigned* t = e->ticket_host();
+    const unsigned want = e->ticket_wait;
+    e->ticket_wait = 0;
+    unsigned long spins = 0;
+    std::chrono::steady_clock::time_point t0;
+    while (__atomic_load_n((const unsigned*)t, __ATOMIC_ACQUIRE) != want) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffff) == 0) {      // a kernel that died never writes the ticket: give up after a minute
+        if (spins == 0x100000) t0 = std::chrono::steady_clock::now();
+        else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) {
+          HIPCHK(hipDeviceSynchronize());
+          return fail(GT_ERR_HIP, "the step's results never arrived in host memory");
+        }
+      }
+    }
+    return GT_OK;
+  }
+  HIPCHK(hipEventSynchronize(e->ev_res));
+  return GT_OK;
+}
+int post_early_results(gt_engine* e, hipStream_t s, unsigned ticket) {
+  if (ticket) { e->ticket_wait = ticket; e->early_done = true; return GT_OK; }
+  e->ticket_wait = 0;
   if (!e->ev_res) HIPCHK(hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
   if (!e->h_res_dev) HIPCHK(hipMemcpyAsync(e->h_res, e->res(), sizeof(StepResults), hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(e->ev_res, s));
@@ -753,6 +784,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (tv_side) CHK(side_join(e, s));
   // data parallel + riders: the head reads the all-reduced count where the collective left it (and files it in the step's scalars):
   // no conversion launch between the join and the head
+  const unsigned d_ticket = plain_early ? take_ticket(e) : 0;
   const double* head_tv = nullptr;
   if (comm_on(e) && e->opt_launch_riders && e->tv_inflight && !tv_known) {
     CHK(comm_tv_join(e, s));
@@ -762,9 +794,9 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
                e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
-               (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv));
+               (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv, d_ticket));
   e->early_done = false;
-  if (plain_early) CHK(post_early_results(e, s));
+  if (plain_early) CHK(post_early_results(e, s, d_ticket));
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
   if (tr) {
     CHK(comm_grads_ready(e, GT_ROLE_D, D.last.dW, (long)D.last.in * D.last.out + D.last.out, s));
@@ -816,7 +848,7 @@ extern "C" int gt_update_discriminator_end(gt_engine* e, int train, gt_d_result*
   }
   if (e->early_done) {
     if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
-    HIPCHK(hipEventSynchronize(e->ev_res));       // only the scalar copy; backward + step stay queued
+    CHK(wait_early_results(e));                   // only the scalars; backward + step stay queued
     e->early_done = false;
   } else {
     if (train) CHK(optimizer_step(e, GT_ROLE_D, &e->sc()->gnorm2_d, s));
@@ -1100,6 +1132,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       fin.part_mge = e->partial.as<double>(); fin.n_mge = mge_pre_blocks;
       fin.part_mse = e->partial.as<double>() + 1024; fin.n_mse = mse_blocks;
       fin.hp = head_blocks ? e->headp.as<HeadPartials>() : (const HeadPartials*)nullptr; fin.n_hp = head_blocks;
+      if (riders) { fin.ticket_value = take_ticket(e); fin.ticket = fin.ticket_value ? e->ticket_dev() : (unsigned*)nullptr; }
     }
     if (tr || !rid)
       hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
@@ -1108,7 +1141,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();
     mge_blocks = nblk;
-    if (riders) CHK(post_early_results(e, s));
+    if (riders) CHK(post_early_results(e, s, fin.ticket_value));
     else if (!early_now && !riders_dp) {   // the split-phase (data-parallel) caller all-reduces the sum itself: it must exist now
       hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, e->partial.as<double>(), nblk, &e->sc()->s_mge);
       LAUNCH_CHECK();
@@ -1148,7 +1181,7 @@ extern "C" int gt_update_generator_end(gt_engine* e, int train, float adv_w, flo
   }
   if (e->early_done) {
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));
-    HIPCHK(hipEventSynchronize(e->ev_res));
+    CHK(wait_early_results(e));
     e->early_done = false;
   } else {
     if (train) CHK(optimizer_step(e, GT_ROLE_G, &e->sc()->gnorm2_g, s));

@@ -222,6 +222,12 @@ struct gt_engine {
   // as soon as THAT copy has landed, leaving the rest of the step queued on the stream.
   bool early = false, early_done = false;
   hipEvent_t ev_res = nullptr;
+  // GT_OPT_POLL_RESULTS: instead of an event behind the finalisation (its record is a system-scope release in the MIDDLE of the step:
+  // ~6 us of idle stream, twice per step), the finalising thread writes a ticket number behind the results in the host page and
+  // the call polls for it.  ticket_* : last number handed out / the one the pending early results carry (0 = the event is used)
+  unsigned ticket_next = 0, ticket_wait = 0;
+  unsigned* ticket_dev() { return h_res_dev ? (unsigned*)((char*)h_res_dev + 64) : nullptr; }
+  volatile unsigned* ticket_host() { return (volatile unsigned*)((char*)h_res + 64); }
   // deferred results of the split-phase calls (out == NULL): own pinned copy + event per role, fetched by gt_*_result
   StepResults* h_def[2] = {nullptr, nullptr}; hipEvent_t ev_def[2] = {nullptr, nullptr}; bool def_pending[2] = {false, false};
   std::vector<DropoutSpec> g_specs, d_specs;   // dropout sites of the stashed passes
@@ -270,6 +276,7 @@ struct gt_engine {
   bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
        opt_comm_group = env_flag("GT_COMM_GROUP", false), opt_comm_force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
   bool opt_comm_close_inline = env_flag("GT_COMM_CLOSE_INLINE", true);   // GT_OPT_COMM_CLOSE_INLINE: a step's closing messages on the step stream itself
+  bool opt_poll_results = env_flag("GT_POLL_RESULTS", false);     // measured: no gain (cfg2 1.380 / 1.384 vs 1.381 / 1.375 ms; b = 4: 0.411 vs 0.417)
   bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
@@ -356,7 +363,7 @@ int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const i
 int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, const int* sstride, int Ds,
                   float* gy, int ldgy, int B, int T, float mse_w, const float* yhat, const float* ytgt, int ldt,
                   const float* mask, hipStream_t s);
-int post_early_results(gt_engine* e, hipStream_t s);
+int post_early_results(gt_engine* e, hipStream_t s, unsigned ticket = 0);
 int cond_dim(gt_engine* e);
 
 // ------------------------------------------------------------------------------------------

@@ -80,19 +80,32 @@ struct StepResults {
   float loss_mse, loss_mge, loss_adv, loss_g;                           // train.py:320 order
   float gnorm_d, gnorm_g, tv;
 };
+// the results above are in host-visible memory: publish them to a polling host thread (call from the ONE thread that wrote them)
+__device__ __forceinline__ void publish_ticket(unsigned* ticket, unsigned value) {
+  if (!ticket) return;
+  __threadfence_system();
+  __hip_atomic_store(ticket, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
+// sum(mask[0..n)) over one workgroup (valid in thread 0); 8 independent loads in flight per lane (one workgroup is latency-bound)
+__device__ __forceinline__ double mask_total_body(const float* __restrict__ mask, int n, double* sh /* [16] */) {
+  float p[8];      // 0/1 values: float partial sums of <= 2^24 terms are exact
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p[u] = 0.f;
+  const int bd = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + 7 * bd < n; i += 8 * bd) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += mask[i + u * bd];
+  }
+  for (; i < n; i += bd) p[0] += mask[i];
+  const double v = (((double)p[0] + (double)p[1]) + ((double)p[2] + (double)p[3])) + (((double)p[4] + (double)p[5]) + ((double)p[6] + (double)p[7]));
+  return block_sum_d(v, sh);
+}
 // tv = sum(mask[0..n)) ; single workgroup (n = B*T is small); any workgroup size that is a multiple of 64
 __device__ __forceinline__ void mask_sum_body(const float* __restrict__ mask, int n, float tv_override, const double* __restrict__ tv_dev,
                                               StepScalars* sc, double* sh /* [16] */) {
-  double v = 0.0;
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // 0/1 values: float partial sums of <= 2^24 terms are exact
-  int i = threadIdx.x;
-  for (; i + 3 * (int)blockDim.x < n; i += 4 * blockDim.x) {
-    p0 += mask[i]; p1 += mask[i + blockDim.x]; p2 += mask[i + 2 * blockDim.x]; p3 += mask[i + 3 * blockDim.x];
-  }
-  for (; i < n; i += blockDim.x) p0 += mask[i];
-  v = ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
-  const double tot = block_sum_d(v, sh);
+  const double tot = mask_total_body(mask, n, sh);
   if (threadIdx.x == 0) {
     const float tv = tv_dev ? (float)*tv_dev : (tv_override > 0.f ? tv_override : (float)tot);
     sc->tv = tv;
@@ -108,9 +121,7 @@ static __global__ void mask_sum_kernel(const float* __restrict__ mask, int n, fl
 // out[0] = sum(mask[0..n)) as a double (data parallel: the local term of the global valid-frame count)
 static __global__ void mask_total_kernel(const float* __restrict__ mask, int n, double* __restrict__ out) {
   __shared__ double sh[16];
-  double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)mask[i];
-  const double tot = block_sum_d(v, sh);
+  const double tot = mask_total_body(mask, n, sh);
   if (threadIdx.x == 0) out[0] = tot;
 }
 
@@ -209,9 +220,7 @@ static __global__ void build_adv_kernel(const float* __restrict__ fa, const floa
   if (tv_mask && blockIdx.x == gridDim.x - 1) {
     __shared__ double sh[16];
     if (tv_total) {
-      double v = 0.0;
-      for (int i = threadIdx.x; i < tv_n; i += blockDim.x) v += (double)tv_mask[i];
-      const double tot = block_sum_d(v, sh);
+      const double tot = mask_total_body(tv_mask, tv_n, sh);
       if (threadIdx.x == 0) tv_total[0] = tot;
     } else mask_sum_body(tv_mask, tv_n, tv_override, nullptr, sc, sh);
     return;
@@ -743,7 +752,8 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
                                                                int nblk, int K, int mode, StepScalars* sc,
                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate,
-                                                               StepResults* early_res /* D step: also finalize_d (gnorm 0) */) {
+                                                               StepResults* early_res /* D step: also finalize_d (gnorm 0) */,
+                                                               unsigned* ticket = nullptr, unsigned ticket_value = 0) {
   __shared__ float shw[16][64];
   __shared__ double shd[16];
   const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -789,6 +799,7 @@ static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const Head
           early_res->loss_real_d = lr; early_res->loss_fake_d = lf; early_res->loss_d = lr + lf;
           early_res->real_correct = (float)r[2]; early_res->fake_correct = (float)r[3];
           early_res->gnorm_d = 0.f; early_res->tv = T;
+          publish_ticket(ticket, ticket_value);
         }
       } else sc->s_adv = r[0];
       if (db) db[0] = accumulate ? db[0] + (float)r[4] : (float)r[4];
@@ -815,11 +826,13 @@ struct GFinalize {
   const double* part_mge; int n_mge;
   const double* part_mse; int n_mse;
   const HeadPartials* hp; int n_hp;
+  unsigned* ticket; unsigned ticket_value;
 };
 __device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* out, float adv_w, float mse_w, float mge_w, int has_adv,
                                                 int zero_gnorm, const double* __restrict__ part_mge, int n_mge,
                                                 const double* __restrict__ part_mse, int n_mse,
-                                                const HeadPartials* __restrict__ hp, int n_hp, double* shp /* [16] */) {
+                                                const HeadPartials* __restrict__ hp, int n_hp, double* shp /* [16] */,
+                                                unsigned* ticket = nullptr, unsigned ticket_value = 0) {
   if (part_mge || part_mse || hp) {
     if (part_mge) {
       double v = 0.0;
@@ -848,6 +861,7 @@ __device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* ou
   out->loss_mse = mse; out->loss_mge = mge; out->loss_adv = adv;
   out->loss_g = (mse_w * mse + mge_w * mge) + adv_w * adv;
   out->gnorm_g = zero_gnorm ? 0.f : (float)sqrt(sc->gnorm2_g); out->tv = T;
+  publish_ticket(ticket, ticket_value);
 }
 
 // partial == null: no sum of squares (g_losses_kernel produced it)
@@ -862,7 +876,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   if (fin.on) {
     if (blockIdx.x == gridDim.x - 1) {
       finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
-                      fin.hp, fin.n_hp, sh);
+                      fin.hp, fin.n_hp, sh, fin.ticket, fin.ticket_value);
       return;
     }
     --nblk;
@@ -900,7 +914,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
 static __global__ __launch_bounds__(RED_THREADS) void finalize_g_rider_kernel(const GFinalize fin) {
   __shared__ double sh[16];
   finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
-                  fin.hp, fin.n_hp, sh);
+                  fin.hp, fin.n_hp, sh, fin.ticket, fin.ticket_value);
 }
 
 static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {

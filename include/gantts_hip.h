@@ -215,7 +215,10 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * LSTM weight gradients beside the next layer's recurrence; GT_OPT_COMM_D_ONE_MSG (1) / _EARLY_G (1) / _GROUP (0) data-parallel
  * message schedule; GT_OPT_COMM_FORCE (0) issue the collectives with one rank as well (bench.py --force-dp, tests);
  * GT_OPT_LAUNCH_RIDERS (1) the fused single-GPU step's small reductions (valid-frame count, the head's scalars in the generator
- * step, the generator step's finalisation) ride as an extra workgroup of a neighbouring launch instead of launches of their own. */
+ * step, the generator step's finalisation) ride as an extra workgroup of a neighbouring launch instead of launches of their own;
+ * GT_OPT_COMM_CLOSE_INLINE (1) a data-parallel step's closing messages are issued on the step's own stream (no event hand-off on
+ * the critical path); GT_OPT_POLL_RESULTS (0; measured: no gain) the fused single-GPU calls learn that their scalars have landed in host memory from
+ * a ticket the finalising kernel writes behind them, not from an event recorded in the middle of the step. */
 #define GT_OPT_SIDE_OVERLAP 8
 #define GT_OPT_LSTM_SIDE 9
 #define GT_OPT_COMM_D_ONE_MSG 10
@@ -224,6 +227,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_COMM_FORCE 13
 #define GT_OPT_LAUNCH_RIDERS 14
 #define GT_OPT_COMM_CLOSE_INLINE 15
+#define GT_OPT_POLL_RESULTS 16
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,

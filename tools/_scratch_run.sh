@@ -1,14 +1,12 @@
 #!/bin/bash
 # scratch driver for one gpurun call (not part of the product; overwritten per experiment)
 set -u
-O=gpurun_out/r4s; mkdir -p $O
+O=gpurun_out/r4w; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-B="python bench.py --no-cpu-baseline --no-other-configs"
-for r in 1 2; do
-  timeout 200 $B --force-dp > $O/dp$r.json 2> $O/dp$r.err
-  timeout 120 $B > $O/plain$r.json 2> $O/plain$r.err
-done
-GT_LAUNCH_RIDERS=0 timeout 200 $B --force-dp > $O/dp_norid.json 2> $O/dp_norid.err
-timeout 200 $B --force-dp --batch 4 > $O/dp_b4.json 2> $O/dp_b4.err
-tail -3 $O/pytest.log
+B="python bench.py --no-cpu-baseline --no-other-configs --trace-steps"
+timeout 120 $B --steps 20 --warmup 5 > $O/drv1.json 2> $O/drv1.err
+timeout 120 $B --steps 20 --warmup 5 --no-roofline > $O/drv_noroof.json 2> $O/drv_noroof.err
+timeout 120 $B --steps 20 --warmup 30 > $O/drv_w30.json 2> $O/drv_w30.err
+timeout 120 $B --steps 50 --warmup 10 > $O/s50.json 2> $O/s50.err
+timeout 120 $B --steps 20 --warmup 5 > $O/drv2.json 2> $O/drv2.err
+grep "host ms" $O/*.err
