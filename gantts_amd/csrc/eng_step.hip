@@ -507,6 +507,10 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
                        (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L, tv_dev);            \
+  else if ((KP_) % 4 == 0 && gt_tuning().head_vec)                                                                       \
+    hipLaunchKernelGGL((d_head_kernel<((KP_) % 4 == 0 ? (KP_) : 4), float, false, true>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev); \
   else                                                                                                                   \
     hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \

@@ -82,6 +82,7 @@ struct GtTuning {
   int b16_wg_tile = 0;        // GT_B16_WG_TILE    ... their weight gradients
   int b16_dma = 1;            // GT_B16_DMA        LDS-DMA operand stages
   int mlpg_fpl = 2;           // GT_MLPG_FPL       frames per lane of the MLPG compute phase
+  int head_vec = 1;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units)
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
   int sru_lw = 1;             // GT_SRU_LW         loader-wave SRU scans (0: one-wave kernels, bit-identical results)
 };

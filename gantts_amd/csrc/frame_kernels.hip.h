@@ -595,7 +595,10 @@ struct HeadPartials {   // one per workgroup; summed in fixed order afterwards
 // KP = hidden units per lane (K <= 64*KP): the row, the weight vector and the dw accumulators live
 // in registers; the next row is prefetched while the current one goes through the reduction chain.
 // TH: storage type of the activation (float, or __bf16 with GT_OPT_MATMUL_BF16: the bf16 image the last hidden layer wrote)
-template <int KP, typename TH = float, bool B16OUT = false>
+// VEC (float32 storage, KP % 4 == 0): lane <-> FOUR consecutive hidden units (k = 4 lane + j, + 256 per further group of four): the
+// row and the seed gradient move as 16-byte accesses instead of four 4-byte ones per lane.  Philox bits are keyed by the unit's index,
+// not by the lane that holds it: same masks.
+template <int KP, typename TH = float, bool B16OUT = false, bool VEC = false>
 __global__ __launch_bounds__(256) void d_head_kernel(
     const TH* __restrict__ H, int ldh, int K, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, int n_mask, int n_real, int n_rows, int mode, float eps,
@@ -616,10 +619,11 @@ __global__ __launch_bounds__(256) void d_head_kernel(
   const float b0 = bias[0];
   double s_real = 0, s_fake = 0, n_rok = 0, n_fok = 0, dbs = 0;
   float wreg[KP], dwacc[KP];
-  int kidx[KP];
+  int kidx[KP], kof[KP];
 #pragma unroll
   for (int j = 0; j < KP; ++j) {
-    const int k = lane + 64 * j;
+    const int k = VEC ? 4 * lane + (j & 3) + 256 * (j >> 2) : lane + 64 * j;
+    kof[j] = k;
     kidx[j] = min(k, K - 1);                       // clamped: loads stay in bounds, extra lanes use w = 0
     wreg[j] = k < K ? w[k] : 0.f;
     dwacc[j] = 0.f;
@@ -634,8 +638,22 @@ __global__ __launch_bounds__(256) void d_head_kernel(
 #pragma unroll
     for (int ri = 0; ri < 8; ++ri) {
       const int r = min(16 * g + 8 * (ri >> 2) + 4 * h + (ri & 3), n_rows - 1);
+      if constexpr (VEC) {
 #pragma unroll
-      for (int j = 0; j < KP; ++j) hrow[ri][j] = (float)H[(long)r * ldh + kidx[j]];
+        for (int jj = 0; jj < KP / 4; ++jj) {
+          if (kof[4 * jj] + 3 < K) {
+            const f32x4 v = ld4u(reinterpret_cast<const float*>(H) + (long)r * ldh + kof[4 * jj]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hrow[ri][4 * jj + q] = v[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hrow[ri][4 * jj + q] = (float)H[(long)r * ldh + kidx[4 * jj + q]];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) hrow[ri][j] = (float)H[(long)r * ldh + kidx[j]];
+      }
     }
     float outv[B16OUT ? 8 : 1][KP];      // B16OUT: the item's dH values, kept for the transposed 8-byte stores below
 #pragma unroll
@@ -682,9 +700,10 @@ __global__ __launch_bounds__(256) void d_head_kernel(
       if (want_grad) {
         const float dz = dD * ((1.f - D) * D);
         if (lane == 0) dbs += (double)dz;
+        float vals[KP];
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
-          const int k = lane + 64 * j;
+          const int k = kof[j];
           const float hv = hrow[ri][j];
           dwacc[j] = fmaf(dz, hv, dwacc[j]);
           float f = 1.f;
@@ -694,10 +713,28 @@ __global__ __launch_bounds__(256) void d_head_kernel(
             f = leaky_drop_grad(hv, keep, drop.mode == DROP_NONE ? 1.f : drop.scale);
           }
           const float val = dz * wreg[j] * f;
+          vals[j] = val;
           if (B16OUT) outv[ri][j] = val;
-          if (k < K) {
+          if (!VEC && k < K) {
             if (dH) dH[(long)r * lddh + k] = val;
             if (B16OUT && dHb) dHb[(long)r * lddhb + k] = (__bf16)val;
+          }
+        }
+        if constexpr (VEC) {
+          if (dH) {
+#pragma unroll
+            for (int jj = 0; jj < KP / 4; ++jj) {
+              float* dst = dH + (long)r * lddh + kof[4 * jj];
+              if (kof[4 * jj] + 3 < K) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = vals[4 * jj + q];
+                st4u(dst, v);
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (kof[4 * jj + q] < K) dst[q] = vals[4 * jj + q];
+              }
+            }
           }
         }
       }
@@ -705,7 +742,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     if (B16OUT && want_grad && dHbT) {     // the item's rows are two runs of 4 consecutive rows: 16g + 4h + {0..3} and 16g + 8 + 4h + {0..3}
 #pragma unroll
       for (int j = 0; j < KP; ++j) {
-        const int k = lane + 64 * j;
+        const int k = kof[j];
         if (k >= K) continue;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -728,7 +765,7 @@ __global__ __launch_bounds__(256) void d_head_kernel(
   if (lane == 0) { shd[0][wv] = s_real; shd[1][wv] = s_fake; shd[2][wv] = n_rok; shd[3][wv] = n_fok; shd[4][wv] = dbs; }
   if (want_grad && dw_partial) {
 #pragma unroll
-    for (int j = 0; j < KP; ++j) { const int k = lane + 64 * j; if (k < K) smf[wv * K + k] = dwacc[j]; }
+    for (int j = 0; j < KP; ++j) { const int k = kof[j]; if (k < K) smf[wv * K + k] = dwacc[j]; }
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -418,6 +418,31 @@ def test_launch_riders_match_the_separate_launches(name):
             assert np.array_equal(on[k], off[k]), k
 
 
+@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_chain_d"])
+def test_head_16_byte_accesses_match_the_4_byte_form(name):
+    """The discriminator head with lane <-> four consecutive hidden units (16-byte loads of the row, 16-byte stores of the seed
+    gradient; gt_set_tuning("head_vec")) against lane <-> every 64th unit: the same products, the row's dot product summed in a
+    different order -- a whole run agrees at 1e-4 (counts exactly), with the engine's own Philox dropout (bits keyed by unit index)."""
+    from gantts_amd import _lib as L
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    try:
+        L.check(L.lib.gt_set_tuning(b"head_vec", 0))
+        scalar = run_hip_case(case, philox=True)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"head_vec", 1))
+    vec = run_hip_case(case, philox=True)
+    for k in scalar:
+        if "scalars" in k:
+            _close(vec[k], scalar[k], msg=k)
+            if k.startswith("d_scalars"):
+                assert vec[k][3] == scalar[k][3] and vec[k][4] == scalar[k][4], k
+        elif ".opt." in k:
+            _close_state(vec[k], scalar[k], k)
+        else:
+            _close(vec[k], scalar[k], msg=k)
+
+
 def test_split_first_layer_one_launch_equals_two_launches():
     """The split first layer's forward as ONE two-segment launch with two result halves (GEMM_A_LEAKY_PHILOX_SEG: the production
     path with Philox dropout) against its two-launch form (x product, then the K = 58 pass that adds it: GEMM_A_LEAKY_PHILOX_ADDM):

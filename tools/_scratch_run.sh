@@ -1,12 +1,12 @@
 #!/bin/bash
 # scratch driver for one gpurun call (not part of the product; overwritten per experiment)
 set -u
-O=gpurun_out/r4w; mkdir -p $O
+O=gpurun_out/r4x; mkdir -p $O
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-other-configs --trace-steps"
-timeout 120 $B --steps 20 --warmup 5 > $O/drv1.json 2> $O/drv1.err
-timeout 120 $B --steps 20 --warmup 5 --no-roofline > $O/drv_noroof.json 2> $O/drv_noroof.err
-timeout 120 $B --steps 20 --warmup 30 > $O/drv_w30.json 2> $O/drv_w30.err
-timeout 120 $B --steps 50 --warmup 10 > $O/s50.json 2> $O/s50.err
-timeout 120 $B --steps 20 --warmup 5 > $O/drv2.json 2> $O/drv2.err
-grep "host ms" $O/*.err
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_at_size.py -m gpu -x -q -k "head or golden or cfg2 or philox or full_size" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+B="python bench.py --no-cpu-baseline --no-other-configs"
+for r in 1 2; do
+  GT_HEAD_VEC=1 timeout 120 $B > $O/vec$r.json 2> $O/vec$r.err
+  GT_HEAD_VEC=0 timeout 120 $B > $O/sca$r.json 2> $O/sca$r.err
+done
+tail -3 $O/pytest.log
