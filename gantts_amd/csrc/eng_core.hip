@@ -128,6 +128,7 @@ extern "C" int gt_engine_create(const gt_stream_config* cfg, gt_engine** out) {
   if (hipHostMalloc((void**)&e->h_res, 128) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
   memset(e->h_res, 0, 128);
   if (hipHostGetDevicePointer((void**)&e->h_res_dev, e->h_res, 0) != hipSuccess) { (void)hipGetLastError(); e->h_res_dev = nullptr; }
+  if (!env_flag("GT_RES_HOSTMAP", true)) e->h_res_dev = nullptr;      // (measurement: results through a device -> host copy instead)
   if (hipMalloc((void**)&e->d_fault, 64) != hipSuccess || hipMemset(e->d_fault, 0, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipMalloc failed"); }
   if (hipHostMalloc((void**)&e->h_fault, 64) != hipSuccess) { delete e; return fail(GT_ERR_HIP, "hipHostMalloc failed"); }
   for (int i = 0; i < 16; ++i) e->h_fault[i] = 0;   // [0] copy of the device word, [1] its mirror by the optimizer kernel, [2 + role] skipped steps
