@@ -218,7 +218,7 @@ int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float a
   GtComm* c = e->comm;
   CHK(comm_allreduce_after(e, sums, (size_t)n_sums, GT_NCCL_DOUBLE, compute));
   StepResults* target = e->h_res_dev ? e->h_res_dev : e->res();     // see post_early_results
-  if (role == GT_ROLE_D) hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), target, 1);
+  if (role == GT_ROLE_D) hipLaunchKernelGGL(finalize_d_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), target, 1, e->d_unnorm ? 1 : 0);
   else hipLaunchKernelGGL(finalize_g_kernel, dim3(1), dim3(1), 0, c->stream, e->sc(), target, adv_w, mse_w, mge_w, e->g_has_adv ? 1 : 0, 1,
                           (const double*)nullptr, 0, (const double*)nullptr, 0);
   LAUNCH_CHECK();

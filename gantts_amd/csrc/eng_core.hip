@@ -357,6 +357,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_COMM_GROUP: e->opt_comm_group = value != 0; return GT_OK;
     case GT_OPT_COMM_FORCE: e->opt_comm_force = value != 0; return GT_OK;
     case GT_OPT_COMM_CLOSE_INLINE: e->opt_comm_close_inline = value != 0; return GT_OK;
+    case GT_OPT_COMM_TV_IN_SUMS: e->opt_comm_tv_in_sums = value != 0; return GT_OK;
     case GT_OPT_POLL_RESULTS: e->opt_poll_results = value != 0; return GT_OK;
     case GT_OPT_LAUNCH_RIDERS: e->opt_launch_riders = value != 0; return GT_OK;
     case GT_OPT_MATMUL_BF16:
@@ -448,7 +449,7 @@ extern "C" int gt_zero_grad(gt_engine* e, int role) {
   e->net[role].grads_dirty = false;   // lazily: the next backward overwrites
   { SlabDefer& sd = e->sdefer[role]; sd.active = false; sd.jobs.n = 0; sd.blocks = 0; sd.used = 0; }   // nothing recorded survives a zero_grad
   e->tv_mask = nullptr; e->tv_inflight = false;
-  if (role == GT_ROLE_G) e->leak_pending = false;
+  if (role == GT_ROLE_G) { e->leak_pending = false; e->leak_unnorm = false; }
   return GT_OK;
 }
 extern "C" int gt_scalar_buffer(gt_engine* e, double** dev_ptr, int* n) {

@@ -494,7 +494,8 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                     StepResults* early_res = nullptr, int h_ld = 0, B16Img* dz_img = nullptr, bool dz_t = false,
                     int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */,
                     const double* tv_dev = nullptr /* the valid-frame count when it is not in the step's scalars yet */,
-                    unsigned ticket = 0 /* early_res in host memory: the ticket that announces it */) {
+                    unsigned ticket = 0 /* early_res in host memory: the ticket that announces it */,
+                    bool unit_tv = false /* seed the backward pass of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS) */) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -506,15 +507,15 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
     hipLaunchKernelGGL((d_head_kernel<KP_, __bf16, true>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
-                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L, tv_dev);            \
+                       (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L, tv_dev, unit_tv ? 1 : 0);            \
   else if ((KP_) % 4 == 0 && gt_tuning().head_vec)                                                                       \
     hipLaunchKernelGGL((d_head_kernel<((KP_) % 4 == 0 ? (KP_) : 4), float, false, true>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
-                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev); \
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev, unit_tv ? 1 : 0); \
   else                                                                                                                   \
     hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
                        (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
-                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev)
+                       e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev, unit_tv ? 1 : 0)
   if (K <= 128) { GT_HEAD_LAUNCH(2); }
   else if (K <= 256) { GT_HEAD_LAUNCH(4); }
   else if (K <= 512) { GT_HEAD_LAUNCH(8); }
@@ -541,6 +542,9 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   o.kind = n.od.kind; o.lr = n.od.lr; o.weight_decay = n.od.weight_decay; o.eps = n.od.eps; o.lr_decay = n.od.lr_decay;
   o.beta1 = n.od.beta1; o.beta2 = n.od.beta2; o.step = n.step + 1; o.max_norm = n.od.max_grad_norm;
   unsigned int* skipped = e->h_fault_dev ? e->h_fault_dev + 1 + role : (unsigned int*)nullptr;
+  // the discriminator's gradient of a GT_OPT_COMM_TV_IN_SUMS step is that of the unnormalised loss: x 1 / Tv in the update kernel
+  const float* gscale = (role == GT_ROLE_D && e->d_unnorm) ? &e->sc()->inv_tv : (const float*)nullptr;
+  if (role == GT_ROLE_D) e->d_unnorm = false;
   SlabDefer& sd = e->sdefer[role];
   if (sd.active && sd.jobs.n > 0) {
     // The fused step recorded this network's weight-gradient combines.  They write disjoint ranges of the flat gradient; whatever
@@ -574,7 +578,7 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
       }
       if (i < cov.size()) pos = cov[i].first + cov[i].second;
     }
-    if (ok && e->opt_fused_optimizer) {
+    if (ok && e->opt_fused_optimizer && !gscale) {
       if (!e->opt_bar.p) { CHK(e->opt_bar.ensure(64)); HIPCHK(hipMemsetAsync(e->opt_bar.p, 0, 64, s)); e->opt_bar_count = 0; }
       const int grid = std::min(4 * gemm_cu_count(), std::max(sd.blocks, 64));
       e->opt_bar_count += (unsigned long long)grid;
@@ -595,7 +599,7 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
       n.step += 1;
       const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
       hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
-                         part, n_partial, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped);
+                         part, n_partial, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped, gscale);
       LAUNCH_CHECK();
       return GT_OK;
     }
@@ -608,7 +612,7 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
   n.step += 1;
   const int grid = (int)std::min<long>(1024, cdiv(np, RED_THREADS));
   hipLaunchKernelGGL(optim_step_kernel, dim3(grid), dim3(RED_THREADS), 0, s, n.d.params, n.d.grads, n.od.state0, n.od.state1, np,
-                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped);
+                     part, nblk, norm2_out, o, (const unsigned int*)e->d_fault, e->h_fault_dev, skipped, gscale);
   LAUNCH_CHECK();
   return GT_OK;
 }
@@ -714,9 +718,17 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // data parallel: the global count travels under the D forward pass.  With the split first layer its local term is summed by a
   // rider of the gather launch below (tv_ride_dp), else by a launch of its own right here.
   const bool tv_known = e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override;
-  const bool tv_ride_dp = e->early && e->opt_launch_riders && comm_on(e) && !tv_known && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight &&
-                          !use_b16(e, GT_ROLE_D) && d_split_ok(e, x, false);
-  if (!tv_ride_dp) CHK(ensure_tv_begin(e, mask, N, s));
+  const bool dp_count = e->early && e->opt_launch_riders && comm_on(e) && !tv_known && !e->tv_dev && !(e->tv_override > 0.f) && !e->tv_inflight;
+  // GT_OPT_COMM_TV_IN_SUMS: no collective for the count at all -- it leaves with the loss sums (engine_internal.hip.h)
+  const bool unnorm = dp_count && e->opt_comm_tv_in_sums && tr && D.has_opt && D.d.grads;
+  e->d_unnorm = unnorm;
+  const bool split_gather = !use_b16(e, GT_ROLE_D) && d_split_ok(e, x, false);
+  const bool tv_ride_dp = dp_count && !unnorm && split_gather;
+  if (!tv_ride_dp && !unnorm) CHK(ensure_tv_begin(e, mask, N, s));
+  if (unnorm && !split_gather) {
+    hipLaunchKernelGGL(mask_total_kernel, dim3(1), dim3(1024), 0, s, mask, (int)N, &e->sc()->tv_sum);
+    LAUNCH_CHECK();
+  }
   const bool tv_side = e->early && !comm_on(e) && e->opt_side_overlap && !(e->tv_mask == mask && e->tv_n == N && e->tv_ovr == e->tv_override);
   if (tv_side) { CHK(side_fork(e, s)); CHK(ensure_tv(e, mask, N, e->side)); }      // single GPU: the count is summed under the D forward pass
   const int passes[2] = {0, 1};
@@ -746,9 +758,10 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
     // (the valid-frame count rides in this launch when it is not known yet: fused single-GPU call)
     const bool tv_ride = e->early && e->opt_launch_riders && !comm_on(e) && !tv_side && !tv_known;
-    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (tv_ride || tv_ride_dp ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static,
-                       e->Ds, e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, tv_ride || tv_ride_dp ? mask : (const float*)nullptr,
-                       (int)N, e->tv_override, e->sc(), tv_ride_dp ? e->comm_tv.as<double>() : (double*)nullptr);
+    const bool any_ride = tv_ride || tv_ride_dp || unnorm;
+    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (any_ride ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static,
+                       e->Ds, e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, any_ride ? mask : (const float*)nullptr,
+                       (int)N, e->tv_override, e->sc(), unnorm ? &e->sc()->tv_sum : tv_ride_dp ? e->comm_tv.as<double>() : (double*)nullptr);
     LAUNCH_CHECK();
     if (tv_ride) { e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override; }
     if (tv_ride_dp) CHK(comm_tv_sent(e, s));          // all-reduce of the count on the communicator's stream, joined in front of the head
@@ -790,7 +803,9 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // no conversion launch between the join and the head
   const unsigned d_ticket = plain_early ? take_ticket(e) : 0;
   const double* head_tv = nullptr;
-  if (comm_on(e) && e->opt_launch_riders && e->tv_inflight && !tv_known) {
+  if (unnorm) {      // the normaliser arrives with the sums (finalize_d_kernel on the communicator's stream files it); valid from the join on
+    e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
+  } else if (comm_on(e) && e->opt_launch_riders && e->tv_inflight && !tv_known) {
     CHK(comm_tv_join(e, s));
     head_tv = e->comm_tv.as<double>();
     e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
@@ -798,10 +813,10 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
                e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
-               (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv, d_ticket));
+               (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv, d_ticket, unnorm));
   e->early_done = false;
   if (plain_early) CHK(post_early_results(e, s, d_ticket));
-  if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, &e->sc()->s_real, 4, 0.f, 0.f, 0.f, s));
+  if (comm_early) CHK(comm_early_results(e, GT_ROLE_D, unnorm ? &e->sc()->tv_sum : &e->sc()->s_real, unnorm ? 5 : 4, 0.f, 0.f, 0.f, s));
   if (tr) {
     CHK(comm_grads_ready(e, GT_ROLE_D, D.last.dW, (long)D.last.in * D.last.out + D.last.out, s));
     // keep dloss_d/dy_hat_static only when y_hat_static is the tensor apply_generator produced
@@ -820,7 +835,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
                          e->dzB.as<float>(), true, leak, e->Da, col0, e->Da, N, N, s, split ? &fs : nullptr));
     }
     D.grads_dirty = true;
-    if (want_leak) e->leak_pending = true;
+    if (want_leak) { e->leak_pending = true; e->leak_unnorm = unnorm; }
   }
   // data parallel: the rest of D's gradient + the four loss / count sums, then the step stream waits for the communicator
   CHK(comm_finish_step(e, GT_ROLE_D, tr, &e->sc()->s_real, comm_early ? 0 : 4, s));
@@ -1140,7 +1155,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     }
     if (tr || !rid)
       hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
-                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, rid ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin);
+                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, rid ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin,
+                         leak && e->leak_unnorm ? 1 : 0);
     else      // phase != "train": no gradient to assemble, the finalisation alone
       hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();
@@ -1162,7 +1178,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   if (comm_early) CHK(comm_early_results(e, GT_ROLE_G, &e->sc()->s_adv, 3, adv_w, mse_w, mge_w, s));
   if (tr) {
     CHK(generator_backward(e, e->last_x, y, y_hat, mask, mse_w, s));  // G's own input (cat(x, z), train.py:542)
-    e->leak_pending = false;
+    e->leak_pending = false; e->leak_unnorm = false;
   }
   CHK(comm_finish_step(e, GT_ROLE_G, tr, &e->sc()->s_adv, comm_early ? 0 : 3, s));
   e->g_begin_done = true;
@@ -1236,10 +1252,11 @@ extern "C" int gt_flush_generator_grads(gt_engine* e, void* stream) {
       hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, e->leak.as<float>(), e->Da, j, (const int*)nullptr,
                          e->gs.as<float>(), Ds, cols[j], (int)N, 1);
     }
+    if (e->leak_unnorm) hipLaunchKernelGGL(scale_by_inv_tv_kernel, dim3(cdiv(N * Ds, 256)), dim3(256), 0, s, e->gs.as<float>(), N * Ds, e->sc());
     LAUNCH_CHECK();
   }
   CHK(generator_backward(e, e->last_x, e->last_yhat, e->last_yhat, (const float*)nullptr, 0.f, s));
-  e->leak_pending = false;
+  e->leak_pending = false; e->leak_unnorm = false;
   HIPCHK(hipStreamSynchronize(s));
   return GT_OK;
 }

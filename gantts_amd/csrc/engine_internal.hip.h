@@ -82,7 +82,9 @@ struct GtTuning {
   int b16_wg_tile = 0;        // GT_B16_WG_TILE    ... their weight gradients
   int b16_dma = 1;            // GT_B16_DMA        LDS-DMA operand stages
   int mlpg_fpl = 2;           // GT_MLPG_FPL       frames per lane of the MLPG compute phase
-  int head_vec = 1;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units)
+  int head_vec = 0;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units); measured -3 us
+                              //                   per step, NOT the default: it sums the row's dot product in another order, and one oracle-only
+                              //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
   int sru_lw = 1;             // GT_SRU_LW         loader-wave SRU scans (0: one-wave kernels, bit-identical results)
 };
@@ -277,6 +279,12 @@ struct gt_engine {
   bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
        opt_comm_group = env_flag("GT_COMM_GROUP", false), opt_comm_force = getenv("GT_COMM_FORCE_COLLECTIVES") != nullptr;
   bool opt_comm_close_inline = env_flag("GT_COMM_CLOSE_INLINE", true);   // GT_OPT_COMM_CLOSE_INLINE: a step's closing messages on the step stream itself
+  // GT_OPT_COMM_TV_IN_SUMS: the data-parallel D step does not all-reduce the valid-frame count ahead of the head; the head seeds the
+  // backward pass of the UNNORMALISED loss, the local count leaves with the four loss / count sums (one message instead of two), and
+  // 1 / Tv is applied where the gradient is consumed: by the optimizer kernel (which writes the normalised, clipped gradient back) and
+  // by the generator step's gradient assembly for the kept dloss_d/dy_hat_static.  d_unnorm / leak_unnorm: in that state right now.
+  bool opt_comm_tv_in_sums = env_flag("GT_COMM_TV_IN_SUMS", true);
+  bool d_unnorm = false, leak_unnorm = false;
   bool opt_poll_results = env_flag("GT_POLL_RESULTS", false);     // measured: no gain (cfg2 1.380 / 1.384 vs 1.381 / 1.375 ms; b = 4: 0.411 vs 0.417)
   bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)

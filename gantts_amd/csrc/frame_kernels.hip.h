@@ -67,6 +67,8 @@ static __global__ void philox_mask_kernel(const DropoutSpec d, long rows, int co
 struct StepScalars {
   float tv;          // sum(mask)  (valid frames, reference train.py:258,286)
   float inv_tv;
+  double tv_sum;     // data parallel, GT_OPT_COMM_TV_IN_SUMS: the local valid-frame count, summed over the ranks TOGETHER with the four
+                     // doubles behind it (one message); tv / inv_tv are derived from it when that message has landed
   // additive sums (all-reduced across ranks in data-parallel runs): D step [0..3], G step [4..6]
   double s_real, s_fake;          // sum(log(..)*mask)
   double n_real_ok, n_fake_ok;    // correct counts
@@ -607,11 +609,12 @@ __global__ __launch_bounds__(256) void d_head_kernel(
     HeadPartials* __restrict__ hp, float* __restrict__ dw_partial /* [grid][K] */,
     __bf16* __restrict__ dHb = nullptr, int lddhb = 0,        // bf16 image of dH (GT_OPT_MATMUL_BF16), instead of / beside dH
     __bf16* __restrict__ dHbT = nullptr, long lddhbt = 0,     // and its transposed twin [K][rows]: 4 consecutive rows per 8-byte store
-    const double* __restrict__ tv_dev = nullptr) {            // data parallel: the all-reduced valid-frame count, not yet in *sc (workgroup 0 puts it there)
+    const double* __restrict__ tv_dev = nullptr,              // data parallel: the all-reduced valid-frame count, not yet in *sc (workgroup 0 puts it there)
+    int unit_tv = 0) {                                        // GT_OPT_COMM_TV_IN_SUMS: the count is not known yet -- unnormalised losses' gradient (the optimizer applies 1 / Tv)
   extern __shared__ __attribute__((aligned(16))) float smf[];   // [4][K] dw staging
   __shared__ double shd[5][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float inv_tv = tv_dev ? 1.0f / (float)*tv_dev : sc->inv_tv;
+  const float inv_tv = unit_tv ? 1.0f : tv_dev ? 1.0f / (float)*tv_dev : sc->inv_tv;
   if (tv_dev && blockIdx.x == 0 && threadIdx.x == 0) {
     StepScalars* scw = const_cast<StepScalars*>(sc);
     scw->tv = (float)*tv_dev; scw->inv_tv = 1.0f / (float)*tv_dev;
@@ -907,7 +910,8 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     const float* __restrict__ mask, long rows, int Ds, float mge_w,
     const int* __restrict__ adv_inv /* [Ds] -> j or -1 */, const float* __restrict__ leak, int ldl,
     const float* __restrict__ gadv, int lda, float adv_w,
-    float* __restrict__ gs, int ldg, double* __restrict__ partial, StepScalars* __restrict__ sc, const GFinalize fin) {
+    float* __restrict__ gs, int ldg, double* __restrict__ partial, StepScalars* __restrict__ sc, const GFinalize fin,
+    int leak_unnorm = 0 /* the kept dloss_d/dy_hat_static is that of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS): x 1 / Tv here */) {
   __shared__ double sh[16];
   int nblk = gridDim.x;
   if (fin.on) {
@@ -921,6 +925,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   double acc = 0.0;
   const long total = rows * Ds;
   const float sc2 = 2.f * mge_w * sc->inv_tv;
+  const float leak_s = leak_unnorm ? sc->inv_tv : 1.f;
   const long stride = (long)nblk * blockDim.x;
   const long sr = stride / Ds;
   const int sd = (int)(stride - sr * Ds);
@@ -936,7 +941,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
       float v = sc2 * diff * m;
       const int j = adv_inv ? adv_inv[c] : -1;
       if (j >= 0) {
-        if (leak) v += leak[r * ldl + j];
+        if (leak) v += leak_s * leak[r * ldl + j];
         if (gadv) v += adv_w * gadv[r * lda + j];
       }
       gs[r * ldg + c] = v;
@@ -952,6 +957,12 @@ static __global__ __launch_bounds__(RED_THREADS) void finalize_g_rider_kernel(co
   __shared__ double sh[16];
   finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
                   fin.hp, fin.n_hp, sh, fin.ticket, fin.ticket_value);
+}
+
+// g[i] *= 1 / Tv  (the rare consumers of an unnormalised kept gradient outside the fused step)
+static __global__ void scale_by_inv_tv_kernel(float* __restrict__ g, long n, const StepScalars* __restrict__ sc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] *= sc->inv_tv;
 }
 
 static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
@@ -1122,7 +1133,8 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ s0, float* __restrict__ s1, long n,
     const double* __restrict__ norm_partial, int n_partial, double* __restrict__ norm2_out, OptimSpec o,
     const unsigned int* __restrict__ fault_dev, unsigned int* fault_host /* pinned, or null */,
-    unsigned int* skipped_host /* pinned, or null */) {
+    unsigned int* skipped_host /* pinned, or null */,
+    const float* __restrict__ gscale = nullptr /* the gradient in g is that of a loss still to be multiplied by *gscale (1 / Tv) */) {
   __shared__ float coef_sh;
   __shared__ double shn[16];
   // A persistent launch of this step that gave up raised the device fault word: its gradients are garbage.  Mirror the
@@ -1138,15 +1150,17 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
   }
   double part = 0.0;
   for (int i = threadIdx.x; i < n_partial; i += blockDim.x) part += norm_partial[i];
-  const double tot = block_sum_d(part, shn);      // same fixed order in every workgroup
+  double tot = block_sum_d(part, shn);      // same fixed order in every workgroup
   if (threadIdx.x == 0) {
+    const float gsc = gscale ? *gscale : 1.f;
+    tot *= (double)gsc * (double)gsc;
     if (blockIdx.x == 0 && norm2_out) *norm2_out = tot;
     float coef = 1.f;
     if (o.max_norm > 0.f) {
       const float total_norm = (float)sqrt(tot);
       coef = fminf(o.max_norm / (total_norm + 1e-6f), 1.f);
     }
-    coef_sh = coef;
+    coef_sh = coef * gsc;       // (the scaled, clipped gradient is what optim_update writes back)
   }
   __syncthreads();
   const float coef = coef_sh;
@@ -1446,8 +1460,10 @@ static __global__ void highway_backward_kernel(const float* __restrict__ g, int 
 // results of one update_* call, written by a single thread and copied D2H once
 // ---------------------------------------------------------------------------------------
 // zero_gnorm: the gradient norm is not known / not applicable at this point (early results, phase != "train"): report 0
-static __global__ void finalize_d_kernel(const StepScalars* sc, StepResults* out, int zero_gnorm) {
+// tv_from_sum: the valid-frame count arrived with the sums (StepScalars::tv_sum): file it first
+static __global__ void finalize_d_kernel(StepScalars* sc, StepResults* out, int zero_gnorm, int tv_from_sum = 0) {
   if (threadIdx.x || blockIdx.x) return;
+  if (tv_from_sum) { sc->tv = (float)sc->tv_sum; sc->inv_tv = 1.0f / (float)sc->tv_sum; }
   const float T = sc->tv;
   const float lr = -((float)sc->s_real) / T, lf = -((float)sc->s_fake) / T;
   out->loss_real_d = lr; out->loss_fake_d = lf; out->loss_d = lr + lf;

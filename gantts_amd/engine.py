@@ -222,7 +222,8 @@ class StepEngine(object):
                 "fused_optimizer": L.OPT_FUSED_OPTIMIZER, "side_overlap": L.OPT_SIDE_OVERLAP, "lstm_side": L.OPT_LSTM_SIDE,
                 "comm_d_one_msg": L.OPT_COMM_D_ONE_MSG, "comm_early_g": L.OPT_COMM_EARLY_G, "comm_group": L.OPT_COMM_GROUP,
                 "comm_force": L.OPT_COMM_FORCE, "launch_riders": L.OPT_LAUNCH_RIDERS,
-                "comm_close_inline": L.OPT_COMM_CLOSE_INLINE, "poll_results": L.OPT_POLL_RESULTS}
+                "comm_close_inline": L.OPT_COMM_CLOSE_INLINE, "poll_results": L.OPT_POLL_RESULTS,
+                "comm_tv_in_sums": L.OPT_COMM_TV_IN_SUMS}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

@@ -218,7 +218,10 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * step, the generator step's finalisation) ride as an extra workgroup of a neighbouring launch instead of launches of their own;
  * GT_OPT_COMM_CLOSE_INLINE (1) a data-parallel step's closing messages are issued on the step's own stream (no event hand-off on
  * the critical path); GT_OPT_POLL_RESULTS (0; measured: no gain) the fused single-GPU calls learn that their scalars have landed in host memory from
- * a ticket the finalising kernel writes behind them, not from an event recorded in the middle of the step. */
+ * a ticket the finalising kernel writes behind them, not from an event recorded in the middle of the step;
+ * GT_OPT_COMM_TV_IN_SUMS (1) the data-parallel discriminator step sends its valid-frame count WITH its loss sums (five collectives
+ * per G+D step instead of six): the backward pass runs on the unnormalised loss, 1 / Tv is applied by the optimizer kernel (the
+ * gradient it writes back is the normalised, clipped one) and by the generator step where it adds the kept gradient. */
 #define GT_OPT_SIDE_OVERLAP 8
 #define GT_OPT_LSTM_SIDE 9
 #define GT_OPT_COMM_D_ONE_MSG 10
@@ -228,6 +231,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_LAUNCH_RIDERS 14
 #define GT_OPT_COMM_CLOSE_INLINE 15
 #define GT_OPT_POLL_RESULTS 16
+#define GT_OPT_COMM_TV_IN_SUMS 17
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,

@@ -426,12 +426,12 @@ def test_head_16_byte_accesses_match_the_4_byte_form(name):
     from gantts_amd import _lib as L
     from hip_runner import run_hip_case
     case = C.CASES[name]
+    scalar = run_hip_case(case, philox=True)
     try:
-        L.check(L.lib.gt_set_tuning(b"head_vec", 0))
-        scalar = run_hip_case(case, philox=True)
-    finally:
         L.check(L.lib.gt_set_tuning(b"head_vec", 1))
-    vec = run_hip_case(case, philox=True)
+        vec = run_hip_case(case, philox=True)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"head_vec", 0))
     for k in scalar:
         if "scalars" in k:
             _close(vec[k], scalar[k], msg=k)
