@@ -1273,16 +1273,25 @@ def test_inference_path_matches_reference_golden():
         INF.gen_parameters(gold["acoustic_predicted.mlp"], Y_mean, Y_std, mge_training=False)
 
 
+_DP_SCHEDULES = {
+    "default": None,        # count with the D loss sums (unnormalised seeds), closing messages on the step stream, riders
+    "round3": {"comm_tv_in_sums": 0, "comm_close_inline": 0, "launch_riders": 0},      # six collectives, all on the communicator's stream
+    "count_ahead": {"comm_tv_in_sums": 0},                                              # the count all-reduced ahead of the head
+}
+
+
+@pytest.mark.parametrize("schedule", sorted(_DP_SCHEDULES))
 @pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out"])
-def test_engine_communicator_world_1_matches_reference_golden(name):
+def test_engine_communicator_world_1_matches_reference_golden(name, schedule):
     """gt_comm_init with one rank: the step goes through the engine's data-parallel path (global valid-frame count,
     per-layer gradient buckets handed to RCCL on the communicator's stream under the backward pass, loss sums, join,
     clip + optimizer on the reduced gradient) and must reproduce the reference-generated fixture exactly like the
-    plain path does."""
+    plain path does -- in every message schedule (GT_OPT_COMM_*): the default one (the count leaves with the D loss sums, the
+    backward pass runs on the unnormalised loss and the optimizer kernel applies 1 / Tv), the round-3 one, and the one in between."""
     from hip_runner import run_hip_case
     case = C.CASES[name]
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
-    got = run_hip_case(case, comm_world_1=True)
+    got = run_hip_case(case, comm_world_1=True, engine_options=_DP_SCHEDULES[schedule])
     for k in gold.files:
         if k.startswith("g_leak_norm"):
             continue
