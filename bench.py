@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--dense-x", action="store_true", help="x resident with dense 425-float rows (the engine then makes the 16-byte-pitch "
                     "copy its weight-gradient products read, once per step) instead of the pitched rows the batch pipeline stages")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
+    ap.add_argument("--dp-ipc", action="store_true", help="data parallel: the step's messages over the engine's two-shot all-reduce on hipIpc "
+                    "peer arenas (gt_comm_ipc_*) instead of RCCL; falls back to RCCL with a warning if the arenas cannot be attached")
     ap.add_argument("--dp-python", action="store_true", help="data parallelism orchestrated from Python (torch.distributed "
                     "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
     args = ap.parse_args()
@@ -241,6 +243,17 @@ def main():
             dist.broadcast(mg.flat_params(), src=0)
             dist.broadcast(md.flat_params(), src=0)
             eng.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+            if args.dp_ipc:
+                try:
+                    mine = torch.frombuffer(bytearray(eng.comm_ipc_export()), dtype=torch.uint8).to(dev)
+                    allh = [torch.zeros_like(mine) for _ in range(world)]
+                    if world > 1:
+                        dist.all_gather(allh, mine)
+                    else:
+                        allh = [mine]
+                    eng.comm_ipc_attach(rank, world, b"".join(bytes(h.cpu().numpy().tobytes()) for h in allh))
+                except Exception as e:      # noqa: BLE001 -- the collective of record is RCCL; the arenas are an option
+                    print("warning: rank %d: interprocess arenas not attached (%s); RCCL carries every message" % (rank, e), file=sys.stderr)
 
 
         def step():
@@ -368,7 +381,7 @@ def main():
                                       "Adagrad, MGE+ADV loss, global B=%d T=%d (%d sequences per GPU, %s scaling), fp32, "
                                       "dropout 0.5 (Philox)" % (Bglobal, Tn, B, args.scaling),
                           "global_batch": Bglobal, "per_gpu_batch": B, "frames_per_step": Bglobal * Tn,
-                          "parallelism": "dp%d" % world},
+                          "parallelism": "dp%d" % world, "collective": "two-shot all-reduce over hipIpc arenas" if args.dp_ipc else "rccl"},
                "step_algorithmic_gflop": step_flops / 1e9,
                "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},

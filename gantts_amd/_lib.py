@@ -15,7 +15,8 @@ ROLE_G, ROLE_D = 0, 1
 OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_SPLIT_FIRST_LAYER, OPT_FUSED_OPTIMIZER = 2, 3, 4, 5, 6, 7
 OPT_SIDE_OVERLAP, OPT_LSTM_SIDE, OPT_COMM_D_ONE_MSG, OPT_COMM_EARLY_G, OPT_COMM_GROUP, OPT_COMM_FORCE = 8, 9, 10, 11, 12, 13
 OPT_LAUNCH_RIDERS, OPT_COMM_CLOSE_INLINE, OPT_POLL_RESULTS = 14, 15, 16
-OPT_COMM_TV_IN_SUMS = 17
+OPT_COMM_TV_IN_SUMS, OPT_COMM_IPC = 17, 18
+IPC_HANDLE_BYTES, IPC_MAX_WORLD = 64, 8
 PROFILE_SLOTS = 16
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4
 OPT_ADAGRAD, OPT_ADAM = 0, 1
@@ -99,6 +100,9 @@ SIGNATURES = {
     "gt_comm_destroy": (_I, [_P]),
     "gt_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "gt_set_shard": (_I, [_P, _I, _I]),
+    "gt_comm_ipc_export": (_I, [_P, _P]),
+    "gt_comm_ipc_attach": (_I, [_P, _I, _I, _P]),
+    "gt_comm_ipc_messages": (_I, [_P, C.POINTER(C.c_longlong)]),
     "gt_update_discriminator_begin": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "gt_update_discriminator_end": (_I, [_P, _I, C.POINTER(DResult), _P]),
     "gt_update_generator_begin": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _F, _F, _F, _P]),

@@ -72,6 +72,7 @@ extern "C" int gt_comm_unique_id(void* id_out) {
 }
 extern "C" int gt_comm_destroy(gt_engine* e) {
   if (!e) return fail(GT_ERR_INVALID, "null engine");
+  ipc_destroy(e);
   if (!e->comm) return GT_OK;
   (void)hipDeviceSynchronize();
   GtComm* c = e->comm;
@@ -131,7 +132,11 @@ bool comm_on(const gt_engine* e) {
 // hand-off to the communicator's stream and back on the critical path (RCCL orders successive calls on one communicator)
 static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype, hipStream_t compute, bool on_compute = false) {
   GtComm* c = e->comm;
+  // messages that fit the interprocess arena's slots take the full-mesh two-shot path (eng_ipc.hip) once the arenas are attached
+  const bool dbl = dtype == GT_NCCL_DOUBLE;
+  const bool ipc = ipc_usable(e, count * (dbl ? sizeof(double) : sizeof(float)));
   if (on_compute) {
+    if (ipc) return ipc_allreduce(e, buf, count, dbl, compute);
     NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, compute));
     return GT_OK;
   }
@@ -139,6 +144,7 @@ static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype
   c->next_ev = (c->next_ev + 1) % 8;
   HIPCHK(hipEventRecord(ev, compute));
   HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  if (ipc) return ipc_allreduce(e, buf, count, dbl, c->stream);
   NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, c->stream));
   return GT_OK;
 }

@@ -240,6 +240,8 @@ struct gt_engine {
   Scratch l_state, l_dout, l_hshift;
   Scratch l_xch;                                   // persistent recurrence: exchange granules
   struct GtComm* comm = nullptr;                   // gt_comm_init: RCCL communicator + comm stream (data parallel)
+  struct GtIpc* ipc = nullptr;                     // gt_comm_ipc_*: interprocess arenas of the two-shot all-reduce (eng_ipc.hip)
+  bool opt_comm_ipc = env_flag("GT_COMM_IPC", true);      // GT_OPT_COMM_IPC: messages that fit the arena's slots take that path once the arenas are attached
   int dp_rank = 0, dp_world = 1;                   // this engine's shard of the minibatch (gt_comm_init / gt_set_shard): sequence b here
                                                    // is sequence dp_rank + dp_world * b of the whole minibatch (round-robin dealing)
   int chk_B = 0, chk_T = 0;                        // (B, T) of the entry point that is running (check_common)
@@ -390,6 +392,10 @@ bool comm_on(const gt_engine* e);
 int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);
 int comm_flush(gt_engine* e, int role, hipStream_t compute, bool closing = false);
 int comm_tv_sent(gt_engine* e, hipStream_t s);
+// eng_ipc.hip
+void ipc_destroy(gt_engine* e);
+bool ipc_usable(const gt_engine* e, size_t bytes);
+int ipc_allreduce(gt_engine* e, void* buf, size_t count, bool dtype_double, hipStream_t s);
 int comm_tv_join(gt_engine* e, hipStream_t s);
 int comm_finish_step(gt_engine* e, int role, bool grads, double* sums, int n_sums, hipStream_t compute);
 int comm_early_results(gt_engine* e, int role, double* sums, int n_sums, float adv_w, float mse_w, float mge_w, hipStream_t compute);

@@ -170,6 +170,26 @@ class StepEngine(object):
     def comm_destroy(self):
         check(lib.gt_comm_destroy(self._h))
 
+    def comm_ipc_export(self):
+        """This rank's interprocess arena for the two-shot all-reduce (``gt_comm_ipc_export``): the handle to ship to every rank."""
+        buf = (C.c_char * L.IPC_HANDLE_BYTES)()
+        check(lib.gt_comm_ipc_export(self._h, buf))
+        return bytes(buf.raw)
+
+    def comm_ipc_attach(self, rank, world, handles):
+        """``handles``: the ``world`` exported handles in rank order (bytes, ``world * IPC_HANDLE_BYTES``).  From here on every
+        message of the step that fits a slot is reduced over the peers' arenas instead of by RCCL (``set_option("comm_ipc", 0)``
+        switches back)."""
+        if len(handles) != world * L.IPC_HANDLE_BYTES:
+            raise ValueError("handles must be world * %d bytes" % L.IPC_HANDLE_BYTES)
+        buf = (C.c_char * len(handles)).from_buffer_copy(handles)
+        check(lib.gt_comm_ipc_attach(self._h, int(rank), int(world), buf))
+
+    def comm_ipc_messages(self):
+        n = C.c_longlong()
+        check(lib.gt_comm_ipc_messages(self._h, C.byref(n)))
+        return n.value
+
     def set_shard(self, rank, world):
         """This engine holds sequences rank, rank + world, ... of the minibatch (no communicator: the host all-reduces between
         the split-phase calls).  Keys the dropout streams globally, so a world-k run reproduces the one-process masks."""
@@ -223,7 +243,7 @@ class StepEngine(object):
                 "comm_d_one_msg": L.OPT_COMM_D_ONE_MSG, "comm_early_g": L.OPT_COMM_EARLY_G, "comm_group": L.OPT_COMM_GROUP,
                 "comm_force": L.OPT_COMM_FORCE, "launch_riders": L.OPT_LAUNCH_RIDERS,
                 "comm_close_inline": L.OPT_COMM_CLOSE_INLINE, "poll_results": L.OPT_POLL_RESULTS,
-                "comm_tv_in_sums": L.OPT_COMM_TV_IN_SUMS}
+                "comm_tv_in_sums": L.OPT_COMM_TV_IN_SUMS, "comm_ipc": L.OPT_COMM_IPC}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

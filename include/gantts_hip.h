@@ -221,7 +221,8 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * a ticket the finalising kernel writes behind them, not from an event recorded in the middle of the step;
  * GT_OPT_COMM_TV_IN_SUMS (1) the data-parallel discriminator step sends its valid-frame count WITH its loss sums (five collectives
  * per G+D step instead of six): the backward pass runs on the unnormalised loss, 1 / Tv is applied by the optimizer kernel (the
- * gradient it writes back is the normalised, clipped one) and by the generator step where it adds the kept gradient. */
+ * gradient it writes back is the normalised, clipped one) and by the generator step where it adds the kept gradient;
+ * GT_OPT_COMM_IPC (1) see gt_comm_ipc_* below. */
 #define GT_OPT_SIDE_OVERLAP 8
 #define GT_OPT_LSTM_SIDE 9
 #define GT_OPT_COMM_D_ONE_MSG 10
@@ -232,6 +233,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_COMM_CLOSE_INLINE 15
 #define GT_OPT_POLL_RESULTS 16
 #define GT_OPT_COMM_TV_IN_SUMS 17
+#define GT_OPT_COMM_IPC 18
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,
@@ -274,6 +276,21 @@ int gt_comm_unique_id(void* id_out);
 int gt_comm_init(gt_engine* e, int rank, int world, const void* id);
 int gt_comm_destroy(gt_engine* e);
 int gt_comm_info(gt_engine* e, int* rank, int* world);
+/* The small-message collective of SURVEY 8(e): a full-mesh TWO-SHOT all-reduce over hipIpc peer buffers (gantts_amd/csrc/eng_ipc.hip),
+ * for every message of the step that fits an 8 MB slot -- at cfg2 all of them.  Every rank exports an arena in its own HBM
+ * (gt_comm_ipc_export fills `handle_out`, GT_IPC_HANDLE_BYTES), the handles travel to all ranks by any means (like the unique id),
+ * gt_comm_ipc_attach maps the peers' arenas (`handles`: world x GT_IPC_HANDLE_BYTES, in rank order; the own entry is ignored).  From
+ * then on (GT_OPT_COMM_IPC, default 1) such messages are reduced by three launches of the engine's own -- publish, reduce my 1/W
+ * chunk in rank order and push it to every rank, collect -- instead of an RCCL call: two link latencies per message instead of a
+ * ring's 2 (W - 1), bit-identical results on all replicas; larger messages and everything before the attach use RCCL.  A
+ * communicator (gt_comm_init) must be attached as well: it provides the stream, the fallback and the rank / world the arenas must
+ * agree with.  Cross-device waits are bounded by a wall-clock timeout that raises the fault word (gt_check_faults).
+ * gt_comm_ipc_messages: how many messages have taken this path (tests). */
+#define GT_IPC_HANDLE_BYTES 64
+#define GT_IPC_MAX_WORLD 8
+int gt_comm_ipc_export(gt_engine* e, void* handle_out);
+int gt_comm_ipc_attach(gt_engine* e, int rank, int world, const void* handles);
+int gt_comm_ipc_messages(gt_engine* e, long long* n);
 /* The shard this engine holds, for hosts that all-reduce themselves between the split-phase calls (no communicator):
  * sequence b of this engine is sequence rank + world * b of the whole minibatch (round-robin dealing).
  * gt_comm_init implies it.  It keys the dropout streams by GLOBAL frame / sequence: with T % 16 == 0 a world-k run draws, for

@@ -66,6 +66,8 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
             from gantts_amd.engine import engine_for
             eng = engine_for(hp, mg)
             eng.comm_init(rank, world, comm_id)
+            if extra is not None and callable(extra.get("after_comm")):      # (test hook: e.g. attach the interprocess arenas)
+                extra["after_comm"](eng)
     x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
     if pitch_x:       # rows on a 16-byte pitch, as DevicePrefetcher(pitch_x=True) stages them (gt_set_x_pitch)
         from gantts_amd.engine import pitched_empty

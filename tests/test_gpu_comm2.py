@@ -31,7 +31,7 @@ def build_fake_rccl():
     return FAKE
 
 
-def _worker(rank, world, case, idq, outq, philox=False):
+def _worker(rank, world, case, idq, outq, philox=False, ipc_qs=None):
     os.environ["GT_RCCL_LIB"] = FAKE
     os.environ.pop("GT_COMM_FORCE_COLLECTIVES", None)
     import sys
@@ -50,8 +50,28 @@ def _worker(rank, world, case, idq, outq, philox=False):
         else:
             cid = idq.get(timeout=120)
         extra = {}
+        held = {}
+        if ipc_qs is not None:       # the two-shot all-reduce over hipIpc arenas: every rank exports, the handles cross, every rank attaches
+            from gantts_amd import _lib as L
+
+            def attach(eng):
+                mine = eng.comm_ipc_export()
+                for r in range(world):
+                    if r != rank:
+                        ipc_qs[r].put((rank, mine))
+                handles = {rank: mine}
+                while len(handles) < world:
+                    r, h = ipc_qs[rank].get(timeout=120)
+                    handles[r] = h
+                eng.comm_ipc_attach(rank, world, b"".join(handles[r] for r in range(world)))
+                assert len(mine) == L.IPC_HANDLE_BYTES
+                held["eng"] = eng
+            extra["after_comm"] = attach
         got = run_hip_case(case, shard=(rank, world), comm_id=cid, extra=extra, philox=philox)
         torch.cuda.synchronize()
+        if ipc_qs is not None:
+            held["eng"].check_faults()
+            got["ipc_messages"] = np.asarray(held["eng"].comm_ipc_messages())
         got["philox_g"], got["philox_d"] = extra["philox_g"], extra["philox_d"]
         outq.put((rank, None, got))
     except Exception as e:      # noqa: BLE001 -- reported to the parent, which fails the test
@@ -59,7 +79,7 @@ def _worker(rank, world, case, idq, outq, philox=False):
         outq.put((rank, "%s\n%s" % (e, traceback.format_exc()), None))
 
 
-def _run_world2(case, philox=False):
+def _run_world2(case, philox=False, ipc=False):
     import torch.multiprocessing as mp
     try:
         build_fake_rccl()
@@ -67,7 +87,8 @@ def _run_world2(case, philox=False):
         pytest.skip("the RCCL test double could not be built: %s" % e)
     ctx = mp.get_context("spawn")
     idq, outq = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, case, idq, outq, philox)) for r in range(2)]
+    ipc_qs = [ctx.Queue(), ctx.Queue()] if ipc else None
+    procs = [ctx.Process(target=_worker, args=(r, 2, case, idq, outq, philox, ipc_qs)) for r in range(2)]
     for p in procs:
         p.start()
     results = {}
@@ -161,3 +182,20 @@ def test_engine_communicator_philox_world_2_equals_world_1(name):
             whole = extra[k].reshape(halves, B, T, -1)
             for rank, got in ((0, r0), (1, r1)):
                 assert np.array_equal(got[k].reshape(halves, B // 2, T, -1), whole[:, rank::2]), (k, rank)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_lstm"])
+def test_two_shot_ipc_allreduce_world_2_equals_whole_batch_reference_golden(name):
+    """SURVEY 8(e)'s small-message collective (gantts_amd/csrc/eng_ipc.hip: gt_comm_ipc_export / _attach): two processes export their
+    arenas, exchange the hipIpc handles and attach; from then on EVERY message of the step (the five- and three-double sums, the
+    gradient buckets) is reduced by the engine's own publish / reduce-my-chunk-and-push / collect launches over the peers' arenas --
+    the RCCL double is attached too but must not be needed.  Same bar as the RCCL path: both ranks return the WHOLE batch's scalars
+    (counts exact), end with the whole-batch parameters of the reference-generated fixture, and are bit-identical replicas (every
+    element of a sum is computed by exactly one rank, in rank order)."""
+    case = C.CASES[name]
+    r0, r1 = _run_world2(case, ipc=True)
+    n0, n1 = int(r0.pop("ipc_messages")), int(r1.pop("ipc_messages"))
+    assert n0 == n1 and n0 >= 4 * case["steps"], (n0, n1)       # at least count+sums, D gradient, G sums, G gradient per step
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    _check(name, r0, r1, {k: gold[k] for k in gold.files})
