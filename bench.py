@@ -138,6 +138,8 @@ def main():
                     help="GPU clock spin-up before the warm-up steps: a generic matrix product on scratch operands (NOT steps of the "
                          "workload) keeps the device busy for this long, so that the W warm-up + K timed steps run at the shader clock a "
                          "training run holds, not on the first milliseconds' ramp of an idle device (0 = off; DESIGN.md 4)")
+    ap.add_argument("--spinup-order", choices=["before", "after-first"], default="after-first",
+                    help="where the clock spin-up runs: before the warm-up steps, or behind the first of them (which loads the kernels)")
     ap.add_argument("--trace-steps", action="store_true", help="diagnostic: host time of every timed step to stderr")
     ap.add_argument("--dense-x", action="store_true", help="x resident with dense 425-float rows (the engine then makes the 16-byte-pitch "
                     "copy its weight-gradient products read, once per step) instead of the pitched rows the batch pipeline stages")
@@ -269,11 +271,13 @@ def main():
         if world > 1 or args.force_dp:
             dist.barrier()
 
-    if args.spinup_ms > 0:
+    def spin_up():
         # an idle MI355X sits at its lowest DPM state; the driver's 25 steps are 40 ms of work in total, all of it inside the
         # ramp.  A training run is never in that state, so the device is brought to its working clocks first -- by a
         # generic matrix product on scratch operands (the library's stand-alone gt_op_linear_forward: matrix-pipe load, like the
         # step's), nothing of the workload: no step function, no model parameter, no tensor the step would find warm.
+        # It runs BEHIND the first warm-up step (--spinup-order): that step loads every kernel's code object and sizes every
+        # scratch buffer with the host in the way, i.e. it leaves the device half idle again.
         import ctypes as C1
         ba = torch.rand(8192, 512, device=dev)
         bw = torch.rand(512, 512, device=dev)
@@ -286,26 +290,40 @@ def main():
                                                    L.current_stream()))
             torch.cuda.synchronize()
         del ba, bw, bo
+
+    spin_after_first = args.spinup_order == "after-first" and args.warmup >= 1
+    if args.spinup_ms > 0 and not spin_after_first:
+        spin_up()
     profile = not args.no_roofline
+    pre_stats = None
     for w in range(args.warmup):
-        # the last warm-up step runs instrumented once, so that the event pool of the launch profiler exists before the
-        # timed region starts (its records are drained and discarded below)
+        # the last warm-up step runs with EVERY product launch instrumented: the per-kernel table of the line (`variants`, the
+        # family figure) comes from it, and it tells which kernel dominates -- inside the timed region only that kernel's
+        # launches carry events (below)
         pre = profile and w == args.warmup - 1
         if pre:
             L.lib.gt_profile_enable(1)
         last = step()
+        if w == 0 and args.spinup_ms > 0 and spin_after_first:
+            spin_up()
         if pre:
             L.lib.gt_profile_enable(0)
             import ctypes as C0
             _a, _b, _c = (C0.c_double * L.PROFILE_SLOTS)(), (C0.c_double * L.PROFILE_SLOTS)(), (C0.c_int64 * L.PROFILE_SLOTS)()
             L.check(L.lib.gt_profile_read(_a, _b, _c))
+            _d = (C0.c_double * L.PROFILE_SLOTS)()
+            L.check(L.lib.gt_profile_bytes(_d))
+            pre_stats = (list(_a), list(_b), list(_c), list(_d))
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides --------------------
     # The dominant kernel's HIP-event timing is taken LIVE inside the timed region, on a sample of its steps: two
     # hipEventRecord per product launch are not free (~3 us each, ~25 launches), so instrumenting every launch of every step
     # would itself cost several % of `value` (measured: 1.515 ms/step un-instrumented, 1.535-1.547 with every 5th step
-    # instrumented).  Every 20th step is sampled, starting with the 11th: one step of the driver's 20-step run, two of the
-    # default 50 -- never the first steps after the warm-up.
-    PROFILE_EVERY, PROFILE_PHASE = 20, 10
+    # instrumented).  When the instrumented warm-up step says the pair launches dominate (slot 8: they do at cfg2), only THOSE five
+    # launches of every 10th step carry events, starting with the 6th step (two steps of the driver's 20, five of the default
+    # 50; ~30 us per sampled step); otherwise every launch of every 20th step, starting with the 11th.
+    PAIR_SLOT, PAIR_KIND = 8, 5
+    pair_only = bool(pre_stats) and max(range(L.PROFILE_SLOTS), key=lambda v: pre_stats[0][v]) == PAIR_SLOT
+    PROFILE_EVERY, PROFILE_PHASE = (10, 5) if pair_only else (20, 10)
     profiled_steps = 0
     step_marks = []
     barrier()
@@ -314,7 +332,7 @@ def main():
     for i in range(args.steps):
         on = profile and (i % PROFILE_EVERY == PROFILE_PHASE or args.steps <= PROFILE_PHASE and i == args.steps - 1)
         if on:
-            L.lib.gt_profile_enable(1)
+            L.lib.gt_profile_enable(2 + PAIR_KIND if pair_only else 1)
             profiled_steps += 1
         last = step()
         if on:
@@ -342,13 +360,22 @@ def main():
         L.check(L.lib.gt_profile_read(ms, fl, cnt))
         alg = (C.c_double * NS)()
         L.check(L.lib.gt_profile_bytes(alg))
+        live = {v: (ms[v], fl[v], cnt[v], alg[v]) for v in range(NS) if cnt[v]}
+        table_steps, table_src = profiled_steps, "timed region (sampled steps)"
+        if pair_only:      # the table of all kernels: the instrumented warm-up step; the dominant kernel's row: live, from the timed region
+            ms, fl, cnt, alg = [list(a) for a in pre_stats]
+            table_steps, table_src = 1, "the instrumented last warm-up step (untimed); the dominant kernel's row is live"
+            if PAIR_SLOT in live:
+                ms[PAIR_SLOT], fl[PAIR_SLOT], alg[PAIR_SLOT] = [live[PAIR_SLOT][i] / profiled_steps for i in (0, 1, 3)]
+                cnt[PAIR_SLOT] = live[PAIR_SLOT][2] // profiled_steps
         per = []
         for v in range(NS):
             if cnt[v]:
-                per.append({"kernel": "gemm_f32_kernel<%s>" % VARIANTS[v], "launches_per_step": cnt[v] / profiled_steps,
+                per.append({"kernel": "gemm_f32_kernel<%s>" % VARIANTS[v], "launches_per_step": cnt[v] / table_steps,
                             "avg_us": 1e3 * ms[v] / cnt[v], "tflops": fl[v] / (ms[v] * 1e-3) / 1e12,
-                            "share_of_step_ms": ms[v] / profiled_steps})
+                            "share_of_step_ms": ms[v] / table_steps})
         tot_ms, tot_fl = sum(ms), sum(fl)
+        profiled_steps_live, profiled_steps = profiled_steps, table_steps
         dom = max(per, key=lambda p: p["share_of_step_ms"])
         dom_v = [v for v in range(NS) if cnt[v] and "gemm_f32_kernel<%s>" % VARIANTS[v] == dom["kernel"]][0]
         traffic, traffic_src = pmc_traffic(dom_v)
@@ -360,7 +387,8 @@ def main():
                     "gemm_family": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                     "ms_per_step": tot_ms / profiled_steps, "gflop_per_step": tot_fl / profiled_steps / 1e9},
-                    "sampled_steps": profiled_steps,
+                    "sampled_steps": profiled_steps_live, "sampled_launches": "the dominant kernel's" if pair_only else "all product launches",
+                    "variants_source": table_src,
                     "variants": per}
 
     # every rank flushes its C stdio (RCCL's NCCL_DEBUG=VERSION banner is block-buffered when piped)

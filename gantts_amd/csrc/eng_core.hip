@@ -40,6 +40,7 @@ GemmProfiler g_prof;
 
 extern "C" int gt_profile_enable(int on) {
   g_prof.on = on != 0;
+  g_prof.only_kind = on >= 2 ? on - 2 : -1;
   return GT_OK;
 }
 // Drains the recorded launches into per-kernel totals (slot layout: include/gantts_hip.h).

@@ -14,7 +14,7 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
   GemmProfiler::Rec rec;
-  if (g_prof.on) {
+  if (g_prof.wants(g.epi)) {
     rec.kind = g.epi; rec.bn = BN; rec.am = -1; rec.flops = 2.0 * g.M * g.N * g.K;
     rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
                 (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
@@ -23,7 +23,7 @@ static int launch_gemm_b16_t(GemmB16Args g, int nslab, hipStream_t s) {
   }
   hipLaunchKernelGGL((gemm_b16_kernel<BM, BN, EPI, AMODE>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  if (g_prof.wants(g.epi)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 // the LDS-DMA forms (gemm_bf16s.hip.h: gemm_b16_tile_dma, ring of 2 stages), 8-wave workgroups (2 x 4): T = 128: 128 x 128
@@ -40,7 +40,7 @@ static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
   GemmProfiler::Rec rec;
-  if (g_prof.on) {
+  if (g_prof.wants(g.epi)) {
     rec.kind = g.epi; rec.bn = T; rec.am = -1; rec.flops = 2.0 * g.M * g.N * g.K;
     rec.bytes = 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N +
                 (g.CbT ? 2.0 : 0.0) * g.M * g.N + ((g.epi == B16_BWD_DATA && g.act != ACT_NONE) ? 2.0 * g.M * g.N : 0.0);
@@ -49,7 +49,7 @@ static int launch_gemm_b16_dma(GemmB16Args g, int nslab, hipStream_t s) {
   }
   hipLaunchKernelGGL((gemm_b16_dma_kernel<T, T, EPI, AMODE, 2, 2, WGN>), dim3(grid), dim3(64 * 2 * WGN), lds, s, g);
   LAUNCH_CHECK();
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  if (g_prof.wants(g.epi)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 // tile: 0 = chosen here from the shape; 64 / 128 = the caller's choice (the weight gradient sizes its slabs for a tile)

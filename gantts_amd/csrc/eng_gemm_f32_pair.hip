@@ -16,7 +16,7 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
                      (am == GEMM_A_LEAKY_PHILOX ? (const void*)gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX> : (const void*)gemm_pair_kernel<PREC_F32>));
   CHK(ensure_dyn_lds(kern, lds));
   GemmProfiler::Rec rec;
-  if (g_prof.on) {
+  if (g_prof.wants(5)) {
     rec.kind = 5; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * nn.M * nn.N * nn.K + 2.0 * tn.M * tn.N * tn.K;
     rec.bytes = gemm_algorithmic_bytes(GEMM_NN, nn) + gemm_algorithmic_bytes(GEMM_TN, tn);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
@@ -29,7 +29,7 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
   else if (am == GEMM_A_LEAKY_PHILOX) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX>), dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   LAUNCH_CHECK();
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  if (g_prof.wants(5)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 
@@ -43,7 +43,7 @@ int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1
   const size_t lds = gemm_lds_bytes<GEMM_TN, 64, 64>();
   CHK(ensure_dyn_lds((const void*)gemm_tn_pair_kernel<PREC_F32>, lds));
   GemmProfiler::Rec rec;
-  if (g_prof.on) {
+  if (g_prof.wants(6)) {
     rec.kind = 6; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * g1.M * g1.N * g1.K + 2.0 * g2.M * g2.N * g2.K;
     rec.bytes = gemm_algorithmic_bytes(GEMM_TN, g1) + 4.0 * (double)g1.M * g1.K + gemm_algorithmic_bytes(GEMM_TN, g2);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
@@ -51,6 +51,6 @@ int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1
   }
   hipLaunchKernelGGL(gemm_tn_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, g1, g2, n1);
   LAUNCH_CHECK();
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  if (g_prof.wants(6)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }

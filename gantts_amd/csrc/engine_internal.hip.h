@@ -93,6 +93,8 @@ GtTuning& gt_tuning();
 // optional per-launch timing of the product families (HIP events on the launch stream); bench.py's live roofline figure
 struct GemmProfiler {
   bool on = false;
+  int only_kind = -1;       // >= 0: only launches of this kind are instrumented (5 = the pair launches): gt_profile_enable(2 + kind)
+  bool wants(int kind) const { return on && (only_kind < 0 || only_kind == kind); }
   struct Rec { int kind, bn, am; double flops, bytes; hipEvent_t e0, e1; };   // am: GemmAmode of a float32 kernel (-1: run-time flavour)
   double last_bytes[GT_PROFILE_SLOTS] = {};   // algorithmic bytes per slot of the last gt_profile_read
   std::vector<Rec> recs;

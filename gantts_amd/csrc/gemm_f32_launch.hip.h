@@ -38,7 +38,7 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
     if (stagger_mode == 3 && !(g.stagger_ticket = gemm_stagger_tickets())) g.stagger_ticks = 0;
   }
   GemmProfiler::Rec rec;
-  if (g_prof.on) {
+  if (g_prof.wants(KIND)) {
     rec.kind = KIND; rec.bn = BN; rec.am = AM; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
     if (g.K_seg > 0) {      // + the second segment over all result rows; the result (and the second segment's A rows) once per half
       const double halves = g.dual_rows > 0 ? 2.0 : 1.0;
@@ -50,7 +50,7 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   }
   hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
-  if (g_prof.on) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
+  if (g_prof.wants(KIND)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
 }
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC>

@@ -400,7 +400,9 @@ int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t
  *   10,11 = 64x64 backward-data kernels with a compiled-in epilogue: none / LeakyReLU + Philox;
  *   12    = the two weight-gradient products of a split first layer in one launch;
  *   13    = the split first layer's forward in one launch (two K segments, two result halves);  14, 15 unused.
- * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries. */
+ * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries.
+ * gt_profile_enable(0) off, (1) every product launch, (2 + k) only launches of kind k (5 = the pair launches: what bench.py samples
+ * inside its timed region -- two events per launch are not free). */
 #define GT_PROFILE_SLOTS 16
 int gt_profile_enable(int on);
 int gt_profile_read(double* ms_per_slot, double* flops_per_slot, int64_t* launches_per_slot);
