@@ -40,7 +40,11 @@ def test_fixture_is_complete_and_self_consistent(name):
         assert float(np.sqrt((fx[k + ".sample"].astype(np.float64) ** 2).sum())) <= float(fx[k + ".norm"]) * (1 + 1e-6)
     for st in range(case["steps"]):
         for k in ("d_scalars_%d" % st, "g_scalars_%d" % st):
-            np.testing.assert_allclose(fx[k + ".f32"], fx[k + ".f64"], rtol=2e-5, atol=1e-7)      # (atol: a saturated loss_adv of 2e-6)
+            # the reference's own float32 and float64 runs agree to rounding for the first steps and then drift apart (ten steps of
+            # cfg3: 1e-7 .. 2e-6 up to the 5th step, 1.6e-3 on loss_adv and 20 of 8457 counts at the 10th): the fixture must show that
+            # drift, not hide it -- it is what the GPU tests' per-step limits are derived from
+            rtol = 2e-5 if st < 4 else 5e-3
+            np.testing.assert_allclose(fx[k + ".f32"], fx[k + ".f64"], rtol=rtol, atol=1e-7)      # (atol: a saturated loss_adv of 2e-6)
     # the sample positions are a function of the key alone
     a = np.arange(100000, dtype=np.float32)
     assert np.array_equal(A.sample_of("Ggrad.x", a), A.sample_of("Ggrad.x", a)) and A.sample_of("Ggrad.x", a).size == A.SAMPLE

@@ -1,13 +1,9 @@
 #!/bin/bash
 # scratch driver for one gpurun call (not part of the product; overwritten per experiment)
 set -u
-O=gpurun_out/r4sq; mkdir -p $O
+O=gpurun_out/r4rep; mkdir -p $O
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-other-configs --trace-steps"
-for r in 1 2 3; do
-  timeout 120 $B --steps 20 --warmup 5 > $O/drv$r.json 2> $O/drv$r.err
-done
-timeout 120 $B > $O/s50.json 2> $O/s50.err
-timeout 120 $B --batch 4 > $O/b4.json 2> $O/b4.err
-timeout 120 $B --steps 3 --warmup 1 > $O/tiny.json 2> $O/tiny.err
-grep "host ms" $O/drv*.err
+rm -f $O/parity_report.txt
+GT_PARITY_REPORT=$O/parity_report.txt timeout 1500 python -m pytest tests/test_gpu_at_size.py -m gpu -q > $O/pytest_at_size.log 2>&1; echo "rc=$?" >> $O/pytest_at_size.log
+GT_PARITY_REPORT=$O/parity_report_philox.txt timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "philox_on or full_size or cfg2" > $O/pytest_philox.log 2>&1; echo "rc=$?" >> $O/pytest_philox.log
+tail -15 $O/pytest_at_size.log; tail -5 $O/pytest_philox.log
