@@ -144,7 +144,9 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& s : e->g_act) s.release();
   for (auto& s : e->d_act) s.release();
-  for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd}) for (auto& s : *v) s.release();
+  for (auto* v : {&e->l_xproj, &e->l_gates, &e->l_cst, &e->l_out, &e->l_outd, &e->dl_xproj, &e->dl_gates, &e->dl_cst, &e->dl_out, &e->dl_outd})
+    for (auto& s : *v) s.release();
+  e->dl_dout.release(); e->dl_hshift.release(); e->d_dx0.release();
   e->i2o_gout.release();
   (void)gt_comm_destroy(e);
   e->comm_tv.release();
@@ -222,8 +224,10 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
   if (desc->n_params != expected_params(*desc))
     return fail(GT_ERR_INVALID, "n_params %ld does not match the architecture (%ld)", (long)desc->n_params, expected_params(*desc));
   if (desc->arch == GT_ARCH_LSTM && desc->hidden_dim < 1) return fail(GT_ERR_INVALID, "hidden_dim must be positive");
-  if (role == GT_ROLE_D && (desc->arch != GT_ARCH_MLP || desc->out_dim != 1 || !desc->last_sigmoid))
-    return fail(GT_ERR_INVALID, "discriminator must be MLP(out_dim=1, last_sigmoid=True) (hparams.py:56-64,230-239)");
+  if (role == GT_ROLE_D && ((desc->arch != GT_ARCH_MLP && desc->arch != GT_ARCH_LSTM) || desc->out_dim != 1 || !desc->last_sigmoid))
+    return fail(GT_ERR_INVALID, "discriminator must be MLP or LSTMRNN with out_dim=1, last_sigmoid=True (hparams.py:56-64,230-239; train.py:773-774)");
+  if (role == GT_ROLE_D && desc->arch == GT_ARCH_LSTM && desc->hidden_dim * (desc->bidirectional ? 2 : 1) > 1024)
+    return fail(GT_ERR_INVALID, "recurrent discriminator: hidden_dim x directions > 1024 is not supported by the fused head kernel");
   Net& n = e->net[role];
   n.d = *desc;
   n.hidden.clear();
@@ -259,8 +263,13 @@ extern "C" int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc) 
       n.lstm.push_back(L);
     }
     n.last = take(desc->out_dim, H * dirs);
-    e->l_xproj.resize(desc->num_hidden); e->l_gates.resize(desc->num_hidden);
-    e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden); e->l_outd.resize(desc->num_hidden);
+    if (role == GT_ROLE_G) {
+      e->l_xproj.resize(desc->num_hidden); e->l_gates.resize(desc->num_hidden);
+      e->l_cst.resize(desc->num_hidden); e->l_out.resize(desc->num_hidden); e->l_outd.resize(desc->num_hidden);
+    } else {
+      e->dl_xproj.resize(desc->num_hidden); e->dl_gates.resize(desc->num_hidden);
+      e->dl_cst.resize(desc->num_hidden); e->dl_out.resize(desc->num_hidden); e->dl_outd.resize(desc->num_hidden);
+    }
   } else if (desc->arch == GT_ARCH_SRU) {
     if (desc->rnn_dropout < 0.f || desc->rnn_dropout >= 1.f) return fail(GT_ERR_INVALID, "rnn_dropout must be in [0,1)");
     if (desc->num_hidden > 8) return fail(GT_ERR_INVALID, "SRURNN: at most 8 layers (two dropout sites per layer)");
@@ -425,9 +434,11 @@ extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, 
     if (lengths_host[b] < 0 || lengths_host[b] > 0x3fffffff) return fail(GT_ERR_INVALID, "length out of range");
     e->h_lengths[b] = (int)lengths_host[b];
   }
-  if (B > e->len_cap) {          // (re)allocate the pinned slots; device slots grow on demand
+  // the device copy holds the lengths TWICE ([len | len]): a recurrent discriminator runs the natural and the generated sequences of a
+  // D step as one batch of 2B sequences
+  if (2 * B > e->len_cap) {          // (re)allocate the pinned slots; device slots grow on demand
     HIPCHK(hipStreamSynchronize(s));
-    const int cap = std::max(64, B + B / 2);
+    const int cap = std::max(64, 2 * B + B);
     for (int i = 0; i < gt_engine::LEN_RING; ++i) {
       if (e->len_ev[i]) HIPCHK(hipEventSynchronize(e->len_ev[i]));
       if (e->len_host[i]) { HIPCHK(hipHostFree(e->len_host[i])); e->len_host[i] = nullptr; }
@@ -439,8 +450,9 @@ extern "C" int gt_set_lengths(gt_engine* e, const int64_t* lengths_host, int B, 
   const int slot = (e->len_slot + 1) % gt_engine::LEN_RING;
   HIPCHK(hipEventSynchronize(e->len_ev[slot]));          // the copy that last used this pinned slot (4 batches ago)
   memcpy(e->len_host[slot], e->h_lengths.data(), (size_t)B * sizeof(int));
+  memcpy(e->len_host[slot] + B, e->h_lengths.data(), (size_t)B * sizeof(int));
   CHK(e->len_dev[slot].ensure((size_t)e->len_cap * sizeof(int)));
-  HIPCHK(hipMemcpyAsync(e->len_dev[slot].p, e->len_host[slot], (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->len_dev[slot].p, e->len_host[slot], (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, s));
   HIPCHK(hipEventRecord(e->len_ev[slot], s));
   e->len_slot = slot;
   return GT_OK;

@@ -6,16 +6,26 @@ using namespace gt;
 // ------------------------------------------------------------------------------------------
 // recurrent generator (GT_ARCH_LSTM): forward / backward of the LSTM stack
 // ------------------------------------------------------------------------------------------
-static int lstm_check_lengths(gt_engine* e, int B, int T) {
+// Per-role stashes of a recurrent network: the generator's must survive the discriminator passes of a step (its backward runs last),
+// so a recurrent discriminator has its own set
+struct LstmBufs {
+  std::vector<Scratch>& xproj; std::vector<Scratch>& gates; std::vector<Scratch>& cst; std::vector<Scratch>& out; std::vector<Scratch>& outd;
+  Scratch& dout; Scratch& hshift;
+};
+static LstmBufs lstm_bufs(gt_engine* e, int role) {
+  if (role == GT_ROLE_G) return LstmBufs{e->l_xproj, e->l_gates, e->l_cst, e->l_out, e->l_outd, e->l_dout, e->l_hshift};
+  return LstmBufs{e->dl_xproj, e->dl_gates, e->dl_cst, e->dl_out, e->dl_outd, e->dl_dout, e->dl_hshift};
+}
+int lstm_check_lengths(gt_engine* e, int B, int T) {
   if ((int)e->h_lengths.size() != B)
-    return fail(GT_ERR_STATE, "recurrent generator: call with lengths (gt_set_lengths) for this batch of %d sequences "
+    return fail(GT_ERR_STATE, "recurrent network: call with lengths (gt_set_lengths) for this batch of %d sequences "
                 "(reference models.py:204-210 packs the batch by `lengths`)", B);
   for (int b = 0; b < B; ++b)
     if (e->h_lengths[b] > T) return fail(GT_ERR_INVALID, "length %d exceeds the padded length %d", e->h_lengths[b], T);
   return GT_OK;
 }
 
-static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T, bool backward, const float* dout, hipStream_t s) {
+static int lstm_launch_steps(gt_engine* e, const Net& G, const LstmBufs& W, int layer, int B, int T, bool backward, const float* dout, hipStream_t s) {
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   const int Bpad = cdiv(B, 32) * 32;
   const size_t st = (size_t)dirs * Bpad * H;              // floats per state array
@@ -29,10 +39,10 @@ static int lstm_launch_steps(gt_engine* e, const Net& G, int layer, int B, int T
   a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.Bpad = Bpad;
   a.lengths = e->d_lengths();
   for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
-  a.xproj = e->l_xproj[layer].as<float>();
-  a.gates = e->l_gates[layer].as<float>();
-  a.cst = e->l_cst[layer].as<float>();
-  a.out = e->l_out[layer].as<float>();
+  a.xproj = W.xproj[layer].as<float>();
+  a.gates = W.gates[layer].as<float>();
+  a.cst = W.cst[layer].as<float>();
+  a.out = W.out[layer].as<float>();
   a.dout = dout;
   a.dc_state = base + 4 * st;
   for (int step = 0; step < T; ++step) {
@@ -103,8 +113,8 @@ static int launch_bwd_seq(LstmSeqArgs& a, int bt, bool bf16, hipStream_t s, bool
 
 // Runs one layer's recurrence (forward, or backward when `backward`) as ONE persistent launch when the shape fits
 // (H <= 512, grid co-resident); *launched = false leaves the work to the per-step kernels.
-static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, bool backward, const float* dout, hipStream_t s,
-                           bool* launched) {
+static int lstm_launch_seq(gt_engine* e, const Net& G, const LstmBufs& W, bool bf16, int layer, int B, int T, bool backward, const float* dout,
+                           hipStream_t s, bool* launched) {
   *launched = false;
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   if (!e->lstm_persistent || H > 512 || T < 2) return GT_OK;
@@ -119,10 +129,10 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.B = B; a.T = T; a.H = H; a.dirs = dirs; a.nbt = cdiv(B, bt);
   a.lengths = e->d_lengths();
   for (int d = 0; d < dirs; ++d) { a.Whh[d] = G.lstm[layer].d[d].Whh; a.bih[d] = G.lstm[layer].d[d].bih; a.bhh[d] = G.lstm[layer].d[d].bhh; }
-  a.xproj = e->l_xproj[layer].as<float>();
-  a.gates = e->l_gates[layer].as<float>();
-  a.cst = e->l_cst[layer].as<float>();
-  a.out = e->l_out[layer].as<float>();
+  a.xproj = W.xproj[layer].as<float>();
+  a.gates = W.gates[layer].as<float>();
+  a.cst = W.cst[layer].as<float>();
+  a.out = W.out[layer].as<float>();
   a.dout = dout;
   a.fault = e->d_fault;
   a.timeout_ticks = 200000000ULL;          // 2 s at 100 MHz: far beyond any real wait, far below the watchdog
@@ -135,7 +145,7 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   a.allow_xcd_local = e->lstm_xcd_local ? 1 : 0;
   if (backward) {
     a.ncu = cdiv(H, 16);
-    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, e->matmul_bf16, s, launched) : launch_bwd_seq<512>(a, bt, e->matmul_bf16, s, launched));
+    CHK(HP == 256 ? launch_bwd_seq<256>(a, bt, bf16, s, launched) : launch_bwd_seq<512>(a, bt, bf16, s, launched));
     if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     return GT_OK;
   }
@@ -144,25 +154,30 @@ static int lstm_launch_seq(gt_engine* e, const Net& G, int layer, int B, int T, 
   if (upc != 8 && upc != 16) upc = 8;
   for (; upc <= 16 && !*launched; upc *= 2) {
     a.ncu = cdiv(H, upc);
-    if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, bt, e->matmul_bf16, s, launched)) : (launch_fwd_seq<512, 8>(a, bt, e->matmul_bf16, s, launched)));
-    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, bt, e->matmul_bf16, s, launched)) : (launch_fwd_seq<512, 16>(a, bt, e->matmul_bf16, s, launched)));
+    if (upc == 8) CHK(HP == 256 ? (launch_fwd_seq<256, 8>(a, bt, bf16, s, launched)) : (launch_fwd_seq<512, 8>(a, bt, bf16, s, launched)));
+    else          CHK(HP == 256 ? (launch_fwd_seq<256, 16>(a, bt, bf16, s, launched)) : (launch_fwd_seq<512, 16>(a, bt, bf16, s, launched)));
   }
   if (*launched) HIPCHK(hipMemcpyAsync(e->h_fault, e->d_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   return GT_OK;
 }
 
 static bool lstm_b16(const gt_engine* e) { return e->matmul_bf16 && (e->net[GT_ROLE_G].d.hidden_dim & 7) == 0; }
-// x (N, in_dim) -> y_hat (N, out_dim); stashes X-projections / gates / cell states / layer outputs
-int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
-  Net& G = e->net[GT_ROLE_G];
-  CHK(lstm_check_lengths(e, B, T));
+// The LSTM stack of network `role` over nseq sequences (rows = nseq * T of x, row pitch ld_x): X-projections, recurrences, inter-layer
+// dropout; stashes X-projections / gates / cell states / layer outputs in the role's buffers.  passes / npass: the dropout sites of the
+// row groups (the D step runs the natural and the generated sequences as ONE batch of 2B: two groups of nseq / 2 sequences).
+// *top / *ld_top: the top layer's (dropped, if applicable) output.
+int lstm_stack_forward(gt_engine* e, int role, const float* x, int ld_x, int nseq, int T, const int* passes, int npass, hipStream_t s,
+                       const float** top, int* ld_top) {
+  Net& G = e->net[role];
+  LstmBufs W = lstm_bufs(e, role);
+  const int B = nseq;
   const long N = (long)B * T;
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1;
   const float* in = x;
-  int ld_in = G.d.in_dim;
+  int ld_in = ld_x;
   // GT_OPT_MATMUL_BF16: the layer inputs go through bf16 images (both orientations: the weight gradients read the
   // transposed one) and W_ih of all directions is one stacked bf16 shadow -- the X-projection of a layer is ONE product
-  const bool b16 = lstm_b16(e);
+  const bool b16 = role == GT_ROLE_G && lstm_b16(e);
   const bool want_t = G.d.grads != nullptr;
   const int Lc_ = G.d.num_hidden;
   if (b16) {
@@ -185,10 +200,10 @@ int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipSt
   }
   for (int l = 0; l < G.d.num_hidden; ++l) {
     const LstmLayerP& L = G.lstm[l];
-    CHK(e->l_xproj[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
-    CHK(e->l_gates[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
-    CHK(e->l_cst[l].ensure((size_t)N * dirs * H * sizeof(float)));
-    CHK(e->l_out[l].ensure((size_t)N * dirs * H * sizeof(float)));
+    CHK(W.xproj[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
+    CHK(W.gates[l].ensure((size_t)N * dirs * 4 * H * sizeof(float)));
+    CHK(W.cst[l].ensure((size_t)N * dirs * H * sizeof(float)));
+    CHK(W.out[l].ensure((size_t)N * dirs * H * sizeof(float)));
     if (b16) {
       B16Img& I = e->l_in_b[l];
       CHK(I.ensure(N, L.in, want_t));
@@ -196,28 +211,47 @@ int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipSt
       GemmB16Args g = b16_args();
       g.A = I.r(); g.lda = I.ld; g.B = e->lsh[l].w.as<__bf16>(); g.ldb = e->lsh[l].ldw;
       g.M = (int)N; g.N = dirs * 4 * H; g.K = L.in; g.epi = B16_FWD; g.act = ACT_NONE;
-      g.C = e->l_xproj[l].as<float>(); g.ldc = dirs * 4 * H;
+      g.C = W.xproj[l].as<float>(); g.ldc = dirs * 4 * H;
       CHK(launch_gemm_b16(g, 1, s));
     } else {
       for (int d = 0; d < dirs; ++d)   // Xp[:, d*4H:(d+1)*4H] = X W_ih^T (biases are added in the step kernel)
-        CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, e->l_xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
+        CHK(linear_forward(in, ld_in, L.d[d].Wih, L.in, nullptr, W.xproj[l].as<float>() + (size_t)d * 4 * H, dirs * 4 * H, N, L.in,
                            4 * H, ACT_NONE, no_drop(), s));
     }
     bool seq = false;
-    CHK(lstm_launch_seq(e, G, l, B, T, false, nullptr, s, &seq));
-    if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, false, nullptr, s));
-    in = e->l_out[l].as<float>();
+    CHK(lstm_launch_seq(e, G, W, role == GT_ROLE_G && e->matmul_bf16, l, B, T, false, nullptr, s, &seq));
+    if (!seq) CHK(lstm_launch_steps(e, G, W, l, B, T, false, nullptr, s));
+    in = W.out[l].as<float>();
     ld_in = dirs * H;
     if (G.training && G.d.dropout > 0.f && l + 1 < G.d.num_hidden) {
       // nn.LSTM(dropout=p): dropout on the outputs of every layer but the last (training only)
-      CHK(e->l_outd[l].ensure((size_t)N * dirs * H * sizeof(float)));
-      const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l, G.inj[0][l], dirs * H);
-      hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, in, e->l_outd[l].as<float>(), N,
-                         dirs * H, ds);
+      CHK(W.outd[l].ensure((size_t)N * dirs * H * sizeof(float)));
+      const long Ng = N / npass;                        // rows of one pass (its own dropout site)
+      for (int q = 0; q < npass; ++q) {
+        const DropoutSpec ds = drop_spec(e, role, passes[q], l, G.inj[passes[q]][l], dirs * H);
+        hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(Ng * dirs * H, 256)), dim3(256), 0, s, in + q * Ng * dirs * H,
+                           W.outd[l].as<float>() + q * Ng * dirs * H, Ng, dirs * H, ds);
+      }
       LAUNCH_CHECK();
-      in = e->l_outd[l].as<float>();
+      in = W.outd[l].as<float>();
     }
   }
+  *top = in; *ld_top = ld_in;
+  return GT_OK;
+}
+
+// x (N, in_dim) -> y_hat (N, out_dim): the generator's stack + hidden2out
+int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  CHK(lstm_check_lengths(e, B, T));
+  const long N = (long)B * T;
+  const int Lc_ = G.d.num_hidden;
+  const bool b16 = lstm_b16(e);
+  const bool want_t = G.d.grads != nullptr;
+  const int passes[1] = {0};
+  const float* in = nullptr;
+  int ld_in = 0;
+  CHK(lstm_stack_forward(e, GT_ROLE_G, x, G.d.in_dim, B, T, passes, 1, s, &in, &ld_in));
   if (b16) {
     B16Img& I = e->l_in_b[Lc_];
     CHK(I.ensure(N, G.last.in, want_t));
@@ -239,9 +273,7 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
   const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, Do = G.d.out_dim, Lc = G.d.num_hidden;
   const bool acc = G.grads_dirty;
   CHK(e->l_dout.ensure((size_t)2 * N * dirs * H * sizeof(float)));
-  CHK(e->l_hshift.ensure((size_t)N * H * sizeof(float)));
-  float* dout = e->l_dout.as<float>();                       // gradient w.r.t. the current layer's output
-  float* dout_other = dout + (size_t)N * dirs * H;
+  float* dout = e->l_dout.as<float>();                       // gradient w.r.t. the top layer's output
   const bool b16 = lstm_b16(e) && (int)e->l_in_b.size() == Lc + 1 && (int)e->lsh.size() == Lc + 1;
   if (b16) {
     // hidden2out through the bf16 images: gy -> (gy, gyT); dW = gyT . topT^T, d out_top = gy . W_lastT^T
@@ -261,6 +293,26 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
   CHK(comm_grads_ready(e, GT_ROLE_G, G.last.dW, (long)Do * dirs * H + Do, s));
   CHK(linear_backward_data(gy, Do, G.last.W, G.last.in, 0, dout, dirs * H, N, Do, dirs * H, ACT_NONE, nullptr, 0, no_drop(), s));
   }
+  const int passes[1] = {0};
+  return lstm_stack_backward(e, GT_ROLE_G, x, G.d.in_dim, B, T, passes, 1, true, nullptr, s);
+}
+
+// From the gradient w.r.t. the top layer's output (first half of the role's `dout` buffer, row pitch dirs * H) down through the
+// stack: weight gradients of every layer (want_w), and the gradient w.r.t. the stack's input when dx0 != null ([rows][in_dim], dense)
+// -- what a recurrent discriminator hands back to the generator.
+int lstm_stack_backward(gt_engine* e, int role, const float* x, int ld_x, int nseq, int T, const int* passes, int npass, bool want_w,
+                        float* dx0, hipStream_t s) {
+  Net& G = e->net[role];
+  LstmBufs W = lstm_bufs(e, role);
+  const int B = nseq;
+  const long N = (long)B * T;
+  const int H = G.d.hidden_dim, dirs = G.d.bidirectional ? 2 : 1, Lc = G.d.num_hidden;
+  const bool acc = G.grads_dirty;
+  CHK(W.dout.ensure((size_t)2 * N * dirs * H * sizeof(float)));
+  CHK(W.hshift.ensure((size_t)N * H * sizeof(float)));
+  float* dout = W.dout.as<float>();                          // gradient w.r.t. the current layer's output
+  float* dout_other = dout + (size_t)N * dirs * H;
+  const bool b16 = role == GT_ROLE_G && lstm_b16(e) && (int)e->l_in_b.size() == Lc + 1 && (int)e->lsh.size() == Lc + 1;
   // Side stream (GT_LSTM_SIDE=1; OFF by default): a layer's weight-gradient products (dW_ih, dW_hh, the shifts and combines:
   // ~3 ms of a cfg3 step) depend on its dG only, and nothing on the way to the layer below depends on them, so they can
   // run beside the persistent recurrence of the layer below, whose workgroups leave the matrix pipes idle: the step stream
@@ -284,9 +336,9 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
   for (int l = Lc - 1; l >= 0; --l) {
     const LstmLayerP& L = G.lstm[l];
     bool seq = false;
-    CHK(lstm_launch_seq(e, G, l, B, T, true, dout, s, &seq));  // dG overwrites l_xproj[l]
-    if (!seq) CHK(lstm_launch_steps(e, G, l, B, T, true, dout, s));
-    const float* dG = e->l_xproj[l].as<float>();
+    CHK(lstm_launch_seq(e, G, W, role == GT_ROLE_G && e->matmul_bf16, l, B, T, true, dout, s, &seq));  // dG overwrites xproj[l]
+    if (!seq) CHK(lstm_launch_steps(e, G, W, l, B, T, true, dout, s));
+    const float* dG = W.xproj[l].as<float>();
     const bool dropped_in = l > 0 && G.training && G.d.dropout > 0.f;
     if (b16) {
       B16Img& DG0 = e->l_dg_b[l];
@@ -305,8 +357,12 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
         g.M = (int)N; g.N = L.in; g.K = dirs * 4 * H; g.epi = B16_BWD_DATA; g.act = ACT_NONE; g.C = dout_other; g.ldc = L.in;
         CHK(launch_gemm_b16(g, 1, s));
         if (dropped_in) {
-          const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l - 1, G.inj[0][l - 1], dirs * H);
-          hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, dout_other, dout_other, N, dirs * H, ds);
+          const long Ng = N / npass;
+          for (int q = 0; q < npass; ++q) {
+            const DropoutSpec ds = drop_spec(e, role, passes[q], l - 1, G.inj[passes[q]][l - 1], dirs * H);
+            hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(Ng * dirs * H, 256)), dim3(256), 0, s, dout_other + q * Ng * dirs * H,
+                               dout_other + q * Ng * dirs * H, Ng, dirs * H, ds);
+          }
           LAUNCH_CHECK();
         }
         std::swap(dout, dout_other);
@@ -317,21 +373,20 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
         hipLaunchKernelGGL(slab_reduce_small_kernel, dim3(cdiv(4 * H, 64)), dim3(1024), 0, ws, L.d[d].dbih, (long)4 * H, 1, 4 * H,
                            L.d[d].dbhh, 0);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
-                           e->d_lengths(), e->l_hshift.as<float>());
+        hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, W.out[l].as<float>(), dirs * H, d, H, B, T,
+                           e->d_lengths(), W.hshift.as<float>());
         LAUNCH_CHECK();
         CHK(e->l_hs_b.ensure(N, H, true));
-        CHK(cast_transpose(e->l_hshift.as<float>(), H, N, H, (__bf16*)nullptr, 0, e->l_hs_b.t(), e->l_hs_b.ldt, nullptr, false, &wcp, ws));
+        CHK(cast_transpose(W.hshift.as<float>(), H, N, H, (__bf16*)nullptr, 0, e->l_hs_b.t(), e->l_hs_b.ldt, nullptr, false, &wcp, ws));
         CHK(weight_grad_b16(dgt, DG.ldt, e->l_hs_b.t(), e->l_hs_b.ldt, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, wsl, ws));
       }
-      CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
-      CHK(comm_flush(e, GT_ROLE_G, ws));
+      CHK(comm_grads_ready(e, role, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
+      CHK(comm_flush(e, role, ws));
       continue;
     }
-    const float* Xl = l == 0 ? x : (dropped_in ? e->l_outd[l - 1].as<float>() : e->l_out[l - 1].as<float>());
-    const int ldx = l == 0 ? G.d.in_dim : dirs * H;
-    float* const dx_dst = dout_other;
-    for (int d = 0; d < dirs; ++d) {
+    const float* Xl = l == 0 ? x : (dropped_in ? W.outd[l - 1].as<float>() : W.out[l - 1].as<float>());
+    const int ldx = l == 0 ? ld_x : dirs * H;
+    for (int d = 0; d < dirs && want_w; ++d) {
       const float* dGd = dG + (size_t)d * 4 * H;
       // dW_ih = dG_d^T X, db_ih = colsum(dG_d) (= db_hh)
       CHK(linear_backward_weight(dGd, dirs * 4 * H, Xl, ldx, N, 4 * H, L.in, L.d[d].dWih, L.d[d].dbih, acc, wsl, wcp, ws));
@@ -340,30 +395,36 @@ int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, h
                          L.d[d].dbhh, 0);
       LAUNCH_CHECK();
       // dW_hh = dG_d^T H_shift (h that entered each frame)
-      hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, e->l_out[l].as<float>(), dirs * H, d, H, B, T,
-                         e->d_lengths(), e->l_hshift.as<float>());
+      hipLaunchKernelGGL(lstm_shift_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, ws, W.out[l].as<float>(), dirs * H, d, H, B, T,
+                         e->d_lengths(), W.hshift.as<float>());
       LAUNCH_CHECK();
-      CHK(linear_backward_weight(dGd, dirs * 4 * H, e->l_hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, wsl,
+      CHK(linear_backward_weight(dGd, dirs * 4 * H, W.hshift.as<float>(), H, N, 4 * H, H, L.d[d].dWhh, nullptr, acc, wsl,
                                  wcp, ws));
     }
     // this layer's parameters (both directions: W_ih, W_hh, b_ih, b_hh each) are one contiguous bucket
-    CHK(comm_grads_ready(e, GT_ROLE_G, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
-    CHK(comm_flush(e, GT_ROLE_G, ws));              // with hidden2out above it: under the recurrence of the layer below
-    (void)dx_dst;
-    if (l > 0) {   // gradient w.r.t. the layer below's output: sum over directions of dG_d W_ih_d
+    if (want_w) {
+      CHK(comm_grads_ready(e, role, L.d[0].dWih, (long)dirs * (4L * H * L.in + 4L * H * H + 8L * H), ws));
+      if (role == GT_ROLE_G || !e->opt_comm_d_one_msg) CHK(comm_flush(e, role, ws));              // with hidden2out above it: under the recurrence of the layer below
+    }
+    if (l > 0 || dx0) {   // gradient w.r.t. the layer below's output (or the stack's input): sum over directions of dG_d W_ih_d
+      float* const dst = l > 0 ? dout_other : dx0;
       for (int d = 0; d < dirs; ++d) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
-        g.A = dG + (size_t)d * 4 * H; g.lda = dirs * 4 * H; g.B = L.d[d].Wih; g.ldb = L.in; g.C = dout_other; g.ldc = L.in;
+        g.A = dG + (size_t)d * 4 * H; g.lda = dirs * 4 * H; g.B = L.d[d].Wih; g.ldb = L.in; g.C = dst; g.ldc = L.in;
         g.M = (int)N; g.N = L.in; g.K = 4 * H; g.act = ACT_NONE; g.accumulate = d > 0 ? 1 : 0; g.drop = no_drop();
         CHK(launch_gemm(GEMM_NN, g, 1, s));
       }
-      if (dropped_in) {   // through the inter-layer dropout of layer l-1 (same Philox site as the forward)
-        const DropoutSpec ds = drop_spec(e, GT_ROLE_G, 0, l - 1, G.inj[0][l - 1], dirs * H);
-        hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(N * dirs * H, 256)), dim3(256), 0, s, dout_other, dout_other, N, dirs * H, ds);
+      if (dropped_in) {   // through the inter-layer dropout of layer l-1 (same Philox sites as the forward)
+        const long Ng = N / npass;
+        for (int q = 0; q < npass; ++q) {
+          const DropoutSpec ds = drop_spec(e, role, passes[q], l - 1, G.inj[passes[q]][l - 1], dirs * H);
+          hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(Ng * dirs * H, 256)), dim3(256), 0, s, dout_other + q * Ng * dirs * H,
+                           dout_other + q * Ng * dirs * H, Ng, dirs * H, ds);
+      }
         LAUNCH_CHECK();
       }
-      std::swap(dout, dout_other);
+      if (l > 0) std::swap(dout, dout_other);
     }
   }
   if (side_on) { HIPCHK(hipEventRecord(e->ev_side_done, ws)); HIPCHK(hipStreamWaitEvent(s, e->ev_side_done, 0)); }

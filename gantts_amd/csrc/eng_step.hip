@@ -495,7 +495,8 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                     int* defer_scalars = nullptr /* HEAD_G_ADV without weight gradients: the caller reduces the partials; <- their count */,
                     const double* tv_dev = nullptr /* the valid-frame count when it is not in the step's scalars yet */,
                     unsigned ticket = 0 /* early_res in host memory: the ticket that announces it */,
-                    bool unit_tv = false /* seed the backward pass of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS) */) {
+                    bool unit_tv = false /* seed the backward pass of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS) */,
+                    bool has_act = true /* H is LeakyReLU + dropout of a pre-activation (MLP); false: a recurrent stack's output */) {
   Net& D = e->net[GT_ROLE_D];
   const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
@@ -505,16 +506,16 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
 #define GT_HEAD_LAUNCH(KP_)                                                                                              \
   if (h_ld > 0)                                                                                                          \
     hipLaunchKernelGGL((d_head_kernel<KP_, __bf16, true>), dim3(nblk), dim3(256), lds, s, (const __bf16*)H, h_ld, K, D.last.W, D.last.b, mask, (int)n_mask, \
-                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dz_img ? (float*)nullptr : dH, K, want_grad ? 1 : 0, spec, has_act ? 1 : 0, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), dz_img ? dz_img->r() : (__bf16*)nullptr, dz_img ? dz_img->ld : 0,  \
                        (dz_img && dz_t) ? dz_img->t() : (__bf16*)nullptr, dz_img ? dz_img->ldt : 0L, tv_dev, unit_tv ? 1 : 0);            \
   else if ((KP_) % 4 == 0 && gt_tuning().head_vec)                                                                       \
     hipLaunchKernelGGL((d_head_kernel<((KP_) % 4 == 0 ? (KP_) : 4), float, false, true>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
-                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, has_act ? 1 : 0, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev, unit_tv ? 1 : 0); \
   else                                                                                                                   \
     hipLaunchKernelGGL((d_head_kernel<KP_, float, false>), dim3(nblk), dim3(256), lds, s, (const float*)H, K, K, D.last.W, D.last.b, mask, (int)n_mask,  \
-                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, 1, e->sc(), \
+                       (int)n_real, (int)n_rows, mode, eps, e->dout.as<float>(), dH, K, want_grad ? 1 : 0, spec, has_act ? 1 : 0, e->sc(), \
                        e->headp.as<HeadPartials>(), e->headw.as<float>(), (__bf16*)nullptr, 0, (__bf16*)nullptr, 0L, tv_dev, unit_tv ? 1 : 0)
   if (K <= 128) { GT_HEAD_LAUNCH(2); }
   else if (K <= 256) { GT_HEAD_LAUNCH(4); }
@@ -696,7 +697,7 @@ static int side_join(gt_engine* e, hipStream_t s) {
 
 // the split first layer (FirstSplit) applies to the conditioned discriminator on the float32 path
 static bool d_split_ok(gt_engine* e, const float* x, bool b16) {
-  return e->opt_split_first && !b16 && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
+  return e->opt_split_first && !b16 && e->net[GT_ROLE_D].d.arch == GT_ARCH_MLP && tl_gemm_prec == PREC_F32 && e->cfg.discriminator_linguistic_condition && x && cond_dim(e) > 0 &&
          e->Da > 0 && gemm_small_tiles_ok() && (e->net[GT_ROLE_D].d.hidden_dim & 3) == 0;     // (dZ as a 16-byte loadable operand)
 }
 
@@ -785,13 +786,22 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   }
   }
   e->dcat_b_x = x; e->dcat_b_yhs = y_hat_static;
-  if (b16) {
+  // a recurrent discriminator (LSTMRNN in the discriminator slot, train.py:773-774): the natural and the generated sequences run as ONE
+  // batch of 2B sequences through its stack (lengths twice), the fused head reads the top layer's output (hidden2out is its weight)
+  const bool d_rec = has_lstm_body(D.d.arch);
+  const float* rec_top = nullptr;
+  int rec_ld = 0;
+  if (d_rec) {
+    CHK(lstm_check_lengths(e, B, T));
+    CHK(lstm_stack_forward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * B, T, passes, 2, s, &rec_top, &rec_ld));
+  } else if (b16) {
     CHK(refresh_shadows(e, GT_ROLE_D, false, s));
     CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
   } else {
     CHK(stack_forward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s, split ? &fs : nullptr));
   }
-  const int H = D.d.hidden_dim;
+  const int H = d_rec ? rec_ld : D.d.hidden_dim;
+  if (d_rec) CHK(e->dl_dout.ensure((size_t)2 * 2 * N * H * sizeof(float)));
   if (tr && !D.d.grads) return fail(GT_ERR_STATE, "phase == \"train\" but the discriminator was bound without grads");
   CHK(e->dzA.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
   CHK(e->dzB.ensure((size_t)2 * N * std::max(H, 1) * sizeof(float)));
@@ -811,6 +821,10 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     e->tv_mask = mask; e->tv_n = N; e->tv_ovr = e->tv_override;
   } else CHK(ensure_tv(e, mask, N, s));
   if (b16 && tr) CHK(e->dz_b[0].ensure(2 * N, H, true));
+  if (d_rec)
+    CHK(run_head(e, HEAD_D_STEP, (const void*)rec_top, H, 2 * N, N, mask, N, eps, tr, e->dl_dout.as<float>(), no_drop(), true, s,
+                 plain_early ? early_res_target(e) : nullptr, 0, nullptr, true, nullptr, head_tv, d_ticket, unnorm, false));
+  else
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
                e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
                (b16 && tr) ? &e->dz_b[0] : nullptr, true, nullptr, head_tv, d_ticket, unnorm));
@@ -828,7 +842,16 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     float* leak = nullptr;
     if (want_leak) { CHK(e->leak.ensure((size_t)N * e->Da * sizeof(float))); leak = e->leak.as<float>(); }
     const int col0 = cond_dim(e);
-    if (b16) {   // the head wrote its seed gradient as the top dZ image, both orientations
+    if (d_rec) {   // through the recurrent stack: weight gradients, and the gradient w.r.t. the [x | adv] rows when the generator wants it
+      float* dx0 = nullptr;
+      if (leak) { CHK(e->d_dx0.ensure((size_t)2 * N * K0 * sizeof(float))); dx0 = e->d_dx0.as<float>(); }
+      CHK(lstm_stack_backward(e, GT_ROLE_D, e->dcat.as<float>(), ldc, 2 * B, T, passes, 2, true, dx0, s));
+      if (leak) {   // the generated rows' adversarial columns (train.py:265, 274)
+        hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * e->Da, 256)), dim3(256), 0, s, dx0 + N * K0, K0, col0, (const int*)nullptr, leak, e->Da, 0,
+                           (int)N, e->Da);
+        LAUNCH_CHECK();
+      }
+    } else if (b16) {   // the head wrote its seed gradient as the top dZ image, both orientations
       CHK(stack_backward_b16(e, GT_ROLE_D, e->dcat_b.t(), e->dcat_b.ldt, 2 * N, e->d_actb, e->d_specs, 0, true, leak, e->Da, col0, e->Da, N, N, s));
     } else {
       CHK(stack_backward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, e->d_specs, e->dzA.as<float>(),
@@ -1095,6 +1118,13 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       }
       cat = e->dcat.as<float>() + N * ldc;
     }
+    const bool d_rec = has_lstm_body(D.d.arch);
+    const float* rec_top = nullptr;
+    int rec_ld = 0;
+    if (d_rec) {
+      CHK(lstm_check_lengths(e, B, T));
+      CHK(lstm_stack_forward(e, GT_ROLE_D, cat, ldc, B, T, passes, 1, s, &rec_top, &rec_ld));
+    } else
     if (b16) {   // the generated half of the bf16 image: rows N .. 2N, kept from the D step of the same batch or built here
       CHK(e->dcat_b.ensure(2 * N, K0, false));
       if (!(e->dcat_b_ok && e->dcat_b_x == x && e->dcat_b_yhs == y_hat_static)) {
@@ -1112,10 +1142,15 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     } else {
       CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s, split ? &fs : nullptr));
     }
-    const int H = D.d.hidden_dim;
+    const int H = d_rec ? rec_ld : D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
     if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
+    if (d_rec) {
+      CHK(e->dl_dout.ensure((size_t)2 * N * H * sizeof(float)));
+      CHK(run_head(e, HEAD_G_ADV, (const void*)rec_top, H, N, N, mask, N, eps, tr, e->dl_dout.as<float>(), no_drop(), false, s, nullptr, 0, nullptr,
+                   false, riders || riders_dp ? &head_blocks : nullptr, nullptr, 0, false, false));
+    } else
     CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
                  e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false,
                  riders || riders_dp ? &head_blocks : nullptr));
@@ -1123,7 +1158,14 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
       const int col0 = cond_dim(e);
-      if (b16) {
+      if (d_rec) {   // back through the recurrent stack to the generated rows' adversarial columns; no weight gradients (train.py:307-308)
+        CHK(e->d_dx0.ensure((size_t)2 * N * K0 * sizeof(float)));
+        float* dx0 = e->d_dx0.as<float>();
+        CHK(lstm_stack_backward(e, GT_ROLE_D, cat, ldc, B, T, passes, 1, false, dx0, s));
+        hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * e->Da, 256)), dim3(256), 0, s, dx0, K0, col0, (const int*)nullptr, gadv, e->Da, 0, (int)N,
+                           e->Da);
+        LAUNCH_CHECK();
+      } else if (b16) {
         CHK(stack_backward_b16(e, GT_ROLE_D, nullptr, 0, N, e->d_actb, e->d_specs, 0, false, gadv, e->Da, col0, e->Da, 0, N, s));
       } else {
         CHK(stack_backward(e, GT_ROLE_D, cat, ldc, N, e->d_act, e->d_specs, e->dzA.as<float>(), e->dzB.as<float>(), false, gadv,
@@ -1279,8 +1321,18 @@ extern "C" int gt_model_forward(gt_engine* e, int role, const float* x, const fl
     e->g_pass_valid = false;
     return generator_forward(e, x, R, B, T, out, out2, false, s, specs);
   }
+  const int pass0d[1] = {0};
   if (n.d.arch == GT_ARCH_LSTM || n.d.arch == GT_ARCH_SRU) {
-    if (role != GT_ROLE_G) return fail(GT_ERR_INVALID, "recurrent networks are supported in the generator slot only");
+    if (role != GT_ROLE_G) {
+      if (n.d.arch != GT_ARCH_LSTM) return fail(GT_ERR_INVALID, "the discriminator slot takes MLP and LSTMRNN networks");
+      // the recurrent discriminator's plain forward: its stack, then hidden2out (+ sigmoid)
+      CHK(lstm_check_lengths(e, B, T));
+      const float* top = nullptr;
+      int ld = 0;
+      CHK(lstm_stack_forward(e, role, x, n.d.in_dim, B, T, pass0d, 1, s, &top, &ld));
+      return linear_forward(top, ld, n.last.W, n.last.in, n.last.b, out, n.d.out_dim, N, n.last.in, n.last.out,
+                            n.d.last_sigmoid ? ACT_SIGMOID : ACT_NONE, no_drop(), s);
+    }
     e->g_pass_valid = false;
     return n.d.arch == GT_ARCH_LSTM ? lstm_forward(e, x, B, T, out, s) : sru_forward(e, x, B, T, out, s);
   }

@@ -240,6 +240,10 @@ struct gt_engine {
   std::vector<Scratch> l_xproj, l_gates, l_cst, l_out, l_outd;   // l_outd: inter-layer-dropped outputs
   Scratch i2o_gout;                                              // In2OutRNNHighwayNet: hidden2out output G(x)
   Scratch l_state, l_dout, l_hshift;
+  // a recurrent DISCRIMINATOR (train.py:773-774 allows any model class): its own stashes (the generator's must survive the
+  // discriminator passes of a step), the gradient w.r.t. its [x | adv] input
+  std::vector<Scratch> dl_xproj, dl_gates, dl_cst, dl_out, dl_outd;
+  Scratch dl_dout, dl_hshift, d_dx0;
   Scratch l_xch;                                   // persistent recurrence: exchange granules
   struct GtComm* comm = nullptr;                   // gt_comm_init: RCCL communicator + comm stream (data parallel)
   struct GtIpc* ipc = nullptr;                     // gt_comm_ipc_*: interprocess arenas of the two-shot all-reduce (eng_ipc.hip)
@@ -409,6 +413,11 @@ int ensure_tv(gt_engine* e, const float* mask, long N, hipStream_t s);
 // eng_lstm.hip / eng_sru.hip
 // ------------------------------------------------------------------------------------------
 int lstm_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s);
+int lstm_check_lengths(gt_engine* e, int B, int T);
+int lstm_stack_forward(gt_engine* e, int role, const float* x, int ld_x, int nseq, int T, const int* passes, int npass, hipStream_t s,
+                       const float** top, int* ld_top);
+int lstm_stack_backward(gt_engine* e, int role, const float* x, int ld_x, int nseq, int T, const int* passes, int npass, bool want_w,
+                        float* dx0, hipStream_t s);
 int lstm_backward(gt_engine* e, const float* x, const float* gy, int B, int T, hipStream_t s);
 int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStream_t s);
 int sru_backward(gt_engine* e, const float* x, const float* gy, int B, int T, hipStream_t s);

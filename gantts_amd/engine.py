@@ -321,13 +321,19 @@ class StepEngine(object):
             raise RuntimeError("mask must have B*T = %d elements, got %s" % (B * T, tuple(mask.shape)))
         return mask
 
-    def update_discriminator(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
+    def _d_lengths(self, model_d, lengths, B, T):
+        """A recurrent discriminator (LSTMRNN in the discriminator slot, train.py:773-774) packs by `lengths` (train.py:262, 268, 307)."""
+        if getattr(model_d, "needs_lengths", False):
+            self.set_lengths(lengths, B, T)
+
+    def update_discriminator(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20, lengths=None):
         y_static = _check_frames(y_static, "y_static")
         y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
         model_d._check_masks(B, T)
+        self._d_lengths(model_d, lengths, B, T)
         self.bind_model(L.ROLE_D, model_d, with_grads=True)
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
@@ -343,7 +349,7 @@ class StepEngine(object):
         return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
 
     def update_generator(self, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
-                         adv_w, mask, phase, mse_w, mge_w, eps=1e-20):
+                         adv_w, mask, phase, mse_w, mge_w, eps=1e-20, lengths=None):
         y = _check_frames(y, "y", model_g.out_dim)
         y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
         y_static = _check_frames(y_static, "y_static")
@@ -356,6 +362,7 @@ class StepEngine(object):
             self.bind_optimizer(L.ROLE_G, optimizer_g)
         if adv_w > 0:
             model_d._check_masks(B, T)
+            self._d_lengths(model_d, lengths, B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
             x = self._cond_x(x, model_d) if self.signature[5] else None
         else:
@@ -380,13 +387,14 @@ class StepEngine(object):
         t = torch.as_tensor(_Arr(), device="cuda")
         return t if which is None else (t[0:4] if which == "D" else t[4:7])
 
-    def update_discriminator_begin(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20):
+    def update_discriminator_begin(self, model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps=1e-20, lengths=None):
         y_static = _check_frames(y_static, "y_static")
         y_hat_static_c = _same_storage(y_hat_static, _check_frames(y_hat_static, "y_hat_static", y_static.size(-1)), "y_hat_static")
         B, T, _ = y_static.shape
         mask = self._mask2d(mask, B, T)
         train = phase == "train"
         model_d._check_masks(B, T)
+        self._d_lengths(model_d, lengths, B, T)
         self.bind_model(L.ROLE_D, model_d, with_grads=True)
         if train:
             self.bind_optimizer(L.ROLE_D, optimizer_d)
@@ -412,7 +420,7 @@ class StepEngine(object):
         return res.loss_d, res.loss_fake_d, res.loss_real_d, res.real_correct_count, res.fake_correct_count
 
     def update_generator_begin(self, model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
-                               adv_w, mask, phase, mse_w, mge_w, eps=1e-20):
+                               adv_w, mask, phase, mse_w, mge_w, eps=1e-20, lengths=None):
         y = _check_frames(y, "y", model_g.out_dim)
         y_hat_c = _check_frames(y_hat, "y_hat", model_g.out_dim)
         y_static = _check_frames(y_static, "y_static")
@@ -425,6 +433,7 @@ class StepEngine(object):
             self.bind_optimizer(L.ROLE_G, optimizer_g)
         if adv_w > 0:
             model_d._check_masks(B, T)
+            self._d_lengths(model_d, lengths, B, T)
             self.bind_model(L.ROLE_D, model_d, with_grads=False)
             x = self._cond_x(x, model_d) if self.signature[5] else None
         else:

@@ -261,13 +261,13 @@ class LSTMRNN(_FlatNetwork):
     def set_dropout_masks(self, pass_index, masks):
         """Parity hook for nn.LSTM's inter-layer dropout: ``masks[l]`` (B,T,H*dirs) 0/1 keep-mask on
         the outputs of layer ``l`` (l < num_hidden-1); entries for the last layer are ignored."""
-        if pass_index != 0:
-            raise ValueError("recurrent generators have a single forward pass (index 0)")
+        if pass_index not in (0, 1, 2):      # (0: a generator's pass / D(real); 1, 2: D(fake) of the D and of the G step -- a recurrent discriminator)
+            raise ValueError("pass_index must be 0, 1 or 2")
         for layer in range(self.num_hidden):
             m = None if masks is None or layer >= len(masks) else masks[layer]
             if m is not None:
                 m = m.to(self._flat.device, torch.float32).contiguous()
-            self._masks[(0, layer)] = m
+            self._masks[(pass_index, layer)] = m
         self._version += 1
 
     def forward(self, sequence, lengths):

@@ -58,7 +58,7 @@ def update_discriminator(model_d, optimizer_d, x, y_static, y_hat_static, length
                          mask, phase, eps=1e-20):
     """Returns ``(loss_d, loss_fake_d, loss_real_d, real_correct_count, fake_correct_count)``."""
     eng = _engine_of(y_hat_static)
-    return eng.update_discriminator(model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps)
+    return eng.update_discriminator(model_d, optimizer_d, x, y_static, y_hat_static, mask, phase, eps, lengths=lengths)
 
 
 def update_generator(model_g, model_d, optimizer_g,
@@ -68,7 +68,7 @@ def update_generator(model_g, model_d, optimizer_g,
     """Returns ``(loss_mse, loss_mge, loss_adv, loss_g)``."""
     eng = _engine_of(y_hat_static, model_g)
     return eng.update_generator(model_g, model_d, optimizer_g, x, y, y_hat, y_static, y_hat_static,
-                                adv_w, mask, phase, mse_w, mge_w, eps)
+                                adv_w, mask, phase, mse_w, mge_w, eps, lengths=lengths)
 
 
 # ---- distortion metrics of the training loop (train.py:358-432) --------------------------------

@@ -135,6 +135,20 @@ CASES = {
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
         update_d=True, update_g=True),
+    # a RECURRENT discriminator (train.py:773-774: getattr(gantts.models, hp.discriminator) -- any model class may sit there): bidirectional
+    # two-layer LSTMRNN(out_dim=1, last_sigmoid=True) scoring [x | static adversarial features] frame by frame, packed by `lengths`
+    "acoustic_lstm_d": dict(
+        hp="tts_acoustic", B=4, T=21, din=30, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="MLP", in_dim=30, out_dim=187, num_hidden=2, hidden_dim=32,
+               dropout=0.0, last_sigmoid=False),
+        d=dict(kind="LSTMRNN", in_dim=88, out_dim=1, num_hidden=2, hidden_dim=12,
+               bidirectional=True, dropout=0.0, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=False,
+        update_d=True, update_g=True),
     # unidirectional single-layer variant under the GRURNN name (an nn.LSTM as attribute `gru`)
     "acoustic_grurnn_uni": dict(
         hp="tts_acoustic", B=3, T=17, din=20, dout=187,
@@ -201,6 +215,21 @@ ORACLE_ONLY_CASES = {
         opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
         opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
         windows=3, steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True,
+        update_d=True, update_g=True),
+    # recurrent generator AND recurrent discriminator, both with nn.LSTM inter-layer dropout in training mode (three injected D passes:
+    # D(real), D(fake) of the D step -- run as ONE batch of 2B sequences by the engine, each half with its own masks -- and D(fake) of the
+    # G step); unidirectional 3-layer D
+    "acoustic_lstm_d_dropout": dict(
+        hp="tts_acoustic", B=4, T=18, din=22, dout=187,
+        stream_sizes=[180, 3, 1, 3], has_dynamic_features=[True, True, False, True],
+        adversarial_streams=[True, False, False, False], mask_nth_mgc=2, cond=True,
+        g=dict(kind="LSTMRNN", in_dim=22, out_dim=187, num_hidden=2, hidden_dim=12,
+               bidirectional=True, dropout=0.3, last_sigmoid=False),
+        d=dict(kind="LSTMRNN", in_dim=80, out_dim=1, num_hidden=3, hidden_dim=20,
+               bidirectional=False, dropout=0.4, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7)),
+        opt_d=("Adam", dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=0)),
+        windows=3, steps=2, adv_w=1.0, mse_w=0.5, mge_w=1.0, dropout_on=True,
         update_d=True, update_g=True),
     # cfg3 (BASELINE.json configs[2]) at its real widths -- BiLSTM 3 x 256 generator, 425 -> 187, conditioned MLP D
     # 483 -> 256 x 3 -> 1, B = 32 (two 16-sequence batch tiles), variable lengths -- with T cut to what the CPU oracle's

@@ -83,7 +83,7 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
     for step in range(case["steps"]):
         if case["dropout_on"] and not philox:
             gm, dm = C.make_dropout_masks(case, step)
-            nh = case["d"]["num_hidden"]
+            nh = len(C.hidden_sites(case["d"]))      # dropout sites of one D pass (an MLP: every hidden layer; nn.LSTM: between layers)
             mg.set_dropout_masks(0, [torch.from_numpy(m[rows]) for m in gm])
             for p in range(3):
                 md.set_dropout_masks(p, [torch.from_numpy(m[rows]) for m in dm[p * nh:(p + 1) * nh]])

@@ -130,11 +130,12 @@ def _check(name, r0, r1, ref):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out", "duration_mlp"])
+@pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out", "duration_mlp", "acoustic_lstm_d"])
 def test_engine_communicator_world_2_equals_whole_batch_reference_golden(name):
     """MLP (one merged upper-layer message + the first layer's), MLP with injected dropout (masks sharded by sequence),
     BiLSTM (a flush per layer: more collectives per step than the 8-event ring holds), In2Out (gate + MLPG inside the
-    model), duration (R = None, Adam): sharded over two ranks == the reference's whole-batch fixture."""
+    model), duration (R = None, Adam), a recurrent DISCRIMINATOR (its layers' gradients leave as one message): sharded over two ranks ==
+    the reference's whole-batch fixture."""
     case = C.CASES[name]
     r0, r1 = _run_world2(case)
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
