@@ -22,11 +22,13 @@ timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --spinup-ms 0 --no-cpu-baseline --no-other-configs > $OUT/bench_driver_nospin.json 2> /dev/null
 timeout 200 python bench.py --steps 50 --warmup 10 --force-dp --no-cpu-baseline > $OUT/bench_force_dp.json 2> $OUT/bench_force_dp.err
+timeout 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/bench_plain2.json 2> /dev/null      # (the plain line again, next to the data-parallel ones)
+timeout 200 python bench.py --steps 50 --warmup 10 --force-dp --dp-ipc --no-cpu-baseline > $OUT/bench_force_dp_ipc.json 2> $OUT/bench_force_dp_ipc.err
 timeout 200 python bench.py --steps 50 --warmup 10 --dense-x --no-cpu-baseline --no-other-configs > $OUT/bench_dense_x.json 2> /dev/null
 for b in 16 8 4; do timeout 200 python bench.py --steps 50 --warmup 10 --batch $b --no-cpu-baseline --no-other-configs > $OUT/bench_b$b.json 2> /dev/null; done
 bash $ROOT/tools/profile_configs.sh $TAG
 cd $ROOT
-for f in bench bench_driver bench_driver_nospin bench_force_dp bench_dense_x bench_b16 bench_b8 bench_b4; do python - <<PY
+for f in bench bench_driver bench_driver_nospin bench_force_dp bench_plain2 bench_force_dp_ipc bench_dense_x bench_b16 bench_b8 bench_b4; do python - <<PY
 import json
 try:
     d=[json.loads(l) for l in open("$OUT/$f.json") if l.startswith("{")][-1]
