@@ -498,7 +498,7 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                     bool unit_tv = false /* seed the backward pass of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS) */,
                     bool has_act = true /* H is LeakyReLU + dropout of a pre-activation (MLP); false: a recurrent stack's output */) {
   Net& D = e->net[GT_ROLE_D];
-  const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
+  const int nblk = (int)std::min<long>(std::max(64, gt_tuning().head_wgs), (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
   CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));

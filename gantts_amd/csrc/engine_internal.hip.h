@@ -82,6 +82,7 @@ struct GtTuning {
   int b16_wg_tile = 0;        // GT_B16_WG_TILE    ... their weight gradients
   int b16_dma = 1;            // GT_B16_DMA        LDS-DMA operand stages
   int mlpg_fpl = 2;           // GT_MLPG_FPL       frames per lane of the MLPG compute phase
+  int head_wgs = 1024;        // GT_HEAD_WGS       discriminator head: at most this many workgroups (each leaves one row of partial sums for the finalisation)
   int head_vec = 0;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units); measured -3 us
                               //                   per step, NOT the default: it sums the row's dot product in another order, and one oracle-only
                               //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4

@@ -96,6 +96,20 @@ __device__ __forceinline__ double mask_total_body(const float* __restrict__ mask
   for (int u = 0; u < 8; ++u) p[u] = 0.f;
   const int bd = blockDim.x;
   int i = threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(mask) & 15) == 0) {      // 16-byte loads, 8 in flight per lane: 32 values per lane and round trip
+    const f32x4* m4 = reinterpret_cast<const f32x4*>(mask);
+    const int n4 = n >> 2;
+    int j = threadIdx.x;
+    for (; j + 7 * bd < n4; j += 8 * bd) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = m4[j + u * bd];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    for (; j < n4; j += bd) { const f32x4 v = m4[j]; p[0] += (v[0] + v[1]) + (v[2] + v[3]); }
+    i = 4 * n4 + threadIdx.x;       // the tail elements
+  }
   for (; i + 7 * bd < n; i += 8 * bd) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) p[u] += mask[i + u * bd];

@@ -1,7 +1,8 @@
 #!/bin/bash
 # scratch driver for one gpurun call (not part of the product; overwritten per experiment)
 set -u
-O=gpurun_out/r4re; mkdir -p $O
+O=gpurun_out/r4fin; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_comm2.py -m gpu -q -k "lstm_d" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -40 $O/pytest.log
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+tail -4 $O/pytest.log; tail -3 $O/smoke.log
