@@ -116,7 +116,8 @@ const char* gt_version(void);
 int gt_engine_create(const gt_stream_config* cfg, gt_engine** out);
 void gt_engine_destroy(gt_engine* e);
 
-/* getattr(gantts.models, name)(**params) + .cuda()            (train.py:773-793) */
+/* getattr(gantts.models, name)(**params) + .cuda()            (train.py:773-793).  GT_ROLE_G: every architecture; GT_ROLE_D: GT_ARCH_MLP
+ * or GT_ARCH_LSTM (an LSTMRNN scoring frames), out_dim 1, last_sigmoid set; other combinations are rejected (GT_ERR_INVALID). */
 int gt_bind_model(gt_engine* e, int role, const gt_model_desc* desc);
 /* getattr(optim, hp.optimizer_*)(model.parameters(), **params) (train.py:796-799) */
 int gt_bind_optimizer(gt_engine* e, int role, const gt_optim_desc* desc);
@@ -143,7 +144,8 @@ int gt_op_philox_mask(gt_engine* e, int role, int pass, int layer, int64_t steps
 
 /* Sequence lengths of the NEXT batch (host int64 array, as the `lengths` list the reference passes to
  * model(x, lengths=lengths), train.py:344; models.py:204-210 pack_padded_sequence).  Needed by the
- * recurrent generators only; MLP ignores lengths like the reference.  Unlike pack_padded_sequence the
+ * recurrent networks only -- a recurrent generator, or an LSTMRNN in the discriminator slot (train.py:262, 268, 307) --; MLP ignores
+ * lengths like the reference.  Unlike pack_padded_sequence the
  * batch need not be sorted.  The array is copied before the call returns; it reaches the device IN STREAM ORDER on
  * `stream` (the stream of the following step functions) through a ring of pinned slots, so the still-queued kernels of
  * the previous step keep reading their own lengths and the host never waits for the GPU here. */
