@@ -95,6 +95,10 @@ def _run_world2(case, philox=False, ipc=False):
     try:
         for _ in procs:
             rank, err, got = outq.get(timeout=420)
+            if ipc and err is not None and ("hipIpcGetMemHandle" in err or "hipIpcOpenMemHandle" in err):
+                # the platform does not hand out / open interprocess handles here (e.g. HSA_ENABLE_IPC_MODE_LEGACY not 0 on a dmabuf-only
+                # driver): the arenas cannot exist, which is an environment property, not a defect of the collective
+                pytest.skip("hipIpc handles are not available on this box: %s" % err.splitlines()[0])
             assert err is None, "rank %d failed: %s" % (rank, err)
             results[rank] = got
     finally:
