@@ -56,9 +56,15 @@ extern "C" int gt_invalidate_mlpg_cache(gt_engine* e) {
 // output frames per workgroup of the MLPG kernels: 32, or 64 (gt_set_tuning("mlpg_tt", 64): half the halo re-reads -- (64 + 2 kb) / 64
 // instead of (32 + 2 kb) / 32 staged rows per output frame -- but one workgroup per CU instead of two).  Measured at cfg2
 // (gpurun_out/r4o, one lease): 1.404 / 1.398 ms with 64 vs 1.393 / 1.398 with 32 -- no gain, 32 stays.
+// 16-frame tiles: twice the workgroups for batches whose 32-frame tiles leave CUs empty (a rank's share of a strong-scaling run:
+// B * ceil(T / 32) = 64 workgroups at 4 sequences of 512 frames), at (16 + 2 kb) / 16 staged rows per output frame.
 static int mlpg_tile_frames(gt_engine* e, int B, int T, size_t lds64) {
-  (void)e; (void)B; (void)T;
-  return gt_tuning().mlpg_tt == 64 && lds64 <= 150 * 1024 ? 64 : 32;
+  (void)e;
+  const int tt = gt_tuning().mlpg_tt;
+  if (tt == 64 && lds64 <= 150 * 1024) return 64;
+  if (tt == 16) return 16;
+  if (tt == 0 && gt_tuning().mlpg_small16 && (long)B * cdiv(T, 32) * 2 <= gemm_cu_count()) return 16;
+  return 32;
 }
 int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const int* sstride, int Ds,
                  float* ys, int ldys, int B, int T, hipStream_t s) {
@@ -71,6 +77,7 @@ int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const i
 #define GT_MLPG_FWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F, TTV>, lds)); \
     hipLaunchKernelGGL((mlpg_forward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
   if (tt == 64) { if (fpl == 1) GT_MLPG_FWD(1, 64) else if (fpl == 4) GT_MLPG_FWD(4, 64) else GT_MLPG_FWD(2, 64) }
+  else if (tt == 16) GT_MLPG_FWD(2, 16)
   else { if (fpl == 1) GT_MLPG_FWD(1, 32) else if (fpl == 2) GT_MLPG_FWD(2, 32) else GT_MLPG_FWD(4, 32) }
 #undef GT_MLPG_FWD
   LAUNCH_CHECK();
@@ -89,6 +96,7 @@ int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, cons
     hipLaunchKernelGGL((mlpg_backward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
                        gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
   if (tt == 64) { if (fpl == 1) GT_MLPG_BWD(1, 64) else if (fpl == 4) GT_MLPG_BWD(4, 64) else GT_MLPG_BWD(2, 64) }
+  else if (tt == 16) GT_MLPG_BWD(2, 16)
   else { if (fpl == 1) GT_MLPG_BWD(1, 32) else if (fpl == 2) GT_MLPG_BWD(2, 32) else GT_MLPG_BWD(4, 32) }
 #undef GT_MLPG_BWD
   LAUNCH_CHECK();

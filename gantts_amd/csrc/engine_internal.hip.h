@@ -86,6 +86,7 @@ struct GtTuning {
   int head_vec = 0;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units); measured -3 us
                               //                   per step, NOT the default: it sums the row's dot product in another order, and one oracle-only
                               //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4
+  int mlpg_small16 = 0;       // GT_MLPG_SMALL16   16-frame MLPG tiles when 32-frame tiles would fill at most half the CUs (mlpg_tt == 0)
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
   int sru_lw = 1;             // GT_SRU_LW         loader-wave SRU scans (0: one-wave kernels, bit-identical results)
 };

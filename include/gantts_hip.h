@@ -239,7 +239,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,
- * stagger_ticks, stagger_mode, b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, mlpg_tt, sru_lw, head_vec, head_wgs; the environment variables GT_<NAME>
+ * stagger_ticks, stagger_mode, b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, mlpg_tt, sru_lw, head_vec, head_wgs, mlpg_small16; the environment variables GT_<NAME>
  * provide the initial values. */
 int gt_set_tuning(const char* name, int value);
 /* Row pitch (in floats) of the input tensors `x` of the step functions, like the `lda` of a BLAS call: ld_generator_input for the
