@@ -409,7 +409,7 @@ def main():
                                       "Adagrad, MGE+ADV loss, global B=%d T=%d (%d sequences per GPU, %s scaling), fp32, "
                                       "dropout 0.5 (Philox)" % (Bglobal, Tn, B, args.scaling),
                           "global_batch": Bglobal, "per_gpu_batch": B, "frames_per_step": Bglobal * Tn,
-                          "parallelism": "dp%d" % world, "collective": "two-shot all-reduce over hipIpc arenas" if args.dp_ipc else "rccl"},
+                          "parallelism": "dp%d" % world, "collective": None if (world == 1 and not args.force_dp) else ("two-shot all-reduce over hipIpc arenas" if args.dp_ipc else "rccl")},
                "step_algorithmic_gflop": step_flops / 1e9,
                "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
