@@ -924,7 +924,7 @@ extern "C" int gt_update_discriminator(gt_engine* e, const float* x, const float
   e->early = true;
   int r = gt_update_discriminator_begin(e, x, y_static, y_hat_static, mask, B, T, train, eps, stream);
   e->early = false;
-  if (r != GT_OK) { e->early_done = false; return r; }
+  if (r != GT_OK) { e->early_done = false; e->d_unnorm = false; e->ticket_wait = 0; return r; }
   return gt_update_discriminator_end(e, train, out, stream);
 }
 
