@@ -581,7 +581,7 @@ static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t
       const long next = i < cov.size() ? cov[i].first : np;
       if (next < pos) { ok = false; break; }                       // overlapping jobs: not this path
       if (next > pos) {
-        if (rest.n_rest == 4) { ok = false; break; }
+        if (rest.n_rest == OPTIM_REST_MAX) { ok = false; break; }
         rest.off[rest.n_rest] = pos; rest.n[rest.n_rest] = next - pos; ++rest.n_rest;
         rest_total += next - pos;
       }

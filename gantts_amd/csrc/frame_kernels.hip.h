@@ -1203,7 +1203,8 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
 // another workgroup's cache: a workgroup's own stores precede its own atomic store in program order.  Same arithmetic per element as the three kernels; the norm is the same fixed-order double sum.
 // Requires gridDim.x workgroups to be co-resident (<= 4 per CU: the launcher's choice).
 // ---------------------------------------------------------------------------------------
-struct OptimRest { long off[4]; long n[4]; int n_rest, pad_; };   // ranges of the flat gradient that no slab job writes
+constexpr int OPTIM_REST_MAX = 12;
+struct OptimRest { long off[OPTIM_REST_MAX]; long n[OPTIM_REST_MAX]; int n_rest, pad_; };   // ranges of the flat gradient that no slab job writes
 constexpr unsigned OPT_FAULT_BARRIER = 0x100u;
 __device__ __forceinline__ double slab_own_block(int pass, int blk, const SlabJob& J, float* __restrict__ p, float* __restrict__ g,
                                                  float* __restrict__ s0, float* __restrict__ s1, float coef, const OptimSpec& o,
