@@ -45,10 +45,11 @@ __device__ __forceinline__ void ipc_wait_all(const unsigned* flag, int world, un
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        atomicOr(fault, IPC_FAULT_TIMEOUT);
-        break;
-      }
+      // an IPC timeout raised by another workgroup of this message ends the wait at once; a FOREIGN fault bit (an earlier,
+      // uncleared recurrence timeout: the step's updates are skipped anyway) does not -- the peers are still coming, and
+      // giving up early would reduce unsynchronised data and mis-report the fault as an interprocess one
+      if ((__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IPC_FAULT_TIMEOUT) != 0u) break;
+      if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS) { atomicOr(fault, IPC_FAULT_TIMEOUT); break; }
     }
   }
   __syncthreads();
@@ -96,6 +97,7 @@ struct GtIpc {
   unsigned seq = 0;
   long long messages = 0;
   bool attached = false;
+  bool fine_grained = false;      // the arena is fine-grained device memory: peers' stores / loads are coherent INSIDE a running kernel
 };
 
 void ipc_destroy(gt_engine* e) {
@@ -141,11 +143,24 @@ extern "C" int gt_comm_ipc_export(gt_engine* e, void* handle_out) {
   ipc_destroy(e);
   GtIpc* c = new GtIpc();
   e->ipc = c;
-  // fine-grained device memory where the runtime offers it (peers then never see a stale cached line); plain device memory otherwise
+  // The two-shot protocol needs visibility INSIDE running kernels: peers store flags into this rank's arena while its reduce /
+  // collect kernels spin on them, and read its in slot mid-kernel.  Only fine-grained device memory gives that across devices
+  // (coarse-grained allocations are coherent at kernel boundaries only: a reader on another device may be served a stale line from
+  // its own L2).  So the export FAILS where the runtime does not offer fine-grained memory -- RCCL then carries every message --
+  // instead of silently falling back to hipMalloc.  GT_IPC_ALLOW_COARSE=1 permits the coarse arena for the one setting
+  // where it is coherent: all ranks on ONE device (one L2 -- the two-process test of tests/test_gpu_comm2.py).
   void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, IPC_ARENA_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
+  if (hipExtMallocWithFlags(&p, IPC_ARENA_BYTES, hipDeviceMallocFinegrained) == hipSuccess) {
+    c->fine_grained = true;
+  } else {
     (void)hipGetLastError();
     p = nullptr;
+    const char* allow = getenv("GT_IPC_ALLOW_COARSE");
+    if (!(allow && atoi(allow) == 1)) {
+      ipc_destroy(e);
+      return fail(GT_ERR_HIP, "gt_comm_ipc_export: no fine-grained device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed): the two-shot "
+                              "all-reduce needs in-kernel cross-device coherence; RCCL stays the collective (GT_IPC_ALLOW_COARSE=1: ranks sharing ONE device only)");
+    }
     if (hipMalloc(&p, IPC_ARENA_BYTES) != hipSuccess) { ipc_destroy(e); return fail(GT_ERR_HIP, "the interprocess arena could not be allocated"); }
   }
   c->arena = (char*)p;
@@ -179,6 +194,10 @@ extern "C" int gt_comm_ipc_attach(gt_engine* e, int rank, int world, const void*
     hipError_t r = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
     if (r != hipSuccess) {
       (void)hipGetLastError();
+      // leave nothing half-mapped: a retry would open the earlier peers' handles a second time
+      for (int q2 = 0; q2 < p; ++q2)
+        if (c->peer[q2] && c->peer[q2] != c->arena) (void)hipIpcCloseMemHandle(c->peer[q2]);
+      for (int q2 = 0; q2 < GT_IPC_MAX_WORLD; ++q2) c->peer[q2] = nullptr;
       return fail(GT_ERR_HIP, "hipIpcOpenMemHandle of rank %d's arena failed: %s", p, hipGetErrorString(r));
     }
     c->peer[p] = (char*)q;

@@ -373,16 +373,45 @@ static int stack_backward_b16(gt_engine* e, int role, const __bf16* in_t, long l
 
 
 // row pitch of the generator's input / of the conditioning x (gt_set_x_pitch; dense by default)
-static int gx_pitch(const gt_engine* e) { return e->ld_gx > 0 ? e->ld_gx : e->net[GT_ROLE_G].d.in_dim; }
+static int gx_pitch(const gt_engine* e) { return (e->ld_gx > 0 && !e->gx_dense_on) ? e->ld_gx : e->net[GT_ROLE_G].d.in_dim; }
 static int cx_pitch(gt_engine* e) { return e->ld_cx > 0 ? e->ld_cx : cond_dim(e); }
+// the generator input as the network can read it: pitched rows (gt_set_x_pitch) stay where they are for the float32 MLP generator;
+// every other generator reads a dense copy made here (the copy is also what its backward pass reads: e->last_x)
+static int dense_gx(gt_engine* e, const float** x, long N, hipStream_t s) {
+  Net& G = e->net[GT_ROLE_G];
+  e->gx_dense_on = false;
+  if (e->ld_gx <= 0 || e->ld_gx == G.d.in_dim) return GT_OK;
+  if (e->ld_gx < G.d.in_dim) return fail(GT_ERR_INVALID, "gt_set_x_pitch: pitch %d for %d generator input columns", e->ld_gx, G.d.in_dim);
+  if (G.d.arch == GT_ARCH_MLP && !use_b16(e, GT_ROLE_G)) return GT_OK;
+  CHK(e->gx_dense.ensure((size_t)N * G.d.in_dim * sizeof(float)));
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * G.d.in_dim, 256)), dim3(256), 0, s, *x, e->ld_gx, 0, (const int*)nullptr,
+                     e->gx_dense.as<float>(), G.d.in_dim, 0, (int)N, G.d.in_dim);
+  LAUNCH_CHECK();
+  *x = e->gx_dense.as<float>();
+  e->gx_dense_on = true;
+  return GT_OK;
+}
+// the conditioning x of the discriminator passes that cannot read pitched rows (no split first layer): a dense copy, once per step
+static int dense_cx(gt_engine* e, const float** x, long N, hipStream_t s) {
+  if (!*x || !e->cfg.discriminator_linguistic_condition || e->ld_cx <= 0 || e->ld_cx == cond_dim(e)) return GT_OK;
+  const int cd = cond_dim(e);
+  if (e->ld_cx < cd) return fail(GT_ERR_INVALID, "gt_set_x_pitch: pitch %d for %d conditioning columns", e->ld_cx, cd);
+  if (!(e->cxd_src == *x && e->cxd_step == e->step_counter && e->cx_dense.p)) {
+    CHK(e->cx_dense.ensure((size_t)N * cd * sizeof(float)));
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * cd, 256)), dim3(256), 0, s, *x, e->ld_cx, 0, (const int*)nullptr,
+                       e->cx_dense.as<float>(), cd, 0, (int)N, cd);
+    LAUNCH_CHECK();
+    e->cxd_src = *x; e->cxd_step = e->step_counter;
+  }
+  *x = e->cx_dense.as<float>();
+  return GT_OK;
+}
 
 static int generator_forward(gt_engine* e, const float* x, const float* R, int B, int T, float* y_hat, float* y_hat_static,
                              bool stash, hipStream_t s, std::vector<DropoutSpec>& specs) {
   Net& G = e->net[GT_ROLE_G];
-  if (gx_pitch(e) != G.d.in_dim && (G.d.arch != GT_ARCH_MLP || use_b16(e, GT_ROLE_G) || gx_pitch(e) < G.d.in_dim))
-    return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense generator input (pitch %d for %d columns) is supported by the float32 MLP generator only",
-                gx_pitch(e), G.d.in_dim);
   const long N = (long)B * T;
+  CHK(dense_gx(e, &x, N, s));
   const int pass0[1] = {0};
   const float* gsrc = y_hat;            // what MLPG is applied to
   if (G.d.arch == GT_ARCH_LSTM) {
@@ -464,7 +493,8 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false;
   e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
-  e->last_x = x; e->last_yhat = y_hat; e->last_yhs = y_hat_static;
+  e->last_x = e->gx_dense_on ? e->gx_dense.as<float>() : x;      // (what the backward pass reads: the dense copy when one was made)
+  e->last_yhat = y_hat; e->last_yhs = y_hat_static;
   e->g_pass_valid = true;
   return GT_OK;
 }
@@ -744,8 +774,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // the [x | adv] image of both halves: real rows, then generated rows
   const bool b16 = use_b16(e, GT_ROLE_D);
   const bool split = d_split_ok(e, x, b16);
-  if (!split && x && e->cfg.discriminator_linguistic_condition && cx_pitch(e) != cond_dim(e))
-    return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense conditioning x is supported by the conditioned float32 discriminator's split first layer only");
+  if (!split) CHK(dense_cx(e, &x, N, s));        // pitched rows are read in place by the split first layer only
   FirstSplit fs;
   memset(&fs, 0, sizeof(fs));
   if (b16) {
@@ -1103,8 +1132,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     const bool b16 = use_b16(e, GT_ROLE_D);
     const float* cat = nullptr;
     const bool split = d_split_ok(e, x, b16);
-    if (!split && x && e->cfg.discriminator_linguistic_condition && cx_pitch(e) != cond_dim(e))
-      return fail(GT_ERR_INVALID, "gt_set_x_pitch: a non-dense conditioning x is supported by the conditioned float32 discriminator's split first layer only");
+    if (!split) CHK(dense_cx(e, &x, N, s));
     FirstSplit fs;
     memset(&fs, 0, sizeof(fs));
     if (split) {     // the generated rows' adversarial columns: kept from the D step of the same batch, or gathered here

@@ -298,6 +298,12 @@ struct gt_engine {
   bool opt_poll_results = env_flag("GT_POLL_RESULTS", false);     // measured: no gain (cfg2 1.380 / 1.384 vs 1.381 / 1.375 ms; b = 4: 0.411 vs 0.417)
   bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
+  // Pitched rows are read in place by the float32 MLP generator and by the split first layer of the conditioned float32 MLP
+  // discriminator.  Every other network gets a DENSE copy made by the engine, once per step (dense_gx / dense_cx in eng_step.hip):
+  // gt_set_x_pitch never makes a step fail (DevicePrefetcher(pitch_x=True) with a recurrent discriminator did).
+  Scratch gx_dense, cx_dense;
+  bool gx_dense_on = false;                        // this step's generator input is the dense copy: gx_pitch() == in_dim
+  const float* cxd_src = nullptr; uint64_t cxd_step = ~0ull;
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word

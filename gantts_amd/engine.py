@@ -278,8 +278,8 @@ class StepEngine(object):
 
     def apply_generator(self, model_g, x, R, lengths=None):
         x, ld = _check_x(x, "x", model_g.in_dim)
-        if ld and (type(model_g).__name__ != "MLP" or self._opt_bf16):
-            x, ld = x.contiguous(), 0            # pitched rows: float32 MLP generators only (gt_set_x_pitch)
+        # pitched rows (gt_set_x_pitch) are read in place by the float32 MLP generator; for every other network the ENGINE makes the
+        # dense copy its kernels read (eng_step.hip: dense_gx), so a pitched batch is valid for any model
         self._set_pitch(gx=ld)
         B, T, _ = x.shape
         model_g._check_masks(B, T)
@@ -308,10 +308,10 @@ class StepEngine(object):
             self._pitch_sent = (self._ld_gx, self._ld_cx)
 
     def _cond_x(self, x, model_d):
-        """The conditioning x of D (train.py:254-256): dense, or pitched rows where the engine takes them (float32 D)."""
+        """The conditioning x of D (train.py:254-256): dense or pitched rows.  The split first layer of the conditioned float32 MLP
+        discriminator reads pitched rows in place; for every other discriminator (recurrent, bf16 storage, split switched off) the
+        engine densifies them once per step (eng_step.hip: dense_cx) -- the decision lives in ONE place, next to d_split_ok()."""
         x, ld = _check_x(x, "x", model_d.in_dim - self._adv_width())
-        if ld and self._opt_bf16:
-            x, ld = x.contiguous(), 0
         self._set_pitch(cx=ld)
         return x
 

@@ -277,7 +277,10 @@ def train_loop(models, optimizers, dataset_loaders, w_d=0.0, mse_w=0.0, mge_w=1.
             regard_fake_as_natural = 0
             N = len(dataset_loaders[phase])
             total_num_frames = 0
-            for batch in DevicePrefetcher(dataset_loaders[phase]):
+            # x is staged on a 16-byte row pitch (gt_set_x_pitch): the layout the engine reads with 16-byte loads in every product --
+            # free here, the batch is being copied anyway, and every network accepts it (others get a dense copy inside the engine);
+            # hp.pitch_x = False restores dense rows
+            for batch in DevicePrefetcher(dataset_loaders[phase], pitch_x=bool(getattr(hp, "pitch_x", True))):
                 x, y, sorted_lengths, cpu_sorted_lengths = batch.x, batch.y, batch.lengths, batch.cpu_lengths
                 max_len = batch.max_len
                 # generator noise z ~ U[0,1) (train.py:504-506), drawn on the device

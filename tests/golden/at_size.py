@@ -64,6 +64,19 @@ _WARM = dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)
 _COLD = dict(lr=0.01, weight_decay=1e-7)      # hparams.py:223-227, 240-244 as they are: torch's default accumulator 0
 
 AT_SIZE_CASES = {
+    # BASELINE.json configs[0] at the size it states (VERDICT r4 missing #2): the VC plumbing configuration -- In2OutHighwayNet
+    # generator 75 -> 512 x 3 -> 75 with static_dim 25 (mgc-only, order 25; gantts/models.py:21-69, hparams.py:38-55) + MLP
+    # discriminator 25 -> 256 x 2 -> 1 (hparams.py:56-64), Adagrad lr 0.01 (hparams.py:50-53, 65-68; warm accumulator like the other
+    # multi-step at-size cases: the cold first step is what cfg2_cold covers), B = 8, T = 256, both dropouts 0.5 with injected masks,
+    # TWO steps.  Source: the REAL reference (0.2 s of CPU per step).
+    "cfg1_vc": dict(
+        hp="vc", B=8, T=256, din=75, dout=75, noise_dim=0, source="reference",
+        stream_sizes=[75], has_dynamic_features=[True], adversarial_streams=[True], mask_nth_mgc=0, cond=False, windows=3,
+        g=dict(kind="In2OutHighwayNet", in_dim=75, out_dim=75, static_dim=25, num_hidden=3, hidden_dim=512, dropout=0.5),
+        d=dict(kind="MLP", in_dim=25, out_dim=1, num_hidden=2, hidden_dim=256, dropout=0.5, last_sigmoid=True),
+        opt_g=("Adagrad", dict(lr=0.01, weight_decay=0, initial_accumulator_value=1e-4)),
+        opt_d=("Adagrad", dict(lr=0.01, weight_decay=0, initial_accumulator_value=1e-4)),
+        steps=2, adv_w=1.0, mse_w=0.0, mge_w=1.0, dropout_on=True, update_d=True, update_g=True),
     # BASELINE.json configs[1], the HEADLINE config exactly as hparams state its optimizers (VERDICT r3 missing #5): MLP G 425 ->
     # 512 x 3 -> 187 + conditioned MLP D 483 -> 256 x 3 -> 1, B = 32, T = 512, Adagrad(lr 0.01, weight_decay 1e-7) with the COLD
     # accumulator (initial_accumulator_value 0: the first update is lr * g / (|g| + 1e-10) = lr * sign(g)), D and G dropout 0.5

@@ -33,6 +33,9 @@ def build_fake_rccl():
 
 def _worker(rank, world, case, idq, outq, philox=False, ipc_qs=None):
     os.environ["GT_RCCL_LIB"] = FAKE
+    # both ranks of these tests share ONE device (one L2): a coarse-grained interprocess arena is coherent there, so the export may
+    # fall back to it where the runtime has no fine-grained memory (gt_comm_ipc_export refuses that fallback by default)
+    os.environ["GT_IPC_ALLOW_COARSE"] = "1"
     os.environ.pop("GT_COMM_FORCE_COLLECTIVES", None)
     import sys
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE, GOLDEN):

@@ -373,6 +373,22 @@ def test_pitched_x_is_bit_identical_to_dense_x(name):
         assert np.array_equal(dense[k], pitched[k]), k
 
 
+@pytest.mark.parametrize("name,options", [("acoustic_lstm_d", None), ("acoustic_lstm", None), ("vc_in2out", None), ("acoustic_grurnn_uni", None),
+                                          ("acoustic_chain_d", {"split_first_layer": 0}), ("acoustic_mlp_dropout", {"matmul_bf16": 1})])
+def test_pitched_x_is_accepted_by_every_network(name, options):
+    """a batch staged by DevicePrefetcher(pitch_x=True) -- what train_loop hands over by default -- must be a valid
+    input for EVERY network, not only for the float32 MLP pair whose kernels read pitched rows in place: a recurrent generator or
+    discriminator (LSTMRNN in the discriminator slot), In2OutHighwayNet, a discriminator with the split first layer switched off,
+    bf16 storage.  The engine makes the dense copy those paths read (eng_step.hip: dense_gx / dense_cx); results are bit-identical
+    to handing over dense rows."""
+    from hip_runner import run_hip_case
+    case = C.CASES[name]
+    dense, pitched = run_hip_case(case, engine_options=options), run_hip_case(case, engine_options=options, pitch_x=True)
+    assert set(dense) == set(pitched)
+    for k in dense:
+        assert np.array_equal(dense[k], pitched[k]), k
+
+
 @pytest.mark.parametrize("name", ["acoustic_mlp", "acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm"])
 def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
     """GT_OPT_SPLIT_FIRST_LAYER (x . W_x^T once per D step + adv . W_adv^T, weight gradient with the two halves summed in the
@@ -687,10 +703,11 @@ def _close_arbiter(got, ref32, ref64, msg, factor=ARBITER_FACTOR, floor=ARBITER_
         msg, err, lim, e32, worst)
 
 
-@pytest.mark.parametrize("tag,B,Tn,gh,dh", [("cfg2-full-size", 32, 512, 512, 256),
-                                             ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250),
-                                             ("64-row-tiles", 4, 200, 256, 128)])
-def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh):
+@pytest.mark.parametrize("tag,B,Tn,gh,dh,x_layout", [("cfg2-full-size", 32, 512, 512, 256, "dense"),
+                                                      ("cfg2-full-size-pitched-x", 32, 512, 512, 256, "pitched"),
+                                                      ("ragged-tiles-narrow-epilogue", 3, 171, 130, 250, "dense"),
+                                                      ("64-row-tiles", 4, 200, 256, 128, "dense")])
+def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh, x_layout):
     """The path bench.py times: dropout 0.5 ON through the engine's own Philox stream (no injected masks on the HIP
     side).  The keep masks the engine is about to use are dumped through gt_op_philox_mask -- the layout-independent
     definition philox_keep(row, col) -- and handed to the CPU oracle as its nn.Dropout masks (the oracle is pinned to
@@ -727,6 +744,12 @@ def test_philox_dropout_step_matches_oracle_with_dumped_masks(tag, B, Tn, gh, dh
     eng = engine_for(hp, mg)
     eng.set_seed(1234)
     x, y, R = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda(), torch.from_numpy(R_np).cuda()
+    if x_layout == "pitched":       # the layout bench.py times and train_loop stages (DevicePrefetcher(pitch_x=True); gt_set_x_pitch)
+        from gantts_amd.engine import pitched_empty
+        xp = pitched_empty(B, Tn, 425)
+        xp.copy_(x)
+        x = xp
+        assert x.stride(1) == 428 and not x.is_contiguous()
     ys = get_static_features(y, 3, hp.stream_sizes, hp.has_dynamic_features)
     mask = sequence_mask(torch.from_numpy(lengths).cuda()).unsqueeze(-1)
     hip, masks = [], []
