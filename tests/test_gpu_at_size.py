@@ -243,9 +243,10 @@ def test_at_size_step_matches_fixture(name):
 #                      measured:  y_hat    y_hat_static  Ggrad    Gupd     Dgrad    Dupd     losses
 #   cfg3_lstm (T = 1024)          2.3e-3   2.2e-3        3.8e-3   4.3e-3   2.1e-2   2.0e-2   < 1e-3
 #   cfg5_acoustic (B = 64)        4.3e-3   3.4e-3        2.1e-2   3.8e-2   1.9e-2   1.5e-2   < 1e-3
-#   cfg4_sru (B = 16, T = 2048)   (round 5: profiles/r05_parity_report.txt; against the ORACLE's float64 digest -- un-vendored SRU cell, parity unpinned)
+#   cfg4_sru (B = 16, T = 2048)   3.0e-3   2.3e-3        8.9e-3   7.0e-3   9.6e-3   9.3e-3   7.1e-5   (round 5: profiles/r05_parity_report.txt;
+#                                 against the ORACLE's float64 digest -- un-vendored SRU cell, parity unpinned)
 BF16_LIMITS = {
-    "cfg4_sru": {"y_hat": 2e-2, "y_hat_static": 2e-2, "Ggrad": 8e-2, "Gupd": 8e-2, "Dgrad": 8e-2, "Dupd": 8e-2, "scalars": 2e-2},
+    "cfg4_sru": {"y_hat": 5.9e-3, "y_hat_static": 4.6e-3, "Ggrad": 1.8e-2, "Gupd": 1.4e-2, "Dgrad": 1.9e-2, "Dupd": 1.9e-2, "scalars": 5e-3},
     "cfg3_lstm": {"y_hat": 4.6e-3, "y_hat_static": 4.4e-3, "Ggrad": 7.6e-3, "Gupd": 8.6e-3, "Dgrad": 4.2e-2, "Dupd": 4.0e-2, "scalars": 5e-3},
     "cfg5_acoustic": {"y_hat": 8.6e-3, "y_hat_static": 6.8e-3, "Ggrad": 4.2e-2, "Gupd": 7.6e-2, "Dgrad": 3.9e-2, "Dupd": 3.1e-2, "scalars": 5e-3},
 }
