@@ -15,7 +15,7 @@ ROLE_G, ROLE_D = 0, 1
 OPT_LSTM_PERSISTENT, OPT_LSTM_FWD_UNITS, OPT_LSTM_XCD_LOCAL, OPT_MATMUL_BF16, OPT_SPLIT_FIRST_LAYER, OPT_FUSED_OPTIMIZER = 2, 3, 4, 5, 6, 7
 OPT_SIDE_OVERLAP, OPT_LSTM_SIDE, OPT_COMM_D_ONE_MSG, OPT_COMM_EARLY_G, OPT_COMM_GROUP, OPT_COMM_FORCE = 8, 9, 10, 11, 12, 13
 OPT_LAUNCH_RIDERS, OPT_COMM_CLOSE_INLINE, OPT_POLL_RESULTS = 14, 15, 16
-OPT_COMM_TV_IN_SUMS, OPT_COMM_IPC = 17, 18
+OPT_COMM_TV_IN_SUMS, OPT_COMM_IPC, OPT_FUSED_DSTACK = 17, 18, 19
 IPC_HANDLE_BYTES, IPC_MAX_WORLD = 64, 8
 PROFILE_SLOTS = 16
 ARCH_MLP, ARCH_IN2OUT, ARCH_LSTM, ARCH_SRU, ARCH_IN2OUT_RNN = 0, 1, 2, 3, 4

@@ -1,5 +1,6 @@
 // libgantts_hip.so -- the G+D step: MLPG, MLP stacks, apply_generator / update_discriminator / update_generator (reference train.py:245-355), plain forward
 #include "engine_internal.hip.h"
+#include "dstack_f32.hip.h"
 
 using namespace gt;
 // ------------------------------------------------------------------------------------------
@@ -158,7 +159,8 @@ static int pitched_rows(gt_engine* e, int slot, const float* p, int ld, int cols
 // hidden stack forward: in -> acts[0..L-1]; returns specs used (for backward)
 static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, long rows, std::vector<Scratch>& acts,
                          const int* passes, int npass, long rows_each, std::vector<DropoutSpec>& specs, hipStream_t s,
-                         const FirstSplit* fs = nullptr) {
+                         const FirstSplit* fs = nullptr, int max_layers = 1 << 30 /* launch only the first max_layers layers (the dropout
+                         sites and the stash buffers of ALL layers are still set up: the fused stack launch takes over from there) */) {
   Net& n = e->net[role];
   specs.resize(n.hidden.size());
   const float* cur = in;
@@ -169,6 +171,7 @@ static int stack_forward(gt_engine* e, int role, const float* in, int ld_in, lon
     const float* inj = nullptr;
     CHK(stage_injected(e, role, (int)l, passes, npass, rows_each, L.out, &inj, s));
     specs[l] = drop_spec(e, role, passes[0], (int)l, inj, L.out, npass == 2 ? rows_each : 0);
+    if ((int)l >= max_layers) continue;
     if (l == 0 && fs && specs[l].mode == DROP_PHILOX && gt_tuning().split_fused && gemm_vec_ok(fs->x, fs->ldx, true) &&
         gemm_vec_ok(L.W, L.in, true) && gemm_vec_ok(fs->adv, fs->ld_adv, true) && fs->wrap > 64 && gemm_small_tiles_ok() &&
         tl_gemm_prec == PREC_F32 && (rows == fs->wrap || rows == 2 * fs->wrap)) {
@@ -526,6 +529,59 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
   return GT_OK;
 }
 
+// the head's per-workgroup partials (e->headp, e->headw: nblk of them) -> the step's scalars and d last_linear
+static int head_finalize(gt_engine* e, int mode, int nblk, int K, bool w, hipStream_t s, StepResults* early_res, int* defer_scalars, unsigned ticket) {
+  Net& D = e->net[GT_ROLE_D];
+  if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
+                     early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
+  LAUNCH_CHECK();
+  return GT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused discriminator stack (dstack_f32.hip.h): layers 1 .. L-1 + head (+ the generator step's backward-data chain) in one launch
+// ------------------------------------------------------------------------------------------
+static bool d_fused_ok(gt_engine* e, bool b16) {
+  Net& D = e->net[GT_ROLE_D];
+  if (!e->opt_fused_dstack || b16 || D.d.arch != GT_ARCH_MLP || tl_gemm_prec != PREC_F32 || !dstack_hidden_ok(D.d.hidden_dim)) return false;
+  if (D.hidden.empty() || (int)D.hidden.size() > DS_MAXL || D.last.out != 1 || e->Da < 1 || e->Da > 64) return false;
+  for (size_t l = 0; l < D.hidden.size(); ++l)
+    if (D.hidden[l].out != D.d.hidden_dim || (l > 0 && D.hidden[l].in != D.d.hidden_dim)) return false;
+  return true;
+}
+// mode DSTACK_D_STEP: rows = 2N (natural then generated), writes the stashes e->d_act[1 ..], the seed gradient e->dzA and the head's
+// partials, then finalises them (as run_head does).  mode DSTACK_G_ADV: rows = N, writes gadv (want_grad) and the partials.
+static int run_dstack(gt_engine* e, int mode, long rows, long n_real, const float* mask, long n_mask, float eps, bool want_grad,
+                      float* gadv, hipStream_t s, StepResults* early_res, int* defer_scalars, const double* tv_dev, unsigned ticket, bool unit_tv) {
+  Net& D = e->net[GT_ROLE_D];
+  const int H = D.d.hidden_dim, L = (int)D.hidden.size();
+  const int nblk = dstack_panels(rows);
+  CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
+  CHK(e->dout.ensure((size_t)rows * sizeof(float)));
+  DStackArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mode = mode; a.L = L; a.rows = (int)rows; a.n_real = (int)n_real;
+  a.H0 = e->d_act[0].as<float>();
+  for (int l = 0; l < L; ++l) {
+    a.W[l] = D.hidden[l].W; a.b[l] = D.hidden[l].b; a.drop[l] = e->d_specs[l];
+    if (a.drop[l].mode == DROP_BUFFER && a.drop[l].ld_mask != H) return fail(GT_ERR_INVALID, "injected dropout mask pitch");
+  }
+  a.w_last = D.last.W; a.b_last = D.last.b; a.mask = mask; a.n_mask = (int)n_mask; a.eps = eps; a.unit_tv = unit_tv ? 1 : 0; a.tv_dev = tv_dev;
+  a.sc = e->sc(); a.want_grad = want_grad ? 1 : 0; a.Dout = e->dout.as<float>(); a.hp = e->headp.as<HeadPartials>();
+  if (mode == DSTACK_D_STEP) {
+    for (int l = 1; l < L; ++l) a.Hout[l] = e->d_act[l].as<float>();
+    a.dZtop = e->dzA.as<float>();
+    if (want_grad) { CHK(e->headw.ensure((size_t)nblk * H * sizeof(float))); a.dw_partial = e->headw.as<float>(); }
+  } else {
+    a.W0 = D.hidden[0].W; a.ldw0 = D.hidden[0].in; a.col0 = cond_dim(e); a.Da = e->Da; a.gadv = gadv; a.ld_gadv = e->Da;
+    if (want_grad && !gadv) return fail(GT_ERR_INVALID, "fused discriminator stack: no gradient buffer");
+  }
+  CHK(launch_dstack(a, H, s));
+  return head_finalize(e, mode == DSTACK_D_STEP ? HEAD_D_STEP : HEAD_G_ADV, nblk, H, mode == DSTACK_D_STEP && want_grad, s, early_res, defer_scalars, ticket);
+}
+
 // H: the top hidden activation, float32 [n_rows][K] or (h_ld > 0) its bf16 image with row pitch h_ld
 static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, long n_real, const float* mask, long n_mask,
                     float eps, bool want_grad, float* dH, const DropoutSpec& spec, bool want_w, hipStream_t s,
@@ -562,13 +618,7 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
   else return fail(GT_ERR_INVALID, "discriminator hidden_dim > 1024 is not supported by the fused head kernel");
 #undef GT_HEAD_LAUNCH
   LAUNCH_CHECK();
-  const bool w = want_grad && want_w;
-  if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
-  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
-                     nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
-                     early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
-  LAUNCH_CHECK();
-  return GT_OK;
+  return head_finalize(e, mode, nblk, K, want_grad && want_w, s, early_res, defer_scalars, ticket);
 }
 
 static int optimizer_step(gt_engine* e, int role, double* norm2_out, hipStream_t s) {
@@ -826,6 +876,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // a recurrent discriminator (LSTMRNN in the discriminator slot, train.py:773-774): the natural and the generated sequences run as ONE
   // batch of 2B sequences through its stack (lengths twice), the fused head reads the top layer's output (hidden2out is its weight)
   const bool d_rec = has_lstm_body(D.d.arch);
+  const bool fused = !d_rec && d_fused_ok(e, b16);        // layers 1 .. L-1 + the head as ONE launch (dstack_f32.hip.h)
   const float* rec_top = nullptr;
   int rec_ld = 0;
   if (d_rec) {
@@ -835,7 +886,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     CHK(refresh_shadows(e, GT_ROLE_D, false, s));
     CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r(), e->dcat_b.ld, 2 * N, e->d_actb, passes, 2, N, e->d_specs, tr, s));
   } else {
-    CHK(stack_forward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s, split ? &fs : nullptr));
+    CHK(stack_forward(e, GT_ROLE_D, split ? nullptr : e->dcat.as<float>(), ldc, 2 * N, e->d_act, passes, 2, N, e->d_specs, s, split ? &fs : nullptr,
+                      fused ? 1 : 1 << 30));
   }
   const int H = d_rec ? rec_ld : D.d.hidden_dim;
   if (d_rec) CHK(e->dl_dout.ensure((size_t)2 * 2 * N * H * sizeof(float)));
@@ -861,6 +913,8 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   if (d_rec)
     CHK(run_head(e, HEAD_D_STEP, (const void*)rec_top, H, 2 * N, N, mask, N, eps, tr, e->dl_dout.as<float>(), no_drop(), true, s,
                  plain_early ? early_res_target(e) : nullptr, 0, nullptr, true, nullptr, head_tv, d_ticket, unnorm, false));
+  else if (fused)
+    CHK(run_dstack(e, DSTACK_D_STEP, 2 * N, N, mask, N, eps, tr, nullptr, s, plain_early ? early_res_target(e) : nullptr, nullptr, head_tv, d_ticket, unnorm));
   else
   CHK(run_head(e, HEAD_D_STEP, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, 2 * N, N, mask, N, eps, tr,
                e->dzA.as<float>(), e->d_specs.back(), true, s, plain_early ? early_res_target(e) : nullptr, b16 ? e->d_actb.back().ld : 0,
@@ -1155,6 +1209,8 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       cat = e->dcat.as<float>() + N * ldc;
     }
     const bool d_rec = has_lstm_body(D.d.arch);
+    // layers 1 .. L-1, the head and the backward-data chain down to the adversarial columns as ONE launch (dstack_f32.hip.h)
+    const bool fused = !d_rec && d_fused_ok(e, b16);
     const float* rec_top = nullptr;
     int rec_ld = 0;
     if (d_rec) {
@@ -1176,12 +1232,16 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       CHK(refresh_shadows(e, GT_ROLE_D, false, s));        // D has just been stepped (train.py:276 before :307)
       CHK(stack_forward_b16(e, GT_ROLE_D, e->dcat_b.r() + N * e->dcat_b.ld, e->dcat_b.ld, N, e->d_actb, passes, 1, N, e->d_specs, false, s));
     } else {
-      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s, split ? &fs : nullptr));
+      CHK(stack_forward(e, GT_ROLE_D, cat, ldc, N, e->d_act, passes, 1, N, e->d_specs, s, split ? &fs : nullptr, fused ? 1 : 1 << 30));
     }
     const int H = d_rec ? rec_ld : D.d.hidden_dim;
     CHK(e->dzA.ensure((size_t)2 * N * H * sizeof(float)));
     CHK(e->dzB.ensure((size_t)2 * N * H * sizeof(float)));
     if (b16 && tr) CHK(e->dz_b[0].ensure(N, H, false));
+    if (fused) {
+      if (tr) { CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float))); gadv = e->gadv.as<float>(); }
+      CHK(run_dstack(e, DSTACK_G_ADV, N, N, mask, N, eps, tr, gadv, s, nullptr, riders || riders_dp ? &head_blocks : nullptr, nullptr, 0, false));
+    } else
     if (d_rec) {
       CHK(e->dl_dout.ensure((size_t)2 * N * H * sizeof(float)));
       CHK(run_head(e, HEAD_G_ADV, (const void*)rec_top, H, N, N, mask, N, eps, tr, e->dl_dout.as<float>(), no_drop(), false, s, nullptr, 0, nullptr,
@@ -1190,7 +1250,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     CHK(run_head(e, HEAD_G_ADV, b16 ? (const void*)e->d_actb.back().r() : (const void*)e->d_act.back().as<float>(), H, N, N, mask, N, eps, tr,
                  e->dzA.as<float>(), e->d_specs.back(), false, s, nullptr, b16 ? e->d_actb.back().ld : 0, (b16 && tr) ? &e->dz_b[0] : nullptr, false,
                  riders || riders_dp ? &head_blocks : nullptr));
-    if (tr) {
+    if (tr && !fused) {
       CHK(e->gadv.ensure((size_t)N * e->Da * sizeof(float)));
       gadv = e->gadv.as<float>();
       const int col0 = cond_dim(e);

@@ -280,6 +280,9 @@ struct gt_engine {
   struct Pitched { Scratch buf; const float* src = nullptr; int ld = 0, cols = 0; long rows = 0; uint64_t step = ~0ULL; };
   Pitched pitched[2];                              // 16-byte-pitch copies of caller tensors (slot 0: D's x, 1: G's input), once per step
   // GT_OPT_SPLIT_FIRST_LAYER / GT_OPT_FUSED_OPTIMIZER (per engine; the environment only provides the default at creation)
+  // GT_OPT_FUSED_DSTACK: the float32 MLP discriminator's layers above the first one + the head (+, in the generator step, the
+  // backward-data chain down to the adversarial columns) as ONE launch per pass (dstack_f32.hip.h)
+  bool opt_fused_dstack = env_flag("GT_FUSED_DSTACK", true);
   bool opt_split_first = env_flag("GT_D_SPLIT", true);
   bool opt_fused_optimizer = env_flag("GT_OPT_FUSED", false);      // measured slower: off
   bool opt_side_overlap = env_flag("GT_SIDE_OVERLAP", false);      // GT_OPT_SIDE_OVERLAP: tv / MSE kernels on the side stream (measured slower: off)
@@ -349,6 +352,11 @@ extern thread_local int tl_gemm_prec;
 bool gemm_vec_ok(const float* p, int ld, bool k_contiguous = false);
 bool gemm_wide_store_ok(int kind, const gt::GemmArgs& g);
 bool gemm_small_tiles_ok();
+// fused discriminator stack (eng_dstack.hip, dstack_f32.hip.h)
+namespace gt { struct DStackArgs; }
+bool dstack_hidden_ok(int hidden_dim);
+int dstack_panels(long rows);
+int launch_dstack(const gt::DStackArgs& a, int hidden_dim, hipStream_t s);
 gt::DropoutSpec no_drop();
 int launch_gemm(int kind, const gt::GemmArgs& g, int nslab, hipStream_t s);
 int linear_forward(const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int ldy,

@@ -243,7 +243,7 @@ class StepEngine(object):
                 "comm_d_one_msg": L.OPT_COMM_D_ONE_MSG, "comm_early_g": L.OPT_COMM_EARLY_G, "comm_group": L.OPT_COMM_GROUP,
                 "comm_force": L.OPT_COMM_FORCE, "launch_riders": L.OPT_LAUNCH_RIDERS,
                 "comm_close_inline": L.OPT_COMM_CLOSE_INLINE, "poll_results": L.OPT_POLL_RESULTS,
-                "comm_tv_in_sums": L.OPT_COMM_TV_IN_SUMS, "comm_ipc": L.OPT_COMM_IPC}
+                "comm_tv_in_sums": L.OPT_COMM_TV_IN_SUMS, "comm_ipc": L.OPT_COMM_IPC, "fused_dstack": L.OPT_FUSED_DSTACK}
         if name not in opts:
             raise ValueError("unknown engine option %r" % (name,))
         check(lib.gt_set_option(self._h, opts[name], int(value)))

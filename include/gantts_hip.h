@@ -236,6 +236,12 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 #define GT_OPT_POLL_RESULTS 16
 #define GT_OPT_COMM_TV_IN_SUMS 17
 #define GT_OPT_COMM_IPC 18
+/* GT_OPT_FUSED_DSTACK (default 1): the float32 MLP discriminator (gantts/models.py:121-141; hidden_dim 128 or 256, <= 4 hidden
+ * layers) runs its hidden layers above the first one, last_linear + sigmoid + the BCE terms (train.py:261-271) and -- in the
+ * generator step (train.py:307-308) -- the whole backward-data chain down to the adversarial input columns as ONE launch per pass,
+ * panel of 32 frames by panel, activations resident in LDS.  0 = one launch per layer + the head kernel.  Same sums up to float32
+ * association. */
+#define GT_OPT_FUSED_DSTACK 19
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,

@@ -54,6 +54,30 @@ def _close(a, b, rtol=RTOL, atol=1e-6, msg="", frac_ok=0.0):
         msg, bad, worst, rtol, atol)
 
 
+def _kink_frac(case):
+    """Fraction of a parameter tensor's elements that may sit outside the flat 1e-4 because of LeakyReLU slope flips, for the
+    small-case comparisons that have no float64 arbiter.  LeakyReLU is differentiated by the sign of its stored output
+    (gantts/models.py:132): a pre-activation within rounding (~1e-7 relative) of 0 picks slope 1 or 0.01, so two correct float32
+    evaluations with different summation orders disagree on a given activation with probability p ~ 1e-7 (measured by the slope
+    census of the at-size fixtures, tests/golden/at_size.py), and each disagreement moves the gradient of ONE unit's bias (and its
+    weight row) by about one frame's dZ -- about 1 % of an element that is a sum over thousands of frames with random signs.  A case
+    with more than 1e6 LeakyReLU activations (cfg3 / cfg4 widths at T ~ 64 .. 96: 1.4e7) expects about one flip per run; cases
+    below that get the flat rule.  Returns (frac_ok, worst_ok)."""
+    acts = 0
+    for spec, passes in ((case["g"], 1), (case["d"], 3)):
+        if spec["kind"] in ("MLP", "In2OutHighwayNet"):
+            acts += case["B"] * case["T"] * spec["hidden_dim"] * spec["num_hidden"] * passes * case["steps"]
+    return (0.01, 20.0) if acts > 1e6 else (0.0, 0.0)
+
+
+def _close_kink(a, b, msg, frac_ok, worst_ok, **kw):
+    """_close with the documented LeakyReLU-flip allowance: at most frac_ok of the elements outside, none by more than worst_ok x."""
+    if frac_ok <= 0.0:
+        return _close(a, b, msg=msg, **kw)
+    _close(a, b, msg=msg, frac_ok=frac_ok, **kw)
+    _close(a, b, msg=msg + " (worst element)", rtol=kw.pop("rtol", RTOL) * worst_ok, **kw)
+
+
 def _close_state(got, ref, msg):
     """Optimizer state at the suite's 1e-4: first moments (Adam exp_avg) directly; second moments (Adagrad `sum`, Adam
     `exp_avg_sq`) are sums of SQUARED gradients -- a gradient that is right to 1e-4 gives a second moment that is right to
@@ -412,6 +436,37 @@ def test_split_first_layer_and_fused_optimizer_match_the_plain_launches(name):
         else:
             _close(on[k], off[k], msg=k)
         _close(fused_only[k], off[k], rtol=2e-6, atol=1e-9, msg="fused optimizer " + k)
+
+
+@pytest.mark.parametrize("name,philox", [("acoustic_chain_d", False), ("acoustic_chain_d", True), ("acoustic_chain_d_uncond", False),
+                                         ("acoustic_sru_at_size", False), ("acoustic_lstm_at_size", False)])
+def test_fused_discriminator_stack_matches_the_per_layer_launches(name, philox):
+    """GT_OPT_FUSED_DSTACK (dstack_f32.hip.h): the MLP discriminator's layers above the first one + head (+ the generator step's
+    backward-data chain down to the adversarial columns) as ONE launch per pass, against one launch per layer + d_head_kernel.
+    The reference goldens hold for the default (fused) setting (test_step_matches_reference_golden, the at-size fixtures); here the
+    two settings are compared with each other at 1e-4, counts exactly: injected masks (3 x 128 conditioned, ragged last panel of
+    10 rows), the engine's own Philox bits (the same bits must be drawn whatever the tiling), no dropout (2 x 128 unconditioned),
+    3 x 256 behind recurrent generators."""
+    from hip_runner import run_hip_case
+    case = (C.CASES if name in C.CASES else C.ORACLE_ONLY_CASES)[name]
+    on = run_hip_case(case, engine_options={"fused_dstack": 1}, philox=philox)
+    off = run_hip_case(case, engine_options={"fused_dstack": 0}, philox=philox)
+    assert set(on) == set(off)
+    frac_ok, worst_ok = _kink_frac(case)      # the two settings sum the pre-activations in different orders: LeakyReLU flips at these sizes
+    for k in off:
+        if "scalars" in k:
+            _close(on[k], off[k], msg=k)
+            if k.startswith("d_scalars"):
+                assert on[k][3] == off[k][3] and on[k][4] == off[k][4], k
+        elif ".opt." in k and frac_ok > 0.0:
+            sq = ".opt.sum." in k or ".opt.exp_avg_sq." in k
+            _close_kink(np.sqrt(np.maximum(on[k], 0.0)) if sq else on[k], np.sqrt(np.maximum(off[k], 0.0)) if sq else off[k], k, frac_ok, worst_ok, atol=1e-9)
+        elif ".opt." in k:
+            _close_state(on[k], off[k], k)
+        elif k.startswith(("G.", "D.")):
+            _close_kink(on[k], off[k], k, frac_ok, worst_ok)
+        else:
+            _close(on[k], off[k], msg=k)
 
 
 @pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm", "duration_mlp", "vc_in2out"])
@@ -891,13 +946,21 @@ def test_oracle_only_step_matches_oracle(name):
     from oracle_runner import run_oracle_case
     case = C.ORACLE_ONLY_CASES[name]
     got, ref = run_hip_case(case), run_oracle_case(case)
+    frac_ok, worst_ok = _kink_frac(case)      # (parameters / optimizer state of the at-size cases: see _kink_frac)
     for k, r in ref.items():
         if k.startswith("g_leak_norm"):
             continue
         if "scalars" in k:
             _close(got[k], r, msg=k)
         elif ".opt." in k:
-            _close_state(got[k], r, k)
+            if frac_ok > 0.0 and (".opt.sum." in k or ".opt.exp_avg_sq." in k):
+                _close_kink(np.sqrt(np.maximum(got[k], 0.0)), np.sqrt(np.maximum(r, 0.0)), k + " (sqrt)", frac_ok, worst_ok, atol=1e-9)
+            elif frac_ok > 0.0:
+                _close_kink(got[k], r, k, frac_ok, worst_ok, atol=1e-9)
+            else:
+                _close_state(got[k], r, k)
+        elif k.startswith(("G.", "D.")):
+            _close_kink(got[k], r, k, frac_ok, worst_ok)
         else:
             _close(got[k], r, msg=k)
 
