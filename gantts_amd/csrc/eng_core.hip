@@ -368,7 +368,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
     case GT_OPT_COMM_FORCE: e->opt_comm_force = value != 0; return GT_OK;
     case GT_OPT_COMM_CLOSE_INLINE: e->opt_comm_close_inline = value != 0; return GT_OK;
     case GT_OPT_COMM_IPC: e->opt_comm_ipc = value != 0; return GT_OK;
-    case GT_OPT_FUSED_DSTACK: e->opt_fused_dstack = value != 0; return GT_OK;
+    case GT_OPT_FUSED_DSTACK: e->opt_fused_dstack = value < 0 ? 0 : value > 2 ? 2 : value; return GT_OK;
     case GT_OPT_COMM_TV_IN_SUMS: e->opt_comm_tv_in_sums = value != 0; return GT_OK;
     case GT_OPT_POLL_RESULTS: e->opt_poll_results = value != 0; return GT_OK;
     case GT_OPT_LAUNCH_RIDERS: e->opt_launch_riders = value != 0; return GT_OK;

@@ -543,8 +543,13 @@ static int head_finalize(gt_engine* e, int mode, int nblk, int K, bool w, hipStr
 // ------------------------------------------------------------------------------------------
 // fused discriminator stack (dstack_f32.hip.h): layers 1 .. L-1 + head (+ the generator step's backward-data chain) in one launch
 // ------------------------------------------------------------------------------------------
-static bool d_fused_ok(gt_engine* e, bool b16) {
+// rows: frames of the pass.  A panel is walked through all layers by ONE workgroup (about 60 us of latency at 3 x 256): the fused
+// launch pays when the pass has at least one panel per CU; below that (per-rank batches of a few sequences) the per-layer launches,
+// which spread every layer over all CUs, are faster (b = 4: 0.413 vs 0.417 ms per step).  GT_OPT_FUSED_DSTACK = 2 forces the fused
+// path at any size (tests).
+static bool d_fused_ok(gt_engine* e, bool b16, long rows) {
   Net& D = e->net[GT_ROLE_D];
+  if (e->opt_fused_dstack < 2 && dstack_panels(rows) < gemm_cu_count()) return false;
   if (!e->opt_fused_dstack || b16 || D.d.arch != GT_ARCH_MLP || tl_gemm_prec != PREC_F32 || !dstack_hidden_ok(D.d.hidden_dim)) return false;
   if (D.hidden.empty() || (int)D.hidden.size() > DS_MAXL || D.last.out != 1 || e->Da < 1 || e->Da > 64) return false;
   for (size_t l = 0; l < D.hidden.size(); ++l)
@@ -876,7 +881,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
   // a recurrent discriminator (LSTMRNN in the discriminator slot, train.py:773-774): the natural and the generated sequences run as ONE
   // batch of 2B sequences through its stack (lengths twice), the fused head reads the top layer's output (hidden2out is its weight)
   const bool d_rec = has_lstm_body(D.d.arch);
-  const bool fused = !d_rec && d_fused_ok(e, b16);        // layers 1 .. L-1 + the head as ONE launch (dstack_f32.hip.h)
+  const bool fused = !d_rec && d_fused_ok(e, b16, 2 * N);        // layers 1 .. L-1 + the head as ONE launch (dstack_f32.hip.h)
   const float* rec_top = nullptr;
   int rec_ld = 0;
   if (d_rec) {
@@ -1210,7 +1215,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
     }
     const bool d_rec = has_lstm_body(D.d.arch);
     // layers 1 .. L-1, the head and the backward-data chain down to the adversarial columns as ONE launch (dstack_f32.hip.h)
-    const bool fused = !d_rec && d_fused_ok(e, b16);
+    const bool fused = !d_rec && d_fused_ok(e, b16, N);
     const float* rec_top = nullptr;
     int rec_ld = 0;
     if (d_rec) {

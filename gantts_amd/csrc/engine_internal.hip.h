@@ -282,7 +282,7 @@ struct gt_engine {
   // GT_OPT_SPLIT_FIRST_LAYER / GT_OPT_FUSED_OPTIMIZER (per engine; the environment only provides the default at creation)
   // GT_OPT_FUSED_DSTACK: the float32 MLP discriminator's layers above the first one + the head (+, in the generator step, the
   // backward-data chain down to the adversarial columns) as ONE launch per pass (dstack_f32.hip.h)
-  bool opt_fused_dstack = env_flag("GT_FUSED_DSTACK", true);
+  int opt_fused_dstack = getenv("GT_FUSED_DSTACK") ? atoi(getenv("GT_FUSED_DSTACK")) : 1;      // 0 off, 1 when the pass has >= one panel per CU, 2 always
   bool opt_split_first = env_flag("GT_D_SPLIT", true);
   bool opt_fused_optimizer = env_flag("GT_OPT_FUSED", false);      // measured slower: off
   bool opt_side_overlap = env_flag("GT_SIDE_OVERLAP", false);      // GT_OPT_SIDE_OVERLAP: tv / MSE kernels on the side stream (measured slower: off)

@@ -239,8 +239,9 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 /* GT_OPT_FUSED_DSTACK (default 1): the float32 MLP discriminator (gantts/models.py:121-141; hidden_dim 128 or 256, <= 4 hidden
  * layers) runs its hidden layers above the first one, last_linear + sigmoid + the BCE terms (train.py:261-271) and -- in the
  * generator step (train.py:307-308) -- the whole backward-data chain down to the adversarial input columns as ONE launch per pass,
- * panel of 32 frames by panel, activations resident in LDS.  0 = one launch per layer + the head kernel.  Same sums up to float32
- * association. */
+ * panel of 32 frames by panel, activations resident in LDS.  1 (default): when the pass has at least one panel per CU (a panel is
+ * walked by ONE workgroup: small per-rank batches are faster as per-layer launches); 2: always; 0: one launch per layer + the head
+ * kernel.  Same sums up to float32 association. */
 #define GT_OPT_FUSED_DSTACK 19
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
