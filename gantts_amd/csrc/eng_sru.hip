@@ -1,5 +1,6 @@
 // libgantts_hip.so -- recurrent generator (GT_ARCH_SRU)
 #include "engine_internal.hip.h"
+#include "sru_cs_kernels.hip.h"
 #include "sru_kernels.hip.h"
 using namespace gt;
 // ------------------------------------------------------------------------------------------
@@ -39,6 +40,11 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
 // the scans with loader waves (sru_kernels.hip.h); GT_SRU_LW=0 selects the one-wave kernels (A/B reference, bit-identical results)
 // (read at every launch: the A/B test flips it between two steps of one process)
 static bool sru_loader_waves() { return gt_tuning().sru_lw != 0; }
+// GT_SRU_LW=2 (default): the cooperative block scans (sru_cs_kernels.hip.h): every wave of a workgroup loads AND walks eight frames
+// of a block, the waves' composites are combined through LDS.  Eight waves per 64 columns where that still fits the CUs' wave slots
+// (B x ncols / 64 workgroups <= CUs: cfg4's B = 16), four otherwise.
+static bool sru_coop() { return gt_tuning().sru_lw >= 2; }
+static int sru_coop_waves(long B, int ncols) { return cdiv(B * ncols, 64) <= gemm_cu_count() ? 8 : 4; }
 // Measured and dropped (round 4, gpurun_out/r4k): 32 columns per workgroup (twice the recurrence waves per CU, half of every wave
 // idle) for the shapes that give fewer than three 64-column workgroups per CU -- cfg4 (B = 16, T = 2048) 11.36 vs 10.84 ms, the
 // hparams-default generator at B = 32 9.49 vs 9.32 ms: the scan is not bound by one wave's per-frame latency.
@@ -126,7 +132,11 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
       CHK(launch_gemm(GEMM_NN, g, 1, s));
     }
     SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
-    if (sru_loader_waves()) {
+    if (sru_coop()) {
+      const int grid = cdiv((long)B * ncols, 64);
+      if (sru_coop_waves(B, ncols) == 8) hipLaunchKernelGGL(sru_fwd_cs_kernel<8>, dim3(grid), dim3(512), sru_fwd_cs_lds<8>(), s, a);
+      else hipLaunchKernelGGL(sru_fwd_cs_kernel<4>, dim3(grid), dim3(256), sru_fwd_cs_lds<4>(), s, a);
+    } else if (sru_loader_waves()) {
       CHK(ensure_dyn_lds((const void*)sru_fwd_lw_kernel, sru_fwd_lw_lds()));
       hipLaunchKernelGGL(sru_fwd_lw_kernel, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_fwd_lw_lds(), s, a);
     } else {
@@ -206,6 +216,19 @@ int sru_backward(gt_engine* e, const float* x, const float* gy, int B, int T, hi
       B16Img& DU = e->s_du_b;
       CHK(DU.ensure(N, ncols * L.k, true));
       a.dU = nullptr; a.dU_b = DU.r(); a.ld_dub = DU.ld; a.dU_bt = DU.t(); a.ld_dubt = DU.ldt;
+    }
+    if (sru_coop()) {
+      const int grid = cdiv((long)B * ncols, 64);
+      const bool w8 = sru_coop_waves(B, ncols) == 8;
+#define GT_SRU_CS_LAUNCH(NW_, B16_)                                                                                           \
+      do {                                                                                                                     \
+        CHK(ensure_dyn_lds((const void*)sru_bwd_cs_kernel<NW_, B16_>, sru_bwd_cs_lds<NW_>(B16_)));                             \
+        hipLaunchKernelGGL((sru_bwd_cs_kernel<NW_, B16_>), dim3(grid), dim3(64 * NW_), sru_bwd_cs_lds<NW_>(B16_), s, a);        \
+      } while (0)
+      if (du_b16) { if (w8) GT_SRU_CS_LAUNCH(8, true); else GT_SRU_CS_LAUNCH(4, true); }
+      else { if (w8) GT_SRU_CS_LAUNCH(8, false); else GT_SRU_CS_LAUNCH(4, false); }
+#undef GT_SRU_CS_LAUNCH
+    } else if (du_b16) {
       CHK(ensure_dyn_lds((const void*)sru_bwd_lw_kernel<true>, sru_bwd_lw_lds()));
       hipLaunchKernelGGL(sru_bwd_lw_kernel<true>, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_bwd_lw_lds(), s, a);
     } else if (sru_loader_waves()) {

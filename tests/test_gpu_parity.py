@@ -75,6 +75,7 @@ def _close_kink(a, b, msg, frac_ok, worst_ok, **kw):
     if frac_ok <= 0.0:
         return _close(a, b, msg=msg, **kw)
     _close(a, b, msg=msg, frac_ok=frac_ok, **kw)
+    kw = dict(kw)
     _close(a, b, msg=msg + " (worst element)", rtol=kw.pop("rtol", RTOL) * worst_ok, **kw)
 
 
@@ -1086,13 +1087,52 @@ def test_sru_loader_wave_scans_equal_the_one_wave_scans_bit_for_bit(name, bf16):
     try:
         L.check(L.lib.gt_set_tuning(b"sru_lw", 0))
         ref = run_hip_case(case, engine_options=opts)
-    finally:
         L.check(L.lib.gt_set_tuning(b"sru_lw", 1))
-    got = run_hip_case(case, engine_options=opts)
+        got = run_hip_case(case, engine_options=opts)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 2))      # the default: cooperative block scans
     assert set(got) == set(ref)
     for k in ref:
         a, b = np.asarray(got[k]), np.asarray(ref[k])
         assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), k
+
+
+@pytest.mark.parametrize("name,bf16", [("acoustic_sru_at_size", 0), ("acoustic_sru_uni_k3_dropout", 0), ("vc_sru_multistream", 0), ("acoustic_sru_uni_k3", 0),
+                                       ("acoustic_sru_bi_saturated", 0), ("acoustic_sru_at_size", 1), ("acoustic_sru_dropout", 1)])
+def test_sru_cooperative_block_scans_match_the_sequential_scans(name, bf16):
+    """The cooperative block scans (sru_cs_kernels.hip.h, the default: every wave of a workgroup walks eight frames of a block from a
+    zero state, the waves' composites (prod f, end state) are combined through LDS, each wave corrects its frames by prefix
+    product x incoming state) against the sequential loader-wave scans: the same linear recurrence under another association of the
+    products, so a whole G+D step agrees to rounding -- 1e-4 like every float32 comparison of the suite (bf16 storage: the products
+    around the scans round their operands to bf16, where a last-bit difference of a scan output can flip a rounding: 2e-2) --
+    forward and backward, both directions, k = 3 and 4, tanh / relu, saturated gates, ragged T (partial blocks: frames past T are
+    the identity), partial workgroups, dU as float32 and as bf16 images."""
+    from hip_runner import run_hip_case
+    case = C.ORACLE_ONLY_CASES[name]
+    from gantts_amd import _lib as L
+    opts = {"matmul_bf16": 1} if bf16 else None
+    try:
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 1))
+        ref = run_hip_case(case, engine_options=opts)
+    finally:
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 2))
+    got = run_hip_case(case, engine_options=opts)
+    assert set(got) == set(ref)
+    rtol = 2e-2 if bf16 else RTOL
+    frac_ok, worst_ok = _kink_frac(case)
+    for k in ref:
+        if "scalars" in k:
+            _close(got[k], ref[k], rtol=rtol, msg=k)
+            if k.startswith("d_scalars") and not bf16:
+                assert got[k][3] == ref[k][3] and got[k][4] == ref[k][4], k
+        elif ".opt." in k:
+            sq = ".opt.sum." in k or ".opt.exp_avg_sq." in k
+            _close_kink(np.sqrt(np.maximum(got[k], 0.0)) if sq else got[k], np.sqrt(np.maximum(ref[k], 0.0)) if sq else ref[k], k, frac_ok, worst_ok,
+                        rtol=(8e-2 if bf16 else RTOL), atol=1e-9)
+        elif k.startswith(("G.", "D.")):
+            _close_kink(got[k], ref[k], k, frac_ok, worst_ok, rtol=(8e-2 if bf16 else RTOL))
+        else:
+            _close(got[k], ref[k], rtol=rtol, msg=k)
 
 
 def test_lstm_full_size_persistent_equals_per_step_kernels():
