@@ -37,7 +37,8 @@ VARIANTS = ["fwd X.W^T BN64 (run-time epilogue)", "fwd X.W^T BN128", "bwd-data d
             "pair bwd-data dZ.W + bwd-weight dZ^T.X BN64", "fwd X.W^T 64x64 <LeakyReLU + Philox, added matrix>",
             "bwd-data dZ.W 64x64 <no activation>", "bwd-data dZ.W 64x64 <LeakyReLU + Philox>",
             "bwd-weight pair of the split first layer (x block + adversarial block)",
-            "fwd split first layer 64x64 <two K segments, LeakyReLU + Philox>", "-", "-"]
+            "fwd split first layer 64x64 <two K segments, LeakyReLU + Philox>",
+            "fused discriminator stack: layers 1..L-1 + head (+ the generator step's backward-data chain), one launch per pass", "-"]
 
 G_SPEC = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
 D_SPEC = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256, dropout=0.5, last_sigmoid=True)
@@ -371,13 +372,13 @@ def main():
         per = []
         for v in range(NS):
             if cnt[v]:
-                per.append({"kernel": "gemm_f32_kernel<%s>" % VARIANTS[v], "launches_per_step": cnt[v] / table_steps,
+                per.append({"kernel": ("dstack_kernel<%s>" if v == 14 else "gemm_f32_kernel<%s>") % VARIANTS[v], "launches_per_step": cnt[v] / table_steps,
                             "avg_us": 1e3 * ms[v] / cnt[v], "tflops": fl[v] / (ms[v] * 1e-3) / 1e12,
                             "share_of_step_ms": ms[v] / table_steps})
         tot_ms, tot_fl = sum(ms), sum(fl)
         profiled_steps_live, profiled_steps = profiled_steps, table_steps
         dom = max(per, key=lambda p: p["share_of_step_ms"])
-        dom_v = [v for v in range(NS) if cnt[v] and "gemm_f32_kernel<%s>" % VARIANTS[v] == dom["kernel"]][0]
+        dom_v = [v for v in range(NS) if cnt[v] and dom["kernel"].endswith("<%s>" % VARIANTS[v])][0]
         traffic, traffic_src = pmc_traffic(dom_v)
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
@@ -390,6 +391,65 @@ def main():
                     "sampled_steps": profiled_steps_live, "sampled_launches": "the dominant kernel's" if pair_only else "all product launches",
                     "variants_source": table_src,
                     "variants": per}
+
+    # ---- companion measurements BEHIND the timed region (never part of `value`) -----------------------------------------------------
+    def timed_steps(step_fn, n, w=3):
+        for _ in range(w):
+            step_fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t1) / n
+
+    companion = {}
+    if world == 1 and not args.force_dp and not args.no_roofline:
+        # (a) the other x layout: dense 425-float rows when the headline ran on the pitched rows train_loop stages (or vice versa)
+        x_other = x.contiguous() if not args.dense_x else None
+        if x_other is None:
+            from gantts_amd.engine import pitched_empty
+            x_other = pitched_empty(B, Tn, 425, dev)
+            x_other.copy_(x)
+
+        def step_other():
+            og.zero_grad()
+            od.zero_grad()
+            y_hat, y_hat_static = T.apply_generator(mg, x_other, R, cpu_lengths)
+            T.update_discriminator(md, od, x_other, y_static, y_hat_static, cpu_lengths, mask, "train")
+            T.update_generator(mg, md, og, x_other, y, y_hat, y_static, y_hat_static, 1.0, cpu_lengths, mask, "train", mse_w=0.0, mge_w=1.0)
+        companion["ms_per_step_dense_x" if not args.dense_x else "ms_per_step_pitched_x"] = timed_steps(step_other, args.steps)
+        del x_other
+        # (b) single-GPU PROXY of strong scaling (no multi-GPU node is available to the builder): the per-rank step of N ranks is the step
+        # on B / N whole sequences; measured here for N = 2, 4, 8, communication NOT included
+        if args.scaling == "strong" and B % 8 == 0:
+            proxy = {}
+            for n in (2, 4, 8):
+                b = B // n
+                xs, ys_, yss, ms_, cl = x[:b], y[:b].contiguous(), y_static[:b].contiguous(), mask[:b].contiguous(), cpu_lengths[:b]
+                if not args.dense_x:
+                    from gantts_amd.engine import pitched_empty
+                    xq = pitched_empty(b, Tn, 425, dev)
+                    xq.copy_(xs)
+                    xs = xq
+                else:
+                    xs = xs.contiguous()
+
+                def step_b(xs=xs, ys_=ys_, yss=yss, ms_=ms_, cl=cl):
+                    og.zero_grad()
+                    od.zero_grad()
+                    y_hat, y_hat_static = T.apply_generator(mg, xs, R, cl)
+                    T.update_discriminator(md, od, xs, yss, y_hat_static, cl, ms_, "train")
+                    T.update_generator(mg, md, og, xs, ys_, y_hat, yss, y_hat_static, 1.0, cl, ms_, "train", mse_w=0.0, mge_w=1.0)
+                proxy[n] = timed_steps(step_b, max(10, args.steps))
+            companion["scaling_model"] = {
+                "status": "UNMEASURED on more than one GPU: a single-GPU proxy",
+                "method": "per-rank step of N ranks = this step on B/N whole sequences (measured below, one GPU, no communication) + the "
+                          "step's five collectives (measured with one rank through RCCL: +2.7 % at N = 1, profiles/r04_summary.md; the "
+                          "link time of 4.4 MB of gradient per step over xGMI is not modelled)",
+                "ms_per_rank_step": {str(n): proxy[n] for n in proxy},
+                "speedup_over_one_gpu_without_communication": {str(n): (1e3 * elapsed / args.steps) / proxy[n] for n in proxy},
+            }
 
     # every rank flushes its C stdio (RCCL's NCCL_DEBUG=VERSION banner is block-buffered when piped)
     # before rank 0 prints, so the JSON line is the last line of the job's stdout
@@ -415,6 +475,7 @@ def main():
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
                "roofline": roofline}
         out["config"]["clock_spinup_ms"] = args.spinup_ms
+        out.update(companion)
         if world == 1 and not args.no_other_configs and not args.force_dp:
             # the other BASELINE.json configurations, a few steps each, BEHIND the headline's timed region
             sys.path.insert(0, os.path.join(ROOT, "tools"))

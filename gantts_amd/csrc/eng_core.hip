@@ -54,6 +54,7 @@ extern "C" int gt_profile_read(double* out_ms, double* out_flops, int64_t* out_c
     int v = r.kind * 2 + (r.bn == 128 ? 1 : 0);
     if (r.kind == 5) v = 8;                                   // pair launch
     else if (r.kind == 6) v = 12;                             // weight-gradient pair of a split first layer
+    else if (r.kind == 7) v = 14;                             // fused discriminator stack (dstack_f32.hip.h)
     else if (r.kind == GEMM_NT && r.am == GEMM_A_NONE) v = 6;
     else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX) v = 7;
     else if (r.kind == GEMM_NT && r.am == GEMM_A_LEAKY_PHILOX_ADDM) v = 9;

@@ -408,7 +408,8 @@ int gt_op_linear_bf16(const float* X, const float* W, const float* bias, int64_t
  *   9     = 64x64 forward, LeakyReLU + Philox dropout on (product + added matrix): the split first layer of the conditioned D;
  *   10,11 = 64x64 backward-data kernels with a compiled-in epilogue: none / LeakyReLU + Philox;
  *   12    = the two weight-gradient products of a split first layer in one launch;
- *   13    = the split first layer's forward in one launch (two K segments, two result halves);  14, 15 unused.
+ *   13    = the split first layer's forward in one launch (two K segments, two result halves);
+ *   14    = the fused discriminator stack (GT_OPT_FUSED_DSTACK: layers 1..L-1 + head [+ backward-data chain] of one pass);  15 unused.
  * flops are algorithmic 2*M*N*K of the unpadded problems.  The three arrays hold GT_PROFILE_SLOTS entries.
  * gt_profile_enable(0) off, (1) every product launch, (2 + k) only launches of kind k (5 = the pair launches: what bench.py samples
  * inside its timed region -- two events per launch are not free). */

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""The BASELINE.json configurations besides the headline (configs[2..4]) as timed G+D steps on one MI355X, for
+"""The BASELINE.json configurations besides the headline (configs[0], configs[2..4]) as timed G+D steps on one MI355X, for
 `bench.py`'s `other_configs` object ("let the driver see every config") and for the profile scripts.
 
+    cfg1                   VC In2OutHighwayNet 75 -> 512 x 3 -> 75 + MLP D 25 -> 256 x 2 -> 1, B=8, T=256 (configs[0])
     cfg3_bf16 / cfg3_fp32  BiLSTM 3x256 generator + conditioned MLP D, B=32, T=1024, variable lengths (configs[2])
     cfg4_bf16              VC SRU 6x512 bidirectional generator on mgc/lf0/bap streams + MLP D, B=16, T=2048 (configs[3])
     cfg5                   duration (416+200 -> 5, Adam, R=None) + acoustic (425+200 -> 187, Adagrad) pairs with
@@ -58,9 +59,14 @@ def _macs_sru(spec):
     return tot + spec["out_dim"] * ncols, first
 
 
+def _macs_i2o(spec):
+    tot, first = _macs_mlp(spec)
+    return tot + spec["static_dim"] * spec["static_dim"], first      # + the transform gate T (gantts/models.py:36)
+
+
 def step_flops_per_frame(kind, g_spec, d_spec):
     """2 * (3g - g1 + 8d - d1) flops per padded frame of one G+D step."""
-    g, g1 = {"MLP": _macs_mlp, "LSTMRNN": _macs_lstm, "SRURNN": _macs_sru}[kind](g_spec)
+    g, g1 = {"MLP": _macs_mlp, "LSTMRNN": _macs_lstm, "SRURNN": _macs_sru, "In2OutHighwayNet": _macs_i2o}[kind](g_spec)
     d, d1 = _macs_mlp(d_spec)
     return 2.0 * (3 * g - g1 + 8 * d - d1)
 
@@ -139,6 +145,17 @@ def _build(name):
         step, fl, fr = _pair(hp_set, "SRURNN", g, d, 16, 2048, "Adagrad", 0, True, 0)
         return step, fl, fr, "bf16", "cfg4: VC SRU 6x512 bidirectional G 183->183 (mgc/lf0/bap streams [177,3,3]) + MLP D 59-256x2-1, " \
                                      "B=16 T=2048, both variational dropouts 0.2, Adagrad"
+    if name == "cfg1":
+        hp = hparams.vc
+        vals = dict(hp.values())
+        vals.update(stream_sizes=[75], has_dynamic_features=[True], adversarial_streams=[True], mask_nth_mgc_for_adv_loss=0,
+                    discriminator_linguistic_condition=False)
+        hp_set = types.SimpleNamespace(values=lambda: vals)
+        g = dict(in_dim=75, out_dim=75, static_dim=25, num_hidden=3, hidden_dim=512, dropout=0.5)
+        d = dict(in_dim=25, out_dim=1, num_hidden=2, hidden_dim=256, dropout=0.5, last_sigmoid=True)
+        step, fl, fr = _pair(hp_set, "In2OutHighwayNet", g, d, 8, 256, "Adagrad", 0, False, 0, variable_lengths=False)
+        return step, fl, fr, "f32", "cfg1 (BASELINE.json configs[0], the reference's CPU plumbing configuration, here on the GPU): VC In2OutHighwayNet " \
+                                    "75->512x3->75 (static 25, mgc order 25) + MLP D 25-256x2-1, B=8 T=256, Adagrad"
     if name == "cfg2_bf16":
         g = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512, dropout=0.5, last_sigmoid=False)
         step, fl, fr = _pair(hparams.tts_acoustic, "MLP", g, _D_ACOUSTIC, 32, 512, "Adagrad", 0, True, 0, variable_lengths=False)
@@ -157,7 +174,7 @@ def _build(name):
     raise KeyError(name)
 
 
-ALL = ["cfg3_bf16", "cfg3_fp32", "cfg4_bf16", "cfg5", "cfg2_bf16"]
+ALL = ["cfg1", "cfg3_bf16", "cfg3_fp32", "cfg4_bf16", "cfg5", "cfg2_bf16"]
 
 
 def run_config(name, steps=5, warmup=2):
@@ -178,14 +195,18 @@ def run_config(name, steps=5, warmup=2):
            "step_algorithmic_gflop": flops / 1e9,
            "roofline": {"bound": "mfma", "level": "step (SURVEY 8(d) algorithmic flops / step time)", "achieved": ach, "peak": peak,
                         "unit": "TFLOP/s", "frac": ach / peak}}
-    prof = os.path.join(ROOT, "profiles", "r04_other_configs.json")     # HBM bytes per step from the committed PMC passes
-    if os.path.isfile(prof):
+    # HBM bytes per step from the committed PMC passes of the newest round that has this configuration
+    for tag in ("r05", "r04"):
+        prof = os.path.join(ROOT, "profiles", "%s_other_configs.json" % tag)
+        if not os.path.isfile(prof):
+            continue
         try:
             p = json.load(open(prof)).get(name)
             if p and p.get("hbm_bytes_per_step"):
                 bw = p["hbm_bytes_per_step"] / dt / 1e12
                 out["roofline"]["hbm"] = {"traffic": p["hbm_bytes_per_step"], "achieved": bw * 1e3, "peak": 8000.0, "unit": "GB/s",
-                                          "frac": bw / 8.0, "source": "profiles/r04_other_configs.json (rocprofv3 --pmc, FETCH x2 corrected)"}
+                                          "frac": bw / 8.0, "source": "profiles/%s_other_configs.json (rocprofv3 --pmc, FETCH x2 corrected)" % tag}
+                break
         except Exception:      # noqa: BLE001
             pass
     del step
