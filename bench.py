@@ -134,6 +134,8 @@ def main():
                          "weak: every rank gets its own --batch sequences")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-companion", action="store_true", help="skip the companion measurements behind the timed region (the other x layout, "
+                    "the single-GPU scaling proxy): profile runs, whose kernel trace must hold the headline's steps only")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2..4] behind the timed region")
     ap.add_argument("--spinup-ms", type=float, default=400.0,
                     help="GPU clock spin-up before the warm-up steps: a generic matrix product on scratch operands (NOT steps of the "
@@ -404,7 +406,7 @@ def main():
         return 1e3 * (time.perf_counter() - t1) / n
 
     companion = {}
-    if world == 1 and not args.force_dp and not args.no_roofline:
+    if world == 1 and not args.force_dp and not args.no_roofline and not args.no_companion:
         # (a) the other x layout: dense 425-float rows when the headline ran on the pitched rows train_loop stages (or vice versa)
         x_other = x.contiguous() if not args.dense_x else None
         if x_other is None:

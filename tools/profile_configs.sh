@@ -5,7 +5,7 @@
 # domains other than the kernel trace), then the un-profiled line.  tools/summarize_configs.py condenses them into profiles/.
 set -u
 TAG=${1:-r04}; shift || true
-NAMES=${@:-cfg3_bf16 cfg3_fp32 cfg4_bf16 cfg5 cfg2_bf16}
+NAMES=${@:-cfg1 cfg3_bf16 cfg3_fp32 cfg4_bf16 cfg5 cfg2_bf16}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
