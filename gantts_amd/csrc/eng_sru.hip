@@ -71,15 +71,13 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
       CHK(cast_transpose(W, cols, rows, cols, w.w.as<__bf16>(), w.ldw, w.wt.as<__bf16>(), w.ldwt, nullptr, false, &e->colp, s));
     }
   }
-  for (int l = 0; l < G.d.num_hidden; ++l) {
-    const SruLayerP& L = G.sru[l];
-    CHK(e->s_u[l].ensure((size_t)N * ncols * L.k * sizeof(float)));
-    CHK(e->s_h[l].ensure((size_t)N * ncols * sizeof(float)));
-    CHK(e->s_c[l].ensure((size_t)N * ncols * sizeof(float)));
-    const float* xin = in;
-    int ld_xin = ld_in;
-    const bool rdrop = G.training && G.d.rnn_dropout > 0.f;
-    if (rdrop) {      // variational input dropout, mask shared over time: the multipliers of this step, [B][n_in]
+  // bf16 storage + cooperative scans: layer l's scan writes the bf16 input images of the product behind it (layer l + 1's U product, or
+  // hidden2out) itself -- with that layer's variational input dropout applied -- so the multiplier tables of ALL layers are drawn first
+  const bool rdrop_all = G.training && G.d.rnn_dropout > 0.f;
+  const bool fold = b16 && sru_coop() && T % 8 == 0 && H % 64 == 0 && ((long)B * ncols) % 64 == 0;
+  if (rdrop_all) {
+    for (int l = 0; l < G.d.num_hidden; ++l) {
+      const SruLayerP& L = G.sru[l];
       CHK(e->s_xmask[l].ensure((size_t)B * L.in * sizeof(float)));
       uint32_t k0, k1;
       sru_keys(e, l, 0, &k0, &k1);
@@ -88,6 +86,16 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
                          (const float*)G.inj[0][2 * l], e->dp_world, e->dp_rank);     // gt_set_dropout_mask(G, 0, 2*l): [B][n_in]
       LAUNCH_CHECK();
     }
+  }
+  bool img_ready = false;       // the current layer's input images were written by the scan underneath
+  for (int l = 0; l < G.d.num_hidden; ++l) {
+    const SruLayerP& L = G.sru[l];
+    CHK(e->s_u[l].ensure((size_t)N * ncols * L.k * sizeof(float)));
+    CHK(e->s_h[l].ensure((size_t)N * ncols * sizeof(float)));
+    CHK(e->s_c[l].ensure((size_t)N * ncols * sizeof(float)));
+    const float* xin = in;
+    int ld_xin = ld_in;
+    const bool rdrop = rdrop_all;      // (variational input dropout, mask shared over time: the multipliers [B][n_in] were drawn above)
     if (rdrop && !b16) {      // float32 products read a dropped float32 copy
       CHK(e->s_xdrop[l].ensure((size_t)N * L.in * sizeof(float)));
       hipLaunchKernelGGL(sru_input_dropout_kernel, dim3(cdiv(N * L.in, 256)), dim3(256), 0, s, in, ld_in, e->s_xdrop[l].as<float>(),
@@ -99,7 +107,9 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
     if (b16) {
       B16Img& I = e->s_in_b[l];
       CHK(I.ensure(N, L.in, want_t));
-      if (rdrop) {            // bf16 products: dropout rides in the cast, the dropped input exists as bf16 images only
+      if (img_ready) {
+        // written by the scan of the layer underneath (SruArgs::nx_*): no cast pass
+      } else if (rdrop) {            // bf16 products: dropout rides in the cast, the dropped input exists as bf16 images only
         const SeqDropSrc src{in, ld_in, e->s_xmask[l].as<float>(), T, L.in};
         hipLaunchKernelGGL(seqdrop_cast_transpose_kernel, dim3(cdiv(N, 64), cdiv(L.in, 64)), dim3(256), 0, s, src, N, L.in, I.r(), I.ld,
                            want_t ? I.t() : (__bf16*)nullptr, I.ldt);
@@ -132,10 +142,27 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
       CHK(launch_gemm(GEMM_NN, g, 1, s));
     }
     SruArgs a = sru_args(e, G, l, B, T, in, ld_in);
+    img_ready = false;
+    if (fold) {       // the images of the product behind this layer: layer l + 1's input (its dropout applied), or hidden2out's
+      const int nl = l + 1;
+      const int n_in_next = nl < Lc_ ? G.sru[nl].in : G.last.in;
+      if (n_in_next == ncols) {
+        B16Img& NI = e->s_in_b[nl];
+        CHK(NI.ensure(N, ncols, want_t));
+        a.nx_b = NI.r(); a.ld_nxb = NI.ld; a.nx_bt = want_t ? NI.t() : (__bf16*)nullptr; a.ld_nxbt = NI.ldt;
+        a.nx_mul = (nl < Lc_ && rdrop_all) ? e->s_xmask[nl].as<float>() : (const float*)nullptr;
+        img_ready = true;
+      }
+    }
     if (sru_coop()) {
       const int grid = cdiv((long)B * ncols, 64);
-      if (sru_coop_waves(B, ncols) == 8) hipLaunchKernelGGL(sru_fwd_cs_kernel<8>, dim3(grid), dim3(512), sru_fwd_cs_lds<8>(), s, a);
-      else hipLaunchKernelGGL(sru_fwd_cs_kernel<4>, dim3(grid), dim3(256), sru_fwd_cs_lds<4>(), s, a);
+      const bool w8 = sru_coop_waves(B, ncols) == 8;
+      if (img_ready) {
+        if (w8) { CHK(ensure_dyn_lds((const void*)sru_fwd_cs_kernel<8, true>, sru_fwd_cs_lds<8>(true)));
+                  hipLaunchKernelGGL((sru_fwd_cs_kernel<8, true>), dim3(grid), dim3(512), sru_fwd_cs_lds<8>(true), s, a); }
+        else hipLaunchKernelGGL((sru_fwd_cs_kernel<4, true>), dim3(grid), dim3(256), sru_fwd_cs_lds<4>(true), s, a);
+      } else if (w8) hipLaunchKernelGGL((sru_fwd_cs_kernel<8, false>), dim3(grid), dim3(512), sru_fwd_cs_lds<8>(), s, a);
+      else hipLaunchKernelGGL((sru_fwd_cs_kernel<4, false>), dim3(grid), dim3(256), sru_fwd_cs_lds<4>(), s, a);
     } else if (sru_loader_waves()) {
       CHK(ensure_dyn_lds((const void*)sru_fwd_lw_kernel, sru_fwd_lw_lds()));
       hipLaunchKernelGGL(sru_fwd_lw_kernel, dim3(cdiv((long)B * ncols, 64)), dim3(SRU_LW_THREADS), sru_fwd_lw_lds(), s, a);
@@ -149,7 +176,8 @@ int sru_forward(gt_engine* e, const float* x, int B, int T, float* y_hat, hipStr
   if (b16) {
     B16Img& I = e->s_in_b[Lc_];
     CHK(I.ensure(N, G.last.in, want_t));
-    CHK(cast_transpose(in, ld_in, N, G.last.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
+    if (!img_ready)      // (else: written by the last layer's scan)
+      CHK(cast_transpose(in, ld_in, N, G.last.in, I.r(), I.ld, want_t ? I.t() : (__bf16*)nullptr, I.ldt, nullptr, false, &e->colp, s));
     GemmB16Args g = b16_args();
     g.A = I.r(); g.lda = I.ld; g.B = e->ssh[Lc_].w.as<__bf16>(); g.ldb = e->ssh[Lc_].ldw;    // hidden2out.weight (out, ncols): k = ncols contiguous
     g.M = (int)N; g.N = G.last.out; g.K = G.last.in; g.bias = G.last.b; g.epi = B16_FWD;

@@ -21,16 +21,20 @@ namespace gt {
 
 constexpr int SRU_CS_S = 8;       // frames per wave and block
 
-template <int NW> constexpr size_t sru_fwd_cs_lds() { return (size_t)2 * NW * 2 * 64 * sizeof(float); }
+template <int NW> constexpr size_t sru_fwd_cs_lds(bool nxout = false) { return (size_t)(2 * NW * 2 * 64 + (nxout ? NW * SRU_CS_S * 64 : 0)) * sizeof(float); }
 template <int NW> constexpr size_t sru_bwd_cs_lds(bool b16out) {
   return (size_t)(2 * NW * 2 * 64 + NW * 2 * 64 + (b16out ? NW * SRU_CS_S * 4 * 64 : 0)) * sizeof(float);
 }
 
 // grid = ceil(B * ncols / 64) workgroups of 64 * NW threads
-template <int NW>
+// NXOUT: also write the bf16 images of the next product's input (SruArgs::nx_*): the transposed image straight from the registers (a
+// lane's eight frames of its column are 16 contiguous bytes), the row-major image through a wave-private LDS stage -- what
+// seqdrop_cast_transpose_kernel / cast_transpose_kernel did in a pass of their own (cfg4: 0.43 ms per step).
+template <int NW, bool NXOUT = false>
 __global__ __launch_bounds__(64 * NW) void sru_fwd_cs_kernel(const SruArgs a) {
   constexpr int S = SRU_CS_S, FBT = NW * S;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // comp[2][NW][2][64]: (prod f, end state) of wave w, by block parity
+  float* ost = lds + 2 * NW * 2 * 64 + (size_t)(threadIdx.x >> 6) * S * 64;      // NXOUT: this wave's [S][64] stage
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ncols = a.H * a.dirs;
   const long gid0 = (long)blockIdx.x * 64 + lane;
@@ -46,6 +50,8 @@ __global__ __launch_bounds__(64 * NW) void sru_fwd_cs_kernel(const SruArgs a) {
   float* cb = a.c + (long)b * T * ncols + col;
   const float bf = a.bias[col], br = a.bias[ncols + col];
   const float mk = sru_mask(a, b, col);
+  const float nmul = (NXOUT && a.nx_mul) ? a.nx_mul[(long)b * ncols + col] : 1.f;
+  const int col0 = (int)(((long)blockIdx.x * 64) % ncols);           // NXOUT: the workgroup's first column (one sequence, one direction)
   float carry = 0.f;
   float v0[S][4], v1[S][4];
   auto request = [&](float (&v)[S][4], int blk) {
@@ -86,16 +92,40 @@ __global__ __launch_bounds__(64 * NW) void sru_fwd_cs_kernel(const SruArgs a) {
     }
     if (wave == 0) cin = carry;
     carry = all;
+    float hq[S];
 #pragma unroll
     for (int q = 0; q < S; ++q) {
       const int tt = i * FBT + wave * S + q;
+      hq[q] = 0.f;
       if (tt < T && valid) {
         const int t = flip ? T - 1 - tt : tt;
         const float cq = fmaf(P[q], cin, cl[q]);
         const float val = __fmul_rn(sru_act(cq, a.act), mk);
-        hb[(long)t * ncols] = fmaf(val - v[q][3], r[q], v[q][3]);
+        hq[q] = fmaf(val - v[q][3], r[q], v[q][3]);
+        hb[(long)t * ncols] = hq[q];
         cb[(long)t * ncols] = cq;
       }
+    }
+    if (NXOUT && i * FBT + wave * S < T) {      // (T % 8 == 0: the wave's eight frames are all inside the sequence)
+      const int s0 = i * FBT + wave * S;
+      const int t_lo = flip ? T - S - s0 : s0;                     // forward walk: tt = s0 + q; t = tt, or T - 1 - tt for the reverse direction
+      const long row0 = (long)b * T + t_lo;
+      float e[S];
+#pragma unroll
+      for (int fr = 0; fr < S; ++fr) e[fr] = __fmul_rn(hq[flip ? S - 1 - fr : fr], nmul);      // ascending in t
+      if (a.nx_bt) {
+        uint4 w;
+        w.x = sru_pack_bf16x2(e[0], e[1]); w.y = sru_pack_bf16x2(e[2], e[3]); w.z = sru_pack_bf16x2(e[4], e[5]); w.w = sru_pack_bf16x2(e[6], e[7]);
+        *reinterpret_cast<uint4*>(a.nx_bt + (long)col * a.ld_nxbt + row0) = w;
+      }
+#pragma unroll
+      for (int fr = 0; fr < S; ++fr) ost[fr * 64 + lane] = e[fr];
+      // (the wave's own LDS operations execute in order: no barrier between its writes above and its reads below)
+      const int fr = lane >> 3, cc = lane & 7;                    // 64 chunks of 8 columns: one per lane
+      const float* o = ost + fr * 64 + 8 * cc;
+      uint4 w;
+      w.x = sru_pack_bf16x2(o[0], o[1]); w.y = sru_pack_bf16x2(o[2], o[3]); w.z = sru_pack_bf16x2(o[4], o[5]); w.w = sru_pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(a.nx_b + (row0 + fr) * a.ld_nxb + col0 + 8 * cc) = w;
     }
   };
   request(v0, 0);

@@ -45,6 +45,12 @@ struct SruArgs {
   // bf16 images the products read (row-major [N][ld_dub], transposed [ncols*k][ld_dubt]) instead of float32 + a cast pass
   __bf16* dU_b; int ld_dub;
   __bf16* dU_bt; long ld_dubt;
+  // forward, GT_OPT_MATMUL_BF16 with the cooperative scans (T % 8 == 0, H % 64 == 0, B * ncols % 64 == 0): the scan writes the bf16
+  // images of the NEXT product's input (the next SRU layer's dropped input, or hidden2out's input) itself -- row-major [N][ld_nxb] and,
+  // when the backward pass will want it, transposed [ncols][ld_nxbt] -- value h * nx_mul[b][col] rounded as the cast pass rounds it
+  __bf16* nx_b; int ld_nxb;
+  __bf16* nx_bt; long ld_nxbt;
+  const float* nx_mul;            // [B][ncols] multipliers of the next layer's variational input dropout, or null (1)
   const float* up_mul;            // [B][ncols] multipliers {0, 1/(1-p)} of the next layer's input dropout, or null
   const float* up_add; int ld_up_add;   // [N][ncols] highway gradient of the next layer (k == 3), or null
 };
