@@ -149,6 +149,34 @@ def test_engine_communicator_world_2_equals_whole_batch_reference_golden(name):
     _check(name, r0, r1, {k: gold[k] for k in gold.files})
 
 
+class _forced_fused_dstack(object):
+    """GT_FUSED_DSTACK=2 for engines created inside (the spawned ranks inherit the environment): the fused discriminator stack is
+    taken by default only for passes with a 32-frame panel per CU, which no small case has."""
+
+    def __enter__(self):
+        self.old = os.environ.get("GT_FUSED_DSTACK")
+        os.environ["GT_FUSED_DSTACK"] = "2"
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("GT_FUSED_DSTACK", None)
+        else:
+            os.environ["GT_FUSED_DSTACK"] = self.old
+
+
+@pytest.mark.timeout(900)
+def test_engine_communicator_world_2_with_the_fused_discriminator_stack():
+    """The fused discriminator stack (dstack_f32.hip.h) under the engine's communicator with two ranks: conditioned 3 x 128 MLP D with
+    injected dropout masks (sharded by sequence), 69 rows per rank and pass half (ragged last panel): the unnormalised seeds of
+    GT_OPT_COMM_TV_IN_SUMS, the head's partial sums handed to the collective, the generator step's backward-data chain -- sharded over
+    two ranks == the reference's whole-batch fixture, replicas bit-identical."""
+    case = C.CASES["acoustic_chain_d"]
+    with _forced_fused_dstack():
+        r0, r1 = _run_world2(case)
+    gold = np.load(os.path.join(GOLDEN, "acoustic_chain_d.npz"))
+    _check("acoustic_chain_d/fused", r0, r1, {k: gold[k] for k in gold.files})
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("name", ["acoustic_lstm_dropout", "acoustic_sru_dropout"])
 def test_engine_communicator_world_2_equals_whole_batch_oracle(name):
@@ -167,6 +195,13 @@ PHILOX_CASES = {
     "lstm": dict(C.ORACLE_ONLY_CASES["acoustic_lstm_dropout"], B=4, T=32),
     # SRU with both variational dropouts (masks per (sequence, column), counted globally) + an MLP D with row dropout (T % 16 == 0)
     "sru": dict(C.ORACLE_ONLY_CASES["acoustic_sru_dropout"], B=4, T=32),
+    # conditioned 3 x 128 MLP D through the FUSED discriminator stack (forced): its Philox sites map the panel's 16-row groups to the
+    # groups the same frames have in the one-process minibatch (two-half D pass included)
+    # (warm Adagrad accumulators: the cold first step lr * g / (|g| + 1e-10) turns the rounding of a near-zero gradient element -- the two
+    # world sizes sum it in different orders -- into a parameter error of the size of the tolerance; one element of 16 384 sat at 1.55x)
+    "mlp_fused_dstack": dict(C.CASES["acoustic_chain_d"], B=4, T=48,
+                             opt_g=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4)),
+                             opt_d=("Adagrad", dict(lr=0.01, weight_decay=1e-7, initial_accumulator_value=1e-4))),
 }
 
 
@@ -180,9 +215,11 @@ def test_engine_communicator_philox_world_2_equals_world_1(name):
     suite's 1e-4, replicas bit-identical, and each rank's keep masks == its rows of the one-process masks."""
     from hip_runner import run_hip_case
     case = PHILOX_CASES[name]
-    r0, r1 = _run_world2(case, philox=True)
-    extra = {}
-    ref = run_hip_case(case, extra=extra, philox=True)          # world 1, same seed, same step counter
+    import contextlib
+    with (_forced_fused_dstack() if name == "mlp_fused_dstack" else contextlib.nullcontext()):
+        r0, r1 = _run_world2(case, philox=True)
+        extra = {}
+        ref = run_hip_case(case, extra=extra, philox=True)          # world 1, same seed, same step counter
     _check(name, r0, r1, ref)
     B, T = case["B"], case["T"]
     if name != "sru":                                            # (the SRU sites are per-sequence masks, not row masks)

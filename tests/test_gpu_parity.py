@@ -1412,7 +1412,7 @@ _DP_SCHEDULES = {
 
 
 @pytest.mark.parametrize("schedule", sorted(_DP_SCHEDULES))
-@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out"])
+@pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_lstm", "vc_in2out", "acoustic_chain_d+fused"])
 def test_engine_communicator_world_1_matches_reference_golden(name, schedule):
     """gt_comm_init with one rank: the step goes through the engine's data-parallel path (global valid-frame count,
     per-layer gradient buckets handed to RCCL on the communicator's stream under the backward pass, loss sums, join,
@@ -1420,9 +1420,12 @@ def test_engine_communicator_world_1_matches_reference_golden(name, schedule):
     plain path does -- in every message schedule (GT_OPT_COMM_*): the default one (the count leaves with the D loss sums, the
     backward pass runs on the unnormalised loss and the optimizer kernel applies 1 / Tv), the round-3 one, and the one in between."""
     from hip_runner import run_hip_case
+    opts = dict(_DP_SCHEDULES[schedule] or {})
+    if name.endswith("+fused"):      # the fused discriminator stack under the communicator (unnormalised seeds, the count from the collective, deferred head sums)
+        name, opts["fused_dstack"] = name[:-6], 2
     case = C.CASES[name]
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
-    got = run_hip_case(case, comm_world_1=True, engine_options=_DP_SCHEDULES[schedule])
+    got = run_hip_case(case, comm_world_1=True, engine_options=opts or None)
     for k in gold.files:
         if k.startswith("g_leak_norm"):
             continue
