@@ -885,9 +885,42 @@ __device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
 // and the second product's tiles start while the first one's last tiles finish.
 // tn_first: the weight-gradient workgroups (K = frames / slabs: several times the work of a backward-data tile) take the
 // FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (eng_gemm_f32_pair.hip).
+// PERSISTENT form of the launches (gt_set_tuning("gemm_persist", 1); VERDICT r2-r4: "persistent tile loop"): the grid is the number of
+// RESIDENT workgroup slots, every workgroup walks a static, cost-balanced, XCD-local range of the launch's work items (items laid out on a
+// cost axis -- weight-gradient units first, each worth its K depth in stages -- and cut into equal pieces: slot r of G takes the items whose
+// start lies in [r C / G, (r + 1) C / G)); slot ranks are XCD-major (workgroup b runs on XCD b % 8), so an XCD's slots walk one contiguous run
+// of tiles.  One barrier between two tiles of a workgroup.  gemm_persist_range: this slot's piece of the cost axis.
+__device__ __forceinline__ void gemm_persist_range(long C, long& lo, long& hi) {
+  const int G = (int)gridDim.x, nx = G >> 3;                 // (the launchers make G a multiple of 8)
+  const long r = (long)(blockIdx.x & 7) * nx + (blockIdx.x >> 3);
+  lo = r * C / G; hi = (r + 1) * C / G;
+}
+
 template <int PREC, int AMODE = GEMM_A_RUNTIME>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first, const int n2_persist = 0,
+                                                                    const int w1 = 0, const int w2 = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (n2_persist > 0) {      // persistent: items = n2_persist weight-gradient units of cost w2, then n1 backward-data tiles of cost w1
+    const long C = (long)n2_persist * w2 + (long)n1 * w1;
+    long lo, hi;
+    gemm_persist_range(C, lo, hi);
+    const long split = (long)n2_persist * w2;
+    const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
+    bool first = true;
+    for (long i = (lo + w2 - 1) / w2; i < n2_persist && i * w2 < hi; ++i) {          // units whose start i w2 lies in [lo, hi)
+      if (!first) __syncthreads();
+      first = false;
+      const int slab = (int)i / tiles_mn, t = (int)i - slab * tiles_mn;
+      gemm_tile<GEMM_TN, 64, 64, true, true, PREC>(g2, slab, t / g2.n_tiles_n, t % g2.n_tiles_n, smem);
+    }
+    const long nlo = lo > split ? lo - split : 0, nhi = hi > split ? hi - split : 0;
+    for (long j = (nlo + w1 - 1) / w1; j < n1 && j * w1 < nhi; ++j) {
+      if (!first) __syncthreads();
+      first = false;
+      gemm_tile<GEMM_NN, 64, 64, true, true, PREC, 32, AMODE>(g1, 0, (int)j / g1.n_tiles_n, (int)j % g1.n_tiles_n, smem);
+    }
+    return;
+  }
   int bid = blockIdx.x;
   const int n2 = (int)gridDim.x - n1;
   const bool is_nn = tn_first ? bid >= n2 : bid < n1;
@@ -927,8 +960,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const Gem
 
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32, int AMODE = GEMM_A_RUNTIME>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g, const int persist_total = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (persist_total > 0) {      // persistent: this slot's contiguous run of the launch's persist_total tiles (all of one cost)
+    long lo, hi;
+    gemm_persist_range(persist_total, lo, hi);
+    const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
+    for (long t = lo; t < hi; ++t) {
+      if (t > lo) __syncthreads();
+      const int slab = (int)t / tiles_mn, q = (int)t - slab * tiles_mn;
+      gemm_tile<KIND, BM, BN, VA, VB, PREC, BKT, AMODE>(g, slab, q / g.n_tiles_n, q - (q / g.n_tiles_n) * g.n_tiles_n, smem);
+    }
+    return;
+  }
   gemm_start_stagger(g, smem);
   const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;

@@ -48,7 +48,12 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
+  // persistent form (gt_set_tuning("gemm_persist")): 64 x 64 tiles hold four workgroups per CU, larger tiles two
+  const int slots = gemm_cu_count() * (BM == 64 && BN == 64 ? 4 : 2) / 8 * 8;
+  if (gt_tuning().gemm_persist && PREC == PREC_F32 && grid > slots && stagger_ticks <= 0)
+    hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(slots), dim3(GEMM_THREADS), lds, s, g, grid);
+  else
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g, 0);
   LAUNCH_CHECK();
   if (g_prof.wants(KIND)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;
