@@ -69,10 +69,12 @@ struct DStackArgs {
   const float* W0; int ldw0;      // first layer's weight [HD][ldw0]
   int col0, Da;                   // its adversarial columns [col0, col0 + Da), Da <= 64
   float* gadv; int ld_gadv;       // [rows][ld_gadv]: dloss_adv / d(adversarial input columns)
-  // Start stagger.  The two workgroups of a CU run the same program on the same clock: started together they stay in lockstep -- both
-  // in their K loops (sharing the matrix pipe), both in their epilogues / head (pipe idle), both asking L2 for the same weight lines
-  // at once.  The workgroups that fill the SECOND slot of the CUs in the first resident round (block ids [n_cu, 2 n_cu): the
-  // dispatcher fills every CU's first slot before any second one) start `stagger_ticks` (100 MHz wall-clock ticks) late.
+  // Start stagger (MEASUREMENT switch of tools/dstack_bench.hip; the engine leaves it 0).  Hypothesis: the two workgroups of a CU run the
+  // same program on the same clock and stay in lockstep -- both in their K loops (sharing the matrix pipe), both in their epilogues
+  // (pipe idle).  The workgroups that fill the SECOND slot of the CUs in the first resident round (block ids [n_cu, 2 n_cu), or the odd
+  // ticket of a CU) start `stagger_ticks` (100 MHz wall-clock ticks) late.  Measured: 1 - 10 us of stagger change nothing or cost
+  // their own delay (99 -> 97 .. 104 us): the pair is not in lockstep to begin with -- an epilogue (VALU-heavy) stretches under the
+  // partner's product and vice versa (phase stamps).
   int stagger_ticks, n_cu;
   unsigned int* stagger_ticket;   // [2048] per-CU counters (keyed by cu_key(); never reset): when given, the workgroup that draws an odd ticket on its CU is the late one
   unsigned long long* dbg;        // tools/dstack_bench.hip: [grid][16] wall-clock stamps (100 MHz) of the phases, or null
