@@ -290,8 +290,9 @@ __global__ __launch_bounds__(DS_THREADS, 2) void dstack_kernel(const DStackArgs 
   __syncthreads();
   stamp();
 
-  // ---- G step: derivative codes of layer 0 from its stored output ------------------------------------------------------------
-  if (g_mode && want_grad) {
+  // ---- derivative codes of layer 0 from its stored output: the G step's backward chain ends at layer 0; with ONE hidden layer the seed
+  // gradient of either mode sits right on top of it ----------------------------------------------------------------------------------
+  if (want_grad && (g_mode || L == 1)) {
     const DropoutSpec& d = a.drop[0];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {

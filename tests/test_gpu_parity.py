@@ -475,6 +475,31 @@ def test_fused_discriminator_stack_matches_the_per_layer_launches(name, philox):
             _close(on[k], off[k], msg=k)
 
 
+@pytest.mark.parametrize("num_hidden,hidden_dim,cond", [(1, 128, True), (1, 256, False), (2, 256, True), (4, 128, True)])
+def test_fused_discriminator_stack_depths_and_widths_vs_oracle(num_hidden, hidden_dim, cond):
+    """Shapes of the fused discriminator stack no fixture has: ONE hidden layer (no product inside the kernel: head on the first layer's
+    output, seed, the adversarial-column product alone), the maximum of four, 256-wide with and without conditioning (col0 = 0),
+    injected masks, 69-row passes (ragged last panel) -- two G+D steps against the CPU oracle, fused launches forced."""
+    from hip_runner import run_hip_case
+    from oracle_runner import run_oracle_case
+    base = C.CASES["acoustic_chain_d"]
+    din = base["din"]
+    d = dict(base["d"], num_hidden=num_hidden, hidden_dim=hidden_dim, in_dim=58 + (din if cond else 0))
+    case = dict(base, d=d, cond=cond, steps=2)
+    got, ref = run_hip_case(case, engine_options={"fused_dstack": 2}), run_oracle_case(case)
+    for k, r in ref.items():
+        if k.startswith("g_leak_norm"):
+            continue
+        if "scalars" in k:
+            _close(got[k], r, msg=k)
+            if k.startswith("d_scalars"):
+                assert got[k][3] == r[3] and got[k][4] == r[4], k
+        elif ".opt." in k:
+            _close_state(got[k], r, k)
+        else:
+            _close(got[k], r, msg=k)
+
+
 @pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm", "duration_mlp", "vc_in2out"])
 def test_launch_riders_match_the_separate_launches(name):
     """GT_OPT_LAUNCH_RIDERS: the valid-frame count as an extra workgroup of the adversarial-column gather, the generator step's two
