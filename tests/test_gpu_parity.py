@@ -500,6 +500,41 @@ def test_fused_discriminator_stack_depths_and_widths_vs_oracle(num_hidden, hidde
             _close(got[k], r, msg=k)
 
 
+def test_fused_discriminator_stack_eval_phase_reports_the_same_losses():
+    """phase != "train" (the "test" phase of train_loop, train.py:528-585: losses and counts, no gradients, no update, eval-mode
+    networks: no dropout): the fused stack runs with want_grad = 0 and must report the scalars the per-layer launches report; nothing
+    may be written to the parameters."""
+    import gantts_amd.train as T
+    from gantts_amd import optim, paramgen
+    from gantts_amd.engine import engine_for
+    from gantts_amd.multistream import get_static_features
+    from gantts_amd.seqloss import sequence_mask
+    from hip_runner import build_model, make_hp
+    case = C.CASES["acoustic_chain_d"]
+    hp = make_hp(case)
+    x_np, y_np, lengths = C.make_batch(case)
+    res = {}
+    for fused in (2, 0):
+        T.hp = hp
+        mg, md = build_model(case["g"], 11).eval(), build_model(case["d"], 22).eval()
+        og = optim.Adagrad(mg.parameters(), **case["opt_g"][1])
+        od = optim.Adagrad(md.parameters(), **case["opt_d"][1])
+        engine_for(hp, mg).set_option("fused_dstack", fused)
+        x, y = torch.from_numpy(x_np).cuda(), torch.from_numpy(y_np).cuda()
+        R = paramgen.unit_variance_mlpg_matrix_cuda(hp.windows, case["T"])
+        ys = get_static_features(y, len(hp.windows), hp.stream_sizes, hp.has_dynamic_features)
+        mask = sequence_mask(torch.from_numpy(np.ascontiguousarray(lengths)).cuda(), max_len=case["T"]).unsqueeze(-1)
+        w0 = md.flat_params().clone()
+        yh, yhs = T.apply_generator(mg, x, R, list(lengths))
+        d = T.update_discriminator(md, od, x, ys, yhs, list(lengths), mask, "test")
+        g = T.update_generator(mg, md, og, x, y, yh, ys, yhs, 1.0, list(lengths), mask, "test", mse_w=0.0, mge_w=1.0)
+        assert torch.equal(w0, md.flat_params())
+        res[fused] = (np.array(d, dtype=np.float64), np.array(g, dtype=np.float64))
+    _close(res[2][0], res[0][0], msg="eval D scalars")
+    assert res[2][0][3] == res[0][0][3] and res[2][0][4] == res[0][0][4]
+    _close(res[2][1], res[0][1], msg="eval G scalars")
+
+
 @pytest.mark.parametrize("name", ["acoustic_mlp_dropout", "acoustic_chain_d", "acoustic_lstm", "duration_mlp", "vc_in2out"])
 def test_launch_riders_match_the_separate_launches(name):
     """GT_OPT_LAUNCH_RIDERS: the valid-frame count as an extra workgroup of the adversarial-column gather, the generator step's two
