@@ -44,7 +44,11 @@ static bool sru_loader_waves() { return gt_tuning().sru_lw != 0; }
 // of a block, the waves' composites are combined through LDS.  Eight waves per 64 columns where that still fits the CUs' wave slots
 // (B x ncols / 64 workgroups <= CUs: cfg4's B = 16), four otherwise.
 static bool sru_coop() { return gt_tuning().sru_lw >= 2; }
-static int sru_coop_waves(long B, int ncols) { return cdiv(B * ncols, 64) <= gemm_cu_count() ? 8 : 4; }
+static int sru_coop_waves(long B, int ncols) {
+  const int forced = gt_tuning().sru_cs_waves;      // (tests: both instantiations on every shape)
+  if (forced == 4 || forced == 8) return forced;
+  return cdiv(B * ncols, 64) <= gemm_cu_count() ? 8 : 4;
+}
 // Measured and dropped (round 4, gpurun_out/r4k): 32 columns per workgroup (twice the recurrence waves per CU, half of every wave
 // idle) for the shapes that give fewer than three 64-column workgroups per CU -- cfg4 (B = 16, T = 2048) 11.36 vs 10.84 ms, the
 // hparams-default generator at B = 32 9.49 vs 9.32 ms: the scan is not bound by one wave's per-frame latency.

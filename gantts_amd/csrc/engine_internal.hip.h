@@ -89,6 +89,7 @@ struct GtTuning {
   int mlpg_small16 = 0;       // GT_MLPG_SMALL16   16-frame MLPG tiles when 32-frame tiles would fill at most half the CUs (mlpg_tt == 0)
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
   int gemm_persist = 0;       // GT_GEMM_PERSIST   float32 product launches as persistent grids (resident slots, static cost-balanced XCD-local tile runs)
+  int sru_cs_waves = 0;       // GT_SRU_CS_WAVES   waves per 64 columns of the cooperative SRU scans: 0 = by shape (8 where B x ncols / 64 <= CUs, else 4), 4, 8
   int sru_lw = 2;             // GT_SRU_LW         2: cooperative block scans (sru_cs_kernels.hip.h); 1: loader-wave scans; 0: one-wave kernels (1 == 0 bit for bit)
 };
 GtTuning& gt_tuning();

@@ -1157,9 +1157,10 @@ def test_sru_loader_wave_scans_equal_the_one_wave_scans_bit_for_bit(name, bf16):
         assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), k
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("name,bf16", [("acoustic_sru_at_size", 0), ("acoustic_sru_uni_k3_dropout", 0), ("vc_sru_multistream", 0), ("acoustic_sru_uni_k3", 0),
                                        ("acoustic_sru_bi_saturated", 0), ("acoustic_sru_at_size", 1), ("acoustic_sru_dropout", 1)])
-def test_sru_cooperative_block_scans_match_the_sequential_scans(name, bf16):
+def test_sru_cooperative_block_scans_match_the_sequential_scans(name, bf16, waves):
     """The cooperative block scans (sru_cs_kernels.hip.h, the default: every wave of a workgroup walks eight frames of a block from a
     zero state, the waves' composites (prod f, end state) are combined through LDS, each wave corrects its frames by prefix
     product x incoming state) against the sequential loader-wave scans: the same linear recurrence under another association of the
@@ -1174,9 +1175,12 @@ def test_sru_cooperative_block_scans_match_the_sequential_scans(name, bf16):
     try:
         L.check(L.lib.gt_set_tuning(b"sru_lw", 1))
         ref = run_hip_case(case, engine_options=opts)
+        L.check(L.lib.gt_set_tuning(b"sru_lw", 2))
+        L.check(L.lib.gt_set_tuning(b"sru_cs_waves", waves))      # both instantiations (8 / 4 waves per 64 columns) on every shape
+        got = run_hip_case(case, engine_options=opts)
     finally:
         L.check(L.lib.gt_set_tuning(b"sru_lw", 2))
-    got = run_hip_case(case, engine_options=opts)
+        L.check(L.lib.gt_set_tuning(b"sru_cs_waves", 0))
     assert set(got) == set(ref)
     rtol = 2e-2 if bf16 else RTOL
     frac_ok, worst_ok = _kink_frac(case)
