@@ -41,13 +41,13 @@ static SruArgs sru_args(gt_engine* e, const Net& G, int l, int B, int T, const f
 // (read at every launch: the A/B test flips it between two steps of one process)
 static bool sru_loader_waves() { return gt_tuning().sru_lw != 0; }
 // GT_SRU_LW=2 (default): the cooperative block scans (sru_cs_kernels.hip.h): every wave of a workgroup loads AND walks eight frames
-// of a block, the waves' composites are combined through LDS.  Eight waves per 64 columns where that still fits the CUs' wave slots
-// (B x ncols / 64 workgroups <= CUs: cfg4's B = 16), four otherwise.
+// of a block, the waves' composites are combined through LDS.  Eight waves per 64 columns up to two workgroups per CU (cfg4's B = 16, the
+// hparams-default generator's B = 32), four beyond.
 static bool sru_coop() { return gt_tuning().sru_lw >= 2; }
 static int sru_coop_waves(long B, int ncols) {
   const int forced = gt_tuning().sru_cs_waves;      // (tests: both instantiations on every shape)
   if (forced == 4 || forced == 8) return forced;
-  return cdiv(B * ncols, 64) <= gemm_cu_count() ? 8 : 4;
+  return cdiv(B * ncols, 64) <= 2 * gemm_cu_count() ? 8 : 4;      // (measured: cfg4 B = 16 7.39 vs 7.85 ms; hparams-default generator B = 32, T = 1024 8.07 vs 8.32 ms)
 }
 // Measured and dropped (round 4, gpurun_out/r4k): 32 columns per workgroup (twice the recurrence waves per CU, half of every wave
 // idle) for the shapes that give fewer than three 64-column workgroups per CU -- cfg4 (B = 16, T = 2048) 11.36 vs 10.84 ms, the
