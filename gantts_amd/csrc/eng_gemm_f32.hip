@@ -7,7 +7,7 @@ int launch_gemm_nt(const GemmArgs& g, int bm, int bn, hipStream_t s);
 int launch_gemm_nn(const GemmArgs& g, int bm, int bn, hipStream_t s);
 int launch_gemm_tn(const GemmArgs& g, int bm, int bn, int nslab, hipStream_t s);
 int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hipStream_t s);
-int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s);
+int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s, const GemmArgs* rider, bool* rode);
 // ------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------
@@ -225,7 +225,8 @@ int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, l
 // xp: x with a 16-byte row pitch (n-contiguous operand), adv: [rows][ld_adv] with a 16-byte pitch.
 int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap, const float* xp, int ldxp, int cd,
                                  const float* adv, int ld_adv, int Da, int out, float* dW, float* db, bool accumulate,
-                                 Scratch& slabs, hipStream_t s, SlabDefer* defer) {
+                                 Scratch& slabs, hipStream_t s, SlabDefer* defer, const GemmArgs* rider, bool* rode) {
+  if (rode) *rode = false;
   if (rows != wrap && rows != 2 * wrap) return fail(GT_ERR_INVALID, "split weight gradient: rows must be one or two halves");
   if (!gemm_vec_ok(dZ, lddz) || !gemm_vec_ok(xp, ldxp) || !gemm_vec_ok(adv, ld_adv) || tl_gemm_prec != PREC_F32)
     return fail(GT_ERR_INVALID, "split weight gradient: operands must be 16-byte loadable (float32 products)");
@@ -270,7 +271,7 @@ int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap
   g2.A2 = nullptr; g2.B = adv; g2.ldb = ld_adv; g2.C = slab_base + cd; g2.N = Da; g2.K = (int)rows; g2.k_chunk = kc2;
   g2.colsum_slab = db ? bias_slabs : nullptr;
   if (g1.A2) {
-    CHK(launch_gemm_tn_pair(g1, g2, ns1, ns2, s));
+    CHK(launch_gemm_tn_pair(g1, g2, ns1, ns2, s, rider, rode));
   } else {             // one half only: two plain weight-gradient launches
     g1.n_tiles_m = 64; g2.n_tiles_m = 64;
     CHK(launch_gemm(GEMM_TN, g1, ns1, s));

@@ -39,22 +39,35 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
 }
 
 // the two weight-gradient products of a split first layer in one launch (gemm_tn_pair_kernel); float32, 64 x 64 tiles
-int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s) {
-  GemmArgs g1 = g1_in, g2 = g2_in;
+// rider (optional): a backward-data product without activation derivative whose B operand takes the 4-byte loader (K-contiguous A, 16-byte
+// loadable): its 64 x 64 tiles are the launch's last workgroups.  *rode tells the caller whether it was taken.
+int launch_gemm_tn_pair(const GemmArgs& g1_in, const GemmArgs& g2_in, int nslab1, int nslab2, hipStream_t s, const GemmArgs* rider, bool* rode) {
+  GemmArgs g1 = g1_in, g2 = g2_in, g3;
+  memset(&g3, 0, sizeof(g3));
+  int n3 = 0;
+  if (rode) *rode = false;
+  if (rider && rider->act == ACT_NONE && !rider->accumulate && rider->M > 0 && gemm_vec_ok(rider->A, rider->lda, true) && tl_gemm_prec == PREC_F32 &&
+      gemm_small_tiles_ok()) {
+    g3 = *rider;
+    g3.wide_store = gemm_wide_store_ok(GEMM_NN, g3) ? 1 : 0;
+    g3.n_tiles_m = cdiv(g3.M, 64); g3.n_tiles_n = cdiv(g3.N, 64);
+    n3 = g3.n_tiles_m * g3.n_tiles_n;
+    if (rode) *rode = true;
+  }
   g1.wide_store = g2.wide_store = 0;
   g1.n_tiles_m = cdiv(g1.M, 64); g1.n_tiles_n = cdiv(g1.N, 64);
   g2.n_tiles_m = cdiv(g2.M, 64); g2.n_tiles_n = cdiv(g2.N, 64);
   const int n1 = g1.n_tiles_m * g1.n_tiles_n * nslab1, n2 = g2.n_tiles_m * g2.n_tiles_n * nslab2;
-  const size_t lds = gemm_lds_bytes<GEMM_TN, 64, 64>();
+  const size_t lds = std::max(gemm_lds_bytes<GEMM_TN, 64, 64>(), gemm_lds_bytes<GEMM_NN, 64, 64>());
   CHK(ensure_dyn_lds((const void*)gemm_tn_pair_kernel<PREC_F32>, lds));
   GemmProfiler::Rec rec;
   if (g_prof.wants(6)) {
-    rec.kind = 6; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * g1.M * g1.N * g1.K + 2.0 * g2.M * g2.N * g2.K;
-    rec.bytes = gemm_algorithmic_bytes(GEMM_TN, g1) + 4.0 * (double)g1.M * g1.K + gemm_algorithmic_bytes(GEMM_TN, g2);
+    rec.kind = 6; rec.bn = 64; rec.am = -1; rec.flops = 2.0 * g1.M * g1.N * g1.K + 2.0 * g2.M * g2.N * g2.K + (n3 ? 2.0 * g3.M * g3.N * g3.K : 0.0);
+    rec.bytes = gemm_algorithmic_bytes(GEMM_TN, g1) + 4.0 * (double)g1.M * g1.K + gemm_algorithmic_bytes(GEMM_TN, g2) + (n3 ? gemm_algorithmic_bytes(GEMM_NN, g3) : 0.0);
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  hipLaunchKernelGGL(gemm_tn_pair_kernel<PREC_F32>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, g1, g2, n1);
+  hipLaunchKernelGGL(gemm_tn_pair_kernel<PREC_F32>, dim3(n1 + n2 + n3), dim3(GEMM_THREADS), lds, s, g1, g2, n1, g3, n3);
   LAUNCH_CHECK();
   if (g_prof.wants(6)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;

@@ -245,8 +245,11 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       if (l > 0) nn = backward_data_args(cur, Lr.out, Lr.W, Lr.in, 0, other, Lr.in, rows, Lr.out, Lr.in, ACT_LEAKY_DROPOUT,
                                          acts[l - 1].as<float>(), Lr.in, specs[l - 1]);
       if (want_w && l == 0 && fs) {
+        // the kept gradient w.r.t. the generated rows' adversarial columns (no activation derivative) rides in the same launch
+        GemmArgs leak;
+        if (dX) leak = backward_data_args(cur + row0 * Lr.out, Lr.out, Lr.W, Lr.in, col0, dX, lddx, nrows, Lr.out, ncols, ACT_NONE, nullptr, 0, no_drop());
         CHK(linear_backward_weight_split(cur, Lr.out, rows, fs->wrap, fs->xp, fs->ldxp, fs->cd, fs->adv, fs->ld_adv, Lr.in - fs->cd, Lr.out,
-                                         Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role]));
+                                         Lr.dW, Lr.db, n.grads_dirty, e->slabs, s, &e->sdefer[role], dX && gt_tuning().leak_rider ? &leak : nullptr, &rode));
         CHK(comm_grads_ready(e, role, Lr.dW, (long)Lr.out * Lr.in + Lr.out, s));
       } else if (want_w) {
         CHK(linear_backward_weight(cur, Lr.out, Xin, ldx, rows, Lr.out, Lr.in, Lr.dW, Lr.db, n.grads_dirty, e->slabs, e->colp, s, &e->sdefer[role],
@@ -259,7 +262,7 @@ static int stack_backward(gt_engine* e, int role, const float* in, int ld_in, lo
       if (l > 0) {
         if (!rode) CHK(launch_gemm(GEMM_NN, nn, 1, s));
         std::swap(cur, other);
-      } else if (dX) {
+      } else if (dX && !rode) {
         CHK(linear_backward_data(cur + row0 * Lr.out, Lr.out, Lr.W, Lr.in, col0, dX, lddx, nrows, Lr.out, ncols, ACT_NONE, nullptr, 0,
                                  no_drop(), s));
       }

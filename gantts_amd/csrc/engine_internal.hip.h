@@ -88,6 +88,7 @@ struct GtTuning {
                               //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4
   int mlpg_small16 = 0;       // GT_MLPG_SMALL16   16-frame MLPG tiles when 32-frame tiles would fill at most half the CUs (mlpg_tt == 0)
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
+  int leak_rider = 1;         // GT_LEAK_RIDER     D step: the kept dloss_d / dy_hat_static product rides in the split first layer's weight-gradient launch
   int gemm_persist = 0;       // GT_GEMM_PERSIST   float32 product launches as persistent grids (resident slots, static cost-balanced XCD-local tile runs)
   int sru_cs_waves = 0;       // GT_SRU_CS_WAVES   waves per 64 columns of the cooperative SRU scans: 0 = by shape (8 where B x ncols / 64 <= CUs, else 4), 4, 8
   int sru_lw = 2;             // GT_SRU_LW         2: cooperative block scans (sru_cs_kernels.hip.h); 1: loader-wave scans; 0: one-wave kernels (1 == 0 bit for bit)
@@ -374,7 +375,7 @@ int linear_backward_weight(const float* dZ, int lddz, const float* X, int ldx, l
 
 int linear_backward_weight_split(const float* dZ, int lddz, long rows, long wrap, const float* xp, int ldxp, int cd,
                                  const float* adv, int ld_adv, int Da, int out, float* dW, float* db, bool accumulate,
-                                 Scratch& slabs, hipStream_t s, SlabDefer* defer);
+                                 Scratch& slabs, hipStream_t s, SlabDefer* defer, const GemmArgs* rider = nullptr, bool* rode = nullptr);
 
 // ------------------------------------------------------------------------------------------
 // eng_gemm_b16.hip

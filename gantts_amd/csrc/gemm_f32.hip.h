@@ -940,11 +940,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmAr
 // One launch = the two weight-gradient products of a SPLIT first layer (eng_step.hip: FirstSplit): g1 = the x columns, A operand
 // summed over the two halves of the pass (GEMM_A_TN_SUM2), g2 = the adversarial columns over all rows; both write column blocks
 // of the same slab set.  g2's workgroups (twice the frames each) take the FIRST block ids: longest work first.
+// n3 > 0: a THIRD, independent product rides in the launch -- the last n3 workgroups run the 64 x 64 tiles of backward-data product g3 whose B operand
+// takes the 4-byte loader and which has no activation derivative (the kept dloss_d / dy_hat_static of the D step: dZ_0[generated rows] . W_0[:, adv
+// columns], train.py:265, 274 -- it reads the same dZ_0 as the two weight gradients and used to be a launch of its own at its floor).
 template <int PREC>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const GemmArgs g3, const int n3) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int bid = blockIdx.x;
-  const int n2 = (int)gridDim.x - n1;
+  if (bid >= (int)gridDim.x - n3) {
+    bid -= (int)gridDim.x - n3;
+    gemm_tile<GEMM_NN, 64, 64, true, false, PREC, 32, GEMM_A_NONE>(g3, 0, bid / g3.n_tiles_n, bid % g3.n_tiles_n, smem);
+    return;
+  }
+  const int n2 = (int)gridDim.x - n3 - n1;
   if (bid >= n2) {      // g2's (long) workgroups take the first block ids
     bid = gemm_xcd_order(bid - n2, n1);
     const int tiles_mn = g1.n_tiles_m * g1.n_tiles_n;
