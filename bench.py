@@ -122,6 +122,41 @@ def cpu_baseline(B, T, budget_s=20.0):
                       "median %.3f s/step" % (len(times), B, T, med)}
 
 
+def comm_schedule(rec, steps, traced_ms, args):
+    """Condenses the engine's schedule trace (gt_comm_trace_read: kind, bytes, on the step stream, start us, end us) of `steps` steps."""
+    import numpy as np
+    msgs, waits = rec[rec[:, 0] == 0], rec[rec[:, 0] == 1]
+    n_msg = len(msgs) // steps
+    out = {"source": "gt_comm_trace: timed HIP events around every message (on the stream that carries it) and around every wait of the "
+                     "step stream for the communicator's stream; rank 0, %d steps behind the timed region" % steps,
+           "transport": ("tests/fake_rccl.cpp (host-staged test double), every rank on ONE device: message DURATIONS are the double's, "
+                         "only the schedule (count, sizes, what overlaps what) carries over to RCCL over xGMI") if args.one_device
+                        else ("two-shot all-reduce over hipIpc arenas" if args.dp_ipc else "RCCL"),
+           "ms_per_step_traced": traced_ms, "messages_per_step": len(msgs) / steps, "waits_per_step": len(waits) / steps,
+           "bytes_per_step": float(msgs[:, 1].sum()) / steps,
+           "step_stream_wait_us_per_step": float((waits[:, 4] - waits[:, 3]).sum()) / steps}
+    # per position in the step (the schedule is the same every step): size, duration, exposed share
+    per = []
+    if n_msg and len(msgs) == n_msg * steps:
+        m = msgs.reshape(steps, n_msg, 5)
+        for j in range(n_msg):
+            dur = m[:, j, 4] - m[:, j, 3]
+            exposed = np.zeros(steps)
+            for i in range(steps):
+                if m[i, j, 2]:            # a closing message on the step stream itself: nothing of the step runs beside it
+                    exposed[i] = dur[i]
+                else:                     # the part of the message during which the step stream stood waiting
+                    lo = np.maximum(waits[:, 3], m[i, j, 3])
+                    hi = np.minimum(waits[:, 4], m[i, j, 4])
+                    exposed[i] = np.clip(hi - lo, 0, None).sum()
+            per.append({"bytes": float(m[0, j, 1]), "on_step_stream": bool(m[0, j, 2]), "duration_us": float(np.median(dur)),
+                        "exposed_us": float(np.median(exposed)), "hidden_us": float(np.median(dur - exposed))})
+        out["messages"] = per
+        out["exposed_us_per_step"] = sum(p["exposed_us"] for p in per)
+        out["hidden_us_per_step"] = sum(p["hidden_us"] for p in per)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +184,14 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel code path (RCCL all-reduce) even with one rank")
     ap.add_argument("--dp-ipc", action="store_true", help="data parallel: the step's messages over the engine's two-shot all-reduce on hipIpc "
                     "peer arenas (gt_comm_ipc_*) instead of RCCL; falls back to RCCL with a warning if the arenas cannot be attached")
+    ap.add_argument("--comm-trace", type=int, default=0, metavar="STEPS",
+                    help="data parallel: BEHIND the timed region, run STEPS more steps with the engine's schedule trace on (gt_comm_trace) and "
+                         "add `comm_schedule` to the line: messages per step, how long each holds the communicator's stream, how long the "
+                         "step stream waits for them (exposed) and how much ran under compute (hidden)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="SCHEDULE measurement without a multi-GPU node, never a throughput claim: all ranks share device 0 and the engine's "
+                         "communicator binds the tests' RCCL double (tests/fake_rccl.cpp: all-reduce staged through host shared memory), "
+                         "because RCCL refuses two ranks on one device; the bootstrap group is gloo")
     ap.add_argument("--dp-python", action="store_true", help="data parallelism orchestrated from Python (torch.distributed "
                     "all-reduce between the split-phase calls) instead of the engine's own RCCL communicator")
     args = ap.parse_args()
@@ -173,12 +216,29 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
     local_rank %= max(1, torch.cuda.device_count())
+    if args.one_device:
+        if args.dp_python:
+            raise SystemExit("bench.py --one-device: the engine's own communicator only")
+        local_rank = 0
+        fake, fake_src = os.path.join(ROOT, "tests", "libfake_rccl.so"), os.path.join(ROOT, "tests", "fake_rccl.cpp")
+        if rank == 0 and (not os.path.isfile(fake) or os.path.getmtime(fake) < os.path.getmtime(fake_src)):
+            import subprocess
+            hipcc = os.environ.get("HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.isfile("/opt/rocm/bin/hipcc") else "hipcc")
+            subprocess.check_call([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=" + os.environ.get("ARCH", "gfx950"),
+                                   fake_src, "-o", fake, "-lrt"])
+        os.environ["GT_RCCL_LIB"] = fake
+        os.environ["GT_IPC_ALLOW_COARSE"] = "1"       # one device, one L2: a coarse-grained arena is coherent here (eng_ipc.hip)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    boot_dev = torch.device("cpu") if args.one_device else dev       # where the bootstrap group's tensors live
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()       # (rank 0 has built the double)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if torch.cuda.device_count() < world and rank == 0:
@@ -241,16 +301,20 @@ def main():
             # buckets per layer on its communicator stream, overlapped with the backward pass
             from gantts_amd.engine import engine_for
             eng = engine_for(hp, mg)
-            idt = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            idt = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8, device=boot_dev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            dist.broadcast(mg.flat_params(), src=0)
-            dist.broadcast(md.flat_params(), src=0)
+            for m in (mg, md):
+                fp = m.flat_params()
+                staged = fp.to(boot_dev)
+                dist.broadcast(staged, src=0)
+                if staged is not fp:
+                    fp.copy_(staged)
             eng.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
             if args.dp_ipc:
                 try:
-                    mine = torch.frombuffer(bytearray(eng.comm_ipc_export()), dtype=torch.uint8).to(dev)
+                    mine = torch.frombuffer(bytearray(eng.comm_ipc_export()), dtype=torch.uint8).to(boot_dev)
                     allh = [torch.zeros_like(mine) for _ in range(world)]
                     if world > 1:
                         dist.all_gather(allh, mine)
@@ -351,7 +415,7 @@ def main():
               " | drain %.3f" % (1e3 * (t0 + elapsed - marks[-1])), file=sys.stderr)
     L.check(L.lib.gt_profile_enable(0))
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=boot_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -453,6 +517,20 @@ def main():
                 "speedup_over_one_gpu_without_communication": {str(n): (1e3 * elapsed / args.steps) / proxy[n] for n in proxy},
             }
 
+    # (c) data parallel: the step's communication schedule from the engine's own trace (timed events around every message and every wait)
+    if args.comm_trace > 0 and (world > 1 or args.force_dp) and not args.dp_python:
+        for _ in range(3):
+            step()
+        eng.comm_trace(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.comm_trace):
+            step()
+        torch.cuda.synchronize()
+        traced_ms = 1e3 * (time.perf_counter() - t1) / args.comm_trace
+        eng.comm_trace(False)
+        companion["comm_schedule"] = comm_schedule(eng.comm_trace_read(), args.comm_trace, traced_ms, args)
+
     # every rank flushes its C stdio (RCCL's NCCL_DEBUG=VERSION banner is block-buffered when piped)
     # before rank 0 prints, so the JSON line is the last line of the job's stdout
     import ctypes
@@ -471,7 +549,8 @@ def main():
                                       "Adagrad, MGE+ADV loss, global B=%d T=%d (%d sequences per GPU, %s scaling), fp32, "
                                       "dropout 0.5 (Philox)" % (Bglobal, Tn, B, args.scaling),
                           "global_batch": Bglobal, "per_gpu_batch": B, "frames_per_step": Bglobal * Tn,
-                          "parallelism": "dp%d" % world, "collective": None if (world == 1 and not args.force_dp) else ("two-shot all-reduce over hipIpc arenas" if args.dp_ipc else "rccl")},
+                          "parallelism": "dp%d" % world, "collective": None if (world == 1 and not args.force_dp) else ("two-shot all-reduce over hipIpc arenas" if args.dp_ipc else
+                                                                                          ("tests/fake_rccl.cpp, ALL RANKS ON ONE DEVICE: a schedule measurement, not a throughput" if args.one_device else "rccl"))},
                "step_algorithmic_gflop": step_flops / 1e9,
                "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},

@@ -99,6 +99,8 @@ SIGNATURES = {
     "gt_comm_init": (_I, [_P, _I, _I, _P]),
     "gt_comm_destroy": (_I, [_P]),
     "gt_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "gt_comm_trace": (_I, [_P, _I]),
+    "gt_comm_trace_read": (_I, [_P, C.POINTER(C.c_double), _I, C.POINTER(_I)]),
     "gt_set_shard": (_I, [_P, _I, _I]),
     "gt_comm_ipc_export": (_I, [_P, _P]),
     "gt_comm_ipc_attach": (_I, [_P, _I, _I, _P]),

@@ -63,6 +63,7 @@ enum { GT_NCCL_SUM = 0, GT_NCCL_FLOAT = 7, GT_NCCL_DOUBLE = 8 };
 // stream).  GT_COMM_FORCE_COLLECTIVES=1 issues every call anyway -- the launch / cross-stream cost of the schedule can
 // then be measured on one GPU (bench.py --force-dp).
 
+static void trace_clear(GtComm* c);
 extern "C" int gt_comm_unique_id(void* id_out) {
   if (!id_out) return fail(GT_ERR_INVALID, "null argument");
   RcclApi* api = rccl_api();
@@ -79,6 +80,7 @@ extern "C" int gt_comm_destroy(gt_engine* e) {
   if (c->comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  trace_clear(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   e->comm = nullptr;
@@ -124,6 +126,51 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
   return GT_OK;
 }
 
+// Schedule trace: while it is on, comm_allreduce_after brackets every message with two timed events on the stream that carries it
+// (the first one behind the hand-off wait: the message may start there) and comm_join brackets the step stream's wait, so a run tells
+// how many messages a step sends, how long each one holds the communicator's stream and how long the step stream stands still for them.
+static void trace_clear(GtComm* c) {
+  for (auto& r : c->trec) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+  c->trec.clear();
+}
+static GtComm::TraceRec* trace_open(GtComm* c, int kind, bool inl, double bytes, hipStream_t on) {
+  if (!c->trace || c->trec.size() >= 65536) return nullptr;
+  GtComm::TraceRec r;
+  r.kind = kind; r.inl = inl ? 1 : 0; r.bytes = bytes; r.e0 = r.e1 = nullptr;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess || hipEventRecord(r.e0, on) != hipSuccess) {
+    if (r.e0) (void)hipEventDestroy(r.e0);
+    if (r.e1) (void)hipEventDestroy(r.e1);
+    return nullptr;
+  }
+  c->trec.push_back(r);
+  return &c->trec.back();
+}
+extern "C" int gt_comm_trace(gt_engine* e, int enable) {
+  if (!e) return fail(GT_ERR_INVALID, "null engine");
+  if (!e->comm) return fail(GT_ERR_STATE, "gt_comm_trace without a communicator");
+  HIPCHK(hipDeviceSynchronize());
+  if (enable) trace_clear(e->comm);
+  e->comm->trace = enable != 0;
+  return GT_OK;
+}
+extern "C" int gt_comm_trace_read(gt_engine* e, double* out, int max_records, int* n_records) {
+  if (!e || !n_records || (max_records > 0 && !out)) return fail(GT_ERR_INVALID, "null argument");
+  if (!e->comm) return fail(GT_ERR_STATE, "gt_comm_trace_read without a communicator");
+  HIPCHK(hipDeviceSynchronize());
+  GtComm* c = e->comm;
+  int n = 0;
+  for (size_t i = 0; i < c->trec.size() && n < max_records; ++i) {
+    const GtComm::TraceRec& r = c->trec[i];
+    float t0 = 0.f, t1 = 0.f;
+    HIPCHK(hipEventElapsedTime(&t0, c->trec[0].e0, r.e0));
+    HIPCHK(hipEventElapsedTime(&t1, c->trec[0].e0, r.e1));
+    double* o = out + 5 * (size_t)n++;
+    o[0] = r.kind; o[1] = r.bytes; o[2] = r.inl; o[3] = 1e3 * (double)t0; o[4] = 1e3 * (double)t1;
+  }
+  *n_records = max_records > 0 ? n : (int)c->trec.size();
+  return GT_OK;
+}
+
 bool comm_on(const gt_engine* e) {
   return e->comm != nullptr && (e->comm->world > 1 || e->opt_comm_force);
 }
@@ -135,24 +182,30 @@ static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype
   // messages that fit the interprocess arena's slots take the full-mesh two-shot path (eng_ipc.hip) once the arenas are attached
   const bool dbl = dtype == GT_NCCL_DOUBLE;
   const bool ipc = ipc_usable(e, count * (dbl ? sizeof(double) : sizeof(float)));
-  if (on_compute) {
-    if (ipc) return ipc_allreduce(e, buf, count, dbl, compute);
-    NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, compute));
-    return GT_OK;
+  const double bytes = (double)count * (dbl ? sizeof(double) : sizeof(float));
+  hipStream_t on = compute;
+  if (!on_compute) {
+    hipEvent_t ev = c->ev[c->next_ev];
+    c->next_ev = (c->next_ev + 1) % 8;
+    HIPCHK(hipEventRecord(ev, compute));
+    HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+    on = c->stream;
   }
-  hipEvent_t ev = c->ev[c->next_ev];
-  c->next_ev = (c->next_ev + 1) % 8;
-  HIPCHK(hipEventRecord(ev, compute));
-  HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
-  if (ipc) return ipc_allreduce(e, buf, count, dbl, c->stream);
-  NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, c->stream));
+  GtComm::TraceRec* tr = trace_open(c, 0, on_compute, bytes, on);
+  hipEvent_t tr_e1 = tr ? tr->e1 : nullptr;
+  if (ipc) CHK(ipc_allreduce(e, buf, count, dbl, on));
+  else NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, on));
+  if (tr_e1) HIPCHK(hipEventRecord(tr_e1, on));
   return GT_OK;
 }
 // `compute` continues only after everything handed to the communicator so far has finished
 static int comm_join(gt_engine* e, hipStream_t compute) {
   GtComm* c = e->comm;
   HIPCHK(hipEventRecord(c->ev_done, c->stream));
+  GtComm::TraceRec* tr = trace_open(c, 1, false, 0.0, compute);
+  hipEvent_t tr_e1 = tr ? tr->e1 : nullptr;
   HIPCHK(hipStreamWaitEvent(compute, c->ev_done, 0));
+  if (tr_e1) HIPCHK(hipEventRecord(tr_e1, compute));
   return GT_OK;
 }
 // the gradient of [lo, lo + count) of `role` is final on `compute`.  Ranges are collected and handed to RCCL by

@@ -536,6 +536,18 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 static int head_finalize(gt_engine* e, int mode, int nblk, int K, bool w, hipStream_t s, StepResults* early_res, int* defer_scalars, unsigned ticket) {
   Net& D = e->net[GT_ROLE_D];
   if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
+  if (w && nblk >= 256 && gt_tuning().head_fin2) {       // many partials: the two-stage form (frame_kernels.hip.h)
+    const size_t bytes = sizeof(HeadStage) + (size_t)HF2_PARTS * K * sizeof(float);
+    if (e->headf.bytes < bytes) {
+      CHK(e->headf.ensure(bytes));
+      HIPCHK(hipMemsetAsync(e->headf.p, 0, sizeof(HeadStage), s));       // the arrival counter starts at 0; every launch leaves it there
+    }
+    hipLaunchKernelGGL(d_head_finalize2_kernel, dim3(cdiv(K, 64) * HF2_PARTS), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+                       nblk, K, mode, e->sc(), D.last.dW, D.last.db, D.grads_dirty ? 1 : 0, early_res, e->headf.as<HeadStage>(),
+                       ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
+    LAUNCH_CHECK();
+    return GT_OK;
+  }
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
                      early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
@@ -1171,10 +1183,14 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const bool riders = early_fold && e->opt_launch_riders && !mse_side;
   // data parallel: the same launches, the rider then only files the three sums for the collective (nothing is reported from it)
   const bool riders_dp = e->early && comm_on(e) && e->opt_launch_riders && !(tr && direct && mse_w != 0.f);
+  // phase "train": the two sums ride in the gradient-assembly launch instead (GLossRide, frame_kernels.hip.h): one launch and one pass
+  // over y_hat_static / y_static less
+  const bool loss_ride = (riders || riders_dp) && tr && gt_tuning().g_loss_ride;
   if (riders || riders_dp) {
     mse_blocks = (int)std::min<long>(1024, cdiv(N * Do, RED_THREADS * 4));
     mge_pre_blocks = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
     CHK(e->partial.ensure(4096 * sizeof(double)));
+    if (!loss_ride)
     hipLaunchKernelGGL(g_losses_kernel, dim3(mse_blocks + mge_pre_blocks), dim3(RED_THREADS), 0, s, y_hat, Do, y, Do, Do, mse_blocks,
                        e->partial.as<double>() + 1024, y_hat_static, Ds, y_static, Ds, Ds, e->partial.as<double>(), mask, N);
     LAUNCH_CHECK();
@@ -1299,10 +1315,17 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       fin.hp = head_blocks ? e->headp.as<HeadPartials>() : (const HeadPartials*)nullptr; fin.n_hp = head_blocks;
       if (riders) { fin.ticket_value = take_ticket(e); fin.ticket = fin.ticket_value ? e->ticket_dev() : (unsigned*)nullptr; }
     }
+    GLossRide gl;
+    memset(&gl, 0, sizeof(gl));
+    if (loss_ride) {       // (mge_pre_blocks == nblk: the assembly workgroups leave exactly the partials g_losses_kernel would)
+      if (!e->gl_counter.p) { CHK(e->gl_counter.ensure(64)); HIPCHK(hipMemsetAsync(e->gl_counter.p, 0, 64, s)); }
+      gl.on = 1; gl.n_mse = mse_blocks; gl.a = y_hat; gl.lda = Do; gl.b = y; gl.ldb = Do; gl.D = Do;
+      gl.part_mse = e->partial.as<double>() + 1024; gl.counter = e->gl_counter.as<unsigned>();
+    }
     if (tr || !rid)
-      hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds, y_static, Ds, mask, N, Ds, mge_w,
-                         e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds, rid ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin,
-                         leak && e->leak_unnorm ? 1 : 0);
+      hipLaunchKernelGGL(static_grad_kernel, dim3(loss_ride ? nblk + mse_blocks : nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds,
+                         y_static, Ds, mask, N, Ds, mge_w, e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds,
+                         rid && !loss_ride ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin, leak && e->leak_unnorm ? 1 : 0, gl);
     else      // phase != "train": no gradient to assemble, the finalisation alone
       hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();

@@ -88,6 +88,10 @@ struct GtTuning {
                               //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4
   int mlpg_small16 = 0;       // GT_MLPG_SMALL16   16-frame MLPG tiles when 32-frame tiles would fill at most half the CUs (mlpg_tt == 0)
   int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
+  int g_loss_ride = 0;        // GT_G_LOSS_RIDE    G step (train): loss_mse / loss_mge sums ride in the gradient-assembly launch, last-arrival finalisation.
+                              //                   MEASURED SLOWER (cfg2 1.324 -> 1.499 ms): every workgroup's agent-scope release is an L2 write-back on this 8-XCD part
+  int head_fin2 = 0;          // GT_HEAD_FIN2      head partials of >= 256 workgroups: two-stage finalisation (64 workgroups, last-arrival finish).
+                              //                   MEASURED SLOWER (1.324 -> 1.327-1.329 ms) for the same reason; both stay as measurement switches
   int leak_rider = 1;         // GT_LEAK_RIDER     D step: the kept dloss_d / dy_hat_static product rides in the split first layer's weight-gradient launch
   int gemm_persist = 0;       // GT_GEMM_PERSIST   float32 product launches as persistent grids (resident slots, static cost-balanced XCD-local tile runs)
   int sru_cs_waves = 0;       // GT_SRU_CS_WAVES   waves per 64 columns of the cooperative SRU scans: 0 = by shape (8 where B x ncols / 64 <= CUs, else 4), 4, 8
@@ -215,7 +219,7 @@ struct gt_engine {
   MlpgCache mlpg;
   // workspace
   std::vector<Scratch> g_act, d_act;       // hidden activations
-  Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, dmask, tx, gx, dgx, dtz, dout;
+  Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, headf, gl_counter, dmask, tx, gx, dgx, dtz, dout;
   Scratch scal;                            // StepScalars + StepResults
   StepResults* h_res = nullptr;            // pinned
   StepResults* h_res_dev = nullptr;        // the same page as the kernels see it: the fused calls' finalisation writes the
@@ -412,6 +416,10 @@ struct GtComm {
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int next_ev = 0;
   hipEvent_t ev_done = nullptr;
+  // schedule trace (gt_comm_trace, a measurement): every message and every join of the step stream bracketed by timed events
+  struct TraceRec { int kind, inl; double bytes; hipEvent_t e0, e1; };     // kind 0 message, 1 join
+  bool trace = false;
+  std::vector<TraceRec> trec;
 };
 bool comm_on(const gt_engine* e);
 int comm_grads_ready(gt_engine* e, int role, const float* lo, long count, hipStream_t compute);

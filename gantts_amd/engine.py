@@ -195,6 +195,20 @@ class StepEngine(object):
         the split-phase calls).  Keys the dropout streams globally, so a world-k run reproduces the one-process masks."""
         check(lib.gt_set_shard(self._h, int(rank), int(world)))
 
+    def comm_trace(self, enable):
+        """Starts (clearing the records) or stops the schedule trace of the data-parallel step (gt_comm_trace)."""
+        check(lib.gt_comm_trace(self._h, 1 if enable else 0))
+
+    def comm_trace_read(self):
+        """Records of the schedule trace as an (n, 5) float64 array: kind (0 message, 1 wait of the step stream), bytes, issued on
+        the step stream itself, start us, end us."""
+        import numpy as np
+        n = C.c_int()
+        check(lib.gt_comm_trace_read(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 5), dtype=np.float64)
+        check(lib.gt_comm_trace_read(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+        return out[:n.value]
+
     def comm_info(self):
         r, w = C.c_int(), C.c_int()
         check(lib.gt_comm_info(self._h, C.byref(r), C.byref(w)))

@@ -285,6 +285,14 @@ int gt_comm_unique_id(void* id_out);
 int gt_comm_init(gt_engine* e, int rank, int world, const void* id);
 int gt_comm_destroy(gt_engine* e);
 int gt_comm_info(gt_engine* e, int* rank, int* world);
+/* Schedule trace of the data-parallel step (a measurement, bench.py --comm-trace): while it is on, every message of the step and every
+ * wait of the step stream for the communicator's stream is bracketed by timed events.  gt_comm_trace(e, 1) clears and starts,
+ * gt_comm_trace(e, 0) stops; gt_comm_trace_read synchronises the device and fills `out` with up to max_records records of five doubles
+ * {kind (0 message, 1 wait of the step stream), bytes, issued on the step stream itself (closing message) 0/1, start, end} -- times in
+ * microseconds after the first record's start -- and sets *n_records (max_records == 0: the number of records held).  The reference
+ * has no counterpart: train.py:538-585 is one process. */
+int gt_comm_trace(gt_engine* e, int enable);
+int gt_comm_trace_read(gt_engine* e, double* out, int max_records, int* n_records);
 /* The small-message collective of SURVEY 8(e): a full-mesh TWO-SHOT all-reduce over hipIpc peer buffers (gantts_amd/csrc/eng_ipc.hip),
  * for every message of the step that fits an 8 MB slot -- at cfg2 all of them.  Every rank exports an arena in its own HBM
  * (gt_comm_ipc_export fills `handle_out`, GT_IPC_HANDLE_BYTES), the handles travel to all ranks by any means (like the unique id),

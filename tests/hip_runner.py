@@ -56,6 +56,8 @@ def run_hip_case(case, return_objects=False, engine_options=None, comm_world_1=F
         from gantts_amd.engine import engine_for
         eng = engine_for(hp, mg)
         eng.comm_init(0, 1, eng.comm_unique_id())
+        if extra is not None and callable(extra.get("after_comm")):
+            extra["after_comm"](eng)
     x_np, y_np, lengths = C.make_batch(case)
     rows = slice(None)
     if shard is not None:

@@ -258,6 +258,25 @@ def test_cfg1_at_size_with_the_fused_discriminator_stack_forced():
     compare_with_fixture("cfg1_vc/fused", got, fx)
 
 
+def test_cfg2_at_size_with_the_last_arrival_finalisations():
+    """The two measurement switches of round 5 (gt_set_tuning): `head_fin2` -- the head's 1024 per-panel partials summed by 64 workgroups, the
+    last one to arrive adding the 16 rows -- and `g_loss_ride` -- the reported sums of squares riding in the gradient-assembly launch, the
+    last workgroup to arrive finalising the step.  Both measured SLOWER than the launches they replace (an agent-scope release per workgroup
+    is an L2 write-back on an 8-XCD part) and are off by default; switched on, the cold cfg2 step must still meet the real
+    reference's fixture (sums in a different, still fixed, order)."""
+    from gantts_amd import _lib as L
+    case = A.AT_SIZE_CASES["cfg2_cold"]
+    fx = np.load(os.path.join(GOLDEN, "at_size_cfg2_cold.npz"))
+    try:
+        L.check(L.lib.gt_set_tuning(b"head_fin2", 1))
+        L.check(L.lib.gt_set_tuning(b"g_loss_ride", 1))
+        got = run_hip_at_size(case, engine_options={"fused_dstack": 2})
+    finally:
+        L.check(L.lib.gt_set_tuning(b"head_fin2", 0))
+        L.check(L.lib.gt_set_tuning(b"g_loss_ride", 0))
+    compare_with_fixture("cfg2_cold/last-arrival", got, fx, cold=True)
+
+
 # Relative rms distance to the float64 reference with bf16 storage, per case, network and kind: MEASURED on MI355X (round 4,
 # GT_PARITY_REPORT run of these tests, committed as profiles/r04_parity_report.txt) and limited at <= 2x the measurement:
 #                      measured:  y_hat    y_hat_static  Ggrad    Gupd     Dgrad    Dupd     losses

@@ -1503,6 +1503,37 @@ def test_engine_communicator_world_1_matches_reference_golden(name, schedule):
             _close(got[k], gold[k], msg=k)
 
 
+def test_engine_communicator_schedule_trace_accounts_for_every_gradient_byte():
+    """gt_comm_trace (bench.py --comm-trace): with one rank and forced collectives every step's messages carry each network's whole
+    gradient exactly once plus its loss sums; every record is a well-formed interval, and the traced run still reproduces the fixture."""
+    from hip_runner import run_hip_case
+    name = "acoustic_mlp_dropout"
+    case = C.CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    held = {}
+
+    def start(eng):
+        eng.comm_trace(True)
+        held["eng"] = eng
+    got = run_hip_case(case, comm_world_1=True, extra={"after_comm": start})
+    rec = held["eng"].comm_trace_read()
+    held["eng"].comm_trace(False)
+    assert rec.shape[1] == 5 and len(rec) > 0
+    assert set(np.unique(rec[:, 0])) <= {0.0, 1.0}
+    assert (rec[:, 4] >= rec[:, 3]).all() and rec[0, 3] == 0.0
+    msgs, waits = rec[rec[:, 0] == 0], rec[rec[:, 0] == 1]
+    assert len(waits) >= 2 * case["steps"]                      # each backward pass ends with the step stream joining the communicator
+    n_g = sum(v.size for k, v in gold.items() if k.startswith("G.") and ".opt." not in k)
+    n_d = sum(v.size for k, v in gold.items() if k.startswith("D.") and ".opt." not in k)
+    grad_bytes = msgs[msgs[:, 1] > 64][:, 1].sum()               # (the sums are a few doubles)
+    assert grad_bytes == 4.0 * (n_g + n_d) * case["steps"], (grad_bytes, n_g, n_d)
+    small = msgs[msgs[:, 1] <= 64]
+    assert len(small) >= 2 * case["steps"] and (small[:, 1] % 8 == 0).all()
+    for k in gold.files:
+        if "scalars" in k:
+            _close(got[k], gold[k], msg=k)
+
+
 def _dp2_hip_worker(rank, world, port, q):
     """One of two processes sharing cuda:0: HipStepBackend on its shard, DataParallelStep over a gloo group (device
     tensors staged through the host -- two RCCL ranks cannot share one GPU)."""
