@@ -305,7 +305,8 @@ struct gt_engine {
   // by the generator step's gradient assembly for the kept dloss_d/dy_hat_static.  d_unnorm / leak_unnorm: in that state right now.
   bool opt_comm_tv_in_sums = env_flag("GT_COMM_TV_IN_SUMS", true);
   bool d_unnorm = false, leak_unnorm = false;
-  bool opt_poll_results = env_flag("GT_POLL_RESULTS", false);     // measured: no gain (cfg2 1.380 / 1.384 vs 1.381 / 1.375 ms; b = 4: 0.411 vs 0.417)
+  bool opt_poll_results = env_flag("GT_POLL_RESULTS", true);      // round 4: no gain (1.380 / 1.384 vs 1.381 / 1.375 ms); round 5, the step 60 us shorter: 1.3125 / 1.312 vs
+                                                                  // 1.319 / 1.315 / 1.3175 / 1.3206 ms, b = 4 0.400 vs 0.406 -- the two 5.8 us holes behind the finalising launches now show
   bool opt_launch_riders = env_flag("GT_LAUNCH_RIDERS", true);     // GT_OPT_LAUNCH_RIDERS: small reductions as extra workgroups of neighbouring launches
   int ld_gx = 0, ld_cx = 0;                        // gt_set_x_pitch: row pitch of the generator input / the conditioning x (0 = dense)
   // Pitched rows are read in place by the float32 MLP generator and by the split first layer of the conditioned float32 MLP
