@@ -591,7 +591,7 @@ static int run_dstack(gt_engine* e, int mode, long rows, long n_real, const floa
   a.w_last = D.last.W; a.b_last = D.last.b; a.mask = mask; a.n_mask = (int)n_mask; a.eps = eps; a.unit_tv = unit_tv ? 1 : 0; a.tv_dev = tv_dev;
   a.sc = e->sc(); a.want_grad = want_grad ? 1 : 0; a.Dout = e->dout.as<float>(); a.hp = e->headp.as<HeadPartials>();
   if (mode == DSTACK_D_STEP) {
-    for (int l = 1; l < L; ++l) a.Hout[l] = e->d_act[l].as<float>();
+    for (int l = 1; l + 1 < L; ++l) a.Hout[l] = e->d_act[l].as<float>();      // (the top layer's activation only feeds the head, which is fused: no stash)
     a.dZtop = e->dzA.as<float>();
     if (want_grad) { CHK(e->headw.ensure((size_t)nblk * H * sizeof(float))); a.dw_partial = e->headw.as<float>(); }
   } else {
