@@ -867,7 +867,7 @@ extern "C" int gt_update_discriminator_begin(gt_engine* e, const float* x, const
     // (the valid-frame count rides in this launch when it is not known yet: fused single-GPU call)
     const bool tv_ride = e->early && e->opt_launch_riders && !comm_on(e) && !tv_side && !tv_known;
     const bool any_ride = tv_ride || tv_ride_dp || unnorm;
-    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * e->ld_adv2, 256) + (any_ride ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static,
+    hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(2 * N * (e->ld_adv2 / 4), 256) + (any_ride ? 1 : 0)), dim3(256), 0, s, y_static, y_hat_static,
                        e->Ds, e->d_adv_cols, e->Da, e->adv2.as<float>(), e->ld_adv2, N, 2 * N, any_ride ? mask : (const float*)nullptr,
                        (int)N, e->tv_override, e->sc(), unnorm ? &e->sc()->tv_sum : tv_ride_dp ? e->comm_tv.as<double>() : (double*)nullptr);
     LAUNCH_CHECK();
@@ -1218,7 +1218,7 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       CHK(e->adv2.ensure((size_t)2 * N * e->ld_adv2 * sizeof(float)));
       float* fake = e->adv2.as<float>() + N * e->ld_adv2;
       if (!(e->adv2_fake_ok && e->adv2_yhs == y_hat_static)) {
-        hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(N * e->ld_adv2, 256)), dim3(256), 0, s, y_hat_static, y_hat_static, Ds, e->d_adv_cols, e->Da,
+        hipLaunchKernelGGL(build_adv_kernel, dim3(cdiv(N * (e->ld_adv2 / 4), 256)), dim3(256), 0, s, y_hat_static, y_hat_static, Ds, e->d_adv_cols, e->Da,
                            fake, e->ld_adv2, N, N, (const float*)nullptr, 0, 0.f, (StepScalars*)nullptr, (double*)nullptr);
         LAUNCH_CHECK();
         e->adv2_fake_ok = true; e->adv2_yhs = y_hat_static;

@@ -241,13 +241,23 @@ static __global__ void build_adv_kernel(const float* __restrict__ fa, const floa
     } else mask_sum_body(tv_mask, tv_n, tv_override, nullptr, sc, sh);
     return;
   }
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * ldo) return;
-  const long r = e / ldo;
-  const int c = (int)(e - r * ldo);
-  float v = 0.f;
-  if (c < na) v = r < split ? fa[r * ldf + idx[c]] : fb[(r - split) * ldf + idx[c]];
-  out[e] = v;
+  // one thread per FOUR output columns (ldo % 4 == 0, `out` 16-byte aligned: a hipMalloc'd image): four independent gathers in flight and one
+  // 16-byte store, a quarter of the threads and of the 64-bit divisions (round 5: one element per thread took 10.8 us for 17 MB)
+  const long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g4 = ldo >> 2;
+  if (e4 >= rows * g4) return;
+  const long r = e4 / g4;
+  const int c = (int)(e4 - r * g4) * 4;
+  const float* src = r < split ? fa + r * ldf : fb + (r - split) * ldf;
+  int ix[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ix[k] = idx[min(c + k, na - 1)];
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = src[ix[k]];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = c + k < na ? v[k] : 0.f;
+  *reinterpret_cast<f32x4*>(out + r * ldo + c) = v;
 }
 // [rows][cols] with row pitch ld_in -> the same rows with row pitch ldo (multiple of 4 floats, pad columns 0): the operand image of
 // products that read a caller tensor along its rows' direction (n-contiguous operand of a weight gradient)
@@ -563,6 +573,28 @@ __device__ __forceinline__ double masked_sqerr_body(
   long e = (long)blk * blockDim.x + threadIdx.x;
   long r = e / D;
   int d = (int)(e - r * D);
+  // FOUR grid strides per trip (round 5): the twelve loads of four elements are in flight together -- a thread of the cfg2 launch walks
+  // ~12 elements, and one dependent memory round trip per element made the kernel latency-bound (g_losses 11.3 us for 33 MB).  The
+  // squares are added in the order the one-element loop adds them.
+  for (; e + 3 * stride < total; e += 4 * stride) {
+    long rr[4];
+    int dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rr[u] = r; dd[u] = d;
+      r += sr; d += sd;
+      if (d >= D) { d -= D; ++r; }
+    }
+    float m[4], av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { m[u] = mask[rr[u]]; av[u] = a[rr[u] * lda + dd[u]]; bv[u] = b[rr[u] * ldb + dd[u]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float diff = av[u] * m[u] - bv[u] * m[u];
+      acc += (double)diff * (double)diff;
+      if (g) g[rr[u] * ldg + dd[u]] = gs * diff * m[u];
+    }
+  }
   for (; e < total; e += stride) {
     const float m = mask[r];
     const float diff = a[r * lda + d] * m - b[r * ldb + d] * m;
@@ -1060,6 +1092,43 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   long e = blk < 0 ? total : (long)blk * blockDim.x + threadIdx.x;
   long r = e / Ds;
   int c = (int)(e - r * Ds);
+  // FOUR grid strides per trip (a thread of the cfg2 launch walks four elements): their loads -- mask, the two features, the column map,
+  // then the two kept gradients -- are in flight together instead of one dependent round trip per element (round 5)
+  for (; e + 3 * stride < total; e += 4 * stride) {
+    long rr[4];
+    int cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c >= Ds) { c -= Ds; ++r; }
+      rr[u] = r; cc[u] = c;
+      r += sr; c += sd;
+    }
+    float m[4], yv[4], tv[4], lk[4], ga[4];
+    int jj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      m[u] = mask[rr[u]]; yv[u] = yhs[rr[u] * ld1 + cc[u]]; tv[u] = ys[rr[u] * ld2 + cc[u]];
+      jj[u] = (gs && adv_inv) ? adv_inv[cc[u]] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      lk[u] = (jj[u] >= 0 && leak) ? leak[rr[u] * ldl + jj[u]] : 0.f;
+      ga[u] = (jj[u] >= 0 && gadv) ? gadv[rr[u] * lda + jj[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float diff = yv[u] * m[u] - tv[u] * m[u];
+      if (partial) acc += (double)diff * (double)diff;
+      if (gs) {
+        float v = sc2 * diff * m[u];
+        if (jj[u] >= 0) {
+          if (leak) v += leak_s * lk[u];
+          if (gadv) v += adv_w * ga[u];
+        }
+        gs[rr[u] * ldg + cc[u]] = v;
+      }
+    }
+  }
   for (; e < total; e += stride, r += sr, c += sd) {
     if (c >= Ds) { c -= Ds; ++r; }
     const float m = mask[r];
