@@ -548,9 +548,11 @@ static int head_finalize(gt_engine* e, int mode, int nblk, int K, bool w, hipStr
     LAUNCH_CHECK();
     return GT_OK;
   }
-  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
+  const int cgw = (w && nblk >= 512) ? 16 : 64;       // many rows of partials: narrower column groups, more workgroups (frame_kernels.hip.h)
+  const int n_dw = cdiv(K, cgw), extra = cgw == 16 ? 1 : 0;       // (with many partials the scalars get a workgroup of their own, beside the dw ones)
+  hipLaunchKernelGGL(d_head_finalize_kernel, dim3(n_dw + extra), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
                      nblk, K, mode, e->sc(), w ? D.last.dW : (float*)nullptr, w ? D.last.db : (float*)nullptr, D.grads_dirty ? 1 : 0,
-                     early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
+                     early_res, ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket, cgw, extra ? n_dw : 0);
   LAUNCH_CHECK();
   return GT_OK;
 }

@@ -847,37 +847,41 @@ static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const Head
                                                                int nblk, int K, int mode, StepScalars* sc,
                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate,
                                                                StepResults* early_res /* D step: also finalize_d (gnorm 0) */,
-                                                               unsigned* ticket = nullptr, unsigned ticket_value = 0) {
-  __shared__ float shw[16][64];
+                                                               unsigned* ticket = nullptr, unsigned ticket_value = 0,
+                                                               int cgw = 64 /* columns per workgroup: 64, or 16 for many partials (grid = ceil(K / cgw)) */,
+                                                               int scal_blk = 0 /* the workgroup that sums the scalars: 0, or one extra workgroup behind the dw ones */) {
+  __shared__ float shw[1024];                      // [1024 / cgw row parts][cgw columns]
   __shared__ double shd[16];
-  const int kl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kl;
+  // cgw = 16 (round 5; the fused stack leaves 1024 rows of partials at cfg2): 64 row parts x 16 columns per workgroup -- a thread's sixteen
+  // loads cover ITS share of 1024 rows in one round trip and the 1 MB is read by 16 CUs instead of four (four dependent trips each)
+  const int nparts = (int)blockDim.x / cgw;
+  const int kl = threadIdx.x % cgw, part = threadIdx.x / cgw;
+  const int k = blockIdx.x * cgw + kl;
   if (dw) {
     float sa[16];                                  // 16 independent loads in flight per thread (latency-bound otherwise)
 #pragma unroll
     for (int u = 0; u < 16; ++u) sa[u] = 0.f;
     if (k < K) {
       int i = part;
-      for (; i + 15 * 16 < nblk; i += 256) {
+      for (; i + 15 * nparts < nblk; i += 16 * nparts) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sa[u] += dw_partial[(long)(i + 16 * u) * K + k];
+        for (int u = 0; u < 16; ++u) sa[u] += dw_partial[(long)(i + nparts * u) * K + k];
       }
-      for (; i < nblk; i += 16) sa[0] += dw_partial[(long)i * K + k];
+      for (; i < nblk; i += nparts) sa[0] += dw_partial[(long)i * K + k];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) sa[u] += sa[u + 8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) sa[u] += sa[u + 4];
-    shw[part][kl] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    shw[part * cgw + kl] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     __syncthreads();
     if (part == 0 && k < K) {
       float tot = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) tot += shw[q][kl];
+      for (int q = 0; q < nparts; ++q) tot += shw[q * cgw + kl];
       dw[k] = accumulate ? dw[k] + tot : tot;
     }
   }
-  if (blockIdx.x == 0) {
+  if ((int)blockIdx.x == scal_blk) {
     double v[5] = {0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
       v[0] += hp[i].s_real; v[1] += hp[i].s_fake; v[2] += hp[i].n_real_ok; v[3] += hp[i].n_fake_ok; v[4] += hp[i].db;
@@ -1360,7 +1364,15 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     return;
   }
   double part = 0.0;
-  for (int i = threadIdx.x; i < n_partial; i += blockDim.x) part += norm_partial[i];
+  {
+    const int bd = blockDim.x;
+    int i = threadIdx.x;
+    for (; i + 3 * bd < n_partial; i += 4 * bd) {      // four partials in flight per thread, added in index order as before
+      const double a0 = norm_partial[i], a1 = norm_partial[i + bd], a2 = norm_partial[i + 2 * bd], a3 = norm_partial[i + 3 * bd];
+      part += a0; part += a1; part += a2; part += a3;
+    }
+    for (; i < n_partial; i += bd) part += norm_partial[i];
+  }
   double tot = block_sum_d(part, shn);      // same fixed order in every workgroup
   if (threadIdx.x == 0) {
     const float gsc = gscale ? *gscale : 1.f;
@@ -1384,7 +1396,25 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
     step_size = (float)((double)o.lr / bc1);
     bc2_sqrt = (float)sqrt(bc2);
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+  // four grid strides per trip: the loads of four elements are in flight together (a thread of the cfg2 generator's launch walks 3-4)
+  const long gstride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * gstride < n; i += 4 * gstride) {
+    float pv[4], gv[4], sv[4], mv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long k = i + u * gstride;
+      pv[u] = p[k]; gv[u] = g[k]; sv[u] = s0[k]; mv[u] = s1 ? s1[k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long k = i + u * gstride;
+      optim_update(pv[u], gv[u], sv[u], s1 ? &mv[u] : nullptr, coef, o, clr, step_size, bc2_sqrt);
+      p[k] = pv[u]; g[k] = gv[u]; s0[k] = sv[u];
+      if (s1) s1[k] = mv[u];
+    }
+  }
+  for (; i < n; i += gstride)
     optim_update(p[i], g[i], s0[i], s1 ? s1 + i : nullptr, coef, o, clr, step_size, bc2_sqrt);
 }
 
