@@ -25,6 +25,11 @@ timeout 200 python bench.py --steps 50 --warmup 10 --force-dp --no-cpu-baseline 
 timeout 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/bench_plain2.json 2> /dev/null      # (the plain line again, next to the data-parallel ones)
 timeout 200 python bench.py --steps 50 --warmup 10 --force-dp --dp-ipc --no-cpu-baseline > $OUT/bench_force_dp_ipc.json 2> $OUT/bench_force_dp_ipc.err
 timeout 200 python bench.py --steps 50 --warmup 10 --dense-x --no-cpu-baseline --no-other-configs > $OUT/bench_dense_x.json 2> /dev/null
+# the data-parallel step's communication SCHEDULE (engine trace; tools/summarize_comm_schedule.py): one rank over RCCL, two ranks on this one
+# device over the tests' RCCL double, and the same over the interprocess arenas
+timeout 200 python bench.py --force-dp --comm-trace 20 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/sched_dp1_rccl.json 2> $OUT/sched_dp1_rccl.err
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --one-device --comm-trace 20 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/sched_dp2_fake.json 2> $OUT/sched_dp2_fake.err
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --one-device --dp-ipc --comm-trace 20 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $OUT/sched_dp2_ipc.json 2> $OUT/sched_dp2_ipc.err
 for b in 16 8 4; do timeout 200 python bench.py --steps 50 --warmup 10 --batch $b --no-cpu-baseline --no-other-configs > $OUT/bench_b$b.json 2> /dev/null; done
 bash $ROOT/tools/profile_configs.sh $TAG
 cd $ROOT
