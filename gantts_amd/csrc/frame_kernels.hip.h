@@ -576,32 +576,29 @@ __device__ __forceinline__ double masked_sqerr_body(
   // FOUR grid strides per trip (round 5): the twelve loads of four elements are in flight together -- a thread of the cfg2 launch walks
   // ~12 elements, and one dependent memory round trip per element made the kernel latency-bound (g_losses 11.3 us for 33 MB).  The
   // squares are added in the order the one-element loop adds them.
-  for (; e + 3 * stride < total; e += 4 * stride) {
+  // (the last trip is predicated, not a one-element tail loop: a thread with 11 elements takes three round trips like one with 12, not five)
+  for (; e < total; e += 4 * stride) {
     long rr[4];
     int dd[4];
+    bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      rr[u] = r; dd[u] = d;
+      rr[u] = r; dd[u] = d; ok[u] = e + u * stride < total;
       r += sr; d += sd;
       if (d >= D) { d -= D; ++r; }
     }
     float m[4], av[4], bv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { m[u] = mask[rr[u]]; av[u] = a[rr[u] * lda + dd[u]]; bv[u] = b[rr[u] * ldb + dd[u]]; }
+    for (int u = 0; u < 4; ++u) {
+      m[u] = ok[u] ? mask[rr[u]] : 0.f; av[u] = ok[u] ? a[rr[u] * lda + dd[u]] : 0.f; bv[u] = ok[u] ? b[rr[u] * ldb + dd[u]] : 0.f;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
       const float diff = av[u] * m[u] - bv[u] * m[u];
       acc += (double)diff * (double)diff;
       if (g) g[rr[u] * ldg + dd[u]] = gs * diff * m[u];
     }
-  }
-  for (; e < total; e += stride) {
-    const float m = mask[r];
-    const float diff = a[r * lda + d] * m - b[r * ldb + d] * m;
-    acc += (double)diff * (double)diff;
-    if (g) g[r * ldg + d] = gs * diff * m;
-    r += sr; d += sd;
-    if (d >= D) { d -= D; ++r; }
   }
   return acc;
 }
@@ -1399,23 +1396,23 @@ static __global__ __launch_bounds__(RED_THREADS) void optim_step_kernel(
   // four grid strides per trip: the loads of four elements are in flight together (a thread of the cfg2 generator's launch walks 3-4)
   const long gstride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * gstride < n; i += 4 * gstride) {
+  for (; i < n; i += 4 * gstride) {      // (the last trip is predicated: no one-element tail)
     float pv[4], gv[4], sv[4], mv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long k = i + u * gstride;
-      pv[u] = p[k]; gv[u] = g[k]; sv[u] = s0[k]; mv[u] = s1 ? s1[k] : 0.f;
+      const bool ok = k < n;
+      pv[u] = ok ? p[k] : 0.f; gv[u] = ok ? g[k] : 0.f; sv[u] = ok ? s0[k] : 0.f; mv[u] = (ok && s1) ? s1[k] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long k = i + u * gstride;
+      if (k >= n) continue;
       optim_update(pv[u], gv[u], sv[u], s1 ? &mv[u] : nullptr, coef, o, clr, step_size, bc2_sqrt);
       p[k] = pv[u]; g[k] = gv[u]; s0[k] = sv[u];
       if (s1) s1[k] = mv[u];
     }
   }
-  for (; i < n; i += gstride)
-    optim_update(p[i], g[i], s0[i], s1 ? s1 + i : nullptr, coef, o, clr, step_size, bc2_sqrt);
 }
 
 // ---------------------------------------------------------------------------------------
