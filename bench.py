@@ -122,6 +122,34 @@ def cpu_baseline(B, T, budget_s=20.0):
                       "median %.3f s/step" % (len(times), B, T, med)}
 
 
+# The data-parallel step's messages as the engine's own trace recorded them with one rank over RCCL (profiles/r05_comm_schedule.md;
+# `bench.py --force-dp --comm-trace 20` re-measures them): the two closing messages run on the step stream, nothing overlaps them.
+COMM_SCHEDULE_R05 = {"messages_per_step": 5, "bytes_per_step": 4380464, "exposed_message_bytes": [1022980, 872448],
+                     "one_rank_exposed_us": 12.7, "one_rank_hidden_us": 17.5, "source": "profiles/r05_comm_schedule.md"}
+XGMI_LINK_GBS = 153.0       # per link and direction (MI355X_MICROARCH.md)
+
+
+def scaling_model(proxy_ms, one_gpu_ms):
+    """`scaling_model` of the JSON line: the measured single-GPU proxy of a rank's step at B/N sequences, plus what the traced schedule says
+    must be added -- the exposed messages' launch cost (measured with one rank) and the BANDWIDTH LOWER BOUND of their ring all-reduce
+    over xGMI (2 (N-1)/N x bytes at one link's rate; per-hop latency not modelled).  Everything here is labelled unmeasured."""
+    exposed_bytes = float(sum(COMM_SCHEDULE_R05["exposed_message_bytes"]))
+    wire = {n: 1e6 * 2.0 * (n - 1) / n * exposed_bytes / (XGMI_LINK_GBS * 1e9) for n in proxy_ms}
+    with_comm = {n: proxy_ms[n] + 1e-3 * (COMM_SCHEDULE_R05["one_rank_exposed_us"] + wire[n]) for n in proxy_ms}
+    return {
+        "status": "UNMEASURED on more than one GPU: a single-GPU proxy + a bandwidth lower bound for the exposed messages",
+        "method": "per-rank step of N ranks = this step on B/N whole sequences (measured below, one GPU, no communication); + the two "
+                  "closing messages of the traced schedule (1.02 MB + 0.87 MB per step, on the step stream: nothing overlaps them): their "
+                  "one-rank cost as measured (12.7 us) + the ring all-reduce's wire time at one xGMI link's 153 GB/s, latency not modelled "
+                  "-- so the speed-up WITH communication is an UPPER bound",
+        "collectives": COMM_SCHEDULE_R05,
+        "ms_per_rank_step": {str(n): proxy_ms[n] for n in proxy_ms},
+        "speedup_over_one_gpu_without_communication": {str(n): one_gpu_ms / proxy_ms[n] for n in proxy_ms},
+        "exposed_wire_time_lower_bound_us": {str(n): wire[n] for n in proxy_ms},
+        "speedup_over_one_gpu_upper_bound_with_exposed_messages": {str(n): one_gpu_ms / with_comm[n] for n in proxy_ms},
+    }
+
+
 def comm_schedule(rec, steps, traced_ms, args):
     """Condenses the engine's schedule trace (gt_comm_trace_read: kind, bytes, on the step stream, start us, end us) of `steps` steps."""
     import numpy as np
@@ -508,14 +536,7 @@ def main():
                     T.update_discriminator(md, od, xs, yss, y_hat_static, cl, ms_, "train")
                     T.update_generator(mg, md, og, xs, ys_, y_hat, yss, y_hat_static, 1.0, cl, ms_, "train", mse_w=0.0, mge_w=1.0)
                 proxy[n] = timed_steps(step_b, max(10, args.steps))
-            companion["scaling_model"] = {
-                "status": "UNMEASURED on more than one GPU: a single-GPU proxy",
-                "method": "per-rank step of N ranks = this step on B/N whole sequences (measured below, one GPU, no communication) + the "
-                          "step's five collectives (measured with one rank through RCCL: +2.7 % at N = 1, profiles/r04_summary.md; the "
-                          "link time of 4.4 MB of gradient per step over xGMI is not modelled)",
-                "ms_per_rank_step": {str(n): proxy[n] for n in proxy},
-                "speedup_over_one_gpu_without_communication": {str(n): (1e3 * elapsed / args.steps) / proxy[n] for n in proxy},
-            }
+            companion["scaling_model"] = scaling_model(proxy, 1e3 * elapsed / args.steps)
 
     # (c) data parallel: the step's communication schedule from the engine's own trace (timed events around every message and every wait)
     if args.comm_trace > 0 and (world > 1 or args.force_dp) and not args.dp_python:

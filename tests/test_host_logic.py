@@ -170,6 +170,57 @@ def test_committed_bench_line_has_the_contract_fields():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
 
 
+def _load_bench():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_condenses_a_schedule_trace_into_exposed_and_hidden_time():
+    """bench.py --comm-trace: records of gt_comm_trace_read {kind, bytes, on the step stream, start us, end us} of two identical steps ->
+    per message: duration, the part of it during which the step stream stood waiting (exposed) and the rest (hidden); a message issued
+    on the step stream itself is exposed for its whole duration."""
+    bench = _load_bench()
+    step = [
+        [0, 40, 0, 0.0, 6.0],            # sums on the communicator's stream, nobody waits: hidden
+        [0, 1000000, 1, 10.0, 16.0],     # closing message on the step stream: exposed
+        [0, 2000000, 0, 20.0, 60.0],     # under compute ...
+        [1, 0, 0, 50.0, 60.0],           # ... until the step stream joins: its last 10 us are exposed
+    ]
+    rec = np.array(step + [[k, b, i, t0 + 100.0, t1 + 100.0] for k, b, i, t0, t1 in step], dtype=np.float64)
+
+    class A:
+        one_device, dp_ipc = False, False
+    c = bench.comm_schedule(rec, 2, 1.5, A())
+    assert c["messages_per_step"] == 3 and c["waits_per_step"] == 1 and c["bytes_per_step"] == 3000040
+    assert c["step_stream_wait_us_per_step"] == pytest.approx(10.0)
+    m = c["messages"]
+    assert [x["on_step_stream"] for x in m] == [False, True, False]
+    assert (m[0]["exposed_us"], m[0]["hidden_us"]) == pytest.approx((0.0, 6.0))
+    assert (m[1]["exposed_us"], m[1]["hidden_us"]) == pytest.approx((6.0, 0.0))
+    assert (m[2]["exposed_us"], m[2]["hidden_us"]) == pytest.approx((10.0, 30.0))
+    assert c["exposed_us_per_step"] == pytest.approx(16.0) and c["hidden_us_per_step"] == pytest.approx(36.0)
+    assert c["transport"] == "RCCL"
+
+
+def test_bench_scaling_model_is_a_labelled_upper_bound():
+    """`scaling_model` of the bench line: the measured per-rank proxy, plus the traced schedule's exposed messages at the bandwidth lower
+    bound of their ring all-reduce -- the speed-up with communication can only be below the one without, and everything says UNMEASURED."""
+    bench = _load_bench()
+    m = bench.scaling_model({2: 0.754, 4: 0.5045, 8: 0.3937}, 1.3144)
+    assert "UNMEASURED" in m["status"] and m["collectives"]["messages_per_step"] == 5
+    assert sum(m["collectives"]["exposed_message_bytes"]) < m["collectives"]["bytes_per_step"]
+    for n in ("2", "4", "8"):
+        assert m["speedup_over_one_gpu_upper_bound_with_exposed_messages"][n] < m["speedup_over_one_gpu_without_communication"][n] <= int(n)
+    w = m["exposed_wire_time_lower_bound_us"]
+    assert w["2"] < w["4"] < w["8"] < 2.0 * w["2"]                  # 2 (N - 1) / N of the bytes: saturates at twice the N = 2 time
+    assert w["8"] == pytest.approx(1e6 * 2 * 7 / 8 * (1022980 + 872448) / 153e9)
+
+
 def test_fast_gate_functions_stay_at_rounding_level():
     """The fast gate functions of the recurrent kernels (gantts_amd/csrc/fast_math.hip.h: e^x = 2^(x log2 e) with the product's
     rounding error folded back in, sigmoid = rcp(1 + e^-x), tanh by its odd polynomial below 0.3 and (1 - e^-2|x|) / (1 + e^-2|x|)
