@@ -351,6 +351,16 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
   // Staging is one wave per LDS row (64 lanes = the 64 columns of a data row / the taps of a band row), rows strided over
   // the 16 waves, (row, window) advanced incrementally: no integer division per element, 8 independent loads in flight.
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
+  // The first batch of band rows (taps jp = lane of rows wv, wv + 16, ...) is requested FIRST and parked in registers: it depends on
+  // nothing, so it travels with the column-map loads and the first batch of tile rows instead of being a fourth dependent round trip
+  // behind them (round 5).
+  float vb0[8];
+  {
+    const long src_rows = (long)T * nW;
+    const int jc = min(max(lane - MLPG_PAD, 0), nb - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vb0[q] = band[min((long)t0 * nW + wv + q * nwv, src_rows - 1) * nb + jc];
+  }
   {  // data tile: LDS row rw = r * nW + w holds frame t0 - kb + r, window w
     const bool c_ok = lane < nc;
     const int my_col = c_ok ? scol[c0 + lane] : 0, my_st = c_ok ? sstride[c0 + lane] : 0;
@@ -378,11 +388,20 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
   {  // band rows: LDS row tw = tl * nW + w  <-  band row t0 * nW + tw (the band is [t][w][nb], so rows are consecutive)
     const int nrow = TT * nW;
     const long src_rows = (long)T * nW;
+    if (lane < nbp) {       // the batch requested up front
+      const int j = lane - MLPG_PAD;
+      const bool j_ok = j >= 0 && j < nb;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int tw = wv + q * nwv;
+        if (tw < nrow) sb[tw * nbp + lane] = (j_ok && (long)t0 * nW + tw < src_rows) ? vb0[q] : 0.f;
+      }
+    }
     for (int jp = lane; jp < nbp; jp += 64) {      // one pass for half-widths up to 28 (nbp <= 64 taps)
       const int j = jp - MLPG_PAD;
       const bool j_ok = j >= 0 && j < nb;
       const int jc = min(max(j, 0), nb - 1);
-      for (int tw0 = wv; tw0 < nrow; tw0 += 8 * nwv) {
+      for (int tw0 = jp == lane ? wv + 8 * nwv : wv; tw0 < nrow; tw0 += 8 * nwv) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -445,7 +464,8 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_forward_kernel(
 // LDS: gs tile [(TT+2kb)][CC] + the band rows of the same frames, padded, [(TT+2kb)][nW][nb+2*PAD].
 // Lane = 2 columns x 4 frames x all windows: one ds_read_b64 of gs feeds 8*nW FMAs.
 template <int FPL, int TT = MLPG_TT>
-__global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
+__global__ __launch_bounds__(MLPG_THREADS) __attribute__((amdgpu_waves_per_eu(FPL <= 2 ? 8 : 4)))      // two 16-wave workgroups per CU: <= 64 VGPRs AND <= 96 SGPRs
+void mlpg_backward_kernel(
     const float* __restrict__ gs, int ldgs, const float* __restrict__ band, int kb, int nW,
     const int* __restrict__ scol, const int* __restrict__ sstride, int Ds,
     float* __restrict__ gy, int ldgy, int B, int T,
@@ -461,6 +481,13 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
   float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nbp]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
+  float vb0[8];             // the first batch of band rows, requested first (see the forward kernel)
+  {
+    const long src_rows = (long)T * nW, base = (long)(t0 - kb) * nW;
+    const int jc = min(max(lane - MLPG_PAD, 0), nb - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vb0[q] = band[min(max(base + wv + q * nwv, 0L), src_rows - 1) * nb + jc];
+  }
   {  // gradient tile: one wave per frame row (see the forward kernel's staging)
     const bool c_ok = lane < nc;
     const int ccl = c_ok ? c0 + lane : c0;
@@ -483,11 +510,21 @@ __global__ __launch_bounds__(MLPG_THREADS) void mlpg_backward_kernel(
   {  // band rows of the staged frames: LDS row rw = r * nW + w  <-  band row (t0 - kb) * nW + rw; frames outside [0,T) are zero
     const int nrow = rows * nW;
     const long src_rows = (long)T * nW, base = (long)(t0 - kb) * nW;
+    if (lane < nbp) {       // the batch requested up front
+      const int j = lane - MLPG_PAD;
+      const bool j_ok = j >= 0 && j < nb;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int rw = wv + q * nwv;
+        const long row = base + rw;
+        if (rw < nrow) sb[rw * nbp + lane] = (j_ok && row >= 0 && row < src_rows) ? vb0[q] : 0.f;
+      }
+    }
     for (int jp = lane; jp < nbp; jp += 64) {
       const int j = jp - MLPG_PAD;
       const bool j_ok = j >= 0 && j < nb;
       const int jc = min(max(j, 0), nb - 1);
-      for (int rw0 = wv; rw0 < nrow; rw0 += 8 * nwv) {
+      for (int rw0 = jp == lane ? wv + 8 * nwv : wv; rw0 < nrow; rw0 += 8 * nwv) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
