@@ -481,12 +481,12 @@ void mlpg_backward_kernel(
   float* sb = sm + rows * MLPG_CC;                 // [rows][nW][nbp]; frames outside [0,T) are zero
   const float* gb = gs + (long)b * T * ldgs;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = MLPG_THREADS / 64;
-  float vb0[8];             // the first batch of band rows, requested first (see the forward kernel)
+  float vb0[16];            // the first TWO batches of band rows (all of them at TT = 32: (TT + 2 kb) nW / 16 <= 16 rows per wave), requested first
   {
     const long src_rows = (long)T * nW, base = (long)(t0 - kb) * nW;
     const int jc = min(max(lane - MLPG_PAD, 0), nb - 1);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) vb0[q] = band[min(max(base + wv + q * nwv, 0L), src_rows - 1) * nb + jc];
+    for (int q = 0; q < 16; ++q) vb0[q] = band[min(max(base + wv + q * nwv, 0L), src_rows - 1) * nb + jc];
   }
   {  // gradient tile: one wave per frame row (see the forward kernel's staging)
     const bool c_ok = lane < nc;
@@ -514,7 +514,7 @@ void mlpg_backward_kernel(
       const int j = lane - MLPG_PAD;
       const bool j_ok = j >= 0 && j < nb;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 16; ++q) {
         const int rw = wv + q * nwv;
         const long row = base + rw;
         if (rw < nrow) sb[rw * nbp + lane] = (j_ok && row >= 0 && row < src_rows) ? vb0[q] : 0.f;
@@ -524,7 +524,7 @@ void mlpg_backward_kernel(
       const int j = jp - MLPG_PAD;
       const bool j_ok = j >= 0 && j < nb;
       const int jc = min(max(j, 0), nb - 1);
-      for (int rw0 = jp == lane ? wv + 8 * nwv : wv; rw0 < nrow; rw0 += 8 * nwv) {
+      for (int rw0 = jp == lane ? wv + 16 * nwv : wv; rw0 < nrow; rw0 += 8 * nwv) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
