@@ -243,6 +243,14 @@ static __global__ void build_adv_kernel(const float* __restrict__ fa, const floa
   }
   // one thread per FOUR output columns (ldo % 4 == 0, `out` 16-byte aligned: a hipMalloc'd image): four independent gathers in flight and one
   // 16-byte store, a quarter of the threads and of the 64-bit divisions (round 5: one element per thread took 10.8 us for 17 MB)
+  // the column map goes through the LDS once per workgroup (na <= 256; wider maps read it from memory): the gathers then depend on no
+  // other memory access
+  __shared__ int sidx[256];
+  const bool map_lds = na <= 256;
+  if (map_lds) {
+    for (int k = threadIdx.x; k < na; k += blockDim.x) sidx[k] = idx[k];
+    __syncthreads();
+  }
   const long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int g4 = ldo >> 2;
   if (e4 >= rows * g4) return;
@@ -251,7 +259,7 @@ static __global__ void build_adv_kernel(const float* __restrict__ fa, const floa
   const float* src = r < split ? fa + r * ldf : fb + (r - split) * ldf;
   int ix[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ix[k] = idx[min(c + k, na - 1)];
+  for (int k = 0; k < 4; ++k) ix[k] = map_lds ? sidx[min(c + k, na - 1)] : idx[min(c + k, na - 1)];
   f32x4 v;
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = src[ix[k]];
