@@ -57,6 +57,10 @@ out += ["## what this says about DP = 2 / 4 / 8 over xGMI (a MODEL, unmeasured)"
         "  0.40 ms (strong scaling, b = 4 sequences per rank, `scaling_model` in the bench line) or 1.31 ms (weak scaling, b = 32).  Modelled efficiency at N = 8:",
         "  weak 0.92-0.96, strong 0.77-0.87 of the compute-only proxy.  `GT_OPT_COMM_D_ONE_MSG=0` sends D's upper layers early instead (hidden; one launch more) -- the",
         "  one-rank measurement preferred the single message (DESIGN.md 5), a real node may not.",
+        "* `GT_COMM_D_ONE_MSG=0`, traced the same way with one rank (`%s_comm_schedule_dp1_rccl_d_two_messages.json`): six messages, D's gradient leaves as" % tag,
+        "  527,364 B (layers above the first, communicator's stream: hidden) + 495,616 B (first layer, closing: exposed) -- 0.53 MB less exposed for one launch",
+        "  more: 1.3567 vs 1.3495 ms with one rank (+7 us).  At N = 8 the bytes saved are worth 2 x 7/8 x 0.53 MB / 153 GB/s = 6 us of wire: break-even by",
+        "  bandwidth, and the number of exposed messages (the latency term) is the same two -- the single message stays the default.",
         "* The two-shot hipIpc path exists for exactly these two exposed messages (every message of cfg2 fits its 8 MB slots); its refusal rule without fine-grained",
         "  memory is in DESIGN.md 5.", ""]
 open(os.path.join(root, "profiles", "%s_comm_schedule.md" % tag), "w").write("\n".join(out))
