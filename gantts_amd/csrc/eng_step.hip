@@ -74,7 +74,7 @@ int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const i
   const int tt = mlpg_tile_frames(e, B, T, lds_of(64));
   const size_t lds = lds_of(tt);
   dim3 grid(B * cdiv(T, tt), cdiv(Ds, MLPG_CC));
-  const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (4: 24.7 us, 2: 21.8, 1: 26.6)
+  const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (round 4: 4: 24.7 us, 2: 21.8, 1: 26.6; round 5, unrolled tap loops: forward 18.5 / 17.2 / 18.3, backward 24.9 / 19.5 / 20.6)
 #define GT_MLPG_FWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F, TTV>, lds)); \
     hipLaunchKernelGGL((mlpg_forward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
   if (tt == 64) { if (fpl == 1) GT_MLPG_FWD(1, 64) else if (fpl == 4) GT_MLPG_FWD(4, 64) else GT_MLPG_FWD(2, 64) }
