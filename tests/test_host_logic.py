@@ -221,6 +221,65 @@ def test_bench_scaling_model_is_a_labelled_upper_bound():
     assert w["8"] == pytest.approx(1e6 * 2 * 7 / 8 * (1022980 + 872448) / 153e9)
 
 
+def test_committed_schedule_traces_show_one_schedule_on_every_transport():
+    """profiles/r*_comm_schedule_*.json (bench.py --comm-trace on the GPU box): one rank over RCCL, two ranks on one device over the RCCL double
+    and over the interprocess arenas must show the SAME schedule -- five messages of the same sizes in the same order on the same streams,
+    two waits of the step stream -- whose sizes add up to both networks' gradients + the loss sums; exposed + hidden = duration."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_comm_schedule_dp*.json"))):
+        tag = os.path.basename(f).split("_comm_schedule_")[1][:-5]
+        runs[tag] = json.load(open(f))["comm_schedule"]
+    assert {"dp1_rccl", "dp2_fake", "dp2_ipc"} <= set(runs), sorted(runs)
+    ref = [(m["bytes"], m["on_step_stream"]) for m in runs["dp1_rccl"]["messages"]]
+    n_g = 425 * 512 + 512 + 2 * (512 * 512 + 512) + 512 * 187 + 187           # cfg2 generator (bench.py G_SPEC)
+    n_d = 483 * 256 + 256 + 2 * (256 * 256 + 256) + 256 + 1                   # cfg2 discriminator
+    assert sum(b for b, _ in ref) == 4 * (n_g + n_d) + 40 + 24
+    for tag in ("dp1_rccl", "dp2_fake", "dp2_ipc"):
+        c = runs[tag]
+        assert c["messages_per_step"] == 5 and c["waits_per_step"] == 2 and c["bytes_per_step"] == sum(b for b, _ in ref), tag
+        assert [(m["bytes"], m["on_step_stream"]) for m in c["messages"]] == ref, tag
+        for m in c["messages"]:
+            assert m["exposed_us"] >= 0 and m["hidden_us"] >= -1e-6
+            assert m["exposed_us"] + m["hidden_us"] == pytest.approx(m["duration_us"], rel=0.35, abs=2.0)      # (medians of three quantities)
+            if m["on_step_stream"]:
+                assert m["hidden_us"] == pytest.approx(0.0, abs=1e-6)
+    two = runs.get("dp1_rccl_d_two_messages")
+    if two is not None:       # GT_COMM_D_ONE_MSG=0: the same bytes in six messages, less of them on the step stream
+        assert two["messages_per_step"] == 6 and two["bytes_per_step"] == runs["dp1_rccl"]["bytes_per_step"]
+        exposed = lambda c: sum(m["bytes"] for m in c["messages"] if m["on_step_stream"])
+        assert exposed(two) < exposed(runs["dp1_rccl"])
+    bench = _load_bench()
+    assert bench.COMM_SCHEDULE_R05["exposed_message_bytes"] == [b for b, on in ref if on]
+    assert bench.COMM_SCHEDULE_R05["bytes_per_step"] == runs["dp1_rccl"]["bytes_per_step"]
+
+
+def test_trace_tools_on_a_synthetic_kernel_trace(tmp_path):
+    """tools/step_gaps.py and tools/kernel_avgs.py on a hand-made rocprofv3 kernel trace: three steps of four kernels (the second
+    `optim_step_kernel` closes a step), a 5 us hole behind `d_head_finalize_kernel` in every step."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows, t = ["Kernel_Name,Start_Timestamp,End_Timestamp"], 1000
+    for _ in range(3):
+        for name, dur, gap in (("void gt::gemm_pair_kernel<0, 1>(args)", 100000, 0), ("gt::optim_step_kernel(args)", 8000, 0),
+                               ("gt::d_head_finalize_kernel(args)", 10000, 5000), ("gt::optim_step_kernel(args)", 8000, 0)):
+            rows.append('"%s",%d,%d' % (name, t, t + dur))
+            t += dur + gap
+    f = tmp_path / "t_kernel_trace.csv"
+    f.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "step_gaps.py"), str(f)], capture_output=True, text=True, check=True).stdout
+    assert "2 steps: wall 131.0 us/step, sum of kernels 126.0, union 126.0, idle 5.0, launches 4.0" in out, out
+    assert "gt::d_head_finalize_kernel -> gt::optim_step_kernel" in out
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_avgs.py"), str(f), "optim_step", "gemm_pair"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "optim_step" in out and "avg    8.00 us" in out and "avg  100.00 us" in out, out
+
+
 def test_fast_gate_functions_stay_at_rounding_level():
     """The fast gate functions of the recurrent kernels (gantts_amd/csrc/fast_math.hip.h: e^x = 2^(x log2 e) with the product's
     rounding error folded back in, sigmoid = rcp(1 + e^-x), tanh by its odd polynomial below 0.3 and (1 - e^-2|x|) / (1 + e^-2|x|)
