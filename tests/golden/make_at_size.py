@@ -72,8 +72,50 @@ class SlopeCensus(object):
         return out
 
 
-def run_reference(case, dtype):
-    """The real reference on one at-size case; returns {name: full tensor}."""
+def _mlp_hidden_perms(spec, seed):
+    """One permutation per hidden activation of an MLP discriminator (make_drift_spread.py)."""
+    rs = np.random.RandomState(seed)
+    return [rs.permutation(spec["hidden_dim"]) for _ in range(spec["num_hidden"])]
+
+
+def _permute_mlp(sd, perms, inverse=False):
+    """Relabel the hidden units of a gantts.models.MLP state dict (layers.<l>.weight / .bias, last_linear.weight): unit i of the
+    relabelled network's layer l is unit perms[l][i] of the original.  The function the network computes is unchanged; the ORDER in
+    which every product over a hidden layer sums its terms is not -- another correct float32 evaluation of the same step.
+    inverse: map tensors of the relabelled network (gradients, updates) back to the original labelling."""
+    out = dict(sd)
+    L = len(perms)
+    for l in range(L):
+        w, b = "layers.%d.weight" % l, "layers.%d.bias" % l
+        W, B = np.array(out[w]), np.array(out[b])
+        if not inverse:
+            W, B = W[perms[l]], B[perms[l]]
+            if l > 0:
+                W = W[:, perms[l - 1]]
+        else:
+            Wo, Bo = np.empty_like(W), np.empty_like(B)
+            Wo[perms[l]], Bo[perms[l]] = W, B
+            W, B = Wo, Bo
+            if l > 0:
+                Wo = np.empty_like(W)
+                Wo[:, perms[l - 1]] = W
+                W = Wo
+        out[w], out[b] = W, B
+    W = np.array(out["last_linear.weight"])
+    if not inverse:
+        W = W[:, perms[L - 1]]
+    else:
+        Wo = np.empty_like(W)
+        Wo[:, perms[L - 1]] = W
+        W = Wo
+    out["last_linear.weight"] = W
+    return out
+
+
+def run_reference(case, dtype, d_perm_seed=None):
+    """The real reference on one at-size case; returns {name: full tensor}.
+    d_perm_seed (make_drift_spread.py only; MLP discriminators): run the step on a discriminator whose hidden units are relabelled
+    (_permute_mlp; its dropout masks relabelled alike) and report its gradients / updates in the original labelling."""
     import ref_loader
     train, hparams, gantts = ref_loader.load_reference()
     from gantts.multistream import get_static_features
@@ -97,6 +139,13 @@ def run_reference(case, dtype):
             return m.to(dtype)
 
         model_g, model_d = build(case["g"], 11), build(case["d"], 22)
+        d_perms = None
+        if d_perm_seed is not None:
+            assert case["d"]["kind"] == "MLP"
+            d_perms = _mlp_hidden_perms(case["d"], d_perm_seed)
+            sd0 = {k: _np(v) for k, v in model_d.state_dict().items()}
+            model_d.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in _permute_mlp(sd0, d_perms).items()})
+            model_d.to(dtype)
         w0 = {"G." + k: _np(v) for k, v in model_g.state_dict().items()}
         w0.update({"D." + k: _np(v) for k, v in model_d.state_dict().items()})
         og = getattr(torch.optim, case["opt_g"][0])(model_g.parameters(), **case["opt_g"][1])
@@ -123,6 +172,8 @@ def run_reference(case, dtype):
         out = {}
         for step in range(case["steps"]):
             gm, dm = C.make_dropout_masks(case, step)
+            if d_perms is not None:      # the masks of D's hidden layer l follow its relabelling (three passes of D per step)
+                dm = [np.ascontiguousarray(m[..., d_perms[i % len(d_perms)]]) for i, m in enumerate(dm)]
             queue[:] = [torch.from_numpy(m) for m in gm + dm]
             y_static = get_static_features(y, len(windows), hp.stream_sizes, hp.has_dynamic_features)
             mask = sequence_mask(sl).unsqueeze(-1).to(dtype)
@@ -146,6 +197,10 @@ def run_reference(case, dtype):
             out["Gupd." + k] = _np(v) - w0["G." + k]
         for k, v in model_d.state_dict().items():
             out["Dupd." + k] = _np(v) - w0["D." + k]
+        if d_perms is not None:
+            for pre in ("Dupd.", "Dgrad."):
+                back = _permute_mlp({k[len(pre):]: v for k, v in out.items() if k.startswith(pre)}, d_perms, inverse=True)
+                out.update({pre + k: v for k, v in back.items()})
         return out
     finally:
         torch.nn.Dropout.forward = orig_dropout
