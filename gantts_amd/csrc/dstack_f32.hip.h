@@ -69,14 +69,6 @@ struct DStackArgs {
   const float* W0; int ldw0;      // first layer's weight [HD][ldw0]
   int col0, Da;                   // its adversarial columns [col0, col0 + Da), Da <= 64
   float* gadv; int ld_gadv;       // [rows][ld_gadv]: dloss_adv / d(adversarial input columns)
-  // Start stagger (MEASUREMENT switch of tools/dstack_bench.hip; the engine leaves it 0).  Hypothesis: the two workgroups of a CU run the
-  // same program on the same clock and stay in lockstep -- both in their K loops (sharing the matrix pipe), both in their epilogues
-  // (pipe idle).  The workgroups that fill the SECOND slot of the CUs in the first resident round (block ids [n_cu, 2 n_cu), or the odd
-  // ticket of a CU) start `stagger_ticks` (100 MHz wall-clock ticks) late.  Measured: 1 - 10 us of stagger change nothing or cost
-  // their own delay (99 -> 97 .. 104 us): the pair is not in lockstep to begin with -- an epilogue (VALU-heavy) stretches under the
-  // partner's product and vice versa (phase stamps).
-  int stagger_ticks, n_cu;
-  unsigned int* stagger_ticket;   // [2048] per-CU counters (keyed by cu_key(); never reset): when given, the workgroup that draws an odd ticket on its CU is the late one
   unsigned long long* dbg;        // tools/dstack_bench.hip: [grid][16] wall-clock stamps (100 MHz) of the phases, or null
 };
 
@@ -119,21 +111,6 @@ __global__ __launch_bounds__(DS_THREADS, 2) void dstack_kernel(const DStackArgs 
   int dbg_n = 0;
   auto stamp = [&]() { if (a.dbg && tid == 0 && dbg_n < 16) a.dbg[(long)blockIdx.x * 16 + dbg_n++] = wall_clock64(); };
   stamp();
-  if (a.stagger_ticks > 0) {
-    bool late = (int)blockIdx.x >= a.n_cu && (int)blockIdx.x < 2 * a.n_cu;
-    if (a.stagger_ticket) {
-      unsigned* sh = reinterpret_cast<unsigned*>(smem);
-      if (tid == 0) sh[0] = atomicAdd(a.stagger_ticket + cu_key(), 1u);
-      __syncthreads();
-      late = (sh[0] & 1u) != 0u;
-      __syncthreads();
-    }
-    if (late) {
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-
   uint32_t code[DS_MAXL][NT];   // derivative codes of this thread's elements, 16 x 2 bits per tile (layer loops are unrolled: static indices)
 #pragma unroll
   for (int l = 0; l < DS_MAXL; ++l)

@@ -132,11 +132,13 @@ extern "C" int gt_comm_info(gt_engine* e, int* rank, int* world) {
 static void trace_clear(GtComm* c) {
   for (auto& r : c->trec) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
   c->trec.clear();
+  c->trace_dropped = 0;
 }
 static GtComm::TraceRec* trace_open(GtComm* c, int kind, bool inl, double bytes, hipStream_t on) {
-  if (!c->trace || c->trec.size() >= 65536) return nullptr;
+  if (!c->trace) return nullptr;
+  if (c->trec.size() >= 65536) { ++c->trace_dropped; return nullptr; }      // (reported by gt_comm_trace_read)
   GtComm::TraceRec r;
-  r.kind = kind; r.inl = inl ? 1 : 0; r.bytes = bytes; r.e0 = r.e1 = nullptr;
+  r.kind = kind; r.inl = inl ? 1 : 0; r.bytes = bytes; r.e0 = r.e1 = nullptr; r.closed = false;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess || hipEventRecord(r.e0, on) != hipSuccess) {
     if (r.e0) (void)hipEventDestroy(r.e0);
     if (r.e1) (void)hipEventDestroy(r.e1);
@@ -158,16 +160,20 @@ extern "C" int gt_comm_trace_read(gt_engine* e, double* out, int max_records, in
   if (!e->comm) return fail(GT_ERR_STATE, "gt_comm_trace_read without a communicator");
   HIPCHK(hipDeviceSynchronize());
   GtComm* c = e->comm;
-  int n = 0;
+  if (c->trace_dropped > 0)
+    return fail(GT_ERR_STATE, "schedule trace full (65536 records): %ld messages / joins were not recorded -- trace fewer steps", c->trace_dropped);
+  int n = 0, n_closed = 0;
+  for (size_t i = 0; i < c->trec.size(); ++i) n_closed += c->trec[i].closed ? 1 : 0;
   for (size_t i = 0; i < c->trec.size() && n < max_records; ++i) {
     const GtComm::TraceRec& r = c->trec[i];
+    if (!r.closed) continue;                    // the message failed between its two events (its error was reported then)
     float t0 = 0.f, t1 = 0.f;
     HIPCHK(hipEventElapsedTime(&t0, c->trec[0].e0, r.e0));
     HIPCHK(hipEventElapsedTime(&t1, c->trec[0].e0, r.e1));
     double* o = out + 5 * (size_t)n++;
     o[0] = r.kind; o[1] = r.bytes; o[2] = r.inl; o[3] = 1e3 * (double)t0; o[4] = 1e3 * (double)t1;
   }
-  *n_records = max_records > 0 ? n : (int)c->trec.size();
+  *n_records = max_records > 0 ? n : n_closed;
   return GT_OK;
 }
 
@@ -192,10 +198,10 @@ static int comm_allreduce_after(gt_engine* e, void* buf, size_t count, int dtype
     on = c->stream;
   }
   GtComm::TraceRec* tr = trace_open(c, 0, on_compute, bytes, on);
-  hipEvent_t tr_e1 = tr ? tr->e1 : nullptr;
+  const long tr_i = tr ? (long)c->trec.size() - 1 : -1;       // (a record that is not closed below -- the message failed -- is skipped by the reader)
   if (ipc) CHK(ipc_allreduce(e, buf, count, dbl, on));
   else NCCLCHK(rccl_api()->AllReduce(buf, buf, count, dtype, GT_NCCL_SUM, c->comm, on));
-  if (tr_e1) HIPCHK(hipEventRecord(tr_e1, on));
+  if (tr_i >= 0) { HIPCHK(hipEventRecord(c->trec[tr_i].e1, on)); c->trec[tr_i].closed = true; }
   return GT_OK;
 }
 // `compute` continues only after everything handed to the communicator so far has finished
@@ -203,9 +209,9 @@ static int comm_join(gt_engine* e, hipStream_t compute) {
   GtComm* c = e->comm;
   HIPCHK(hipEventRecord(c->ev_done, c->stream));
   GtComm::TraceRec* tr = trace_open(c, 1, false, 0.0, compute);
-  hipEvent_t tr_e1 = tr ? tr->e1 : nullptr;
+  const long tr_i = tr ? (long)c->trec.size() - 1 : -1;
   HIPCHK(hipStreamWaitEvent(compute, c->ev_done, 0));
-  if (tr_e1) HIPCHK(hipEventRecord(tr_e1, compute));
+  if (tr_i >= 0) { HIPCHK(hipEventRecord(c->trec[tr_i].e1, compute)); c->trec[tr_i].closed = true; }
   return GT_OK;
 }
 // the gradient of [lo, lo + count) of `role` is final on `compute`.  Ranges are collected and handed to RCCL by

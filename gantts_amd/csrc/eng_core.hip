@@ -162,7 +162,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   for (auto* v : {&e->s_u, &e->s_h, &e->s_c, &e->s_xdrop, &e->s_xmask, &e->s_wt}) for (auto& s : *v) s.release();
   e->s_du.release(); e->s_dx.release(); e->s_dbias.release();
   Scratch* all[] = {&e->dcat, &e->dzA, &e->dzB, &e->leak, &e->gadv, &e->gs, &e->gy, &e->slabs, &e->colp, &e->partial,
-                    &e->headp, &e->headw, &e->headf, &e->gl_counter, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
+                    &e->headp, &e->headw, &e->gx_dense, &e->cx_dense, &e->dmask, &e->tx, &e->gx, &e->dgx, &e->dtz, &e->dout, &e->scal, &e->mlpg.tmp};
   for (auto* s : all) s->release();
   e->w0pad[0].release(); e->w0pad[1].release();
   e->opt_bar.release(); e->d_pre.release(); e->adv2.release(); e->pitched[0].buf.release(); e->pitched[1].buf.release();
@@ -174,7 +174,7 @@ extern "C" void gt_engine_destroy(gt_engine* e) {
   e->s_du_b.release();
   for (auto& w : e->ssh) { w.w.release(); w.wt.release(); }
   for (auto& b : e->l_dg_b) b.release();
-  e->l_hs_b.release(); e->slabs_side.release(); e->colp_side.release();
+  e->l_hs_b.release();
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
   if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
@@ -362,7 +362,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       return GT_OK;
     case GT_OPT_FUSED_OPTIMIZER: e->opt_fused_optimizer = value != 0; return GT_OK;
     case GT_OPT_SIDE_OVERLAP: e->opt_side_overlap = value != 0; return GT_OK;
-    case GT_OPT_LSTM_SIDE: e->opt_lstm_side = value != 0; return GT_OK;
+    case GT_OPT_LSTM_SIDE: return value ? fail(GT_ERR_INVALID, "GT_OPT_LSTM_SIDE: removed in round 6 (measured: no gain); the value must be 0") : GT_OK;
     case GT_OPT_COMM_D_ONE_MSG: e->opt_comm_d_one_msg = value != 0; return GT_OK;
     case GT_OPT_COMM_EARLY_G: e->opt_comm_early_g = value != 0; return GT_OK;
     case GT_OPT_COMM_GROUP: e->opt_comm_group = value != 0; return GT_OK;
@@ -378,7 +378,7 @@ extern "C" int gt_set_option(gt_engine* e, int option, int value) {
       // interchangeable, so a change drops whatever is stashed -- the next update_* then asks for a fresh apply_generator
       // instead of back-propagating through buffers the forward never filled
       if (e->matmul_bf16 != (value != 0)) {
-        e->g_pass_valid = false; e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false; e->leak_pending = false;
+        e->g_pass_valid = false; e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false; e->leak_pending = false; e->cxd_src = nullptr;
         e->d_begin_done = false; e->g_begin_done = false;
       }
       e->matmul_bf16 = value != 0;
@@ -393,10 +393,9 @@ GtTuning& gt_tuning() {
     v.gemm_pair = geti("GT_GEMM_PAIR", v.gemm_pair); v.pair_order = geti("GT_PAIR_ORDER", v.pair_order);
     { const char* s = getenv("GT_GEMM_TILES"); v.gemm_tiles_big = s && !strcmp(s, "big") ? 1 : 0; }
     v.gemm_unaligned = geti("GT_GEMM_UNALIGNED", v.gemm_unaligned); v.tn_wgs = geti("GT_TN_WGS", v.tn_wgs); v.tn_split_wgs = geti("GT_TN_SPLIT_WGS", v.tn_split_wgs); v.split_fused = geti("GT_SPLIT_FUSED", v.split_fused);
-    v.stagger_ticks = geti("GT_GEMM_STAGGER_TICKS", v.stagger_ticks); v.stagger_mode = geti("GT_GEMM_STAGGER_MODE", v.stagger_mode);
     v.b16_tiles = geti("GT_B16_TILES", v.b16_tiles); v.b16_wg_tile = geti("GT_B16_WG_TILE", v.b16_wg_tile); v.b16_dma = geti("GT_B16_DMA", v.b16_dma);
-    v.mlpg_fpl = geti("GT_MLPG_FPL", v.mlpg_fpl); v.mlpg_tt = geti("GT_MLPG_TT", v.mlpg_tt); v.sru_lw = geti("GT_SRU_LW", v.sru_lw); v.gemm_persist = geti("GT_GEMM_PERSIST", v.gemm_persist); v.sru_cs_waves = geti("GT_SRU_CS_WAVES", v.sru_cs_waves); v.leak_rider = geti("GT_LEAK_RIDER", v.leak_rider); v.head_fin2 = geti("GT_HEAD_FIN2", v.head_fin2); v.g_loss_ride = geti("GT_G_LOSS_RIDE", v.g_loss_ride);
-    v.head_vec = geti("GT_HEAD_VEC", v.head_vec); v.head_wgs = geti("GT_HEAD_WGS", v.head_wgs);
+    v.mlpg_fpl = geti("GT_MLPG_FPL", v.mlpg_fpl); v.mlpg_tt = geti("GT_MLPG_TT", v.mlpg_tt); v.sru_lw = geti("GT_SRU_LW", v.sru_lw); v.sru_cs_waves = geti("GT_SRU_CS_WAVES", v.sru_cs_waves); v.leak_rider = geti("GT_LEAK_RIDER", v.leak_rider);
+    v.head_vec = geti("GT_HEAD_VEC", v.head_vec);
     v.mlpg_small16 = geti("GT_MLPG_SMALL16", v.mlpg_small16);
     return v;
   }();
@@ -407,8 +406,8 @@ extern "C" int gt_set_tuning(const char* name, int value) {
   GtTuning& t = gt_tuning();
   struct { const char* n; int* p; } tab[] = {
       {"gemm_pair", &t.gemm_pair}, {"pair_order", &t.pair_order}, {"gemm_tiles_big", &t.gemm_tiles_big}, {"gemm_unaligned", &t.gemm_unaligned},
-      {"tn_wgs", &t.tn_wgs}, {"tn_split_wgs", &t.tn_split_wgs}, {"split_fused", &t.split_fused}, {"stagger_ticks", &t.stagger_ticks}, {"stagger_mode", &t.stagger_mode}, {"b16_tiles", &t.b16_tiles},
-      {"b16_wg_tile", &t.b16_wg_tile}, {"b16_dma", &t.b16_dma}, {"mlpg_fpl", &t.mlpg_fpl}, {"mlpg_tt", &t.mlpg_tt}, {"sru_lw", &t.sru_lw}, {"gemm_persist", &t.gemm_persist}, {"sru_cs_waves", &t.sru_cs_waves}, {"leak_rider", &t.leak_rider}, {"head_fin2", &t.head_fin2}, {"g_loss_ride", &t.g_loss_ride}, {"head_vec", &t.head_vec}, {"head_wgs", &t.head_wgs}, {"mlpg_small16", &t.mlpg_small16}};
+      {"tn_wgs", &t.tn_wgs}, {"tn_split_wgs", &t.tn_split_wgs}, {"split_fused", &t.split_fused}, {"b16_tiles", &t.b16_tiles},
+      {"b16_wg_tile", &t.b16_wg_tile}, {"b16_dma", &t.b16_dma}, {"mlpg_fpl", &t.mlpg_fpl}, {"mlpg_tt", &t.mlpg_tt}, {"sru_lw", &t.sru_lw}, {"sru_cs_waves", &t.sru_cs_waves}, {"leak_rider", &t.leak_rider}, {"head_vec", &t.head_vec}, {"mlpg_small16", &t.mlpg_small16}};
   for (auto& e : tab) if (!strcmp(e.n, name)) { *e.p = value; return GT_OK; }
   return fail(GT_ERR_INVALID, "unknown tuning knob '%s'", name);
 }
@@ -568,7 +567,7 @@ extern "C" int gt_clear_faults(gt_engine* e, void* stream) {
   if (e->opt_bar.p) { HIPCHK(hipMemset(e->opt_bar.p, 0, 64)); e->opt_bar_count = 0; }      // the barrier counter restarts with the re-armed engine
   for (int r = 0; r < 2; ++r) { e->net[r].step -= (long)e->h_fault[2 + r]; if (e->net[r].step < 0) e->net[r].step = 0; }
   for (int i = 0; i < 4; ++i) e->h_fault[i] = 0;
-  e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false; e->adv2_fake_ok = false;
+  e->g_pass_valid = false; e->leak_pending = false; e->fake_cat_valid = false; e->adv2_fake_ok = false; e->cxd_src = nullptr;
   e->d_begin_done = e->g_begin_done = false; e->early_done = false;
   return GT_OK;
 }

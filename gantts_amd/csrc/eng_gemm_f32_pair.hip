@@ -24,15 +24,11 @@ int launch_gemm_pair(const GemmArgs& nn_in, const GemmArgs& tn_in, int nslab, hi
   }
   // GT_PAIR_ORDER (default 1): weight-gradient workgroups first (longest work first); 0 = backward-data tiles first
   const int tn_first = gt_tuning().pair_order;   // measured: 108.2 -> 104.4 us per pair launch, cfg2 step 1.523 -> 1.499 ms
-  // persistent form: the grid is the resident slots (four 64 x 64 workgroups per CU); an item's cost is its K depth in 32-deep stages
-  const int slots = gemm_cu_count() * 4 / 8 * 8;
-  const bool persist = gt_tuning().gemm_persist && !bf16 && n1 + n2 > slots;
-  const int w1 = cdiv(nn.K, GEMM_BK), w2 = cdiv(std::min(tn.K, tn.k_chunk), GEMM_BK);
-  const int grid = persist ? slots : n1 + n2, n2p = persist ? n2 : 0;
-  if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(n1 + n2), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first, 0, 0, 0);
-  else if (am == GEMM_A_NONE) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_NONE>), dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first, n2p, w1, w2);
-  else if (am == GEMM_A_LEAKY_PHILOX) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX>), dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first, n2p, w1, w2);
-  else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first, n2p, w1, w2);
+  const int grid = n1 + n2;
+  if (bf16) hipLaunchKernelGGL(gemm_pair_kernel<PREC_BF16>, dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else if (am == GEMM_A_NONE) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_NONE>), dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else if (am == GEMM_A_LEAKY_PHILOX) hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, GEMM_A_LEAKY_PHILOX>), dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
+  else      hipLaunchKernelGGL(gemm_pair_kernel<PREC_F32>, dim3(grid), dim3(GEMM_THREADS), lds, s, nn, tn, n1, tn_first);
   LAUNCH_CHECK();
   if (g_prof.wants(5)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;

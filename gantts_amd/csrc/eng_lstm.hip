@@ -313,25 +313,12 @@ int lstm_stack_backward(gt_engine* e, int role, const float* x, int ld_x, int ns
   float* dout = W.dout.as<float>();                          // gradient w.r.t. the current layer's output
   float* dout_other = dout + (size_t)N * dirs * H;
   const bool b16 = role == GT_ROLE_G && lstm_b16(e) && (int)e->l_in_b.size() == Lc + 1 && (int)e->lsh.size() == Lc + 1;
-  // Side stream (GT_LSTM_SIDE=1; OFF by default): a layer's weight-gradient products (dW_ih, dW_hh, the shifts and combines:
-  // ~3 ms of a cfg3 step) depend on its dG only, and nothing on the way to the layer below depends on them, so they can
-  // run beside the persistent recurrence of the layer below, whose workgroups leave the matrix pipes idle: the step stream
-  // carries recurrence -> d(input) product -> next recurrence and joins the side stream before clip-norm + optimizer.
-  // Built, correct (the at-size cfg3 parity test passes with it) and MEASURED NOT TO PAY: cfg3 fp32 25.74 ms with it vs
-  // 25.68 ms without, bf16 19.04 vs 18.14 ms -- the recurrence is bound by its L2 hand-offs, and the products' operand
-  // traffic through the same L2s slows every one of its 1024 steps by about what the overlap hides.
-  const bool side_on = e->opt_lstm_side;
+  // (A side stream for a layer's weight-gradient products -- beside the recurrence of the layer below -- was built in round 3, measured not to
+  //  pay (cfg3 fp32 25.74 vs 25.68 ms, bf16 19.04 vs 18.14: the products' operand traffic slows every step of the recurrence by what the
+  //  overlap hides) and left the library in round 6.)
   hipStream_t ws = s;
-  if (side_on) {
-    if (!e->side) {
-      HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
-    }
-    ws = e->side;
-  }
-  Scratch& wsl = side_on ? e->slabs_side : e->slabs;
-  Scratch& wcp = side_on ? e->colp_side : e->colp;
+  Scratch& wsl = e->slabs;
+  Scratch& wcp = e->colp;
   if (b16) e->l_dg_b.resize(Lc);
   for (int l = Lc - 1; l >= 0; --l) {
     const LstmLayerP& L = G.lstm[l];
@@ -345,7 +332,6 @@ int lstm_stack_backward(gt_engine* e, int role, const float* x, int ld_x, int ns
       CHK(DG0.ensure(N, dirs * 4 * H, true));
       CHK(cast_transpose(dG, dirs * 4 * H, N, dirs * 4 * H, DG0.r(), DG0.ld, DG0.t(), DG0.ldt, nullptr, false, &e->colp, s));
     }
-    if (side_on) { HIPCHK(hipEventRecord(e->ev_side_go, s)); HIPCHK(hipStreamWaitEvent(ws, e->ev_side_go, 0)); }
     if (b16) {
       // dG -> bf16 image in both orientations (one pass), then every product of this layer reads bf16:
       // dW_ih_d = dGT_d . inT^T (+ db from the loader), dW_hh_d = dGT_d . hshiftT^T, d in = dG . W_ihT^T (all directions in ONE product)
@@ -427,7 +413,6 @@ int lstm_stack_backward(gt_engine* e, int role, const float* x, int ld_x, int ns
       if (l > 0) std::swap(dout, dout_other);
     }
   }
-  if (side_on) { HIPCHK(hipEventRecord(e->ev_side_done, ws)); HIPCHK(hipStreamWaitEvent(s, e->ev_side_done, 0)); }
   return GT_OK;
 }
 

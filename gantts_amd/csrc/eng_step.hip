@@ -54,15 +54,13 @@ extern "C" int gt_invalidate_mlpg_cache(gt_engine* e) {
   return GT_OK;
 }
 
-// output frames per workgroup of the MLPG kernels: 32, or 64 (gt_set_tuning("mlpg_tt", 64): half the halo re-reads -- (64 + 2 kb) / 64
-// instead of (32 + 2 kb) / 32 staged rows per output frame -- but one workgroup per CU instead of two).  Measured at cfg2
-// (gpurun_out/r4o, one lease): 1.404 / 1.398 ms with 64 vs 1.393 / 1.398 with 32 -- no gain, 32 stays.
-// 16-frame tiles: twice the workgroups for batches whose 32-frame tiles leave CUs empty (a rank's share of a strong-scaling run:
-// B * ceil(T / 32) = 64 workgroups at 4 sequences of 512 frames), at (16 + 2 kb) / 16 staged rows per output frame.
-static int mlpg_tile_frames(gt_engine* e, int B, int T, size_t lds64) {
+// output frames per workgroup of the MLPG kernels: 32; 16-frame tiles (gt_set_tuning("mlpg_tt", 16) / "mlpg_small16"): twice the workgroups for
+// batches whose 32-frame tiles leave CUs empty (a rank's share of a strong-scaling run: B * ceil(T / 32) = 64 workgroups at 4 sequences of
+// 512 frames), at (16 + 2 kb) / 16 staged rows per output frame.  (64-frame tiles -- half the halo re-reads, one workgroup per CU instead of two --
+// measured no gain in round 4, 1.404 / 1.398 vs 1.393 / 1.398 ms, and left the library in round 6.)
+static int mlpg_tile_frames(gt_engine* e, int B, int T) {
   (void)e;
   const int tt = gt_tuning().mlpg_tt;
-  if (tt == 64 && lds64 <= 150 * 1024) return 64;
   if (tt == 16) return 16;
   if (tt == 0 && gt_tuning().mlpg_small16 && (long)B * cdiv(T, 32) * 2 <= gemm_cu_count()) return 16;
   return 32;
@@ -71,14 +69,13 @@ int mlpg_forward(gt_engine* e, const float* y, int ldy, const int* scol, const i
                  float* ys, int ldys, int B, int T, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   auto lds_of = [&](int tt) { return ((size_t)(tt + 2 * kb) * nW * MLPG_CC + (size_t)tt * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float); };
-  const int tt = mlpg_tile_frames(e, B, T, lds_of(64));
+  const int tt = mlpg_tile_frames(e, B, T);
   const size_t lds = lds_of(tt);
   dim3 grid(B * cdiv(T, tt), cdiv(Ds, MLPG_CC));
   const int fpl = gt_tuning().mlpg_fpl;   // frames per lane of the compute phase: 2 measured best (round 4: 4: 24.7 us, 2: 21.8, 1: 26.6; round 5, unrolled tap loops: forward 18.5 / 17.2 / 18.3, backward 24.9 / 19.5 / 20.6)
 #define GT_MLPG_FWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_forward_kernel<F, TTV>, lds)); \
     hipLaunchKernelGGL((mlpg_forward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, y, ldy, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, ys, ldys, B, T); }
-  if (tt == 64) { if (fpl == 1) GT_MLPG_FWD(1, 64) else if (fpl == 4) GT_MLPG_FWD(4, 64) else GT_MLPG_FWD(2, 64) }
-  else if (tt == 16) GT_MLPG_FWD(2, 16)
+  if (tt == 16) GT_MLPG_FWD(2, 16)
   else { if (fpl == 1) GT_MLPG_FWD(1, 32) else if (fpl == 2) GT_MLPG_FWD(2, 32) else GT_MLPG_FWD(4, 32) }
 #undef GT_MLPG_FWD
   LAUNCH_CHECK();
@@ -89,15 +86,14 @@ int mlpg_backward(gt_engine* e, const float* gs, int ldgs, const int* scol, cons
                   const float* mask, hipStream_t s) {
   const int nW = e->cfg.num_windows, kb = e->mlpg.cur->kb;
   auto lds_of = [&](int tt) { return ((size_t)(tt + 2 * kb) * MLPG_CC + (size_t)(tt + 2 * kb) * nW * (2 * kb + 1 + 2 * MLPG_PAD)) * sizeof(float); };
-  const int tt = mlpg_tile_frames(e, B, T, lds_of(64));
+  const int tt = mlpg_tile_frames(e, B, T);
   const size_t lds = lds_of(tt);
   dim3 grid(B * cdiv(T, tt), cdiv(Ds, MLPG_CC));
   const int fpl = gt_tuning().mlpg_fpl;
 #define GT_MLPG_BWD(F, TTV) { CHK(ensure_dyn_lds((const void*)mlpg_backward_kernel<F, TTV>, lds)); \
     hipLaunchKernelGGL((mlpg_backward_kernel<F, TTV>), grid, dim3(MLPG_THREADS), lds, s, gs, ldgs, e->mlpg.cur->band.as<float>(), kb, nW, scol, sstride, Ds, \
                        gy, ldgy, B, T, mse_w, yhat, ytgt, ldt, mask, e->sc()); }
-  if (tt == 64) { if (fpl == 1) GT_MLPG_BWD(1, 64) else if (fpl == 4) GT_MLPG_BWD(4, 64) else GT_MLPG_BWD(2, 64) }
-  else if (tt == 16) GT_MLPG_BWD(2, 16)
+  if (tt == 16) GT_MLPG_BWD(2, 16)
   else { if (fpl == 1) GT_MLPG_BWD(1, 32) else if (fpl == 2) GT_MLPG_BWD(2, 32) else GT_MLPG_BWD(4, 32) }
 #undef GT_MLPG_BWD
   LAUNCH_CHECK();
@@ -402,12 +398,14 @@ static int dense_cx(gt_engine* e, const float** x, long N, hipStream_t s) {
   if (!*x || !e->cfg.discriminator_linguistic_condition || e->ld_cx <= 0 || e->ld_cx == cond_dim(e)) return GT_OK;
   const int cd = cond_dim(e);
   if (e->ld_cx < cd) return fail(GT_ERR_INVALID, "gt_set_x_pitch: pitch %d for %d conditioning columns", e->ld_cx, cd);
-  if (!(e->cxd_src == *x && e->cxd_step == e->step_counter && e->cx_dense.p)) {
+  // (the copy is keyed on everything it depends on -- ADVICE r5: the pointer and the step alone served a stale or too small copy to a caller that
+  //  refilled x in place or changed B*T between two update_* calls of one step)
+  if (!(e->cxd_src == *x && e->cxd_step == e->step_counter && e->cxd_rows == N && e->cxd_ld == e->ld_cx && e->cxd_cols == cd && e->cx_dense.p)) {
     CHK(e->cx_dense.ensure((size_t)N * cd * sizeof(float)));
     hipLaunchKernelGGL(gather_cols_kernel, dim3(cdiv(N * cd, 256)), dim3(256), 0, s, *x, e->ld_cx, 0, (const int*)nullptr,
                        e->cx_dense.as<float>(), cd, 0, (int)N, cd);
     LAUNCH_CHECK();
-    e->cxd_src = *x; e->cxd_step = e->step_counter;
+    e->cxd_src = *x; e->cxd_step = e->step_counter; e->cxd_rows = N; e->cxd_ld = e->ld_cx; e->cxd_cols = cd;
   }
   *x = e->cx_dense.as<float>();
   return GT_OK;
@@ -496,7 +494,7 @@ extern "C" int gt_apply_generator(gt_engine* e, const float* x, const float* R, 
   e->step_counter++;
   e->B = B; e->T = T; e->N = (long)B * T;
   e->g_pass_valid = false;
-  e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false;
+  e->fake_cat_valid = false; e->dcat_b_ok = false; e->adv2_fake_ok = false; e->cxd_src = nullptr;
   e->tv_mask = nullptr; e->tv_inflight = false;             // a new batch: the mask contents may have changed
   CHK(generator_forward(e, x, R, B, T, y_hat, y_hat_static, true, s, e->g_specs));
   e->last_x = e->gx_dense_on ? e->gx_dense.as<float>() : x;      // (what the backward pass reads: the dense copy when one was made)
@@ -536,18 +534,6 @@ static int build_cat(gt_engine* e, const float* x, const float* feats, int ld_fe
 static int head_finalize(gt_engine* e, int mode, int nblk, int K, bool w, hipStream_t s, StepResults* early_res, int* defer_scalars, unsigned ticket) {
   Net& D = e->net[GT_ROLE_D];
   if (defer_scalars && !w) { *defer_scalars = nblk; return GT_OK; }
-  if (w && nblk >= 256 && gt_tuning().head_fin2) {       // many partials: the two-stage form (frame_kernels.hip.h)
-    const size_t bytes = sizeof(HeadStage) + (size_t)HF2_PARTS * K * sizeof(float);
-    if (e->headf.bytes < bytes) {
-      CHK(e->headf.ensure(bytes));
-      HIPCHK(hipMemsetAsync(e->headf.p, 0, sizeof(HeadStage), s));       // the arrival counter starts at 0; every launch leaves it there
-    }
-    hipLaunchKernelGGL(d_head_finalize2_kernel, dim3(cdiv(K, 64) * HF2_PARTS), dim3(256), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
-                       nblk, K, mode, e->sc(), D.last.dW, D.last.db, D.grads_dirty ? 1 : 0, early_res, e->headf.as<HeadStage>(),
-                       ticket ? e->ticket_dev() : (unsigned*)nullptr, ticket);
-    LAUNCH_CHECK();
-    return GT_OK;
-  }
   const int cgw = (w && nblk >= 512) ? 16 : 64;       // many rows of partials: narrower column groups, more workgroups (frame_kernels.hip.h)
   const int n_dw = cdiv(K, cgw), extra = cgw == 16 ? 1 : 0;       // (with many partials the scalars get a workgroup of their own, beside the dw ones)
   hipLaunchKernelGGL(d_head_finalize_kernel, dim3(n_dw + extra), dim3(1024), 0, s, e->headp.as<HeadPartials>(), e->headw.as<float>(),
@@ -614,7 +600,7 @@ static int run_head(gt_engine* e, int mode, const void* H, int K, long n_rows, l
                     bool unit_tv = false /* seed the backward pass of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS) */,
                     bool has_act = true /* H is LeakyReLU + dropout of a pre-activation (MLP); false: a recurrent stack's output */) {
   Net& D = e->net[GT_ROLE_D];
-  const int nblk = (int)std::min<long>(std::max(64, gt_tuning().head_wgs), (n_rows + 31) / 32);
+  const int nblk = (int)std::min<long>(1024, (n_rows + 31) / 32);
   CHK(e->headp.ensure((size_t)nblk * sizeof(HeadPartials)));
   CHK(e->headw.ensure((size_t)nblk * K * sizeof(float)));
   CHK(e->dout.ensure((size_t)n_rows * sizeof(float)));
@@ -1185,14 +1171,10 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
   const bool riders = early_fold && e->opt_launch_riders && !mse_side;
   // data parallel: the same launches, the rider then only files the three sums for the collective (nothing is reported from it)
   const bool riders_dp = e->early && comm_on(e) && e->opt_launch_riders && !(tr && direct && mse_w != 0.f);
-  // phase "train": the two sums ride in the gradient-assembly launch instead (GLossRide, frame_kernels.hip.h): one launch and one pass
-  // over y_hat_static / y_static less
-  const bool loss_ride = (riders || riders_dp) && tr && gt_tuning().g_loss_ride;
   if (riders || riders_dp) {
     mse_blocks = (int)std::min<long>(1024, cdiv(N * Do, RED_THREADS * 4));
     mge_pre_blocks = (int)std::min<long>(1024, cdiv(N * Ds, RED_THREADS * 4));
     CHK(e->partial.ensure(4096 * sizeof(double)));
-    if (!loss_ride)
     hipLaunchKernelGGL(g_losses_kernel, dim3(mse_blocks + mge_pre_blocks), dim3(RED_THREADS), 0, s, y_hat, Do, y, Do, Do, mse_blocks,
                        e->partial.as<double>() + 1024, y_hat_static, Ds, y_static, Ds, Ds, e->partial.as<double>(), mask, N);
     LAUNCH_CHECK();
@@ -1317,17 +1299,10 @@ extern "C" int gt_update_generator_begin(gt_engine* e, const float* x, const flo
       fin.hp = head_blocks ? e->headp.as<HeadPartials>() : (const HeadPartials*)nullptr; fin.n_hp = head_blocks;
       if (riders) { fin.ticket_value = take_ticket(e); fin.ticket = fin.ticket_value ? e->ticket_dev() : (unsigned*)nullptr; }
     }
-    GLossRide gl;
-    memset(&gl, 0, sizeof(gl));
-    if (loss_ride) {       // (mge_pre_blocks == nblk: the assembly workgroups leave exactly the partials g_losses_kernel would)
-      if (!e->gl_counter.p) { CHK(e->gl_counter.ensure(64)); HIPCHK(hipMemsetAsync(e->gl_counter.p, 0, 64, s)); }
-      gl.on = 1; gl.n_mse = mse_blocks; gl.a = y_hat; gl.lda = Do; gl.b = y; gl.ldb = Do; gl.D = Do;
-      gl.part_mse = e->partial.as<double>() + 1024; gl.counter = e->gl_counter.as<unsigned>();
-    }
     if (tr || !rid)
-      hipLaunchKernelGGL(static_grad_kernel, dim3(loss_ride ? nblk + mse_blocks : nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds,
+      hipLaunchKernelGGL(static_grad_kernel, dim3(nblk + (rid ? 1 : 0)), dim3(RED_THREADS), 0, s, y_hat_static, Ds,
                          y_static, Ds, mask, N, Ds, mge_w, e->d_adv_inv, leak, e->Da, gadv, e->Da, adv_w, gs, Ds,
-                         rid && !loss_ride ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin, leak && e->leak_unnorm ? 1 : 0, gl);
+                         rid ? (double*)nullptr : e->partial.as<double>(), e->sc(), fin, leak && e->leak_unnorm ? 1 : 0);
     else      // phase != "train": no gradient to assemble, the finalisation alone
       hipLaunchKernelGGL(finalize_g_rider_kernel, dim3(1), dim3(RED_THREADS), 0, s, fin);
     LAUNCH_CHECK();

@@ -76,24 +76,16 @@ struct GtTuning {
   int tn_wgs = 512;           // GT_TN_WGS         workgroups of a weight-gradient launch
   int split_fused = 1;        // GT_SPLIT_FUSED    split first layer's forward as one two-segment launch (0: x product + K = 58 pass)
   int tn_split_wgs = 1024;    // GT_TN_SPLIT_WGS   ... of the split first layer's two-block launch
-  int stagger_ticks = 0;      // GT_GEMM_STAGGER_TICKS / _MODE   start stagger (off)
-  int stagger_mode = 3;
   int b16_tiles = 0;          // GT_B16_TILES      bf16-storage products: force 64 / 128 / 256 tiles (0 = by shape)
   int b16_wg_tile = 0;        // GT_B16_WG_TILE    ... their weight gradients
   int b16_dma = 1;            // GT_B16_DMA        LDS-DMA operand stages
   int mlpg_fpl = 2;           // GT_MLPG_FPL       frames per lane of the MLPG compute phase
-  int head_wgs = 1024;        // GT_HEAD_WGS       discriminator head: at most this many workgroups (each leaves one row of partial sums for the finalisation)
   int head_vec = 0;           // GT_HEAD_VEC       discriminator head: 16-byte accesses (lane <-> four consecutive hidden units); measured -3 us
                               //                   per step, NOT the default: it sums the row's dot product in another order, and one oracle-only
                               //                   at-size case (a cold-Adagrad update, lr * g / |g|) then lands 1.2x outside its 1e-4
   int mlpg_small16 = 0;       // GT_MLPG_SMALL16   16-frame MLPG tiles when 32-frame tiles would fill at most half the CUs (mlpg_tt == 0)
-  int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 32, 64)
-  int g_loss_ride = 0;        // GT_G_LOSS_RIDE    G step (train): loss_mse / loss_mge sums ride in the gradient-assembly launch, last-arrival finalisation.
-                              //                   MEASURED SLOWER (cfg2 1.324 -> 1.499 ms): every workgroup's agent-scope release is an L2 write-back on this 8-XCD part
-  int head_fin2 = 0;          // GT_HEAD_FIN2      head partials of >= 256 workgroups: two-stage finalisation (64 workgroups, last-arrival finish).
-                              //                   MEASURED SLOWER (1.324 -> 1.327-1.329 ms) for the same reason; both stay as measurement switches
+  int mlpg_tt = 0;            // GT_MLPG_TT        output frames per MLPG workgroup (0 = by shape, 16, 32)
   int leak_rider = 1;         // GT_LEAK_RIDER     D step: the kept dloss_d / dy_hat_static product rides in the split first layer's weight-gradient launch
-  int gemm_persist = 0;       // GT_GEMM_PERSIST   float32 product launches as persistent grids (resident slots, static cost-balanced XCD-local tile runs)
   int sru_cs_waves = 0;       // GT_SRU_CS_WAVES   waves per 64 columns of the cooperative SRU scans: 0 = by shape (8 where B x ncols / 64 <= CUs, else 4), 4, 8
   int sru_lw = 2;             // GT_SRU_LW         2: cooperative block scans (sru_cs_kernels.hip.h); 1: loader-wave scans; 0: one-wave kernels (1 == 0 bit for bit)
 };
@@ -219,7 +211,7 @@ struct gt_engine {
   MlpgCache mlpg;
   // workspace
   std::vector<Scratch> g_act, d_act;       // hidden activations
-  Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, headf, gl_counter, dmask, tx, gx, dgx, dtz, dout;
+  Scratch dcat, dzA, dzB, leak, gadv, gs, gy, slabs, colp, partial, headp, headw, dmask, tx, gx, dgx, dtz, dout;
   Scratch scal;                            // StepScalars + StepResults
   StepResults* h_res = nullptr;            // pinned
   StepResults* h_res_dev = nullptr;        // the same page as the kernels see it: the fused calls' finalisation writes the
@@ -275,7 +267,6 @@ struct gt_engine {
   B16Img l_hs_b;                                   // h that entered each frame (transposed)
   hipStream_t side = nullptr;                      // recurrent generator: weight-gradient products run beside the next layer's recurrence
   hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
-  Scratch slabs_side, colp_side;
   std::vector<LinShadow> lsh;                      // per LSTM layer: W_ih of all directions stacked [dirs*4H][in]; last entry: hidden2out
   bool dcat_b_ok = false;                          // dcat_b's generated half holds [x | adv(y_hat_static)] of the tensors below
   const float* dcat_b_x = nullptr; const float* dcat_b_yhs = nullptr;
@@ -293,7 +284,6 @@ struct gt_engine {
   bool opt_split_first = env_flag("GT_D_SPLIT", true);
   bool opt_fused_optimizer = env_flag("GT_OPT_FUSED", false);      // measured slower: off
   bool opt_side_overlap = env_flag("GT_SIDE_OVERLAP", false);      // GT_OPT_SIDE_OVERLAP: tv / MSE kernels on the side stream (measured slower: off)
-  bool opt_lstm_side = env_flag("GT_LSTM_SIDE", false);            // GT_OPT_LSTM_SIDE: LSTM weight gradients beside the next layer's recurrence (measured: no gain)
   // data-parallel schedule (GT_OPT_COMM_*): D's gradient as one message, G's loss sums early, grouped closing messages,
   // collectives issued even with one rank (bench.py --force-dp, tests)
   bool opt_comm_d_one_msg = env_flag("GT_COMM_D_ONE_MSG", true), opt_comm_early_g = env_flag("GT_COMM_EARLY_G", true),
@@ -314,7 +304,7 @@ struct gt_engine {
   // gt_set_x_pitch never makes a step fail (DevicePrefetcher(pitch_x=True) with a recurrent discriminator did).
   Scratch gx_dense, cx_dense;
   bool gx_dense_on = false;                        // this step's generator input is the dense copy: gx_pitch() == in_dim
-  const float* cxd_src = nullptr; uint64_t cxd_step = ~0ull;
+  const float* cxd_src = nullptr; uint64_t cxd_step = ~0ull; long cxd_rows = 0; int cxd_ld = 0, cxd_cols = 0;     // what cx_dense holds
   Scratch opt_bar; unsigned long long opt_bar_count = 0;   // arrival counter of optim_fused_kernel's device-wide barrier (monotonic across launches)
   Scratch w0pad[2];                                // per role: first hidden layer's weight with a 16-byte row pitch (stack_forward)
   unsigned int* h_fault_dev = nullptr;             // device view of h_fault[1]: the optimizer kernel mirrors a raised fault word
@@ -418,8 +408,9 @@ struct GtComm {
   int next_ev = 0;
   hipEvent_t ev_done = nullptr;
   // schedule trace (gt_comm_trace, a measurement): every message and every join of the step stream bracketed by timed events
-  struct TraceRec { int kind, inl; double bytes; hipEvent_t e0, e1; };     // kind 0 message, 1 join
+  struct TraceRec { int kind, inl; double bytes; hipEvent_t e0, e1; bool closed; };     // kind 0 message, 1 join; closed: e1 was recorded
   bool trace = false;
+  long trace_dropped = 0;                          // messages / joins that found the trace full
   std::vector<TraceRec> trec;
 };
 bool comm_on(const gt_engine* e);

@@ -947,92 +947,6 @@ static __global__ __launch_bounds__(1024) void d_head_finalize_kernel(const Head
   }
 }
 
-// TWO-STAGE form of d_head_finalize_kernel for passes with many workgroups of partials (the fused discriminator stack leaves one per
-// 32-frame panel: 1024 at cfg2, 1 MB of dw partials that four workgroups took 9.7 us to sum).  Grid = ceil(K/64) column groups x HF2_PARTS
-// row parts, 256 threads = 4 sub-parts x 64 columns: a thread holds ALL of its (at most 16-deep) loads in flight at once, the workgroup
-// leaves one row of stage[part][K] (column group 0 also the part's five scalar sums), and the LAST workgroup to finish (a counter, no
-// waiting: nothing spins) adds the HF2_PARTS rows in fixed order -- the result does not depend on which workgroup that was.
-constexpr int HF2_PARTS = 16;
-struct HeadStage { double sc[HF2_PARTS][5]; unsigned counter; unsigned pad_[15]; };       // followed by float stage[HF2_PARTS][K]
-static __global__ __launch_bounds__(256) void d_head_finalize2_kernel(const HeadPartials* __restrict__ hp, const float* __restrict__ dw_partial,
-                                                                      int nblk, int K, int mode, StepScalars* sc,
-                                                                      float* __restrict__ dw, float* __restrict__ db, int accumulate,
-                                                                      StepResults* early_res, HeadStage* st, unsigned* ticket, unsigned ticket_value) {
-  __shared__ float shw[4][64];
-  __shared__ double shd[16];
-  __shared__ int last_sh;
-  float* stage = reinterpret_cast<float*>(st + 1);
-  const int kl = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  const int ncg = (int)gridDim.x / HF2_PARTS;
-  const int cg = (int)blockIdx.x % ncg, part = (int)blockIdx.x / ncg;
-  const int k = cg * 64 + kl;
-  const int per = (nblk + HF2_PARTS - 1) / HF2_PARTS;
-  const int i0 = part * per, i1 = min(nblk, i0 + per);
-  {
-    float sa[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) sa[u] = 0.f;
-    if (k < K) {
-      int i = i0 + sub;
-      for (; i + 15 * 4 < i1; i += 64) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) sa[u] += dw_partial[(long)(i + 4 * u) * K + k];
-      }
-      for (; i < i1; i += 4) sa[0] += dw_partial[(long)i * K + k];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) sa[u] += sa[u + 8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) sa[u] += sa[u + 4];
-    shw[sub][kl] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-    __syncthreads();
-    if (sub == 0 && k < K) stage[(long)part * K + k] = (shw[0][kl] + shw[1][kl]) + (shw[2][kl] + shw[3][kl]);
-  }
-  if (cg == 0) {
-    double v[5] = {0, 0, 0, 0, 0};
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += blockDim.x) {
-      v[0] += hp[i].s_real; v[1] += hp[i].s_fake; v[2] += hp[i].n_real_ok; v[3] += hp[i].n_fake_ok; v[4] += hp[i].db;
-    }
-    for (int q = 0; q < 5; ++q) {
-      const double r = block_sum_d(v[q], shd);
-      if (threadIdx.x == 0) st->sc[part][q] = r;
-    }
-  }
-  // the last workgroup to get here finishes the job
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(&st->counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last_sh = prev == gridDim.x - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if (!last_sh) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  for (int c = threadIdx.x; c < K; c += blockDim.x) {
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < HF2_PARTS; ++q) tot += __builtin_nontemporal_load(stage + (long)q * K + c);
-    dw[c] = accumulate ? dw[c] + tot : tot;
-  }
-  if (threadIdx.x == 0) {
-    double r[5] = {0, 0, 0, 0, 0};
-    for (int q = 0; q < HF2_PARTS; ++q)
-      for (int j = 0; j < 5; ++j) r[j] += __builtin_nontemporal_load(&st->sc[q][j]);
-    if (mode == HEAD_D_STEP) {
-      sc->s_real = r[0]; sc->s_fake = r[1]; sc->n_real_ok = r[2]; sc->n_fake_ok = r[3];
-      if (early_res) {       // same arithmetic as finalize_d_kernel
-        const float T = sc->tv;
-        const float lr = -((float)r[0]) / T, lf = -((float)r[1]) / T;
-        early_res->loss_real_d = lr; early_res->loss_fake_d = lf; early_res->loss_d = lr + lf;
-        early_res->real_correct = (float)r[2]; early_res->fake_correct = (float)r[3];
-        early_res->gnorm_d = 0.f; early_res->tv = T;
-        publish_ticket(ticket, ticket_value);
-      }
-    } else sc->s_adv = r[0];
-    if (db) db[0] = accumulate ? db[0] + (float)r[4] : (float)r[4];
-    __hip_atomic_store(&st->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // armed for the next launch (stream order)
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // generator-side gradient assembly at y_hat_static (the "linearity trick"):
@@ -1063,7 +977,7 @@ __device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* ou
   if (part_mge || part_mse || hp) {
     if (part_mge) {
       double v = 0.0;
-      for (int i = threadIdx.x; i < n_mge; i += blockDim.x) v += __builtin_nontemporal_load(part_mge + i);      // (may be this launch's: GLossRide)
+      for (int i = threadIdx.x; i < n_mge; i += blockDim.x) v += __builtin_nontemporal_load(part_mge + i);
       const double t = block_sum_d(v, shp);
       if (threadIdx.x == 0) sc->s_mge = t;
     }
@@ -1091,16 +1005,6 @@ __device__ __forceinline__ void finalize_g_body(StepScalars* sc, StepResults* ou
   publish_ticket(ticket, ticket_value);
 }
 
-// g_losses_kernel's work as a rider of static_grad_kernel (fused single-GPU / data-parallel generator step, phase "train"): the first
-// n_mse workgroups sum the masked squared error of (a, b) -> part_mse (loss_mse over y_hat, train.py:294), the gradient-assembly
-// workgroups behind them also leave the MGE partials (`partial`), and the finalisation (GFinalize) is run by the LAST workgroup of the
-// launch to finish -- an arrival counter, nobody waits -- instead of by an extra workgroup that could only read earlier launches' sums.
-struct GLossRide {
-  int on, n_mse;
-  const float* a; int lda; const float* b; int ldb; int D;
-  double* part_mse;
-  unsigned* counter;       // zero before the launch; the finishing workgroup leaves it zero
-};
 // partial == null: no sum of squares (g_losses_kernel produced it)
 static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     const float* __restrict__ yhs, int ld1, const float* __restrict__ ys, int ld2,
@@ -1108,19 +1012,11 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
     const int* __restrict__ adv_inv /* [Ds] -> j or -1 */, const float* __restrict__ leak, int ldl,
     const float* __restrict__ gadv, int lda, float adv_w,
     float* __restrict__ gs, int ldg, double* __restrict__ partial, StepScalars* __restrict__ sc, const GFinalize fin,
-    int leak_unnorm /* the kept dloss_d/dy_hat_static is that of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS): x 1 / Tv here */,
-    const GLossRide gl) {
+    int leak_unnorm /* the kept dloss_d/dy_hat_static is that of the UNNORMALISED loss (GT_OPT_COMM_TV_IN_SUMS): x 1 / Tv here */) {
   __shared__ double sh[16];
-  __shared__ int last_sh;
-  int nblk = gridDim.x, blk = blockIdx.x;
-  if (gl.on) {
-    nblk -= gl.n_mse; blk -= gl.n_mse;
-    if (blk < 0) {
-      const double acc = masked_sqerr_body(gl.a, gl.lda, gl.b, gl.ldb, mask, rows, gl.D, nullptr, 0, 0.f, (int)blockIdx.x, gl.n_mse);
-      const double tot = block_sum_d(acc, sh);
-      if (threadIdx.x == 0) gl.part_mse[blockIdx.x] = tot;
-    }
-  } else if (fin.on) {
+  int nblk = gridDim.x;
+  const int blk = blockIdx.x;
+  if (fin.on) {
     if (blockIdx.x == gridDim.x - 1) {
       finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
                       fin.hp, fin.n_hp, sh, fin.ticket, fin.ticket_value);
@@ -1135,7 +1031,7 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
   const long stride = (long)nblk * blockDim.x;
   const long sr = stride / Ds;
   const int sd = (int)(stride - sr * Ds);
-  long e = blk < 0 ? total : (long)blk * blockDim.x + threadIdx.x;
+  long e = (long)blk * blockDim.x + threadIdx.x;
   long r = e / Ds;
   int c = (int)(e - r * Ds);
   // FOUR grid strides per trip (a thread of the cfg2 launch walks four elements): their loads -- mask, the two features, the column map,
@@ -1190,23 +1086,9 @@ static __global__ __launch_bounds__(RED_THREADS) void static_grad_kernel(
       gs[r * ldg + c] = v;
     }
   }
-  if (partial && blk >= 0) {
+  if (partial) {
     const double tot = block_sum_d(acc, sh);
     if (threadIdx.x == 0) partial[blk] = tot;
-  }
-  if (gl.on) {       // every workgroup's sums are out: the last one to arrive finalises
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(gl.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      last_sh = prev == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_sh) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (threadIdx.x == 0) __hip_atomic_store(gl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    finalize_g_body(fin.sc, fin.out, fin.adv_w, fin.mse_w, fin.mge_w, fin.has_adv, 1, fin.part_mge, fin.n_mge, fin.part_mse, fin.n_mse,
-                    fin.hp, fin.n_hp, sh, fin.ticket, fin.ticket_value);
   }
 }
 

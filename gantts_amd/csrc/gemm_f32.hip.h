@@ -169,15 +169,6 @@ struct GemmArgs {
   long slab_stride;
   float* colsum_slab;        // TN: per-slab column sums of A (bias gradient), [nslab][M], or null
   int n_tiles_m, n_tiles_n;
-  // Start stagger (launcher-set; 0 = off).  The two workgroups that share a CU share its matrix pipes: started together
-  // they also reach their load prologues and their store epilogues together, and the pipes idle through both.  One
-  // of the two ("late") waits `stagger_ticks` (100 MHz wall-clock ticks) before it starts -- the other one has the
-  // pipes to itself meanwhile, so no matrix time is lost -- and from then on one workgroup's prologue / epilogue runs
-  // under the other's K loop.
-  int stagger_ticks;
-  int stagger_mode;          // who is late: 1 = upper half of the grid, 2 = odd wave slot (HW_ID), 3 = odd ticket of its CU
-  unsigned int* stagger_ticket;   // mode 3: [2048] counters keyed by (XCC_ID, SE_ID, SH_ID, CU_ID); never reset (parity alternates)
-  unsigned int* stagger_dbg;      // optional [grid]: cu_key | late << 16
 };
 
 // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), all 32 bits: s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id
@@ -187,25 +178,6 @@ __device__ __forceinline__ unsigned cu_key() {   // CU_ID [11:8], SH_ID [12], SE
   const unsigned h = hw_id_reg();
   return ((xcc_id_reg() & 0xfu) << 7) | (((h >> 13) & 0x7u) << 5) | (((h >> 12) & 0x1u) << 4) | ((h >> 8) & 0xfu);
 }
-__device__ __forceinline__ void gemm_start_stagger(const GemmArgs& g, float* smem) {
-  if (g.stagger_ticks <= 0) return;
-  bool late = false;
-  if (g.stagger_mode == 1) late = blockIdx.x >= (gridDim.x + 1) / 2;
-  else if (g.stagger_mode == 2) late = (hw_id_reg() & 1u) != 0u;
-  else if (g.stagger_mode == 3) {
-    unsigned* sh = reinterpret_cast<unsigned*>(smem);
-    if (threadIdx.x == 0) sh[0] = atomicAdd(g.stagger_ticket + cu_key(), 1u);
-    __syncthreads();
-    late = (sh[0] & 1u) != 0u;
-    __syncthreads();
-  }
-  if (g.stagger_dbg && threadIdx.x == 0) g.stagger_dbg[blockIdx.x] = cu_key() | (late ? 0x10000u : 0u);
-  if (late) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(2);
-  }
-}
-
 // LDS pitches per orientation (floats)
 template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
 template <int KIND, int BN> constexpr int gemm_ldn() { return KIND == GEMM_NT ? BN + 1 : BN + 4; }
@@ -257,9 +229,13 @@ enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1,
                  GEMM_A_LEAKY_PHILOX_ADDM = 2,   // NT: LeakyReLU + Philox dropout on (product + bias + addm)
                  GEMM_A_TN_SUM2 = 3,             // TN: loader sums A + A2
                  GEMM_A_LEAKY_PHILOX_SEG = 4 };  // NT: LeakyReLU + Philox dropout behind a two-segment K loop (A_seg / B_seg)
-template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME>
+// KM: the Philox keep bits of this lane's 16 elements arrive as `kmask` (bit 4 q + s; 64 x 64 tiles only) -- gemm_tile computed them in the MFMA
+// shadows of its last K stage ([r6]: the bits do not depend on the product; two Philox calls per wave tile were ~ 2200 VALU cycles of
+// every epilogue), instead of being drawn here.  Same calls, same bits.
+template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME, bool KM = false>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
-                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem, const int m_lim) {
+                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem, const int m_lim, const uint32_t kmask = 0u) {
+  static_assert(!KM || (BM == 64 && BN == 64), "precomputed keep bits: one 32 x 32 piece per wave");
   constexpr bool RT = AMODE == GEMM_A_RUNTIME || AMODE == GEMM_A_TN_SUM2;
   const int g_act = RT ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
   const int g_dmode = RT ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
@@ -298,11 +274,11 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
-          if (philox && (q & 1) == 0)
+          if (!KM && philox && (q & 1) == 0)
             philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
-            const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
+            const bool keep_px = KM ? ((kmask >> (4 * q + s4)) & 1u) != 0u : philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
             float v = acc[i][j][q * 4 + s4];
             if (KIND == GEMM_NT) {
               v += bias;
@@ -366,12 +342,12 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
-        if (philox && (q & 1) == 0)
+        if (!KM && philox && (q & 1) == 0)
           philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;
-          const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
+          const bool keep_px = KM ? ((kmask >> (4 * q + s)) & 1u) != 0u : philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
           if (!full_tile && (!n_ok || m >= m_lim)) continue;
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
@@ -663,6 +639,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   // body is instantiated three times (steady state / next tile is the K tail / last tile) so
   // `prefetch` and `tail` are compile-time inside the MFMA stream: no branches there.
   constexpr int NG = GEMM_BK / 2, NH = NG / 2;
+  // [r6] Keep bits in the MFMA shadow (plain LeakyReLU + Philox flavour on 64 x 64 tiles, float32): the LAST K stage of a tile requests nothing
+  // (no prefetch), so its groups carry the two Philox calls of this lane's column -- rows 0-15 of the wave's piece in groups 0-5, rows 16-31 in
+  // groups 6-11, two rounds per group -- and hand the epilogue a 16-bit mask.
+  constexpr bool KM = AMODE == GEMM_A_LEAKY_PHILOX && BM == 64 && BN == 64 && PREC == PREC_F32 && KIND != GEMM_TN;
+  uint32_t kmask = 0u, kc0 = 0u, kc1 = 0u, kc2 = 0u, kc3 = 0u, kk0 = 0u, kk1 = 0u;
+  auto km_round = [&]() {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, kc0), lo0 = 0xD2511F53u * kc0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, kc2), lo1 = 0xCD9E8D57u * kc2;
+    const uint32_t n0_ = hi1 ^ kc1 ^ kk0, n2_ = hi0 ^ kc3 ^ kk1;
+    kc0 = n0_; kc1 = lo1; kc2 = n2_; kc3 = lo0;
+    kk0 += 0x9E3779B9u; kk1 += 0xBB67AE85u;
+  };
+  auto km_step = [&](int gi) {       // gi: compile-time after unrolling
+    if (gi == 0 || gi == 6) {
+      const int mrow = m0 + wm * WM + (gi == 0 ? 0 : 16) + 4 * half;
+      kc0 = 2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half; kc1 = (uint32_t)(n0 + wn * WN + l31);
+      kc2 = 0x243F6A88u; kc3 = 0x85A308D3u; kk0 = g.drop.key0; kk1 = g.drop.key1;
+    }
+    if ((gi >= 0 && gi <= 4) || (gi >= 6 && gi <= 10)) { km_round(); km_round(); }
+    if (gi == 5 || gi == 11) {
+      const uint32_t r[4] = {kc0, kc1, kc2, kc3};
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) bits |= (philox_piece(r, pc) >= g.drop.thresh ? 1u : 0u) << pc;
+      kmask |= bits << (gi == 5 ? 0 : 8);
+    }
+  };
   auto k_tile = [&](int kt, auto PF, auto TL) {
     constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
@@ -693,6 +696,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
         for (int j = 0; j < TN_; ++j) b_nxt[j] = bs[(2 * gi + 2) * LDN + j * 32];
       }
 #endif
+      if (KM && !prefetch) km_step(gi);
 #ifdef GT_ABLATE_NO_GLOBAL
       if (false) {
 #else
@@ -738,9 +742,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-#ifdef GT_GEMM_CLK_DBG   // harness only: shader cycles / wall ticks of this workgroup's K loop -> stagger_dbg[4*block ..]
-  const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
-#endif
   auto k_loop = [&]() {
   if (PREC == PREC_BF16) {
     // 8 MFMAs of 32 cycles per K-tile: here the loader, not the matrix pipe, sets the pace (the launch is bound by the
@@ -799,13 +800,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   prologue();
   k_loop();
 
-#ifdef GT_GEMM_CLK_DBG
-  if (g.stagger_dbg && tid == 0) {
-    const unsigned long long dc = clock64() - dbg_c0, dw = wall_clock64() - dbg_w0;
-    g.stagger_dbg[4 * blockIdx.x] = (unsigned)dc; g.stagger_dbg[4 * blockIdx.x + 1] = (unsigned)dw;
-    g.stagger_dbg[4 * blockIdx.x + 2] = (unsigned)(dbg_w0 & 0xffffffffu); g.stagger_dbg[4 * blockIdx.x + 3] = (unsigned)((dbg_w0 + dw) & 0xffffffffu);
-  }
-#endif
   if (KIND == GEMM_TN && want_csum) {
     // all waves are past the last barrier of the K loop; reuse the LDS as scratch.
     // threads tid, tid + BM/VWA, ... own the same VWA columns starting at (tid % (BM/VWA)) * VWA
@@ -869,7 +863,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     }
     return;
   }
-  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0, n0, acc, smem, g.M);
+  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE, KM>(g, slab, m0, n0, acc, smem, g.M, kmask);
 }
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous run of
@@ -885,42 +879,9 @@ __device__ __forceinline__ int gemm_xcd_order(int bid, int nwg) {
 // and the second product's tiles start while the first one's last tiles finish.
 // tn_first: the weight-gradient workgroups (K = frames / slabs: several times the work of a backward-data tile) take the
 // FIRST block ids, i.e. are dispatched first -- longest work first, the short tiles back-fill behind them (eng_gemm_f32_pair.hip).
-// PERSISTENT form of the launches (gt_set_tuning("gemm_persist", 1); VERDICT r2-r4: "persistent tile loop"): the grid is the number of
-// RESIDENT workgroup slots, every workgroup walks a static, cost-balanced, XCD-local range of the launch's work items (items laid out on a
-// cost axis -- weight-gradient units first, each worth its K depth in stages -- and cut into equal pieces: slot r of G takes the items whose
-// start lies in [r C / G, (r + 1) C / G)); slot ranks are XCD-major (workgroup b runs on XCD b % 8), so an XCD's slots walk one contiguous run
-// of tiles.  One barrier between two tiles of a workgroup.  gemm_persist_range: this slot's piece of the cost axis.
-__device__ __forceinline__ void gemm_persist_range(long C, long& lo, long& hi) {
-  const int G = (int)gridDim.x, nx = G >> 3;                 // (the launchers make G a multiple of 8)
-  const long r = (long)(blockIdx.x & 7) * nx + (blockIdx.x >> 3);
-  lo = r * C / G; hi = (r + 1) * C / G;
-}
-
 template <int PREC, int AMODE = GEMM_A_RUNTIME>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first, const int n2_persist = 0,
-                                                                    const int w1 = 0, const int w2 = 0) {
+__global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_pair_kernel(const GemmArgs g1, const GemmArgs g2, const int n1, const int tn_first) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (n2_persist > 0) {      // persistent: items = n2_persist weight-gradient units of cost w2, then n1 backward-data tiles of cost w1
-    const long C = (long)n2_persist * w2 + (long)n1 * w1;
-    long lo, hi;
-    gemm_persist_range(C, lo, hi);
-    const long split = (long)n2_persist * w2;
-    const int tiles_mn = g2.n_tiles_m * g2.n_tiles_n;
-    bool first = true;
-    for (long i = (lo + w2 - 1) / w2; i < n2_persist && i * w2 < hi; ++i) {          // units whose start i w2 lies in [lo, hi)
-      if (!first) __syncthreads();
-      first = false;
-      const int slab = (int)i / tiles_mn, t = (int)i - slab * tiles_mn;
-      gemm_tile<GEMM_TN, 64, 64, true, true, PREC>(g2, slab, t / g2.n_tiles_n, t % g2.n_tiles_n, smem);
-    }
-    const long nlo = lo > split ? lo - split : 0, nhi = hi > split ? hi - split : 0;
-    for (long j = (nlo + w1 - 1) / w1; j < n1 && j * w1 < nhi; ++j) {
-      if (!first) __syncthreads();
-      first = false;
-      gemm_tile<GEMM_NN, 64, 64, true, true, PREC, 32, AMODE>(g1, 0, (int)j / g1.n_tiles_n, (int)j % g1.n_tiles_n, smem);
-    }
-    return;
-  }
   int bid = blockIdx.x;
   const int n2 = (int)gridDim.x - n1;
   const bool is_nn = tn_first ? bid >= n2 : bid < n1;
@@ -968,20 +929,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const Gem
 
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32, int AMODE = GEMM_A_RUNTIME>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g, const int persist_total = 0) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (persist_total > 0) {      // persistent: this slot's contiguous run of the launch's persist_total tiles (all of one cost)
-    long lo, hi;
-    gemm_persist_range(persist_total, lo, hi);
-    const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
-    for (long t = lo; t < hi; ++t) {
-      if (t > lo) __syncthreads();
-      const int slab = (int)t / tiles_mn, q = (int)t - slab * tiles_mn;
-      gemm_tile<KIND, BM, BN, VA, VB, PREC, BKT, AMODE>(g, slab, q / g.n_tiles_n, q - (q / g.n_tiles_n) * g.n_tiles_n, smem);
-    }
-    return;
-  }
-  gemm_start_stagger(g, smem);
   const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
   const int slab = bid / tiles_mn;

@@ -8,18 +8,6 @@ static double gemm_algorithmic_bytes(int kind, const GemmArgs& g) {
   if (kind == GEMM_NN && g.act != ACT_NONE && g.H) b += 4.0 * (double)g.M * g.N;     // the producer's stored activation
   return b;
 }
-// per-device ticket counters of the start stagger (mode 3): the two workgroups of a CU draw consecutive tickets
-static unsigned int* gemm_stagger_tickets() {
-  static std::map<int, unsigned int*> bufs;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  auto it = bufs.find(dev);
-  if (it != bufs.end()) return it->second;
-  unsigned int* p = nullptr;
-  if (hipMalloc((void**)&p, 2048 * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, 2048 * sizeof(unsigned int)) != hipSuccess) p = nullptr;
-  bufs[dev] = p;
-  return p;
-}
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC, int AM>
 static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   const size_t lds = gemm_lds_bytes<KIND, BM, BN, PREC>();
@@ -28,15 +16,6 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
   g.n_tiles_n = cdiv(g.N, BN);
   const int grid = g.n_tiles_m * g.n_tiles_n * nslab;
   if (grid <= 0) return GT_OK;
-  // Start stagger (gemm_f32.hip.h), OFF by default: in isolation (tools/gemm_stagger_bench.hip, dense random operands,
-  // the five big launches of a step back to back) letting one of the two workgroups of a CU start 0.5 .. 2 us late is
-  // worth 10-15 % (372 -> 325 us per sequence); inside the training step it measured 0.0 % in every mode,
-  // so it stays a measurement switch: GT_GEMM_STAGGER_TICKS (10 ns units), GT_GEMM_STAGGER_MODE.
-  const int stagger_ticks = gt_tuning().stagger_ticks, stagger_mode = gt_tuning().stagger_mode;
-  if (stagger_ticks > 0 && grid > gemm_cu_count()) {
-    g.stagger_ticks = stagger_ticks; g.stagger_mode = stagger_mode;
-    if (stagger_mode == 3 && !(g.stagger_ticket = gemm_stagger_tickets())) g.stagger_ticks = 0;
-  }
   GemmProfiler::Rec rec;
   if (g_prof.wants(KIND)) {
     rec.kind = KIND; rec.bn = BN; rec.am = AM; rec.flops = 2.0 * g.M * g.N * g.K; rec.bytes = gemm_algorithmic_bytes(KIND, g);
@@ -48,12 +27,7 @@ static int launch_gemm_impl(GemmArgs g, int nslab, hipStream_t s) {
     rec.e0 = g_prof.get(); rec.e1 = g_prof.get();
     HIPCHK(hipEventRecord(rec.e0, s));
   }
-  // persistent form (gt_set_tuning("gemm_persist")): 64 x 64 tiles hold four workgroups per CU, larger tiles two
-  const int slots = gemm_cu_count() * (BM == 64 && BN == 64 ? 4 : 2) / 8 * 8;
-  if (gt_tuning().gemm_persist && PREC == PREC_F32 && grid > slots && stagger_ticks <= 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(slots), dim3(GEMM_THREADS), lds, s, g, grid);
-  else
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g, 0);
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, BM, BN, VA, VB, PREC, 32, AM>), dim3(grid), dim3(GEMM_THREADS), lds, s, g);
   LAUNCH_CHECK();
   if (g_prof.wants(KIND)) { HIPCHK(hipEventRecord(rec.e1, s)); g_prof.recs.push_back(rec); }
   return GT_OK;

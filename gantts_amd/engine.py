@@ -166,6 +166,7 @@ class StepEngine(object):
             raise ValueError("unique_id must be %d bytes" % L.COMM_ID_BYTES)
         buf = (C.c_char * L.COMM_ID_BYTES).from_buffer_copy(unique_id)
         check(lib.gt_comm_init(self._h, int(rank), int(world), buf))
+        self._dp_world = int(world)
 
     def comm_destroy(self):
         check(lib.gt_comm_destroy(self._h))
@@ -194,6 +195,7 @@ class StepEngine(object):
         """This engine holds sequences rank, rank + world, ... of the minibatch (no communicator: the host all-reduces between
         the split-phase calls).  Keys the dropout streams globally, so a world-k run reproduces the one-process masks."""
         check(lib.gt_set_shard(self._h, int(rank), int(world)))
+        self._dp_world = int(world)
 
     def comm_trace(self, enable):
         """Starts (clearing the records) or stops the schedule trace of the data-parallel step (gt_comm_trace)."""

@@ -44,6 +44,23 @@ def apply_generator(model_g, x, R, lengths):
     """Returns ``(y_hat, y_hat_static)``; for generic models y_hat_static = multi_stream_mlpg(y_hat)."""
     if not model_g.include_parameter_generation():
         assert hp.has_dynamic_features is not None
+        # Deliberate deviation (DESIGN.md 1): a generic packed-sequence generator (LSTMRNN / GRURNN) whose longest sequence is shorter than the
+        # batch's T returns max(lengths) frames in the reference (pad_packed_sequence), which train.py:347-350 then zero-pads ON THE LEFT to T --
+        # every frame moves by T - max(lengths) against x and y.  train_loop cannot reach it (collate_fn pads to the batch's longest sequence);
+        # the engine does not reproduce the shift and refuses the call instead of returning differently aligned frames.  (A data-parallel rank
+        # holds a SHARD of a batch that was padded to ITS longest sequence, which may live on another rank: not this case.)
+        if getattr(model_g, "needs_lengths", False) and lengths is not None:
+            longest = max(int(v) for v in (lengths.view(-1).tolist() if hasattr(lengths, "view") else lengths))
+            sharded = False
+            if longest < x.size(1):
+                try:
+                    sharded = getattr(engine_for(hp, model_g), "_dp_world", 1) > 1
+                except Exception:      # noqa: BLE001 -- no engine (no device): the argument check stands on its own
+                    sharded = False
+            if longest < x.size(1) and not sharded:
+                raise ValueError("apply_generator: the longest sequence has %d frames in a batch padded to %d -- the reference left-pads the "
+                                 "generator's output by the difference here (train.py:347-350), which this engine does not reproduce; "
+                                 "pad the batch to its longest sequence as train.py's collate_fn does" % (longest, x.size(1)))
     return engine_for(hp, model_g).apply_generator(model_g, x, R, lengths)
 
 

@@ -213,8 +213,8 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
  * SLOWER on MI355X (the barrier's wait costs more than two launch edges: cfg2 1.453 vs 1.411 ms), so it is off by default. */
 #define GT_OPT_FUSED_OPTIMIZER 7
 /* Schedule switches (defaults are the measured best; the GT_* environment variables of the same names only provide the default at
- * engine creation): GT_OPT_SIDE_OVERLAP (0; measured slower) small memory-bound kernels on a side stream under the products; GT_OPT_LSTM_SIDE (0)
- * LSTM weight gradients beside the next layer's recurrence; GT_OPT_COMM_D_ONE_MSG (1) / _EARLY_G (1) / _GROUP (0) data-parallel
+ * engine creation): GT_OPT_SIDE_OVERLAP (0; measured slower) small memory-bound kernels on a side stream under the products; GT_OPT_LSTM_SIDE
+ * (removed in round 6: LSTM weight gradients beside the next layer's recurrence measured no gain; only the value 0 is accepted); GT_OPT_COMM_D_ONE_MSG (1) / _EARLY_G (1) / _GROUP (0) data-parallel
  * message schedule; GT_OPT_COMM_FORCE (0) issue the collectives with one rank as well (bench.py --force-dp, tests);
  * GT_OPT_LAUNCH_RIDERS (1) the fused single-GPU step's small reductions (valid-frame count, the head's scalars in the generator
  * step, the generator step's finalisation) ride as an extra workgroup of a neighbouring launch instead of launches of their own;
@@ -246,7 +246,7 @@ int gt_set_loss_normalizer_device(gt_engine* e, const double* tv_global_dev);
 int gt_set_option(gt_engine* e, int option, int value);
 /* Process-wide dispatch knobs of the kernels (tile shapes, pair launches, loader variants ...: measurement switches of the tools/
  * harnesses and A/B runs; none selects different arithmetic).  Names: gemm_pair, pair_order, gemm_tiles_big, gemm_unaligned, tn_wgs, tn_split_wgs, split_fused,
- * stagger_ticks, stagger_mode, b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, mlpg_tt, sru_lw, head_vec, head_wgs, mlpg_small16; the environment variables GT_<NAME>
+ * b16_tiles, b16_wg_tile, b16_dma, mlpg_fpl, mlpg_tt, sru_lw, head_vec, mlpg_small16; the environment variables GT_<NAME>
  * provide the initial values. */
 int gt_set_tuning(const char* name, int value);
 /* Row pitch (in floats) of the input tensors `x` of the step functions, like the `lda` of a BLAS call: ld_generator_input for the

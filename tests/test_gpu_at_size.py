@@ -16,6 +16,26 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _REPORT = os.environ.get("GT_PARITY_REPORT")
 
+# Ratchet.  The arbiter's limits are orders of magnitude above what the engine achieves on most tensors (D gradients of
+# cfg2_cold sit at 2e-7 against 5.5e-4): a change that costs three digits there would stay green.  tests/golden/at_size_ratchet.json holds, per
+# (case label, tensor), the distance to the float64 reference MEASURED on the GPU with the build that was committed with it; a tensor must stay
+# within RATCHET_FACTOR x that (never below RATCHET_FLOOR: a few float32 ulps) AND within the arbiter's limit.  The engine is bit-reproducible run
+# to run, so the ratchet only moves with the code: a change that trips it is looked at, and -- if it is a legitimate re-association (a LeakyReLU
+# slope flip moves a gradient tensor by ~1e-4 at once, at_size.py) -- the file is regenerated in the same commit:
+#     GT_RATCHET_WRITE=tests/golden/at_size_ratchet.json python -m pytest tests/test_gpu_at_size.py -m gpu -q
+RATCHET_FACTOR, RATCHET_FLOOR = 4.0, 4e-7
+_RATCHET_PATH = os.path.join(GOLDEN, "at_size_ratchet.json")
+_RATCHET_WRITE = os.environ.get("GT_RATCHET_WRITE")
+
+
+def _load_ratchet():
+    import json
+    return json.load(open(_RATCHET_PATH)) if os.path.isfile(_RATCHET_PATH) else {}
+
+
+_RATCHET = _load_ratchet()
+_RATCHET_SEEN = {}
+
 
 def run_hip_at_size(case, engine_options=None):
     """The HIP engine on one at-size case, through the reference-shaped API; same record layout as make_at_size.py."""
@@ -181,8 +201,16 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
                      % (name, k, err, lim, e32, kink, lim / max(err, 1e-300), norm_err, worst))
         if measure is not None:
             measure[k] = (err, norm_err, e32)
-        elif not (err <= lim and norm_err <= max(lim, 10 * floor) and worst <= 10 * lim):
-            bad.append(lines[-1])
+        else:
+            _RATCHET_SEEN.setdefault(name, {})[k] = err
+            held = _RATCHET.get(name, {}).get(k)
+            if held is not None and not _RATCHET_WRITE:
+                lim_r = RATCHET_FACTOR * max(held, RATCHET_FLOOR / RATCHET_FACTOR)
+                if err > lim_r:
+                    bad.append(lines[-1] + "   RATCHET: held %.2e, allowed %.2e (tests/golden/at_size_ratchet.json)" % (held, lim_r))
+                    continue
+            if not (err <= lim and norm_err <= max(lim, 10 * floor) and worst <= 10 * lim):
+                bad.append(lines[-1])
     if cold and measure is None:
         for k in keys:
             if k.split(".")[0] not in ("Dupd", "Gupd"):
@@ -233,7 +261,13 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
     if _REPORT:
         with open(_REPORT, "a") as f:
             f.write("\n".join(lines) + "\n")
-    assert not bad, "%d quantities outside the arbiter's limit:\n%s" % (len(bad), "\n".join(bad))
+    if _RATCHET_WRITE and measure is None:
+        import json
+        held = json.load(open(_RATCHET_WRITE)) if os.path.isfile(_RATCHET_WRITE) else {}
+        held[name] = {k: float("%.3e" % v) for k, v in sorted(_RATCHET_SEEN.get(name, {}).items())}
+        with open(_RATCHET_WRITE, "w") as f:
+            json.dump(held, f, indent=0, sort_keys=True)
+    assert not bad, "%d quantities outside the arbiter's limit or the ratchet:\n%s" % (len(bad), "\n".join(bad))
 
 
 @pytest.mark.parametrize("name", sorted(A.AT_SIZE_CASES))
@@ -256,25 +290,6 @@ def test_cfg1_at_size_with_the_fused_discriminator_stack_forced():
     fx = np.load(os.path.join(GOLDEN, "at_size_cfg1_vc.npz"))
     got = run_hip_at_size(case, engine_options={"fused_dstack": 2})
     compare_with_fixture("cfg1_vc/fused", got, fx)
-
-
-def test_cfg2_at_size_with_the_last_arrival_finalisations():
-    """The two measurement switches of round 5 (gt_set_tuning): `head_fin2` -- the head's 1024 per-panel partials summed by 64 workgroups, the
-    last one to arrive adding the 16 rows -- and `g_loss_ride` -- the reported sums of squares riding in the gradient-assembly launch, the
-    last workgroup to arrive finalising the step.  Both measured SLOWER than the launches they replace (an agent-scope release per workgroup
-    is an L2 write-back on an 8-XCD part) and are off by default; switched on, the cold cfg2 step must still meet the real
-    reference's fixture (sums in a different, still fixed, order)."""
-    from gantts_amd import _lib as L
-    case = A.AT_SIZE_CASES["cfg2_cold"]
-    fx = np.load(os.path.join(GOLDEN, "at_size_cfg2_cold.npz"))
-    try:
-        L.check(L.lib.gt_set_tuning(b"head_fin2", 1))
-        L.check(L.lib.gt_set_tuning(b"g_loss_ride", 1))
-        got = run_hip_at_size(case, engine_options={"fused_dstack": 2})
-    finally:
-        L.check(L.lib.gt_set_tuning(b"head_fin2", 0))
-        L.check(L.lib.gt_set_tuning(b"g_loss_ride", 0))
-    compare_with_fixture("cfg2_cold/last-arrival", got, fx, cold=True)
 
 
 # Relative rms distance to the float64 reference with bf16 storage, per case, network and kind: MEASURED on MI355X (round 4,

@@ -278,10 +278,10 @@ def test_linear_backward_fused_activation_derivative():
     _close(dX.cpu().numpy(), ref, msg="dX fused")
 
 
-@pytest.mark.parametrize("tile_frames", [16, 32, 64])
+@pytest.mark.parametrize("tile_frames", [16, 32])
 @pytest.mark.parametrize("B,T", [(1, 1), (2, 2), (3, 7), (2, 100), (4, 513)])
 def test_multi_stream_mlpg_forward_backward_vs_dense(B, T, tile_frames):
-    """Banded MLPG (both tile heights of the kernels: 32 and 64 output frames per workgroup) against the dense R of the oracle."""
+    """Banded MLPG (both tile heights of the kernels: 16 and 32 output frames per workgroup) against the dense R of the oracle."""
     from gantts_amd import _lib as L
     L.check(L.lib.gt_set_tuning(b"mlpg_tt", tile_frames))
     try:

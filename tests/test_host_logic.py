@@ -218,7 +218,49 @@ def test_bench_scaling_model_is_a_labelled_upper_bound():
         assert m["speedup_over_one_gpu_upper_bound_with_exposed_messages"][n] < m["speedup_over_one_gpu_without_communication"][n] <= int(n)
     w = m["exposed_wire_time_lower_bound_us"]
     assert w["2"] < w["4"] < w["8"] < 2.0 * w["2"]                  # 2 (N - 1) / N of the bytes: saturates at twice the N = 2 time
-    assert w["8"] == pytest.approx(1e6 * 2 * 7 / 8 * (1022980 + 872448) / 153e9)
+    assert w["8"] == pytest.approx(1e6 * 2 * 7 / 8 * sum(m["collectives"]["exposed_message_bytes"]) / 153e9)
+    # the schedule is READ from the newest committed trace (named in the line), not copied into bench.py as constants
+    assert m["collectives"]["source"].startswith("profiles/r") and "comm_schedule_dp1_rccl.json" in m["collectives"]["source"]
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    onfile = json.load(open(os.path.join(root, m["collectives"]["source"].split(" ")[0])))["comm_schedule"]
+    assert m["collectives"]["bytes_per_step"] == onfile["bytes_per_step"]
+    assert m["collectives"]["one_rank_exposed_us"] == pytest.approx(onfile["exposed_us_per_step"])
+
+
+def test_algorithmic_bytes_recipe_reproduces_the_survey_figure_for_cfg2():
+    """tools/bench_configs.py: step_bytes_per_step is SURVEY 8(d)'s recipe for cfg2 ("about 45 KB per frame -> 0.74 GB per step") generalised to
+    every configuration (`traffic_algorithmic` of `other_configs`); bf16 storage halves what only feeds products, nothing else."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_configs as bc
+    g = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=512)
+    d = dict(in_dim=483, out_dim=1, num_hidden=3, hidden_dim=256)
+    b32 = bc.step_bytes_per_step("MLP", g, d, 16384, 425, 63, False)
+    assert 0.72e9 < b32 < 0.76e9 and 43e3 < b32 / 16384 < 46e3
+    b16 = bc.step_bytes_per_step("MLP", g, d, 16384, 425, 63, True)
+    hidden = (512 * 3 * 2 + 256 * 3 * 2 * 3) * 16384
+    assert b32 - b16 == pytest.approx(2 * hidden)
+    assert bc._n_params("MLP", g) == 425 * 512 + 512 + 2 * (512 * 512 + 512) + 512 * 187 + 187
+    lstm = dict(in_dim=425, out_dim=187, num_hidden=3, hidden_dim=256, bidirectional=True)
+    assert bc._n_params("LSTMRNN", lstm) == 2 * (4 * 256 * 425 + 4 * 256 * 256 + 8 * 256) + 2 * 2 * (4 * 256 * 512 + 4 * 256 * 256 + 8 * 256) + 512 * 187 + 187
+
+
+def test_apply_generator_refuses_the_reference_left_padding_case():
+    """train.py:347-350: a generic packed-sequence generator whose longest sequence is shorter than the batch's T gets its output zero-padded ON
+    THE LEFT by the reference.  The engine does not reproduce that shift (deliberate deviations) and says so instead of returning
+    frames in another alignment; unreachable from train_loop, whose collate_fn pads to the longest sequence."""
+    import gantts_amd.train as T
+    from gantts_amd import hparams, models
+    T.hp = hparams.tts_acoustic
+    g = models.LSTMRNN(in_dim=8, out_dim=4, num_hidden=1, hidden_dim=8, bidirectional=True)
+    x = torch.zeros(2, 10, 8)
+    with pytest.raises(ValueError, match="left-pads"):
+        T.apply_generator(g, x, None, [7, 5])
+    with pytest.raises(ValueError, match="left-pads"):
+        T.apply_generator(g, x, None, torch.tensor([9, 5]))
 
 
 def test_committed_schedule_traces_show_one_schedule_on_every_transport():
@@ -253,8 +295,9 @@ def test_committed_schedule_traces_show_one_schedule_on_every_transport():
         exposed = lambda c: sum(m["bytes"] for m in c["messages"] if m["on_step_stream"])
         assert exposed(two) < exposed(runs["dp1_rccl"])
     bench = _load_bench()
-    assert bench.COMM_SCHEDULE_R05["exposed_message_bytes"] == [b for b, on in ref if on]
-    assert bench.COMM_SCHEDULE_R05["bytes_per_step"] == runs["dp1_rccl"]["bytes_per_step"]
+    sched = bench.traced_schedule()              # (what bench.py's scaling_model reads: the newest committed one-rank RCCL trace)
+    assert sched["exposed_message_bytes"] == [b for b, on in ref if on]
+    assert sched["bytes_per_step"] == runs["dp1_rccl"]["bytes_per_step"]
 
 
 def test_trace_tools_on_a_synthetic_kernel_trace(tmp_path):

@@ -17,7 +17,7 @@ static float* dev_rand(size_t n, float scale, unsigned seed) {
 }
 int main(int argc, char** argv) {
   const int HD = 256, L = argc > 1 ? atoi(argv[1]) : 3, N = argc > 2 ? atoi(argv[2]) : 16384, K0 = 483, Da = 58, col0 = 425;
-  const int reps = 200, stagger = argc > 3 ? atoi(argv[3]) : 0;
+  const int reps = 200;
   StepScalars hsc; memset(&hsc, 0, sizeof(hsc)); hsc.tv = 12000.f; hsc.inv_tv = 1.f / 12000.f;
   StepScalars* sc; CK(hipMalloc(&sc, sizeof(hsc))); CK(hipMemcpy(sc, &hsc, sizeof(hsc), hipMemcpyHostToDevice));
   for (int mode = 0; mode < 2; ++mode) {
@@ -39,8 +39,6 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.hp, grid * sizeof(HeadPartials))); CK(hipMalloc(&a.dw_partial, (size_t)grid * HD * 4));
     a.W0 = dev_rand((size_t)HD * K0, 0.05f, 5); a.ldw0 = K0; a.col0 = col0; a.Da = Da;
     CK(hipMalloc(&a.gadv, (size_t)rows * Da * 4)); a.ld_gadv = Da;
-    a.stagger_ticks = stagger; a.n_cu = 256;
-    if (getenv("DS_TICKET")) { CK(hipMalloc(&a.stagger_ticket, 2048 * 4)); CK(hipMemset(a.stagger_ticket, 0, 2048 * 4)); }
     const size_t lds = dstack_lds_bytes<256>();
     CK(hipFuncSetAttribute((const void*)dstack_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = -1; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dstack_kernel<256>, DS_THREADS, lds));
@@ -73,7 +71,7 @@ int main(int argc, char** argv) {
       a.dbg = nullptr;
     }
     double flop = 2.0 * rows * HD * HD * (L - 1) * (mode == 1 ? 2 : 1) + (mode == 1 ? 2.0 * rows * HD * Da : 0.0);
-    printf("DS_ABL=%d stagger %d mode %s rows %d L %d: %.1f us per launch, %.1f TFLOP/s (%.2f of 157.3), lds %zu B, grid %d, occupancy %d WG/CU\n", DS_ABL, stagger, mode ? "G_ADV " : "D_STEP", rows, L, us,
+    printf("DS_ABL=%d mode %s rows %d L %d: %.1f us per launch, %.1f TFLOP/s (%.2f of 157.3), lds %zu B, grid %d, occupancy %d WG/CU\n", DS_ABL, mode ? "G_ADV " : "D_STEP", rows, L, us,
            flop / us * 1e-6, flop / us * 1e-6 / 157.3, lds, grid, occ);
   }
   return 0;

@@ -19,7 +19,6 @@ int main(int argc, char** argv) {
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = Cc; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = ACT_NONE;
   g.drop.mode = DROP_NONE; g.drop.scale = 1.f; g.wide_store = getenv("NOWIDE") ? 0 : 1; g.n_tiles_m = M / 128; g.n_tiles_n = N / 128;
-  unsigned* dbg; hipMalloc(&dbg, 4096 * 16); hipMemset(dbg, 0, 4096 * 16); g.stagger_dbg = dbg;
   const size_t lds = gemm_lds_bytes<GEMM_NT, 128, 128>();
   hipFuncSetAttribute((const void*)gemm_f32_kernel<GEMM_NT, 128, 128, VEC, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -33,21 +32,6 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / it;
     printf("K=%d grid %4d: %.1f us/launch  %.1f TFLOP/s (of tiles launched)\n", K, grid, us, 2.0 * M * N * K / grid_div / (us * 1e-6) / 1e12);
-#ifdef GT_GEMM_CLK_DBG
-    {   // K loop of each workgroup of the last launch: shader cycles, MHz, cycles per MFMA slot, start/end spread
-      std::vector<unsigned> h(4 * grid);
-      hipMemcpy(h.data(), dbg, h.size() * 4, hipMemcpyDeviceToHost);
-      double cyc = 0, mhz = 0; unsigned s0 = ~0u, s1 = 0, e0 = ~0u, e1 = 0;
-      for (int b = 0; b < grid; ++b) {
-        cyc += h[4 * b]; mhz += h[4 * b] / (h[4 * b + 1] / 100.0);
-        s0 = std::min(s0, h[4 * b + 2]); s1 = std::max(s1, h[4 * b + 2]); e0 = std::min(e0, h[4 * b + 3]); e1 = std::max(e1, h[4 * b + 3]);
-      }
-      cyc /= grid; mhz /= grid;
-      const double mfma_per_wave = (K / 32.0) * 64.0, share = grid > 256 ? 2.0 : 1.0;
-      printf("     K loop: %.0f shader cycles avg (%.1f us at %.0f MHz), %.1f cycles per MFMA per SIMD;  loop starts spread over %.1f us, ends over %.1f us, first start -> last end %.1f us\n",
-             cyc, cyc / mhz, mhz, cyc / (mfma_per_wave * share), (s1 - s0) / 100.0, (e1 - e0) / 100.0, (e1 - s0) / 100.0);
-    }
-#endif
   }
   return 0;
 }

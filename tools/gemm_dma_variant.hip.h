@@ -99,7 +99,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmArgs& g, const int tile_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next tile has landed
     __syncthreads();                                      // ... everybody's has, and everybody is done reading this one
   }
-  gemm_store_tile<KIND, 64, 64, PREC_F32, 32>(g, 0, m0, n0, acc, smem);
+  gemm_store_tile<KIND, 64, 64, PREC_F32, 32>(g, 0, m0, n0, acc, smem, g.M);
 }
 
 template <int KIND>

@@ -40,7 +40,7 @@ static void spin_up() {      // clocks: ~0.3 s of launches before anything is ti
   g.A = a; g.lda = 512; g.B = b; g.ldb = 512; g.C = c; g.ldc = 512; g.M = 4096; g.N = 512; g.K = 512; g.wide_store = 1; g.n_tiles_m = 64; g.n_tiles_n = 8;
   const size_t lds = gemm_lds_bytes<GEMM_NT, 64, 64>();
   CK(hipFuncSetAttribute((const void*)gemm_f32_kernel<GEMM_NT, 64, 64, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int i = 0; i < 15000; ++i) hipLaunchKernelGGL((gemm_f32_kernel<GEMM_NT, 64, 64, true, true>), dim3(512), dim3(256), lds, 0, g, 0);
+  for (int i = 0; i < 15000; ++i) hipLaunchKernelGGL((gemm_f32_kernel<GEMM_NT, 64, 64, true, true>), dim3(512), dim3(256), lds, 0, g);
   CK(hipDeviceSynchronize());
 }
 static void dump_stamps(const char* what, int grid) {
@@ -79,7 +79,7 @@ static void launch_old(GemmArgs g, int nslab) {
   const size_t lds = gemm_lds_bytes<KIND, 64, 64>();
   static bool once = false;
   if (!once) { CK(hipFuncSetAttribute((const void*)gemm_f32_kernel<KIND, 64, 64, true, true, PREC_F32, 32, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-  hipLaunchKernelGGL((gemm_f32_kernel<KIND, 64, 64, true, true, PREC_F32, 32, AMODE>), dim3(g.n_tiles_m * g.n_tiles_n * nslab), dim3(256), lds, 0, g, 0);
+  hipLaunchKernelGGL((gemm_f32_kernel<KIND, 64, 64, true, true, PREC_F32, 32, AMODE>), dim3(g.n_tiles_m * g.n_tiles_n * nslab), dim3(256), lds, 0, g);
 }
 template <int KIND, int AMODE>
 static void launch_new(GemmArgs g, int nslab) {
@@ -99,7 +99,7 @@ static void launch_pair_old(GemmArgs nn, GemmArgs tn, int nslab) {
   static bool once = false;
   if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pair_kernel<PREC_F32, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
   const int n1 = nn.n_tiles_m * nn.n_tiles_n, n2 = tn.n_tiles_m * tn.n_tiles_n * nslab;
-  hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, AMODE>), dim3(n1 + n2), dim3(256), lds, 0, nn, tn, n1, 1, 0, 0, 0);
+  hipLaunchKernelGGL((gemm_pair_kernel<PREC_F32, AMODE>), dim3(n1 + n2), dim3(256), lds, 0, nn, tn, n1, 1);
 }
 template <int AMODE>
 static void launch_pair_new(GemmArgs nn, GemmArgs tn, int nslab) {
