@@ -229,13 +229,9 @@ enum GemmAmode { GEMM_A_RUNTIME = -1, GEMM_A_NONE = 0, GEMM_A_LEAKY_PHILOX = 1,
                  GEMM_A_LEAKY_PHILOX_ADDM = 2,   // NT: LeakyReLU + Philox dropout on (product + bias + addm)
                  GEMM_A_TN_SUM2 = 3,             // TN: loader sums A + A2
                  GEMM_A_LEAKY_PHILOX_SEG = 4 };  // NT: LeakyReLU + Philox dropout behind a two-segment K loop (A_seg / B_seg)
-// KM: the Philox keep bits of this lane's 16 elements arrive as `kmask` (bit 4 q + s; 64 x 64 tiles only) -- gemm_tile computed them in the MFMA
-// shadows of its last K stage ([r6]: the bits do not depend on the product; two Philox calls per wave tile were ~ 2200 VALU cycles of
-// every epilogue), instead of being drawn here.  Same calls, same bits.
-template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME, bool KM = false>
+template <int KIND, int BM, int BN, int PREC, int BKT, int AMODE = GEMM_A_RUNTIME>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int slab, const int m0, const int n0,
-                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem, const int m_lim, const uint32_t kmask = 0u) {
-  static_assert(!KM || (BM == 64 && BN == 64), "precomputed keep bits: one 32 x 32 piece per wave");
+                                                f32x16 (&acc)[BM / 64][BN / 64], float* smem, const int m_lim) {
   constexpr bool RT = AMODE == GEMM_A_RUNTIME || AMODE == GEMM_A_TN_SUM2;
   const int g_act = RT ? g.act : (AMODE == GEMM_A_NONE ? (int)ACT_NONE : (int)ACT_LEAKY_DROPOUT);
   const int g_dmode = RT ? g.drop.mode : (AMODE == GEMM_A_NONE ? (int)DROP_NONE : (int)DROP_PHILOX);
@@ -274,11 +270,11 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;
-          if (!KM && philox && (q & 1) == 0)
+          if (philox && (q & 1) == 0)
             philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
-            const bool keep_px = KM ? ((kmask >> (4 * q + s4)) & 1u) != 0u : philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
+            const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s4) >= g.drop.thresh;
             float v = acc[i][j][q * 4 + s4];
             if (KIND == GEMM_NT) {
               v += bias;
@@ -342,12 +338,12 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& g, const int sla
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mrow = m0 + wm * WM + i * 32 + 8 * q + 4 * half;  // rows mrow..mrow+3
-        if (!KM && philox && (q & 1) == 0)
+        if (philox && (q & 1) == 0)
           philox4x32_10(2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half, (uint32_t)n, g.drop.key0, g.drop.key1, rnd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int m = mrow + s;
-          const bool keep_px = KM ? ((kmask >> (4 * q + s)) & 1u) != 0u : philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
+          const bool keep_px = philox_piece(rnd, 4 * (q & 1) + s) >= g.drop.thresh;
           if (!full_tile && (!n_ok || m >= m_lim)) continue;
           float v = acc[i][j][q * 4 + s];
           if (KIND == GEMM_NT) {
@@ -639,33 +635,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   // body is instantiated three times (steady state / next tile is the K tail / last tile) so
   // `prefetch` and `tail` are compile-time inside the MFMA stream: no branches there.
   constexpr int NG = GEMM_BK / 2, NH = NG / 2;
-  // [r6] Keep bits in the MFMA shadow (plain LeakyReLU + Philox flavour on 64 x 64 tiles, float32): the LAST K stage of a tile requests nothing
-  // (no prefetch), so its groups carry the two Philox calls of this lane's column -- rows 0-15 of the wave's piece in groups 0-5, rows 16-31 in
-  // groups 6-11, two rounds per group -- and hand the epilogue a 16-bit mask.
-  constexpr bool KM = AMODE == GEMM_A_LEAKY_PHILOX && BM == 64 && BN == 64 && PREC == PREC_F32 && KIND != GEMM_TN;
-  uint32_t kmask = 0u, kc0 = 0u, kc1 = 0u, kc2 = 0u, kc3 = 0u, kk0 = 0u, kk1 = 0u;
-  auto km_round = [&]() {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, kc0), lo0 = 0xD2511F53u * kc0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, kc2), lo1 = 0xCD9E8D57u * kc2;
-    const uint32_t n0_ = hi1 ^ kc1 ^ kk0, n2_ = hi0 ^ kc3 ^ kk1;
-    kc0 = n0_; kc1 = lo1; kc2 = n2_; kc3 = lo0;
-    kk0 += 0x9E3779B9u; kk1 += 0xBB67AE85u;
-  };
-  auto km_step = [&](int gi) {       // gi: compile-time after unrolling
-    if (gi == 0 || gi == 6) {
-      const int mrow = m0 + wm * WM + (gi == 0 ? 0 : 16) + 4 * half;
-      kc0 = 2u * philox_group(g.drop, (uint32_t)mrow >> 4) + (uint32_t)half; kc1 = (uint32_t)(n0 + wn * WN + l31);
-      kc2 = 0x243F6A88u; kc3 = 0x85A308D3u; kk0 = g.drop.key0; kk1 = g.drop.key1;
-    }
-    if ((gi >= 0 && gi <= 4) || (gi >= 6 && gi <= 10)) { km_round(); km_round(); }
-    if (gi == 5 || gi == 11) {
-      const uint32_t r[4] = {kc0, kc1, kc2, kc3};
-      uint32_t bits = 0u;
-#pragma unroll
-      for (int pc = 0; pc < 8; ++pc) bits |= (philox_piece(r, pc) >= g.drop.thresh ? 1u : 0u) << pc;
-      kmask |= bits << (gi == 5 ? 0 : 8);
-    }
-  };
+  // (r6: the two Philox calls of a wave tile drawn in the MFMA shadows of the LAST K stage, handed to the epilogue as a 16-bit mask -- built,
+  //  bit-identical, measured: cfg2 1.3021 / 1.3057 vs 1.3019 ms, pair launches 104.2 vs 104.2 us.  The epilogue's VALU burst already runs under
+  //  the co-resident workgroups' K loops; removed again.)
   auto k_tile = [&](int kt, auto PF, auto TL) {
     constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
@@ -696,7 +668,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
         for (int j = 0; j < TN_; ++j) b_nxt[j] = bs[(2 * gi + 2) * LDN + j * 32];
       }
 #endif
-      if (KM && !prefetch) km_step(gi);
 #ifdef GT_ABLATE_NO_GLOBAL
       if (false) {
 #else
@@ -863,7 +834,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     }
     return;
   }
-  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE, KM>(g, slab, m0, n0, acc, smem, g.M, kmask);
+  gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0, n0, acc, smem, g.M);
 }
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a contiguous run of
