@@ -7,6 +7,12 @@ or ``make -C gantts_amd/csrc``.
 import ctypes as C
 import os
 
+# PyTorch-ROCm first: it carries its own HIP runtime (libamdhip64 of its wheel).  Loaded first, the dynamic loader resolves this library's
+# libamdhip64 dependency to that SAME copy; loaded second it maps a second runtime beside the system one and every HIP call of the process
+# that lands in the late copy fails with "no ROCm-capable device is detected" (seen in round 6 when build() imported the package before
+# smoke() imported torch, in one process).  The tensors the step functions take are torch tensors: torch is a dependency either way.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GT_HIP_LIB") or os.path.join(_HERE, "libgantts_hip.so")      # GT_HIP_LIB: A/B of two builds (tools/)
 

@@ -175,6 +175,25 @@ def sample_of(key, a):
     return flat[np.sort(_rs(key).choice(flat.size, SAMPLE, replace=False))]
 
 
+PROJ_K = 32                   # random projections kept per tensor
+
+
+def proj_of(key, a):
+    """PROJ_K seeded Rademacher projections of the WHOLE tensor (float64 accumulation): for any error e = engine - reference,
+    E[(s . e)^2] = |e|^2 over random sign vectors s, so the rms of the PROJ_K projection differences estimates the full-tensor distance
+    |engine - reference| -- every element takes part, not only the sampled ones ("at-size tensors are judged on a 4096-element
+    sample + the full-tensor norm, not every element").  Chi-square with PROJ_K degrees of freedom: +-12 % at one sigma."""
+    flat = np.asarray(a, dtype=np.float64).reshape(-1)
+    rs = np.random.RandomState((zlib.crc32((key + "#proj").encode()) ^ 0x5bd1e995) & 0x7fffffff)
+    out = np.zeros(PROJ_K, dtype=np.float64)
+    step = 1 << 20
+    for i in range(0, flat.size, step):
+        chunk = flat[i:i + step]
+        signs = rs.randint(0, 2, size=(PROJ_K, chunk.size)).astype(np.float64) * 2.0 - 1.0
+        out += signs @ chunk
+    return out
+
+
 def rms(a):
     a = np.asarray(a, dtype=np.float64)
     return float(np.sqrt((a * a).mean())) if a.size else 0.0
@@ -195,6 +214,7 @@ def digest(run32, run64, cold=False):
         out[k + ".norm"] = np.float64(np.sqrt((v64 * v64).sum()))
         out[k + ".err32"] = np.float64(rms(v32 - v64) / den)          # the reference's own float32 distance, FULL tensor
         out[k + ".sample"] = sample_of(k, v64).astype(np.float32)
+        out[k + ".proj"] = proj_of(k, v64)
         s32 = sample_of(k, v32)
         out[k + ".err32_sample"] = np.float64(rms(s32 - sample_of(k, v64)) / max(rms(sample_of(k, v64)), 1e-300))
         if cold and k[1:5] == "upd.":

@@ -255,9 +255,41 @@ def run_oracle(case, dtype):
     return out
 
 
+def add_projections(names):
+    """python tests/golden/make_at_size.py --add-proj [case ...]: adds the full-tensor random projections (at_size.proj_of) to EXISTING
+    fixtures from a fresh float64 run of the case -- every key the fixture already holds must come out bit-identical (norm and sample
+    are re-derived and compared), only `<tensor>.proj` keys are new."""
+    for name, case in A.AT_SIZE_CASES.items():
+        if names and name not in names:
+            continue
+        path = os.path.join(HERE, "at_size_%s.npz" % name)
+        fx = dict(np.load(path))
+        if all((k[:-7] + ".proj") in fx for k in fx if k.endswith(".sample")):
+            print("%-14s already has projections" % name, flush=True)
+            continue
+        runner = run_reference if case["source"] == "reference" else run_oracle
+        torch.manual_seed(0)
+        t0 = time.time()
+        run = runner(case, torch.float64)
+        n = 0
+        for k, v in run.items():
+            if "scalars" in k:
+                assert np.array_equal(fx[k + ".f64"], np.asarray(v, dtype=np.float64)), k
+                continue
+            v64 = np.asarray(v, dtype=np.float64)
+            assert np.float64(np.sqrt((v64 * v64).sum())) == fx[k + ".norm"], (name, k, "norm differs from the committed fixture")
+            assert np.array_equal(A.sample_of(k, v64).astype(np.float32), fx[k + ".sample"]), (name, k)
+            fx[k + ".proj"] = A.proj_of(k, v64)
+            n += 1
+        np.savez_compressed(path, **fx)
+        print("%-14s %d tensors projected in %.0f s (float64 run reproduced the committed digest bit for bit)" % (name, n, time.time() - t0), flush=True)
+
+
 def main():
     only = sys.argv[1:]
     torch.set_num_threads(int(os.environ.get("AT_SIZE_THREADS", os.cpu_count())))
+    if only and only[0] == "--add-proj":
+        return add_projections(only[1:])
     for name, case in A.AT_SIZE_CASES.items():
         if only and name not in only:
             continue

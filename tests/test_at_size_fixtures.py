@@ -50,6 +50,28 @@ def test_fixture_is_complete_and_self_consistent(name):
     assert np.array_equal(A.sample_of("Ggrad.x", a), A.sample_of("Ggrad.x", a)) and A.sample_of("Ggrad.x", a).size == A.SAMPLE
 
 
+def test_random_projections_estimate_the_full_tensor_distance():
+    """at_size.proj_of: PROJ_K seeded Rademacher projections of the WHOLE tensor.  The rms of the projection differences of two tensors estimates
+    their full distance |a - b| (every element takes part): a dense perturbation and one confined to a block that a 4096-element sample would
+    hardly touch are both recovered to within the estimator's chi-square spread; the projections are a function of (key, tensor) alone."""
+    rs = np.random.RandomState(7)
+    a = rs.randn(300, 2048)
+    for e in (1e-3 * rs.randn(300, 2048), np.pad(0.05 * rs.randn(3, 40), ((100, 197), (1000, 1008)))):
+        est = A.rms(A.proj_of("Ggrad.w", a + e) - A.proj_of("Ggrad.w", a))
+        true = float(np.sqrt((e * e).sum()))
+        assert 0.6 * true < est < 1.5 * true, (est, true)
+    assert np.array_equal(A.proj_of("k", a), A.proj_of("k", a.copy())) and not np.array_equal(A.proj_of("k", a), A.proj_of("k2", a))
+    assert A.proj_of("k", a).shape == (A.PROJ_K,)
+    # the committed fixtures that carry projections carry them for every tensor
+    for name in sorted(A.AT_SIZE_CASES):
+        path = os.path.join(GOLDEN, "at_size_%s.npz" % name)
+        if os.path.isfile(path):
+            fx = np.load(path)
+            tensors = [k[:-7] for k in fx.files if k.endswith(".sample")]
+            have = [k for k in tensors if (k + ".proj") in fx.files]
+            assert not have or len(have) == len(tensors), name
+
+
 def test_ratchet_covers_every_tensor_of_every_float32_at_size_case():
     """tests/golden/at_size_ratchet.json: per at-size case and tensor, the engine's distance to the float64 reference as MEASURED
     on the GPU with the committed build; tests/test_gpu_at_size.py holds every tensor to 4 x that (floor 4e-7) AND to the arbiter's limit.  It

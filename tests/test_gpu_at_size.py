@@ -197,8 +197,13 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
         norm_ref = float(fx[k + ".norm"])
         norm_err = abs(float(np.sqrt((g_full * g_full).sum())) - norm_ref) / max(norm_ref, 1e-300)
         worst = float(np.abs(g - ref).max()) / max(float(np.abs(ref).max()), 1e-300)
-        lines.append("%-14s %-44s rel-rms %.2e  limit %.2e (ref32 %.2e, kink %.1e)  margin x%.1f  |norm| %.2e  worst elem %.2e"
-                     % (name, k, err, lim, e32, kink, lim / max(err, 1e-300), norm_err, worst))
+        # EVERY element, through seeded random projections of the whole tensor ([r6], at_size.proj_of): the rms of the projection
+        # differences estimates |engine - ref64| over the full tensor (chi-square with PROJ_K degrees of freedom: limit x 1.5 = four sigma)
+        full_err = None
+        if (k + ".proj") in fx.files:
+            full_err = A.rms(A.proj_of(k, g_full) - fx[k + ".proj"]) / max(norm_ref, 1e-300)
+        lines.append("%-14s %-44s rel-rms %.2e  limit %.2e (ref32 %.2e, kink %.1e)  margin x%.1f  |norm| %.2e  worst elem %.2e  full-tensor estimate %s"
+                     % (name, k, err, lim, e32, kink, lim / max(err, 1e-300), norm_err, worst, "-" if full_err is None else "%.2e" % full_err))
         if measure is not None:
             measure[k] = (err, norm_err, e32)
         else:
@@ -211,6 +216,8 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
                     continue
             if not (err <= lim and norm_err <= max(lim, 10 * floor) and worst <= 10 * lim):
                 bad.append(lines[-1])
+            elif full_err is not None and full_err > 1.5 * lim:
+                bad.append(lines[-1] + "   FULL TENSOR: projections say %.2e > 1.5 x limit" % full_err)
     if cold and measure is None:
         for k in keys:
             if k.split(".")[0] not in ("Dupd", "Gupd"):
