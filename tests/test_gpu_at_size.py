@@ -141,11 +141,29 @@ def judge_cold_update(k, got, fx, grad_err):
     return float(ambiguous.mean()), out_frac, median
 
 
-# Later steps of a long run: limit = SCALAR_DRIFT_FACTOR x the reference's own float32-vs-float64 envelope (see compare_with_fixture).
-# Two float32 implementations with different summation orders separate by the same law with a RANDOM prefactor: measured with the
-# per-layer discriminator launches (round 4) 1x .. 9x, with the fused discriminator stack (round 5: another k order inside the
-# products) up to 16.5x at steps 7-8 of cfg3_lstm_10 -- same law (x3 .. x5 per step), another draw of the prefactor.
-SCALAR_DRIFT_FACTOR = 30.0
+# Later steps of a long run (cfg3_lstm_10: ten G+D steps): a GAN step with dropout 0.5 in D amplifies a rounding-level perturbation by x3 .. x5 per
+# step, so two CORRECT float32 evaluations with different summation orders separate from the float64 run by the same law with a random prefactor.
+# [r6] That prefactor is MEASURED, not asserted (VERDICT r5 / ADVICE r5): tests/golden/make_drift_spread.py runs the REAL reference's ten steps in
+# float32 under other summation orders (thread counts; the discriminator's hidden units relabelled) and records, per variant, the late-step
+# scalars' distance to the float64 run over the reference's own float32 envelope, and every update tensor's distance over the network's float32
+# level (tests/golden/drift_spread_cfg3_lstm_10.json).  The limits are TWICE the upper end of that spread for the scalars and 1.5 x for the
+# update tensors -- never below the pre-round-5 values (15 x the envelope, the arbiter's own 3 x level); without the file, those old values.
+def _drift_limits():
+    import json
+    path = os.path.join(GOLDEN, "drift_spread_cfg3_lstm_10.json")
+    scal, upd = 15.0, 1.0
+    if os.path.isfile(path):
+        v = json.load(open(path))["variants"]
+        ratios = [r for rec in v.values() for r in rec["scalar_over_envelope"] if r is not None]
+        upds = [rec[k] for rec in v.values() for k in ("worst_over_level_Dupd", "worst_over_level_Gupd") if rec.get(k) is not None]
+        if ratios:
+            scal = max(scal, 2.0 * max(ratios))
+        if upds:
+            upd = max(upd, 1.5 * max(upds) / A.ARBITER_FACTOR)
+    return scal, upd
+
+
+SCALAR_DRIFT_FACTOR, LONG_RUN_FACTOR = _drift_limits()      # LONG_RUN_FACTOR multiplies the arbiter's factor for update tensors of runs > 2 steps
 
 
 def reference_drift_envelope(fx):
@@ -189,10 +207,10 @@ def compare_with_fixture(name, got, fx, factor=A.ARBITER_FACTOR, floor=A.ARBITER
         # Long runs (cfg3_lstm_10: ten steps): the parameter update is the integral of a trajectory that separates from the float64
         # one by the chaotic law described at SCALAR_DRIFT_FACTOR -- a random prefactor per implementation.  Measured distance of the
         # worst ten-step D update to the float64 run: the reference's own float32 7.0e-3, this engine with per-layer discriminator
-        # launches 1.9e-2 (2.7x), with the fused discriminator stack 4.0e-2 (5.7x): update tensors of runs longer than two steps get
-        # twice the arbiter's factor.
+        # launches 1.9e-2 (2.7x), with the fused discriminator stack 4.0e-2 (5.7x), the REAL reference with relabelled hidden units 4.1x
+        # (drift_spread_cfg3_lstm_10.json): update tensors of runs longer than two steps get LONG_RUN_FACTOR x the arbiter's factor.
         long_run = kind in ("Dupd", "Gupd") and ("d_scalars_2.f64" in fx.files)
-        lim = (2.0 * factor if long_run else factor) * e32 + floor + kink
+        lim = (LONG_RUN_FACTOR * factor if long_run else factor) * e32 + floor + kink
         # the whole tensor, through its norm: nothing outside the sample can be far off without moving it
         norm_ref = float(fx[k + ".norm"])
         norm_err = abs(float(np.sqrt((g_full * g_full).sum())) - norm_ref) / max(norm_ref, 1e-300)
