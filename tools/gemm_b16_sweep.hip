@@ -126,6 +126,14 @@ int main() {
   g.A = X; g.lda = 512; g.B = W; g.ldb = 512; g.M = 16384; g.N = 512; g.K = 512; g.C = C; g.ldc = 512; g.epi = B16_FWD;
   run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5);
   run_dma<64, 64, B16_FWD, 2>(g, 1, s, 5); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5);
+  // a float32 product emulated by three bf16 pieces per operand and six piece products IS a bf16 product over
+  // the K-concatenated piece images [A0|A0|A1|A0|A1|A2] . [B0|B1|B0|B2|B1|B0]^T, K' = 6 K: the cfg2 hidden layer as 16384 x 512 x 3072.
+  // (A dedicated kernel would fetch three pieces instead of six images -- the MFMA count is the same.)  Gate: <= 45 us, the f32 launch is 76.
+  printf("bf16x6 gate: 16384 x 512 x 3072 (six piece products of the f32 product 16384 x 512 x 512; the f32 MFMA launch takes 76 us)\n");
+  g.A = DU; g.lda = 3072; g.B = W; g.ldb = 3072; g.M = 16384; g.N = 512; g.K = 3072; g.C = C; g.ldc = 512; g.epi = B16_FWD;
+  run<64, 64, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 1>(g, 1, s, 5); run<128, 128, B16_FWD, 2>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 5);
+  run_dma<128, 128, B16_FWD, 3>(g, 1, s, 5); run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 5); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 5); run_big<B16_FWD>(g, 1, s, 5);
+  g.K = 512; g.lda = 512; g.ldb = 512; g.A = X;
   printf("cfg3 X-projection 32768 x 2048 x 512\n");
   g.M = 32768; g.N = 2048; g.ldc = 2048;
   run<128, 128, B16_FWD, 1>(g, 1, s, 3); run_dma<128, 128, B16_FWD, 2>(g, 1, s, 3); run_dma<128, 128, B16_FWD, 2, 2, 4>(g, 1, s, 3); run_dma<256, 256, B16_FWD, 2, 2, 4>(g, 1, s, 3);
