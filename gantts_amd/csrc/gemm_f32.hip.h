@@ -952,8 +952,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void gemm_tn_pair_kernel(const Gem
 }
 
 // One launch = one product: workgroup -> (slab, tile_m, tile_n).
+// (second launch bound = workgroups per CU the register allocation must leave room for)
+#ifndef GT_SEG_WGS
+#define GT_SEG_WGS 4
+#endif
+template <int BM, int BN, int AMODE> constexpr int gemm_min_wgs() { return (BM == 64 && BN == 64 && AMODE == GEMM_A_LEAKY_PHILOX_SEG) ? GT_SEG_WGS : 2; }
 template <int KIND, int BM, int BN, bool VA, bool VB, int PREC = PREC_F32, int BKT = 32, int AMODE = GEMM_A_RUNTIME>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (gemm_min_wgs<BM, BN, AMODE>())) void gemm_f32_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = gemm_xcd_order(blockIdx.x, gridDim.x);
   const int tiles_mn = g.n_tiles_m * g.n_tiles_n;
