@@ -186,6 +186,7 @@ __global__ __launch_bounds__(DS_THREADS, 2) void dstack_kernel(const DStackArgs 
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     f32x4 fa[2];
     const float* arow = Act + l31 * AP + 8 * half;
+    // (r6: s_setprio 2 for the product / 0 for the epilogues, as the 64 x 64 product kernels do (GT_KLOOP_PRIO): 104.6 -> 104.3 / 107.4 / 105.1 us, not kept)
     fa[0] = *reinterpret_cast<const f32x4*>(arow);
     if (FWD) { commit_fwd(); frags_fwd(bf[0]); if (!(DS_ABL & 2)) issue_fwd(W, 1); }
     auto stage = [&](int t, f32x4 (&cur)[NT][2], f32x4 (&nxt)[NT][2]) {

@@ -209,6 +209,21 @@ constexpr size_t gemm_lds_bytes() {
   return img > stg ? (img > cs ? img : cs) : (stg > cs ? stg : cs);
 }
 
+// GT_KLOOP_PRIO (compile-time): wave issue priority (s_setprio).  Co-resident workgroups are in different phases: while one runs its epilogue (the two
+// Philox calls of a wave tile are ~ 2200 VALU cycles) the others are in their K loops, and an MFMA that becomes ready while the VALU port is taken by
+// another wave's instruction waits for it -- a few cycles per MFMA, the "+ 8" of the 72 cycles per MFMA of DESIGN 3.1.  1 = K loops at priority 2,
+// epilogues at 0; 2 = K loops at 1, every MFMA group issued at 3, epilogues at 0; 0 = everything at the default priority.
+// Measured (r6, cfg2 ms/step, alternating builds, profiles/r06_kloop_prio_ab.txt): 0: 1.2889 1.2905 1.2945   1: 1.2794 1.2800 1.2807 1.2811
+// 2: 1.2797 1.2799 1.2848; forward launch 76.2 -> 74.2 us, pair launch 103.8 -> 101.9 us with 2.  2 it is.
+#ifndef GT_KLOOP_PRIO
+#define GT_KLOOP_PRIO 2
+#endif
+__device__ __forceinline__ void gemm_kloop_prio(bool on) {
+#if GT_KLOOP_PRIO
+  if (on) __builtin_amdgcn_s_setprio(GT_KLOOP_PRIO == 2 ? 1 : 2); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // Result stores of the epilogue.  GT_EPI_STORE (compile-time, measurement): 0 = plain stores (the result stays dirty in the
 // XCD's L2 and is written back at the end of the kernel), 1 = non-temporal, 2 = write-through (sc0 sc1).  Measured: 1 / 2
 // shorten an isolated launch by 1-2 us (tools/gemm_tile_sweep.hip quick) but lengthen the training step (1.555 vs 1.540
@@ -740,11 +755,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
 #endif
         }
       }
+#if GT_KLOOP_PRIO == 2
+      __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_ROWS ? a4_cur[i][gi % 4] : a_cur[i], B_ROWS ? b4_cur[j][gi % 4] : b_cur[j], acc[i][j], 0, 0, 0);
+#if GT_KLOOP_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       if (gi + 1 < NG) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -821,8 +842,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   if (kt + 1 == nk) k_tile(kt, F_{}, F_{});                         // last tile: nothing to prefetch
   }
   };
+  gemm_kloop_prio(true);
   prologue();
   k_loop();
+  gemm_kloop_prio(false);
 
   if (KIND == GEMM_TN && want_csum) {
     // all waves are past the last barrier of the K loop; reuse the LDS as scratch.
@@ -881,8 +904,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
       k_begin = 0; k_end = g.K_seg;
       nk = (k_end + GEMM_BK - 1) / GEMM_BK;
       has_tail = (k_end % GEMM_BK) != 0;
+      gemm_kloop_prio(true);
       prologue();
       k_loop();
+      gemm_kloop_prio(false);
       gemm_store_tile<KIND, BM, BN, PREC, BKT, AMODE>(g, slab, m0 + h * g.dual_rows, n0, acc, smem, nh > 1 ? (h + 1) * g.dual_rows : g.M);
     }
     return;
