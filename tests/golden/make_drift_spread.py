@@ -9,6 +9,7 @@ of ``at_size.AT_SIZE_CASES[case]`` (train.apply_generator / update_discriminator
 /root/reference) in float32 under several summation orders --
 
     threads<n>      torch.set_num_threads(n): another partition of every reduction (8 = the committed fixture's own run)
+    fixture         the committed fixture's own float32 run (8 threads), read from the digest: the envelope / levels themselves
     perm<seed>      the discriminator's hidden units relabelled (make_at_size._permute_mlp): the same function, every product
                     over a hidden layer sums its terms in another order
 
@@ -78,7 +79,53 @@ def measure(run, fx):
     for kind in ("Dupd", "Gupd", "Dgrad", "Ggrad"):
         v = [t["over_level"] for k, t in rec["tensors"].items() if k.startswith(kind + ".")]
         rec["worst_over_level_" + kind] = max(v) if v else None
+    return add_arbiter_ratios(rec, fx)
+
+
+def add_arbiter_ratios(rec, fx):
+    """Every tensor's distance over the UN-WIDENED arbiter limit of tests/test_gpu_at_size.py (3 x float32 level + floor + LeakyReLU-kink allowance;
+    computable from the stored distances, so records of earlier runs are annotated in place: `python make_drift_spread.py <case> annotate`)."""
+    keys = sorted(k[:-7] for k in fx.files if k.endswith(".sample"))
+    e32_of = {k: max(float(fx[k + ".err32"]), float(fx[k + ".err32_sample"])) for k in keys}
+    for k, t in rec["tensors"].items():
+        kind = k.split(".")[0]
+        exposed = not k.startswith("Dgrad.last_linear")
+        e32 = max(e32_of[k], t["level"]) if exposed else e32_of[k]
+        kink = A.kink_allowance(fx, "G" if kind[0] == "G" else "D", first_step=kind.endswith("grad")) if exposed else 0.0
+        t["arbiter_limit"] = A.ARBITER_FACTOR * e32 + A.ARBITER_FLOOR + kink
+        t["over_arbiter"] = t["rel_rms"] / t["arbiter_limit"]
+    for kind in ("Dupd", "Gupd", "Dgrad", "Ggrad"):
+        v = [t["over_arbiter"] for k, t in rec["tensors"].items() if k.startswith(kind + ".")]
+        rec["worst_over_arbiter_" + kind] = max(v) if v else None
     return rec
+
+
+def fixture_record(fx):
+    """The committed fixture's OWN float32 run (8 threads, natural unit order) as a record: its distances are the envelope and the levels by
+    definition (ratios <= 1); no run needed -- the digest holds the float32 scalars and the float32-vs-float64 tensor distances."""
+    env = drift_envelope(fx)
+    rec = {"scalar_rel": [], "scalar_over_envelope": [], "count_diff": [], "envelope": env}
+    for st in range(len(env)):
+        worst = 0.0
+        for k, n in (("d_scalars_%d" % st, 3), ("g_scalars_%d" % st, 4)):
+            g, r = fx[k + ".f32"][:n].astype(np.float64), fx[k + ".f64"][:n].astype(np.float64)
+            worst = max(worst, float((np.abs(g - r) / np.maximum(np.abs(r), 1e-3)).max()))
+        rec["scalar_rel"].append(worst)
+        rec["scalar_over_envelope"].append(worst / env[st] if env[st] > 1e-5 else None)
+        g, r = fx["d_scalars_%d.f32" % st][3:5].astype(np.float64), fx["d_scalars_%d.f64" % st][3:5].astype(np.float64)
+        rec["count_diff"].append([float(v) for v in (g - r)])
+    keys = sorted(k[:-7] for k in fx.files if k.endswith(".sample"))
+    e32_of = {k: max(float(fx[k + ".err32"]), float(fx[k + ".err32_sample"])) for k in keys}
+    level = {}
+    for k in keys:
+        level[k.split(".")[0]] = max(level.get(k.split(".")[0], 0.0), e32_of[k])
+    rec["tensors"] = {k: {"rel_rms": e32_of[k], "level": level[k.split(".")[0]], "over_level": e32_of[k] / max(level[k.split(".")[0]], 1e-300)}
+                      for k in keys if k.split(".")[0] in ("Dupd", "Gupd", "Dgrad", "Ggrad")}
+    for kind in ("Dupd", "Gupd", "Dgrad", "Ggrad"):
+        v = [t["over_level"] for k, t in rec["tensors"].items() if k.startswith(kind + ".")]
+        rec["worst_over_level_" + kind] = max(v) if v else None
+    rec["threads"], rec["d_perm_seed"], rec["seconds"] = 8, None, 0.0
+    return add_arbiter_ratios(rec, fx)
 
 
 def main():
@@ -91,6 +138,17 @@ def main():
     path = os.environ.get("DRIFT_SPREAD_OUT", os.path.join(HERE, "drift_spread_%s.json" % name))     # (parallel runs write part files, merged by hand)
     out = json.load(open(path)) if os.path.isfile(path) else {"case": name, "variants": {}}
     for v in variants:
+        if v == "annotate":
+            for r in out["variants"].values():
+                add_arbiter_ratios(r, fx)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1, sort_keys=True)
+            continue
+        if v == "fixture":
+            out["variants"]["threads8_fixture"] = fixture_record(fx)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1, sort_keys=True)
+            continue
         if v.startswith("threads"):
             n, seed = int(v[7:]), None
         else:

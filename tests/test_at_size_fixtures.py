@@ -97,6 +97,39 @@ def test_ratchet_covers_every_tensor_of_every_float32_at_size_case():
     assert d and max(d) < 5e-6
 
 
+def test_drift_spread_of_the_real_reference_backs_the_long_run_limits():
+    """tests/golden/drift_spread_cfg3_lstm_10.json (written by tests/golden/make_drift_spread.py in the build
+    container): the REAL reference's ten float32 steps of cfg3_lstm_10 under other summation orders -- thread counts and relabelled
+    discriminator hidden units -- each compared with the committed float64 digest exactly as the engine is.  At least five orders beside the
+    fixture's own run; the limits tests/test_gpu_at_size.py derives from them (scalars: 2 x the largest late-step ratio to the reference's own
+    float32 envelope, never below 15; update tensors of long runs: 1.5 x the largest ratio to the network's float32 level) must cover every
+    measured order with room, and must not be looser than twice what was measured: the widening is a measurement, not a guess."""
+    import json
+    path = os.path.join(GOLDEN, "drift_spread_cfg3_lstm_10.json")
+    d = json.load(open(path))
+    v = d["variants"]
+    assert d["case"] == "cfg3_lstm_10" and len([k for k in v if k != "threads8_fixture"]) >= 5, sorted(v)
+    assert sum(1 for k in v if k.startswith("perm")) >= 2 and sum(1 for k in v if k.startswith("threads")) >= 2, sorted(v)
+    ratios, upds = [], []
+    for name, rec in v.items():
+        assert len(rec["scalar_over_envelope"]) == 10 and len(rec["envelope"]) == 10, name
+        late = [r for r in rec["scalar_over_envelope"] if r is not None]
+        assert late, name
+        ratios.append(max(late))
+        upds.append(max(rec["worst_over_level_Dupd"], rec["worst_over_level_Gupd"]))
+        for c in rec["count_diff"][:5]:     # the first steps' accuracy counts agree to the 3 frames the engine is allowed: the variants ARE the same computation
+            assert max(abs(x) for x in c) <= 3.0, (name, c)
+    # correct float32 evaluations of the reference itself leave the old limits (15 x envelope, 3 x level): that is the point of the file
+    assert max(ratios) > 15.0 and max(upds) > 3.0, (ratios, upds)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("t_gpu_at_size", os.path.join(HERE, "test_gpu_at_size.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.SCALAR_DRIFT_FACTOR >= 2.0 * max(ratios) - 1e-9 and m.SCALAR_DRIFT_FACTOR <= max(15.0, 2.0 * max(ratios)) + 1e-9
+    assert m.LONG_RUN_FACTOR * A.ARBITER_FACTOR >= 1.5 * max(upds) - 1e-9
+    assert m.LONG_RUN_FACTOR * A.ARBITER_FACTOR <= max(A.ARBITER_FACTOR, 1.5 * max(upds)) + 1e-9
+
+
 def test_oracle_reproduces_the_reference_fixture_at_full_size():
     """cfg5's duration pair at its real size (B = 64, generator noise 416 + 200 -> 5, conditioned D, Adam, two steps, injected
     dropout masks): the ORACLE in float32 against the digest of the REAL reference's float64 run -- the oracle is the reference's
