@@ -184,6 +184,12 @@ def scaling_model(proxy_ms, one_gpu_ms):
         "exposed_wire_time_lower_bound_us": {str(n): wire[n] for n in proxy_ms},
         "speedup_over_one_gpu_upper_bound_with_exposed_messages": {str(n): one_gpu_ms / with_comm[n] for n in proxy_ms},
     })
+    # the same with a per-message latency on top of the wire time: a ring all-reduce of N ranks is 2 (N - 1) hops, and the builder has no
+    # device pair to measure a hop on -- two assumed values per EXPOSED message bracket what RCCL over xGMI is usually quoted at for ~1 MB
+    n_exposed = len(sched["exposed_message_bytes"])
+    out["speedup_over_one_gpu_with_exposed_messages_and_assumed_latency"] = {
+        "assumed_us_per_exposed_message": [30.0, 60.0],
+        "speedup": {str(n): [one_gpu_ms / (with_comm[n] + 1e-3 * lat * n_exposed) for lat in (30.0, 60.0)] for n in proxy_ms}}
     return out
 
 
@@ -253,6 +259,8 @@ def main():
                     help="data parallel: BEHIND the timed region, run STEPS more steps with the engine's schedule trace on (gt_comm_trace) and "
                          "add `comm_schedule` to the line: messages per step, how long each holds the communicator's stream, how long the "
                          "step stream waits for them (exposed) and how much ran under compute (hidden)")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="measurement: set an engine switch before the run (Engine.set_option), repeatable; recorded in config.engine_options")
     ap.add_argument("--one-device", action="store_true",
                     help="SCHEDULE measurement without a multi-GPU node, never a throughput claim: all ranks share device 0 and the engine's "
                          "communicator binds the tests' RCCL double (tests/fake_rccl.cpp: all-reduce staged through host shared memory), "
@@ -330,6 +338,11 @@ def main():
     mg = models.MLP(**G_SPEC).cuda().train()
     md = models.MLP(**D_SPEC).cuda().train()
     og, od = optim.Adagrad(mg.parameters(), **OPT), optim.Adagrad(md.parameters(), **OPT)
+    if args.engine_option:             # measurement: engine switches by name (gantts_amd.engine.Engine.set_option), e.g. fused_dstack=2
+        from gantts_amd.engine import engine_for
+        for kv in args.engine_option:
+            name, _, val = kv.partition("=")
+            engine_for(hp, mg).set_option(name, int(val))
     if args.scaling == "strong":       # one global batch, sequences dealt round-robin over the ranks
         xg, yg = synthetic_batch(Bglobal, Tn, 1000, "cpu")
         x, y = xg[rank::world].contiguous().to(dev), yg[rank::world].contiguous().to(dev)
@@ -614,6 +627,8 @@ def main():
                "last_step_scalars": {"d": [float(v) for v in last[0]], "g": [float(v) for v in last[1]]},
                "roofline": roofline}
         out["config"]["clock_spinup_ms"] = args.spinup_ms
+        if args.engine_option:
+            out["config"]["engine_options"] = list(args.engine_option)
         if world > 1 or args.force_dp:      # what the communicator itself says (gt_comm_info): a SCALE run proves its N ranks with this
             try:
                 cr, cw = eng.comm_info()
