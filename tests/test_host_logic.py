@@ -219,6 +219,11 @@ def test_bench_scaling_model_is_a_labelled_upper_bound():
     w = m["exposed_wire_time_lower_bound_us"]
     assert w["2"] < w["4"] < w["8"] < 2.0 * w["2"]                  # 2 (N - 1) / N of the bytes: saturates at twice the N = 2 time
     assert w["8"] == pytest.approx(1e6 * 2 * 7 / 8 * sum(m["collectives"]["exposed_message_bytes"]) / 153e9)
+    # the zero-latency bound is optimistic -- the same with 30 / 60 us assumed per exposed message is carried beside it, and is lower
+    lat = m["speedup_over_one_gpu_with_exposed_messages_and_assumed_latency"]
+    assert lat["assumed_us_per_exposed_message"] == [30.0, 60.0]
+    for n in ("2", "4", "8"):
+        assert lat["speedup"][n][1] < lat["speedup"][n][0] < m["speedup_over_one_gpu_upper_bound_with_exposed_messages"][n]
     # the schedule is READ from the newest committed trace (named in the line), not copied into bench.py as constants
     assert m["collectives"]["source"].startswith("profiles/r") and "comm_schedule_dp1_rccl.json" in m["collectives"]["source"]
     import json
