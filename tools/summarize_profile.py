@@ -39,7 +39,10 @@ stats = [r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_sta
 _tot_ns = sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
 for r in stats:
     r["Percentage"] = "%.4f" % (100.0 * float(r["TotalDurationNs"]) / _tot_ns)
-steps = 25.0  # bench.py --steps 20 --warmup 5 under the kernel trace
+# steps in the trace = optimizer launches / 2 (one per network and G+D step; warm-up steps included -- since round 6 the traced command warms
+# the clock with 350 REAL steps instead of the spin-up kernels, so that the trace holds nothing but the step and runs at the un-profiled clock)
+_opt = [float(r["Calls"]) for r in stats if "optim_step_kernel" in r["Name"]]
+steps = _opt[0] / 2.0 if _opt else 25.0
 fetch, nf = agg(os.path.join(src, "pmc_fetch", "k_counter_collection.csv"))
 write, nw = agg(os.path.join(src, "pmc_write", "k_counter_collection.csv"))
 mfma, nm = agg(os.path.join(src, "pmc_mfma", "k_counter_collection.csv"))
@@ -54,6 +57,11 @@ L.append("* value: **%.3f M frames/s**, %.3f ms/step, step-level MFMA fraction %
 r = bench["roofline"]
 L.append("* dominant kernel `%s`: %.1f TFLOP/s = %.3f of the %.1f TFLOP/s f32-MFMA peak, %.1f us per launch (HIP events)"
          % (r["kernel"], r["achieved"], r["frac"], r["peak"], r["avg_launch_us"]))
+_dom = [float(x["AverageNs"]) / 1e3 for x in stats if "gemm_pair_kernel" in x["Name"]]
+if _dom:      # the same kernel by the trace below (its own start-to-end time; the event bracket of the line above includes the dispatch)
+    _fl = r["achieved"] * r["avg_launch_us"]      # TFLOP/s x us = MFLOP per launch
+    L.append("* the same kernel by the rocprofv3 trace below: %.1f us per launch = %.1f TFLOP/s = **%.3f** of the peak (%d steps in the trace, "
+             "350 of them warm-up: the clock of the un-profiled line)" % (_dom[0], _fl / _dom[0], _fl / _dom[0] / r["peak"], int(steps)))
 L.append("* GEMM family: %.1f TFLOP/s (%.3f), %.3f ms of the step" % (r["gemm_family"]["achieved"], r["gemm_family"]["frac"],
                                                                     r["gemm_family"]["ms_per_step"]))
 if "cpu_baseline" in bench:
