@@ -78,18 +78,9 @@ __device__ __forceinline__ void gemm_b16_tile_of(const GemmB16Args& g, int* slab
 constexpr int B16_BK = 64;        // k depth of one LDS stage
 constexpr int B16_KP = 72;        // LDS row pitch in bf16 (144 B: the 16 rows of a ds_read_b128 lane group start in 16 different 16-byte slots)
 
-// GT_B16_PRIO (compile-time, measurement): 1 = every MFMA group of a K loop is issued at wave priority 3 (s_setprio), the rest of the kernel at 0
-// (the float32 family's GT_KLOOP_PRIO, gemm_f32.hip.h).  Measured (r6, tools/gemm_b16_sweep, profiles/r06_b16_prio_sweep.txt): nothing on the 128 x 128
-// tiles (306.5 vs 308.8 us forward, 250.9 vs 251.9 backward-data), the 256 x 256 eight-wave tile LOSES (257 vs 250 us forward, 220 vs 210 backward-data):
-// these K loops have no VALU-heavy neighbour to win against.  0 it is.
-#ifndef GT_B16_PRIO
-#define GT_B16_PRIO 0
-#endif
-__device__ __forceinline__ void b16_mfma_prio(bool on) {
-#if GT_B16_PRIO
-  if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
-}
+// (r6: every MFMA group of these K loops issued at wave priority 3 (s_setprio; what pays in the float32 family, gemm_f32.hip.h: GT_KLOOP_PRIO) measured
+//  nothing on the 128 x 128 tiles (306.5 vs 308.8 us forward, 250.9 vs 251.9 backward-data) and a loss on the 256 x 256 eight-wave tile (257 vs 250,
+//  220 vs 210): these K loops have no VALU-heavy neighbour to win against.  profiles/r06_b16_prio_sweep.txt)
 template <int BM, int BN>
 constexpr size_t gemm_b16_lds_bytes() { return (size_t)2 * (BM + BN) * B16_KP * 2; }
 
@@ -359,13 +350,11 @@ __device__ __forceinline__ void gemm_b16_tile(const GemmB16Args& g, const int sl
 #pragma unroll
           for (int j = 0; j < TN_; ++j) acc[i][j][kk] += (float)fa[i][kk] * (float)fb[j][kk];
       } else {
-      b16_mfma_prio(true);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      b16_mfma_prio(false);
       }
     }
   };
@@ -506,13 +495,11 @@ __device__ __forceinline__ void gemm_b16_tile_dma(const GemmB16Args& g, const in
       for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * 64 + off);
 #pragma unroll
       for (int j = 0; j < TN_; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * 64 + off);
-      b16_mfma_prio(true);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      b16_mfma_prio(false);
     }
     // stage t + 1 (requested NS - 1 iterations ago) has landed for this wave once only the younger requests are outstanding
     if (NS == 2 || !more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -36,7 +36,6 @@ namespace gt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -182,25 +181,12 @@ __device__ __forceinline__ unsigned cu_key() {   // CU_ID [11:8], SH_ID [12], SE
 // LDS pitches per orientation (floats)
 template <int KIND, int BM> constexpr int gemm_ldm() { return KIND == GEMM_TN ? BM + 4 : BM + 1; }
 template <int KIND, int BN> constexpr int gemm_ldn() { return KIND == GEMM_NT ? BN + 1 : BN + 4; }
-// GT_LDS_ROWS (compile-time, measurement): 1 = a k-contiguous operand on the 16-byte loader keeps its ROWS in LDS ([row][BKT + 4], the k of
-// every 8-block stored as 0 2 4 6 1 3 5 7) and a lane fetches the fragments of four MFMA groups with one ds_read_b128 -- the same k in the same
-// group as the k-major image, so the results are bit-identical.  0 = every operand k-major ([k][rows + pad], one ds_read_b32 per group).
-// Measured (r6, profiles/r06_lds_rows_ab.txt): LDS read instructions per wave and K stage 32 -> 8, forward kernel 95 -> 88 VGPRs, and the forward
-// launch 75.6 -> 78.5 us, pair launches 103.7 -> 103.6, cfg2 1.298 -> 1.301 ms/step: the fragment reads are not what holds a K stage at 2.0 us.  0 it is.
-#ifndef GT_LDS_ROWS
-#define GT_LDS_ROWS 0
-#endif
-template <int BKT> constexpr int gemm_row_pitch() { return BKT + 4; }      // 4 x odd floats: the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots
-// floats of ONE buffer of an operand image with R rows (upper bound over the layouts the loader may choose)
-template <int R, int LD, int BKT, bool KC> constexpr size_t gemm_img_floats() {
-  const size_t kmaj = (size_t)BKT * LD, rows = (size_t)R * gemm_row_pitch<BKT>();
-  return (GT_LDS_ROWS && KC && rows > kmaj) ? rows : kmaj;
-}
+// (r6: a k-contiguous operand kept as ROWS in LDS, its fragments of four MFMA groups fetched with one ds_read_b128 -- a quarter of the LDS read
+//  instructions, bit-identical, measured slower: forward launch 75.6 -> 78.5 us; tools/experiments/gemm_f32_lds_rows.patch)
 template <int KIND, int BM, int BN, int PREC = PREC_F32, int BKT = GEMM_BK>
 constexpr size_t gemm_lds_bytes() {
   if (PREC == PREC_F32) {     // the operand image, but never less than the epilogue staging (4 waves x 32 x (BN/2 + 4) floats)
-    size_t img = (size_t)2 * (gemm_img_floats<BM, gemm_ldm<KIND, BM>(), BKT, KIND != GEMM_TN>() +
-                              gemm_img_floats<BN, gemm_ldn<KIND, BN>(), BKT, KIND == GEMM_NT>()) * sizeof(float), stg = (size_t)4 * 32 * (BN / 2 + 4) * 4;
+    size_t img = (size_t)2 * BKT * (gemm_ldm<KIND, BM>() + gemm_ldn<KIND, BN>()) * sizeof(float), stg = (size_t)4 * 32 * (BN / 2 + 4) * 4;
     return img > stg ? img : stg;
   }
   // bf16 image [2][BM + BN rows][GEMM_KP], but never less than what the epilogue staging (4 waves x 32 x (BN/2 + 4) floats)
@@ -428,13 +414,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
   constexpr int VWA = VA ? 4 : 1, VWB = VB ? 4 : 1;
   constexpr int UA = BM * GEMM_BK / GEMM_THREADS / VWA;   // load units (instructions) per thread per K-tile
   constexpr int UB = BN * GEMM_BK / GEMM_THREADS / VWB;
-  constexpr bool A_ROWS = GT_LDS_ROWS && PREC == PREC_F32 && A_KC && VA;   // operand image keeps rows (see GT_LDS_ROWS)
-  constexpr bool B_ROWS = GT_LDS_ROWS && PREC == PREC_F32 && B_KC && VB;
-  constexpr int RP = gemm_row_pitch<BKT>();
-  constexpr int A_BUF = A_ROWS ? BM * RP : GEMM_BK * LDM;                  // floats of one buffer
-  constexpr int B_BUF = B_ROWS ? BN * RP : GEMM_BK * LDN;
-  float* As = smem;                          // [2][BK][LDM] or [2][BM][RP]
-  float* Bs = smem + 2 * gemm_img_floats<BM, LDM, BKT, A_KC>();      // [2][BK][LDN] or [2][BN][RP]
+  float* As = smem;                          // [2][BK][LDM]
+  float* Bs = smem + 2 * GEMM_BK * LDM;      // [2][BK][LDN]
   // PREC_BF16: row-major bf16 images, k contiguous: Ah[2][BM][GEMM_KP], Bh[2][BN][GEMM_KP]
   __bf16* Ah = reinterpret_cast<__bf16*>(smem);
   __bf16* Bh = Ah + 2 * BM * GEMM_KP;
@@ -586,13 +567,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
       }
       return;
     }
-    if (A_ROWS) {            // k = kk .. kk+3 (kk = 8j + 4h): k, k+2 -> positions 8j + 2h, +1;  k+1, k+3 -> 8j + 4 + 2h, +1
-      float* p = as + mm * RP + (kk & ~7) + ((kk >> 1) & 2);
-      f32x2 e, o;
-      e[0] = ra[u * 4 + 0]; e[1] = ra[u * 4 + 2]; o[0] = ra[u * 4 + 1]; o[1] = ra[u * 4 + 3];
-      *reinterpret_cast<f32x2*>(p) = e;
-      *reinterpret_cast<f32x2*>(p + 4) = o;
-    } else if (A_KC) {
+    if (A_KC) {
 #pragma unroll
       for (int c = 0; c < VWA; ++c) as[(kk + c) * LDM + mm] = ra[u * VWA + c];
     } else if (VA) {
@@ -625,13 +600,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
       }
       return;
     }
-    if (B_ROWS) {
-      float* p = bs + nn * RP + (kk & ~7) + ((kk >> 1) & 2);
-      f32x2 e, o;
-      e[0] = rb[u * 4 + 0]; e[1] = rb[u * 4 + 2]; o[0] = rb[u * 4 + 1]; o[1] = rb[u * 4 + 3];
-      *reinterpret_cast<f32x2*>(p) = e;
-      *reinterpret_cast<f32x2*>(p + 4) = o;
-    } else if (B_KC) {
+    if (B_KC) {
 #pragma unroll
       for (int c = 0; c < VWB; ++c) bs[(kk + c) * LDN + nn] = rb[u * VWB + c];
     } else if (VB) {
@@ -690,23 +659,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
     constexpr bool prefetch = decltype(PF)::value, tail = decltype(TL)::value;
     const int buf = kt & 1;
     const int krem = k_end - (k_begin + (kt + 1) * GEMM_BK);
-    // k-major image: the lane's fragment of group gi is row 2 gi + half; row image: of groups 4q .. 4q+3 the 16 bytes at 8q + 4 half
-    const float* as = As + buf * A_BUF + (A_ROWS ? (wm * WM + l31) * RP + 4 * half : wm * WM + l31 + half * LDM);
-    const float* bs = Bs + buf * B_BUF + (B_ROWS ? (wn * WN + l31) * RP + 4 * half : wn * WN + l31 + half * LDN);
-    float* as_w = As + (buf ^ 1) * A_BUF;
-    float* bs_w = Bs + (buf ^ 1) * B_BUF;
+    const float* as = As + buf * GEMM_BK * LDM + wm * WM + l31 + half * LDM;      // the lane's fragment of group gi is row 2 gi + half
+    const float* bs = Bs + buf * GEMM_BK * LDN + wn * WN + l31 + half * LDN;
+    float* as_w = As + (buf ^ 1) * GEMM_BK * LDM;
+    float* bs_w = Bs + (buf ^ 1) * GEMM_BK * LDN;
     float a_cur[TM], b_cur[TN_], a_nxt[TM], b_nxt[TN_];
-    f32x4 a4_cur[TM], b4_cur[TN_], a4_nxt[TM], b4_nxt[TN_];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (A_ROWS) a4_cur[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * RP);
-      else a_cur[i] = as[i * 32];
-    }
+    for (int i = 0; i < TM; ++i) a_cur[i] = as[i * 32];
 #pragma unroll
-    for (int j = 0; j < TN_; ++j) {
-      if (B_ROWS) b4_cur[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * RP);
-      else b_cur[j] = bs[j * 32];
-    }
+    for (int j = 0; j < TN_; ++j) b_cur[j] = bs[j * 32];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
 #ifdef GT_ABLATE_NO_LDSREAD
@@ -719,15 +680,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
 #else
       if (gi + 1 < NG) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) if (!A_ROWS) a_nxt[i] = as[(2 * gi + 2) * LDM + i * 32];
+        for (int i = 0; i < TM; ++i) a_nxt[i] = as[(2 * gi + 2) * LDM + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) if (!B_ROWS) b_nxt[j] = bs[(2 * gi + 2) * LDN + j * 32];
-      }
-      if (gi % 4 == 0 && gi + 4 < NG) {       // row images: the next four groups' fragments, four groups ahead
-#pragma unroll
-        for (int i = 0; i < TM; ++i) if (A_ROWS) a4_nxt[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * RP + 2 * (gi + 4));
-#pragma unroll
-        for (int j = 0; j < TN_; ++j) if (B_ROWS) b4_nxt[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * RP + 2 * (gi + 4));
+        for (int j = 0; j < TN_; ++j) b_nxt[j] = bs[(2 * gi + 2) * LDN + j * 32];
       }
 #endif
 #ifdef GT_ABLATE_NO_GLOBAL
@@ -762,21 +717,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int slab, con
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_ROWS ? a4_cur[i][gi % 4] : a_cur[i], B_ROWS ? b4_cur[j][gi % 4] : b_cur[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
 #if GT_KLOOP_PRIO == 2
       __builtin_amdgcn_s_setprio(1);
 #endif
       if (gi + 1 < NG) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if (!A_ROWS) a_cur[i] = a_nxt[i];
-          else if (gi % 4 == 3) a4_cur[i] = a4_nxt[i];
-        }
+        for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) {
-          if (!B_ROWS) b_cur[j] = b_nxt[j];
-          else if (gi % 4 == 3) b4_cur[j] = b4_nxt[j];
-        }
+        for (int j = 0; j < TN_; ++j) b_cur[j] = b_nxt[j];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
